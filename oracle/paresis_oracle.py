@@ -1,0 +1,317 @@
+"""CPU oracle for the PARESIS hot path -- TEST INFRASTRUCTURE, not product code.
+
+A float64 restatement (numpy + scipy.signal, plus two scalar C loops in oracle_loops.c for what the reference
+JIT-compiles with Numba) of the per-energy, per-membrane-position image formation of quenotl/PARESIS.  Every function
+cites the reference lines it follows (paths relative to /root/reference/CodePython).  The oracle is PINNED: it is
+checked against golden vectors produced by the reference itself (tests/golden/make_golden.py ->
+tests/golden/*.npz; tests/test_oracle_golden.py).
+
+Only tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py may import this module.  The product
+(paresis_amd) never does, and fails loudly when its HIP library is missing.
+"""
+import ctypes
+import os
+
+import numpy as np
+from numpy.fft import fft2, fftshift, ifft2, ifftshift
+from scipy.signal import fftconvolve
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle_loops.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle C loops not built: run `make -C oracle` (or __graft_entry__.build())")
+        lib = ctypes.CDLL(path)
+        dp = ctypes.POINTER(ctypes.c_double)
+        lib.oracle_fastloop.argtypes = [ctypes.c_int64, ctypes.c_int64, dp, dp, dp, dp]
+        lib.oracle_fastloop.restype = None
+        lib.oracle_resize.argtypes = [ctypes.c_int64, ctypes.c_int64, dp, ctypes.c_int64, ctypes.c_int64, dp]
+        lib.oracle_resize.restype = None
+        _LIB = lib
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+# ------------------------------------------------------------------------------------------------- scalars
+H_PLANCK = 6.626e-34   # getk.py:16  (deliberately not CODATA: the reference's constants are the spec)
+C_LIGHT = 2.998e8      # getk.py:17
+E_CHARGE = 1.6e-19     # getk.py:18
+
+
+def getk(energy_eV):
+    """getk.py:12-20."""
+    return 2 * np.pi * energy_eV * E_CHARGE / (H_PLANCK * C_LIGHT)
+
+
+def k_sample(energy_keV):
+    """Sample.py:265 / Sample.py:300 (same constants, different association order)."""
+    return 2 * np.pi * energy_keV * 1000 * 1.6e-19 / (6.626e-34 * 2.998e8)
+
+
+def k_refraction(energy_keV):
+    """refractionFileNumba2.py:47-48."""
+    lam = 6.626 * 1e-34 * 2.998e8 / (energy_keV * 1000 * 1.6e-19)
+    return 2 * np.pi / lam
+
+
+# -------------------------------------------------------------------------------------------- transmission
+def set_wave(wave, geometry, delta, beta, energy_keV):
+    """AnalyticalSample.setWave, Sample.py:248-282.  geometry [nmat,Nx,Ny] (m); delta/beta per material."""
+    geometry = np.asarray(geometry)
+    if geometry.ndim != 3:
+        raise Exception("Sample Geometry has the wrong nb of dim [material, x, y]")
+    k = k_sample(energy_keV)
+    out = wave
+    for m in range(geometry.shape[0]):
+        out = np.exp((-1j * k * delta[m] - k * beta[m]) * geometry[m]) * out      # SAM:279
+    return out
+
+
+def set_wave_rt(intensity, geometry, delta, beta, energy_keV, phi=0):
+    """AnalyticalSample.setWaveRT, Sample.py:285-351 (without the Lung / cylinder_beeds dark-field branch)."""
+    k = k_sample(energy_keV)
+    I = intensity
+    for m in range(np.asarray(geometry).shape[0]):
+        I = np.exp(-2 * k * beta[m] * geometry[m]) * I        # SAM:347
+        phi = phi - k * delta[m] * geometry[m]                # SAM:348
+    return I, phi, 0
+
+
+# ------------------------------------------------------------------------------------------------- Fresnel
+def wave_propagation(wave, z, energy_keV, magnification, study_dims, pix_um):
+    """Experiment.wavePropagation, Experiment.py:219-252."""
+    if z == 0:
+        return wave                                            # EXP:233-234
+    margin = 15
+    w = np.pad(wave, margin, mode="reflect")                   # EXP:237
+    k = getk(energy_keV * 1000)                                # EXP:239
+    Nx, Ny = w.shape
+    # EXP:243-248: uv_sqr[i, j] = u_m(i)^2 + v_m(j)^2, frequency step from the UN-padded study dimensions
+    u_m = (np.arange(Nx) - (Nx // 2)) * 2 * np.pi / (study_dims[0] * pix_um * 1e-6)
+    v_m = (np.arange(Ny) - (Ny // 2)) * 2 * np.pi / (study_dims[1] * pix_um * 1e-6)
+    uv_sqr = u_m[:, None] ** 2 + v_m[None, :] ** 2
+    out = np.exp(1j * k * z / magnification) * ifft2(
+        ifftshift(np.exp(-1j * z * uv_sqr / (2 * k * magnification)) * fftshift(fft2(w))))   # EXP:250
+    return out[margin:Nx - margin, margin:Ny - margin]          # EXP:251
+
+
+# ---------------------------------------------------------------------------------------------- refraction
+def fastloop(I, Dx, Dy, I2=None):
+    """fastloopNumba, refractionFileNumba2.py:198-263 (C loop).  Accumulates into and returns I2."""
+    I = np.ascontiguousarray(I, dtype=np.float64)
+    Dx = np.ascontiguousarray(Dx, dtype=np.float64)
+    Dy = np.ascontiguousarray(Dy, dtype=np.float64)
+    if I2 is None:
+        I2 = np.zeros_like(I)
+    assert I2.flags.c_contiguous and I2.dtype == np.float64 and I.shape == Dx.shape == Dy.shape == I2.shape
+    _lib().oracle_fastloop(I.shape[0], I.shape[1], _dp(I), _dp(I2), _dp(Dx), _dp(Dy))
+    return I2
+
+
+def fast_refraction(intensity, phi, z, energy_keV, magnification, pix_um, variant="v2"):
+    """fastRefraction: refractionFileNumba2.py:25-86 (variant "v2", the one Experiment.py:22 imports) or
+    refractionFileNumba.py:11-68 (variant "v1": margin 10, clamp |D|>1e3).
+
+    Mutates `intensity` in place exactly like the reference (RF2:61-62).  Returns (I2[N,N], Dx[P,P], Dy[P,P]).
+    """
+    k = k_refraction(energy_keV)
+    Nx, Ny = intensity.shape
+    if variant == "v2":
+        margin2, limx, limy = 15, Nx, Ny                       # RF2:50, 61-64
+    elif variant == "v1":
+        margin2, limx, limy = 10, 1e3, 1e3                     # RF1:36, 46-49
+    else:
+        raise ValueError(variant)
+    h = pix_um * 1e-6
+    dphix, dphiy = np.gradient(phi, h, edge_order=2)           # RF2:54
+    Dx = dphix * z / k / (h * magnification)                   # RF2:55
+    Dy = dphiy * z / k / (h * magnification)                   # RF2:56
+    Dx[abs(Dx) < 1e-12] = 0                                    # RF2:59-60
+    Dy[abs(Dy) < 1e-12] = 0
+    intensity[abs(Dx) > limx] = 0                              # RF2:61-62 (in place!)
+    intensity[abs(Dy) > limy] = 0
+    Dx[abs(Dx) > limx] = 0                                     # RF2:63-64
+    Dy[abs(Dy) > limy] = 0
+    Dx = np.pad(Dx, margin2, mode="constant")                  # RF2:65-67
+    Dy = np.pad(Dy, margin2, mode="constant")
+    Ipad = np.pad(intensity, margin2, mode="constant")
+    I2 = fastloop(Ipad, Dx, Dy)                                # RF2:70-77
+    I2 = I2[margin2:Nx + margin2, margin2:Ny + margin2]        # RF2:78
+    if np.isnan(I2).any() or np.any(abs(I2) > 1e50):           # RF2:81-82
+        raise Exception("The calculated intensity refractive includes some nans or insane values")
+    return I2, Dx, Dy
+
+
+# ------------------------------------------------------------------------------------------------ detector
+def py_round(x):
+    """Python 3 round(): round-half-to-even, as used at Detector.py:212 / refractionFileNumba2.py:15."""
+    return int(round(float(x)))
+
+
+def create_gaussian_shape(sigma):
+    """create_gaussian_shape, Detector.py:201-220 (== gaussian_shape, refractionFileNumba2.py:14-23)."""
+    dim = py_round(sigma * 3) * 2 + 1
+    q = np.arange(0, dim) - np.floor(dim / 2)
+    Qx, Qy = np.meshgrid(q, q)
+    g = np.exp(-((Qx ** 2) / 2. / sigma ** 2 + (Qy ** 2) / 2. / sigma ** 2))
+    return g / np.sum(g)
+
+
+def resize(img, sizeX, sizeY):
+    """resize, Detector.py:185-198 (block SUM, same factor on both axes)."""
+    Nx, Ny = img.shape
+    if Nx == sizeX and Ny == sizeY:
+        return img
+    img = np.ascontiguousarray(img, dtype=np.float64)
+    out = np.empty((sizeX, sizeY))
+    _lib().oracle_resize(Nx, Ny, _dp(img), sizeX, sizeY, _dp(out))
+    return out
+
+
+def detection(img, eff_source_fwhm_px, over_sampling, det_dims, psf_sigma_px):
+    """Detector.detection, Detector.py:79-119, WITHOUT the time-seeded Poisson draw (DET:113-115): returns the
+    float64 expectation image that the reference feeds to RandomState.poisson."""
+    margins = 15
+    x = np.pad(img, margins * over_sampling, mode="reflect")                   # DET:93
+    if eff_source_fwhm_px != 0:                                                # DET:96-99
+        x = fftconvolve(x, create_gaussian_shape(eff_source_fwhm_px / 2.355), mode="same")
+    x = resize(x, det_dims[0] + margins * 2, det_dims[1] + margins * 2)        # DET:103
+    if psf_sigma_px != 0:                                                      # DET:106-110
+        x = fftconvolve(x, create_gaussian_shape(psf_sigma_px), mode="same")
+    return x[margins:det_dims[0] + margins, margins:det_dims[1] + margins]      # DET:118
+
+
+# ------------------------------------------------------------------------------------------ full chains
+class Obj:
+    """A thickness stack with its per-energy index decrements: geometry [nmat,Nx,Ny] (m), delta/beta [nmat][nE]."""
+
+    def __init__(self, geometry, delta, beta):
+        self.geometry = np.asarray(geometry, dtype=np.float64)
+        self.delta = np.asarray(delta, dtype=np.float64)
+        self.beta = np.asarray(beta, dtype=np.float64)
+
+
+def _bins(cfg, point):
+    # EXP:296-301 / EXP:425-430: at point 0 the last spectrum energy is appended as the closing threshold
+    thr = list(cfg["bins"])
+    spec = cfg["spectrum"]
+    if point == 0:
+        if any(t < spec[0][0] for t in thr) or any(t > spec[-1][0] for t in thr):
+            raise Exception("At least one of your detector bin threshold is outside your source spectrum.")
+        thr.append(spec[-1][0])
+        cfg["bins"] = thr
+    return thr
+
+
+def _eff_source(cfg):
+    # EXP:380 / EXP:503
+    return cfg["source_size_um"] * cfg["dOD"] / (cfg["dSM"] + cfg["dMO"]) / cfg["det_pix_um"] * cfg["ov"]
+
+
+def compute_fresnel(cfg, point):
+    """Experiment.computeSampleAndReferenceImages_Fresnel, Experiment.py:279-405 (scintillator branch omitted).
+
+    cfg keys: dSM,dMO,dOD,meanShotCount,ov,pix_um,M,inVacuum,N(2),spectrum[(E,w)],source_size_um,energy_sampling,
+    det_dims(2),det_pix_um,psf,bins(list, mutated at point 0 like the reference),membrane/sample/air/plate (Obj|None).
+    """
+    thr = _bins(cfg, point)
+    nb = len(thr)
+    n0, n1 = cfg["det_dims"]
+    N0, N1 = cfg["N"]
+    S = np.zeros((nb, n0, n1)); R = np.zeros((nb, n0, n1)); Pg = np.zeros((nb, n0, n1)); W = np.zeros((nb, n0, n1))
+    I0 = np.ones((N0, N1)) * (cfg["meanShotCount"] / cfg["ov"] ** 2)            # EXP:308
+    accS = np.zeros((N0, N1)); accR = np.zeros((N0, N1)); accP = np.zeros((N0, N1)); white = np.zeros((N0, N1))
+    sumI = 0.0; meanE = 0.0; ibin = 0
+    mem, smp, air, plate = cfg["membrane"], cfg["sample"], cfg["air"], cfg["plate"]
+    prop = lambda w, z, E, M: wave_propagation(w, z, E, M, (N0, N1), cfg["pix_um"])
+    for ie, (E, flux) in enumerate(cfg["spectrum"]):
+        I = I0 * flux                                                          # EXP:320
+        if not cfg["inVacuum"]:
+            I, _, _ = set_wave_rt(I, air.geometry, air.delta[:, ie], air.beta[:, ie], E)     # EXP:323
+        w0 = np.sqrt(I)                                                        # EXP:334
+        wm = set_wave(w0, mem.geometry, mem.delta[:, ie], mem.beta[:, ie], E)  # EXP:338
+        magMemObj = (cfg["dSM"] + cfg["dMO"]) / cfg["dSM"]                     # EXP:340
+        wbs = prop(wm, cfg["dMO"], E, magMemObj)                               # EXP:341
+        was = set_wave(wbs, smp.geometry, smp.delta[:, ie], smp.beta[:, ie], E)  # EXP:344
+        wS = prop(was, cfg["dOD"], E, cfg["M"])                                # EXP:348
+        wR = prop(wm, cfg["dOD"] + cfg["dMO"], E, cfg["M"])                    # EXP:349
+        IS = abs(wS) ** 2; IR = abs(wR) ** 2                                   # EXP:351,354
+        if plate is not None:
+            IS, _, _ = set_wave_rt(IS, plate.geometry, plate.delta[:, ie], plate.beta[:, ie], E)
+            IR, _, _ = set_wave_rt(IR, plate.geometry, plate.delta[:, ie], plate.beta[:, ie], E)
+        accS += IS; accR += IR                                                 # EXP:357-358
+        sumI += np.mean(IR); meanE += E * np.mean(IR)                          # EXP:360-361
+        if point == 0:                                                         # EXP:363-375
+            wp = prop(set_wave(w0, smp.geometry, smp.delta[:, ie], smp.beta[:, ie], E), cfg["dOD"], E, cfg["M"])
+            IP = abs(wp) ** 2
+            Iw = w0 ** 2
+            if plate is not None:
+                IP, _, _ = set_wave_rt(IP, plate.geometry, plate.delta[:, ie], plate.beta[:, ie], E)
+                Iw, _, _ = set_wave_rt(w0 ** 2, plate.geometry, plate.delta[:, ie], plate.beta[:, ie], E)
+            accP += IP; white = white + Iw
+        if E > thr[ibin] - cfg["energy_sampling"] / 2:                         # EXP:378
+            ess = _eff_source(cfg)
+            det = lambda im: detection(im, ess, cfg["ov"], cfg["det_dims"], cfg["psf"])
+            S[ibin] = det(accS); R[ibin] = det(accR)                           # EXP:388-390
+            if point == 0:
+                Pg[ibin] = det(accP)
+            W[ibin] = det(white)                                               # EXP:394
+            accS = np.zeros((N0, N1)); accR = np.zeros((N0, N1)); accP = np.zeros((N0, N1)); white = np.zeros((N0, N1))
+            ibin += 1
+    return S, R, Pg, W, meanE / sumI
+
+
+def compute_rt(cfg, point, variant="v2"):
+    """Experiment.computeSampleAndReferenceImages_RT, Experiment.py:407-526 (scalar dark field only)."""
+    thr = _bins(cfg, point)
+    nb = len(thr)
+    n0, n1 = cfg["det_dims"]
+    N0, N1 = cfg["N"]
+    S = np.zeros((nb, n0, n1)); R = np.zeros((nb, n0, n1)); Pg = np.zeros((nb, n0, n1)); W = np.zeros((nb, n0, n1))
+    I0 = np.ones((N0, N1)) * (cfg["meanShotCount"] / cfg["ov"] ** 2)            # EXP:438
+    phi0 = np.zeros((N0, N1))
+    accS = np.zeros((N0, N1)); accR = np.zeros((N0, N1)); accP = np.zeros((N0, N1)); white = np.zeros((N0, N1))
+    sumI = 0.0; meanE = 0.0; ibin = 0
+    Dxreal = []; Dyreal = []
+    mem, smp, air, plate = cfg["membrane"], cfg["sample"], cfg["air"], cfg["plate"]
+    refr = lambda I, phi, z, E: fast_refraction(abs(I), phi, z, E, cfg["M"], cfg["pix_um"], variant)
+    for ie, (E, flux) in enumerate(cfg["spectrum"]):
+        I = I0 * flux                                                          # EXP:451
+        if not cfg["inVacuum"]:
+            I, _, _ = set_wave_rt(I, air.geometry, air.delta[:, ie], air.beta[:, ie], E)
+        Im, phim, _ = set_wave_rt(I, mem.geometry, mem.delta[:, ie], mem.beta[:, ie], E, phi0)   # EXP:463
+        Ibs, _, _ = refr(Im, phim, cfg["dMO"], E)                              # EXP:466 (total magnification!)
+        Ias, phis, _ = set_wave_rt(Ibs, smp.geometry, smp.delta[:, ie], smp.beta[:, ie], E, phim)  # EXP:469
+        IS, _, _ = refr(Ias, phis, cfg["dOD"], E)                              # EXP:473
+        IR, _, _ = refr(Ibs, phim, cfg["dOD"], E)                              # EXP:474
+        if plate is not None:                                                  # EXP:478-480
+            IS, _, _ = set_wave_rt(IS, plate.geometry, plate.delta[:, ie], plate.beta[:, ie], E)
+            IR, _, _ = set_wave_rt(IR, plate.geometry, plate.delta[:, ie], plate.beta[:, ie], E)
+        accS += IS; accR += IR
+        sumI += np.mean(IR); meanE += E * np.mean(IR)
+        if point == 0:                                                         # EXP:488-498
+            Ip, phip, _ = set_wave_rt(I, smp.geometry, smp.delta[:, ie], smp.beta[:, ie], E, phi0)
+            IP, Dxreal, Dyreal = refr(Ip, phip, cfg["dOD"], E)
+            if plate is not None:
+                IP, _, _ = set_wave_rt(IP, plate.geometry, plate.delta[:, ie], plate.beta[:, ie], E)
+                I, _, _ = set_wave_rt(I, plate.geometry, plate.delta[:, ie], plate.beta[:, ie], E)
+            white = white + I
+            accP += IP
+        if E > thr[ibin] - cfg["energy_sampling"] / 2:                         # EXP:501
+            ess = _eff_source(cfg)
+            det = lambda im: detection(im, ess, cfg["ov"], cfg["det_dims"], cfg["psf"])
+            S[ibin] = det(accS); R[ibin] = det(accR)
+            if point == 0:
+                Pg[ibin] = det(accP)
+            W[ibin] = det(white)
+            accS = np.zeros((N0, N1)); accR = np.zeros((N0, N1)); accP = np.zeros((N0, N1)); white = np.zeros((N0, N1))
+            ibin += 1
+    return S, R, Pg, W, Dxreal, Dyreal, meanE / sumI

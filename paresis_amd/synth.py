@@ -1,0 +1,80 @@
+"""Seeded synthetic thickness maps for tests, goldens and bench.py.
+
+These stand in for the reference's input-synthesis layer (CodePython/Samples/getMembraneFromFile.py:60-171
+and CodePython/Samples/createSampGeom.py:56-107), which needs a sphere list that is not shipped
+(.MISSING_LARGE_BLOBS) and is out of scope for the hot path.  Everything here is plain numpy on the host so
+that the oracle and the HIP path see bit-identical float32 inputs; seed(pointNum) = 1000 + pointNum makes a
+membrane position independent of how positions are sharded over GPUs.
+"""
+import numpy as np
+
+# order-of-magnitude physical index decrements at 52 keV (not from the xls tables)
+DELTA_BETA_52KEV = {
+    "CuSn": (6.2e-7, 4.0e-9),
+    "PMMA": (9.87e-8, 4.5e-11),
+    "Nylon": (9.5e-8, 4.2e-11),
+    "air": (1.0e-10, 1.0e-15),
+    "C": (1.5e-7, 6.0e-11),
+}
+
+
+def position_seed(pointNum):
+    return 1000 + int(pointNum)
+
+
+def sphere_membrane(Nx, Ny, pix_m, pointNum=0, coverage=0.5, rmin=3.0, rmax=8.0, dtype=np.float32):
+    """Thickness map (metres) of randomly placed spheres: sum over spheres of 2*sqrt(r^2-d^2)*pix.
+
+    Mirrors the splat of getMembraneFromFile.py:143-159 (thickness of a sphere along the beam), with a
+    seeded RNG instead of the reference's unseeded np.random.randint offsets (:139-140).
+    """
+    rng = np.random.Generator(np.random.PCG64(position_seed(pointNum)))
+    rbar = 0.5 * (rmin + rmax)
+    n_s = max(1, int(coverage * Nx * Ny / (np.pi * rbar * rbar)))
+    cx = rng.uniform(0, Nx, n_s)
+    cy = rng.uniform(0, Ny, n_s)
+    rr = rng.uniform(rmin, rmax, n_s)
+    R = int(np.ceil(rmax)) + 1
+    off = np.arange(-R, R + 1)
+    ox, oy = np.meshgrid(off, off, indexing="ij")
+    ox = ox.ravel()[None, :]
+    oy = oy.ravel()[None, :]
+    out = np.zeros(Nx * Ny, dtype=np.float64)
+    chunk = 20000
+    for s in range(0, n_s, chunk):
+        ix = np.floor(cx[s:s + chunk]).astype(np.int64)[:, None] + ox
+        iy = np.floor(cy[s:s + chunk]).astype(np.int64)[:, None] + oy
+        d2 = (ix - cx[s:s + chunk, None]) ** 2 + (iy - cy[s:s + chunk, None]) ** 2
+        t = rr[s:s + chunk, None] ** 2 - d2
+        ok = (t > 0) & (ix >= 0) & (ix < Nx) & (iy >= 0) & (iy < Ny)
+        np.add.at(out, (ix[ok] * Ny + iy[ok]), 2.0 * np.sqrt(t[ok]) * pix_m)
+    return out.reshape(Nx, Ny).astype(dtype)
+
+
+def cylinder_sample(Nx, Ny, pix_m, radius_frac=0.23, dtype=np.float32):
+    """Cylinder lying along axis 0 (x), radius = radius_frac*Ny pixels: T = 2*sqrt(R^2 - y^2)*pix."""
+    Rpx = radius_frac * Ny
+    y = np.arange(Ny, dtype=np.float64) - (Ny - 1) / 2.0
+    t = np.clip(Rpx * Rpx - y * y, 0.0, None)
+    row = 2.0 * np.sqrt(t) * pix_m
+    return np.broadcast_to(row[None, :], (Nx, Ny)).astype(dtype).copy()
+
+
+def slab(Nx, Ny, thickness_m, dtype=np.float32):
+    """Uniform slab (Sample.py:239-243, get_my_thickness)."""
+    return np.full((Nx, Ny), thickness_m, dtype=dtype)
+
+
+def bench_geometry(N, pointNum=0, ov=2, det_pix_um=6.0, dSM=140.0, dMO=1.6, dOD=3.6):
+    """The synthetic workload of SURVEY.md section 8d on an N x N study grid."""
+    M = (dSM + dMO + dOD) / (dSM + dMO)
+    pix_um = det_pix_um / ov / M
+    mem_pix_um = pix_um * dSM / (dSM + dMO)
+    membrane = np.stack([
+        sphere_membrane(N, N, mem_pix_um * 1e-6, pointNum),
+        slab(N, N, 6e-3),
+    ])
+    sample = cylinder_sample(N, N, pix_um * 1e-6)[None]
+    return dict(M=M, pix_um=pix_um, membrane=membrane, sample=sample,
+                membrane_materials=["CuSn", "PMMA"], sample_materials=["Nylon"],
+                dSM=dSM, dMO=dMO, dOD=dOD, energy_keV=52.0)

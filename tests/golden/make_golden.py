@@ -1,0 +1,383 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors in tests/golden/*.npz from the reference itself.
+
+Runs ONLY in the build container, where the reference lives at /root/reference (it never travels to the
+GPU box; only the arrays written here do).  The reference is imported unmodified, function by function, with
+the compatibility shims recorded in SURVEY.md section 8c:
+
+  * `numba` is not installed: a stand-in module whose `jit` is the identity decorator, so the two @jit loops
+    (refractionFileNumba2.py:198, Detector.py:185) run in the interpreter;
+  * `np.int` / `np.float` (removed numpy aliases used at refractionFileNumba2.py:72-73) are restored;
+  * empty module objects for the optional third-party imports the hot path never calls
+    (xlrd, xraylib, spekpy, fabio, cv2, imutils, skimage);
+  * Poisson shot noise (Detector.py:113-115, time-seeded) is bypassed by a proxy so that the recorded
+    `detection` output is the deterministic pre-noise image.
+
+Usage:  python tests/golden/make_golden.py            (writes next to this file)
+"""
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/CodePython"
+
+sys.dont_write_bytecode = True
+os.environ["MPLBACKEND"] = "Agg"
+import numpy as np  # noqa: E402
+
+np.int = int
+np.float = float
+
+_nb = types.ModuleType("numba")
+
+
+def _jit(*a, **k):
+    if len(a) == 1 and callable(a[0]) and not k:
+        return a[0]
+    return lambda f: f
+
+
+_nb.jit = _jit
+sys.modules["numba"] = _nb
+for _name in ["xlrd", "xraylib", "spekpy", "fabio", "fabio.edfimage", "fabio.tifimage", "cv2", "imutils",
+              "skimage", "skimage.transform"]:
+    sys.modules[_name] = types.ModuleType(_name)
+sys.modules["skimage.transform"].radon = None
+sys.modules["skimage.transform"].rescale = None
+sys.modules["skimage"].transform = sys.modules["skimage.transform"]
+
+sys.path.insert(0, REPO)
+from paresis_amd import synth  # noqa: E402
+
+_cwd = os.getcwd()
+os.chdir(REF)  # the reference's constructors parse xmlFiles/*.xml relative to cwd
+sys.path.insert(0, REF)
+import refractionFileNumba2 as RF2  # noqa: E402
+import refractionFileNumba as RF1  # noqa: E402
+import Experiment as EXP  # noqa: E402
+import Detector as DET  # noqa: E402
+import Sample as SAM  # noqa: E402
+import Source as SRC  # noqa: E402
+import getk as GETK  # noqa: E402
+
+
+class _NoNoiseRandomState:
+    def __init__(self, seed=None):
+        pass
+
+    def poisson(self, lam):
+        return lam
+
+
+class _NpProxy:
+    """numpy with random.RandomState(seed).poisson(x) == x (Detector.py:113-115)."""
+
+    class random:  # noqa: N801
+        RandomState = _NoNoiseRandomState
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+
+DET.np = _NpProxy()
+
+rng = np.random.Generator(np.random.PCG64(20261004))
+
+
+def save(name, d):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **d)
+    print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024.0))
+
+
+# ---------------------------------------------------------------------------------------------------------
+def gold_scalars():
+    d = {}
+    E = np.array([25000.0, 52000.0, 17.5e3, 100e3, 1.0])
+    d["getk/E_eV"] = E
+    d["getk/k"] = np.array([GETK.getk(e) for e in E])
+    sig = np.array([0.5, 0.8333, 1.0, 1.2, 1.5, 10 * 3.6 / 141.6 / 6 * 2 / 2.355, 2.5, 0.1667, 0.25])
+    d["gauss/sigma"] = sig
+    for i, s in enumerate(sig):
+        d["gauss/%d/det" % i] = DET.create_gaussian_shape(s)
+        d["gauss/%d/rf2" % i] = RF2.gaussian_shape(s)
+    k = 0
+    for shape, (sx, sy) in [((12, 12), (12, 12)), ((12, 8), (6, 4)), ((16, 12), (4, 3)), ((9, 9), (3, 3)),
+                            ((10, 20), (5, 10))]:
+        a = rng.uniform(0, 5, shape)
+        d["resize/%d/in" % k] = a
+        d["resize/%d/size" % k] = np.array([sx, sy])
+        d["resize/%d/out" % k] = np.array(DET.resize(a.copy(), sx, sy))
+        k += 1
+    d["resize/n"] = np.array(k)
+    save("scalars.npz", d)
+
+
+def make_sample(name, mtype, materials, geometry, energies, deltas, betas):
+    s = object.__new__(SAM.AnalyticalSample)
+    s.myName = name
+    s.myType = mtype
+    s.myMaterials = list(materials)
+    s.myGeometry = np.asarray(geometry, dtype=np.float64)
+    s.delta = [[(e, dl[i]) for i, e in enumerate(energies)] for dl in deltas]
+    s.beta = [[(e, bl[i]) for i, e in enumerate(energies)] for bl in betas]
+    s.geom_parameters = None
+    s.myGeometryFunction = "injected"
+    return s
+
+
+def gold_transmission():
+    d = {}
+    Nx, Ny = 40, 36
+    pix = 3e-6
+    T = np.stack([synth.sphere_membrane(Nx, Ny, pix, 3).astype(np.float64), synth.slab(Nx, Ny, 6e-3).astype(np.float64)])
+    energies = [52.0, 30.0]
+    deltas = [[6.2e-7, 1.9e-6], [9.87e-8, 2.9e-7]]
+    betas = [[4.0e-9, 3.0e-8], [4.5e-11, 1.6e-10]]
+    s = make_sample("mem", "membrane", ["CuSn", "PMMA"], T, energies, deltas, betas)
+    wave = (rng.uniform(0.5, 1.5, (Nx, Ny)) * np.exp(1j * rng.uniform(-3, 3, (Nx, Ny))))
+    I0 = rng.uniform(100, 200, (Nx, Ny))
+    phi0 = rng.uniform(-2, 2, (Nx, Ny))
+    d["T"] = T
+    d["energies"] = np.array(energies)
+    d["delta"] = np.array(deltas)
+    d["beta"] = np.array(betas)
+    d["wave_in"] = wave
+    d["I_in"] = I0
+    d["phi_in"] = phi0
+    for ie, E in enumerate(energies):
+        d["setWave/%d" % ie] = s.setWave(wave.copy(), E)
+        I, phi, df = s.setWaveRT(I0.copy(), E, phi0.copy())
+        d["setWaveRT/%d/I" % ie] = I
+        d["setWaveRT/%d/phi" % ie] = phi
+        d["setWaveRT/%d/df" % ie] = np.array(df)
+        I, phi, df = s.setWaveRT(I0.copy(), E)  # default scalar phase 0
+        d["setWaveRT0/%d/I" % ie] = I
+        d["setWaveRT0/%d/phi" % ie] = phi
+    save("transmission.npz", d)
+
+
+class _ExpStub:
+    pass
+
+
+def gold_fresnel():
+    d = {}
+    cases = []
+    k = 0
+    for (Nx, Ny) in [(64, 64), (65, 65), (96, 80), (50, 71)]:
+        pix_um = 6.0 / 2 / (145.2 / 141.6)
+        T = synth.sphere_membrane(Nx, Ny, pix_um * 1e-6, 7 + k).astype(np.float64)
+        amp = np.sqrt(7500.0) * np.exp(-2.63e11 * 4.0e-9 * T)
+        wave = amp * np.exp(-1j * 2.63e11 * 6.2e-7 * T)
+        for (z, E, M) in [(1.6, 52.0, 141.6 / 140.0), (3.6, 52.0, 145.2 / 141.6), (5.2, 25.0, 145.2 / 141.6),
+                          (0.0, 52.0, 1.0), (0.35, 17.5, 2.0)]:
+            stub = _ExpStub()
+            stub.exp_dict = {"studyDimensions": [Nx, Ny], "studyPixelSize": pix_um}
+            out = EXP.Experiment.wavePropagation(stub, wave.copy(), z, E, M)
+            d["%d/wave" % k] = wave
+            d["%d/params" % k] = np.array([z, E, M, pix_um])
+            d["%d/out" % k] = out
+            cases.append(k)
+            k += 1
+    d["n"] = np.array(k)
+    save("fresnel.npz", d)
+
+
+def refraction_inputs(Nx, Ny, pix_um, seed, delta=6.2e-7, E=52.0):
+    kk = 2 * np.pi * E * 1000 * 1.6e-19 / (6.626e-34 * 2.998e8)
+    T = synth.sphere_membrane(Nx, Ny, pix_um * 1e-6, seed).astype(np.float64)
+    phi = -kk * delta * T - kk * 9.87e-8 * 6e-3
+    I = 7500.0 * np.exp(-2 * kk * 4.0e-9 * T) * (1.0 + 0.05 * np.sin(np.arange(Nx)[:, None] * 0.3 + np.arange(Ny)[None, :] * 0.17))
+    return I, phi, T
+
+
+def gold_refraction():
+    d = {}
+    k = 0
+    pix_um = 6.0 / 2 / (145.2 / 141.6)
+    # (shape, z, M, note): small / medium / leaving the margin (|D|>15) / clamp (|D|>N)
+    for (Nx, Ny), z, M, note in [((64, 64), 1.6, 145.2 / 141.6, "small"),
+                                 ((96, 80), 3.6, 145.2 / 141.6, "medium"),
+                                 ((65, 65), 3.6, 145.2 / 141.6, "odd"),
+                                 ((64, 64), 40.0, 145.2 / 141.6, "leave_margin"),
+                                 ((48, 40), 2500.0, 1.0, "clamp"),
+                                 ((33, 47), 14.0, 1.3, "ragged")]:
+        I, phi, T = refraction_inputs(Nx, Ny, pix_um, 11 + k)
+        for ver, mod in (("v2", RF2), ("v1", RF1)):
+            Iin = I.copy()
+            out, Dx, Dy = mod.fastRefraction(Iin, phi.copy(), z, 52.0, M, pix_um)
+            d["%d/%s/out" % (k, ver)] = out
+            d["%d/%s/Dx" % (k, ver)] = Dx
+            d["%d/%s/Dy" % (k, ver)] = Dy
+            d["%d/%s/I_after" % (k, ver)] = Iin  # the reference zeroes clamped entries in place (RF2:61-62)
+        d["%d/I" % k] = I
+        d["%d/phi" % k] = phi
+        d["%d/T" % k] = T
+        d["%d/params" % k] = np.array([z, 52.0, M, pix_um])
+        print("refraction case", k, note, "max|Dx|", np.abs(d["%d/v2/Dx" % k]).max(), "max|Dy|", np.abs(d["%d/v2/Dy" % k]).max())
+        k += 1
+    d["n"] = np.array(k)
+
+    # raw loop on hand-made displacement fields (exercises every sign/|D|>1 branch and the border rules)
+    Nx, Ny = 20, 17
+    I = rng.uniform(1, 2, (Nx, Ny))
+    Dx = rng.uniform(-3.5, 3.5, (Nx, Ny))
+    Dy = rng.uniform(-3.5, 3.5, (Nx, Ny))
+    Dx[2, 3] = 0.0
+    Dy[2, 3] = 0.0
+    Dx[4, 4] = 1.0
+    Dy[4, 4] = -1.0
+    Dx[5, 5] = 0.0
+    Dy[5, 5] = 0.75
+    Dx[6, 6] = -2.0
+    Dy[6, 6] = 0.0
+    Dx[0, :] = -0.5
+    Dx[-1, :] = 0.5
+    Dy[:, 0] = -0.25
+    Dy[:, -1] = 0.25
+    I2 = np.zeros((Nx, Ny))
+    out = RF2.fastloopNumba(Nx, Ny, I.copy(), I2, Dy.copy(), Dx.copy(), Dx.astype(int), Dy.astype(int))
+    d["loop/I"] = I
+    d["loop/Dx"] = Dx
+    d["loop/Dy"] = Dy
+    d["loop/out"] = np.array(out)
+    save("refraction.npz", d)
+
+
+def make_detector(dims, pix_um, psf, bins=None):
+    det = object.__new__(DET.Detector)
+    det.myName = "synthetic"
+    det.det_param = {"myDimensions": np.array(dims), "myPixelSize": float(pix_um), "myPSF": float(psf),
+                     "myBinsThersholds": list(bins or []), "myScintillatorMaterial": None,
+                     "myScintillatorThickness": 0.0, "photonCounting": True}
+    det.mySpectralEfficiency = []
+    det.beta = []
+    return det
+
+
+def gold_detector():
+    d = {}
+    k = 0
+    for dims, ov, fwhm, psf in [((24, 20), 1, 0.0, 0.0), ((24, 20), 2, 0.0, 0.0), ((24, 20), 2, 0.3595, 0.0),
+                                ((20, 24), 4, 1.5 * 2.355, 1.0), ((16, 16), 2, 1.2, 1.2), ((24, 20), 1, 0.9, 1.0),
+                                ((12, 14), 3, 2.0, 0.5)]:
+        det = make_detector(dims, 6.0, psf)
+        N = (dims[0] * ov, dims[1] * ov)
+        img = rng.uniform(50, 150, N) * (1 + 0.3 * np.sin(np.arange(N[0])[:, None] * 0.5))
+        out = det.detection(img.copy(), fwhm, {"overSampling": ov})
+        d["%d/in" % k] = img
+        d["%d/params" % k] = np.array([dims[0], dims[1], ov, fwhm, psf])
+        d["%d/out" % k] = np.asarray(out, dtype=np.float64)
+        k += 1
+    d["n"] = np.array(k)
+    save("detector.npz", d)
+
+
+def build_experiment(det_dims, ov, spectrum, bins, energy_sampling, psf, src_size, in_vacuum, with_plate, seed0):
+    dSM, dMO, dOD = 140.0, 1.6, 3.6
+    exp = object.__new__(EXP.Experiment)
+    M = (dSM + dMO + dOD) / (dSM + dMO)
+    det_pix = 6.0
+    N = [det_dims[0] * ov, det_dims[1] * ov]
+    pix_um = det_pix / ov / M
+    exp.exp_dict = {"experimentName": "synthetic", "overSampling": ov, "nbExpPoints": 2, "simulation_type": "RayT",
+                    "studyPixelSize": pix_um, "studyDimensions": N, "inVacuum": in_vacuum, "meanShotCount": 30000.0,
+                    "meanEnergy": 0, "distSourceToMembrane": dSM, "distMembraneToObject": dMO,
+                    "distObjectToDetector": dOD, "magnification": M}
+    src = object.__new__(SRC.Source)
+    src.myName = "synthetic"
+    src.mySpectrum = list(spectrum)
+    src.source_dict = {"mySize": src_size, "myEnergySampling": energy_sampling,
+                       "myType": "Monochromatic" if len(spectrum) == 1 else "Polychromatic"}
+    exp.mySource = src
+    exp.myDetector = make_detector(det_dims, det_pix, psf, bins)
+    energies = [e for e, _ in spectrum]
+    # synthetic delta/beta ~ E^-2 / E^-3 scaling from the 52 keV values
+    def db(name):
+        d0, b0 = synth.DELTA_BETA_52KEV[name]
+        return [d0 * (52.0 / e) ** 2 for e in energies], [b0 * (52.0 / e) ** 3 for e in energies]
+    mem_pix = pix_um * dSM / (dSM + dMO)
+    def membrane_geom(point):
+        return np.stack([synth.sphere_membrane(N[0], N[1], mem_pix * 1e-6, seed0 + point).astype(np.float64),
+                         synth.slab(N[0], N[1], 6e-3).astype(np.float64)])
+    dl, bl = zip(db("CuSn"), db("PMMA"))
+    exp.myMembrane = make_sample("membrane", "membrane", ["CuSn", "PMMA"], membrane_geom(0), energies, list(dl), list(bl))
+    dl, bl = db("Nylon")
+    exp.mySampleofInterest = make_sample("sample", "sample_of_interest", ["Nylon"],
+                                         synth.cylinder_sample(N[0], N[1], pix_um * 1e-6).astype(np.float64)[None],
+                                         energies, [dl], [bl])
+    dl, bl = db("air")
+    exp.myAirVolume = make_sample("air_volume", "air", ["air"], synth.slab(N[0], N[1], dSM + dMO + dOD).astype(np.float64)[None],
+                                  energies, [dl], [bl])
+    exp.myPlate = None
+    if with_plate:
+        dl, bl = db("C")
+        exp.myPlate = make_sample("plate", "plate", ["C"], synth.slab(N[0], N[1], 1e-3).astype(np.float64)[None],
+                                  energies, [dl], [bl])
+    exp.Dxreal = []
+    exp.Dyreal = []
+    return exp, membrane_geom
+
+
+def record_inputs(d, tag, exp):
+    d[tag + "/exp"] = np.array([exp.exp_dict[k] for k in ("distSourceToMembrane", "distMembraneToObject",
+                                                           "distObjectToDetector", "meanShotCount", "overSampling",
+                                                           "studyPixelSize", "magnification")], dtype=np.float64)
+    d[tag + "/inVacuum"] = np.array(bool(exp.exp_dict["inVacuum"]))
+    d[tag + "/studyDimensions"] = np.array(exp.exp_dict["studyDimensions"])
+    d[tag + "/spectrum"] = np.array(exp.mySource.mySpectrum, dtype=np.float64)
+    d[tag + "/source"] = np.array([exp.mySource.source_dict["mySize"], exp.mySource.source_dict["myEnergySampling"]], dtype=np.float64)
+    d[tag + "/det"] = np.array([exp.myDetector.det_param["myDimensions"][0], exp.myDetector.det_param["myDimensions"][1],
+                                exp.myDetector.det_param["myPixelSize"], exp.myDetector.det_param["myPSF"]], dtype=np.float64)
+    d[tag + "/bins"] = np.array(exp.myDetector.det_param["myBinsThersholds"], dtype=np.float64)
+    for nm, s in (("membrane", exp.myMembrane), ("sample", exp.mySampleofInterest), ("air", exp.myAirVolume), ("plate", exp.myPlate)):
+        if s is None:
+            continue
+        d[tag + "/" + nm + "/geometry"] = s.myGeometry
+        d[tag + "/" + nm + "/delta"] = np.array([[v for _, v in l] for l in s.delta])
+        d[tag + "/" + nm + "/beta"] = np.array([[v for _, v in l] for l in s.beta])
+
+
+def gold_experiment():
+    d = {}
+    configs = [
+        # tag, det_dims, ov, spectrum, bins, sampling, psf, src_size_um, in_vacuum, plate
+        ("mono", (48, 40), 2, [(52.0, 1)], [], 1, 0.0, 10.0, True, False),
+        ("poly", (32, 36), 2, [(20.0, 0.25), (24.0, 0.45), (28.0, 0.30)], [24.0], 4.0, 1.2, 50.0, False, True),
+    ]
+    for tag, dims, ov, spec, bins, samp, psf, ssz, vac, plate in configs:
+        for sim in ("RT", "Fresnel"):
+            exp, membrane_geom = build_experiment(dims, ov, spec, bins, samp, psf, ssz, vac, plate, 40)
+            t = "%s/%s" % (tag, sim)
+            record_inputs(d, t, exp)
+            for point in (0, 1):
+                exp.myMembrane.myGeometry = membrane_geom(point)
+                d["%s/p%d/membrane" % (t, point)] = exp.myMembrane.myGeometry
+                exp.exp_dict["meanEnergy"] = 0
+                if sim == "RT":
+                    S, R, Pg, W, Dx, Dy, DF = exp.computeSampleAndReferenceImages_RT(point)
+                    d["%s/p%d/Dx" % (t, point)] = np.asarray(Dx, dtype=np.float64)
+                    d["%s/p%d/Dy" % (t, point)] = np.asarray(Dy, dtype=np.float64)
+                    d["%s/p%d/DF" % (t, point)] = np.asarray(DF, dtype=np.float64)
+                else:
+                    S, R, Pg, W = exp.computeSampleAndReferenceImages_Fresnel(point)
+                d["%s/p%d/Sample" % (t, point)] = np.asarray(S, dtype=np.float64)
+                d["%s/p%d/Reference" % (t, point)] = np.asarray(R, dtype=np.float64)
+                d["%s/p%d/Propag" % (t, point)] = np.asarray(Pg, dtype=np.float64)
+                d["%s/p%d/White" % (t, point)] = np.asarray(W, dtype=np.float64)
+                d["%s/p%d/meanEnergy" % (t, point)] = np.array(exp.exp_dict["meanEnergy"])
+            d["%s/bins_after" % t] = np.array(exp.myDetector.det_param["myBinsThersholds"], dtype=np.float64)
+    save("experiment.npz", d)
+
+
+if __name__ == "__main__":
+    gold_scalars()
+    gold_transmission()
+    gold_fresnel()
+    gold_refraction()
+    gold_detector()
+    gold_experiment()
+    os.chdir(_cwd)

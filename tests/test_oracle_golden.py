@@ -1,0 +1,135 @@
+"""Pin the CPU oracle (oracle/) against golden vectors generated from the reference itself (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import paresis_oracle as orc
+from tests._golden import experiment_cfg, load, relmax
+
+TOL = 1e-12   # fp64 restatement vs fp64 reference
+
+
+def test_getk():
+    g = load("scalars.npz")
+    for e, k in zip(g["getk/E_eV"], g["getk/k"]):
+        assert orc.getk(e) == k
+    assert abs(orc.getk(25000) - 2 * np.pi * 25000 * 1.6e-19 / (6.626e-34 * 2.998e8)) == 0
+    # the three spellings in the reference (getk.py:19, Sample.py:265, refractionFileNumba2.py:47-48) agree to rounding
+    assert abs(orc.k_sample(52.0) / orc.getk(52000.0) - 1) < 1e-15
+    assert abs(orc.k_refraction(52.0) / orc.getk(52000.0) - 1) < 1e-15
+
+
+def test_gaussian_shapes():
+    g = load("scalars.npz")
+    for i, s in enumerate(g["gauss/sigma"]):
+        mine = orc.create_gaussian_shape(s)
+        assert mine.shape == g["gauss/%d/det" % i].shape
+        assert relmax(mine, g["gauss/%d/det" % i]) < TOL
+        assert relmax(mine, g["gauss/%d/rf2" % i]) < TOL
+        assert abs(mine.sum() - 1) < 1e-14
+    assert orc.create_gaussian_shape(0.5).shape == (5, 5)       # round(1.5)=2 (banker's)
+    assert orc.create_gaussian_shape(0.8333).shape == (5, 5)    # round(2.4999)=2
+
+
+def test_resize():
+    g = load("scalars.npz")
+    for k in range(int(g["resize/n"])):
+        sx, sy = (int(v) for v in g["resize/%d/size" % k])
+        out = orc.resize(g["resize/%d/in" % k].copy(), sx, sy)
+        assert relmax(out, g["resize/%d/out" % k]) < TOL
+    assert np.allclose(orc.resize(np.full((8, 8), 2.0), 4, 4), 2.0 * 4)   # bin SUM (DET:196)
+
+
+def test_transmission():
+    g = load("transmission.npz")
+    T, dl, bl = g["T"], g["delta"], g["beta"]
+    for ie, E in enumerate(g["energies"]):
+        w = orc.set_wave(g["wave_in"].copy(), T, dl[:, ie], bl[:, ie], E)
+        assert relmax(w, g["setWave/%d" % ie]) < TOL
+        I, phi, df = orc.set_wave_rt(g["I_in"].copy(), T, dl[:, ie], bl[:, ie], E, g["phi_in"].copy())
+        assert relmax(I, g["setWaveRT/%d/I" % ie]) < TOL
+        assert relmax(phi, g["setWaveRT/%d/phi" % ie]) < TOL
+        assert df == 0 and int(g["setWaveRT/%d/df" % ie]) == 0
+        I, phi, _ = orc.set_wave_rt(g["I_in"].copy(), T, dl[:, ie], bl[:, ie], E)
+        assert relmax(phi, g["setWaveRT0/%d/phi" % ie]) < TOL
+
+
+def test_wave_propagation():
+    g = load("fresnel.npz")
+    for k in range(int(g["n"])):
+        z, E, M, pix = g["%d/params" % k]
+        w = g["%d/wave" % k]
+        out = orc.wave_propagation(w.copy(), z, E, M, w.shape, pix)
+        assert out.shape == w.shape
+        assert relmax(out, g["%d/out" % k]) < TOL, k
+        if z == 0:
+            assert np.array_equal(out, w)
+
+
+def test_wave_propagation_known_answers():
+    # uniform wave stays uniform in modulus (SURVEY.md section 4 KAT), unitarity on the padded grid
+    w = np.full((40, 44), 3.0 + 0j)
+    out = orc.wave_propagation(w, 2.0, 30.0, 1.1, w.shape, 2.5)
+    assert np.allclose(abs(out), 3.0, rtol=1e-12)
+
+
+@pytest.mark.parametrize("ver", ["v2", "v1"])
+def test_fast_refraction(ver):
+    g = load("refraction.npz")
+    for k in range(int(g["n"])):
+        z, E, M, pix = g["%d/params" % k]
+        I = g["%d/I" % k].copy()
+        out, Dx, Dy = orc.fast_refraction(I, g["%d/phi" % k].copy(), z, E, M, pix, ver)
+        assert relmax(out, g["%d/%s/out" % (k, ver)]) < TOL, k
+        assert relmax(Dx, g["%d/%s/Dx" % (k, ver)]) < TOL
+        assert relmax(Dy, g["%d/%s/Dy" % (k, ver)]) < TOL
+        assert np.array_equal(I, g["%d/%s/I_after" % (k, ver)])   # in-place zeroing of clamped rays
+
+
+def test_fastloop_branches():
+    g = load("refraction.npz")
+    out = orc.fastloop(g["loop/I"], g["loop/Dx"], g["loop/Dy"])
+    assert relmax(out, g["loop/out"]) < TOL
+    # phi = const -> D == 0 -> identity (RF2:222-224)
+    I = np.random.default_rng(0).uniform(1, 2, (16, 12))
+    assert np.array_equal(orc.fastloop(I, np.zeros_like(I), np.zeros_like(I)), I)
+    # integer shift along axis 0
+    Dx = np.full_like(I, 2.0)
+    sh = orc.fastloop(I, Dx, np.zeros_like(I))
+    assert np.allclose(sh[2:], I[:-2])
+
+
+def test_detection():
+    g = load("detector.npz")
+    for k in range(int(g["n"])):
+        d0, d1, ov, fwhm, psf = g["%d/params" % k]
+        out = orc.detection(g["%d/in" % k].copy(), fwhm, int(ov), (int(d0), int(d1)), psf)
+        assert relmax(out, g["%d/out" % k]) < TOL, k
+
+
+@pytest.mark.parametrize("tag", ["mono", "poly"])
+def test_full_chain_rt(tag):
+    g = load("experiment.npz")
+    cfg = experiment_cfg(g, tag + "/RT", orc.Obj)
+    for point in (0, 1):
+        cfg["membrane"] = orc.Obj(g["%s/RT/p%d/membrane" % (tag, point)], cfg["membrane"].delta, cfg["membrane"].beta)
+        S, R, Pg, W, Dx, Dy, mE = orc.compute_rt(cfg, point)
+        t = "%s/RT/p%d/" % (tag, point)
+        for nm, a in (("Sample", S), ("Reference", R), ("Propag", Pg), ("White", W)):
+            assert relmax(a, g[t + nm]) < TOL, (tag, point, nm)
+        if point == 0:
+            assert relmax(Dx, g[t + "Dx"]) < TOL and relmax(Dy, g[t + "Dy"]) < TOL
+        assert abs(mE - float(g[t + "meanEnergy"])) < 1e-9
+    assert list(g[tag + "/RT/bins_after"]) == cfg["bins"]
+
+
+@pytest.mark.parametrize("tag", ["mono", "poly"])
+def test_full_chain_fresnel(tag):
+    g = load("experiment.npz")
+    cfg = experiment_cfg(g, tag + "/Fresnel", orc.Obj)
+    for point in (0, 1):
+        cfg["membrane"] = orc.Obj(g["%s/Fresnel/p%d/membrane" % (tag, point)], cfg["membrane"].delta, cfg["membrane"].beta)
+        S, R, Pg, W, mE = orc.compute_fresnel(cfg, point)
+        t = "%s/Fresnel/p%d/" % (tag, point)
+        for nm, a in (("Sample", S), ("Reference", R), ("Propag", Pg), ("White", W)):
+            assert relmax(a, g[t + nm]) < TOL, (tag, point, nm)
+        assert abs(mE - float(g[t + "meanEnergy"])) < 1e-9
