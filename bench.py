@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s of the Fresnel + refraction step on synthetic grids (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 4096] [--engine auto|rocfft|lds] [--no-cpu-baseline]
+
+One STEP = one pass of the hot path over one membrane position of the 4096x4096 workload (BASELINE.json configs[2],
+SURVEY.md section 8d): the membrane exit wave (2-material transmission fused into the load) is Fresnel-propagated to the
+4 distances z = {1.6, 3.6, 5.2, 7.2} m (one shared forward transform) and the ray-tracing refraction (2-material
+transmission fused) is run at the same 4 distances: 4 units of "Fresnel propagation + refraction" on N^2 pixels.
+value = units * N^2 * n_gpus / time  [Mpixel/s], inputs resident in HBM before the timed region.
+
+N GPUs: one process per GPU (torchrun), each rank runs its own membrane position (seed 1000+rank): weak scaling, no
+data-path collective; the final image gather over RCCL is done once after the timed region and reported as gather_ms.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+DISTANCES = (1.6, 3.6, 5.2, 7.2)
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--engine", default="auto", choices=["auto", "rocfft", "lds"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as td
+    from paresis_amd import _lib, ops, synth
+    from paresis_amd.getk import getk, k_refraction, k_sample
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+    if world > 1:
+        td.init_process_group(backend="nccl", rank=rank, world_size=world)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lib = _lib.lib()
+    assert lib.psx_device_ok() == 1, lib.psx_last_error()
+
+    N = a.size
+    E = 52.0
+    geo = synth.bench_geometry(N, pointNum=rank)
+    M, pix = geo["M"], geo["pix_um"]
+    h = pix * 1e-6
+    db = [synth.DELTA_BETA_52KEV[m] for m in geo["membrane_materials"]]
+    delta, beta = [d for d, _ in db], [b for _, b in db]
+    k = k_sample(E)
+    T = torch.from_numpy(geo["membrane"]).to(dev)
+    I0 = 30000.0 / 4
+    wave_mats = ops.MaterialStack(T, cphase=[-k * d for d in delta], catt=[-k * b for b in beta])
+    rt_mats = ops.MaterialStack(T, cphase=[-k * d for d in delta], catt=[-2 * k * b for b in beta])
+    engine = {"auto": _lib.ENGINE_AUTO, "rocfft": _lib.ENGINE_ROCFFT, "lds": _lib.ENGINE_LDS}[a.engine]
+    plan = ops.FresnelPlan(N, N, max_dist=len(DISTANCES), engine=engine)
+    kk = getk(E * 1000)
+    aa = [z / (2 * kk * M) for z in DISTANCES]
+    gp = [kk * z / M for z in DISTANCES]
+    du = (2 * np.pi / (N * h), 2 * np.pi / (N * h))
+    dsc = [z / k_refraction(E) / (h * M) / h for z in DISTANCES]
+    fres = [torch.empty((N, N), dtype=torch.float32, device=dev) for _ in DISTANCES]
+    refr = [torch.empty((N, N), dtype=torch.float32, device=dev) for _ in DISTANCES]
+    amp = float(np.sqrt(I0))
+
+    def step():
+        plan.propagate(aa, gp, du, amp=amp, mats=wave_mats, want_wave=[False] * len(DISTANCES), inten_out=fres)
+        for i in range(len(DISTANCES)):
+            ops.refract((N, N), rt_mats, dsc[i], (N, N), I0=I0, out=refr[i])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    timing = not a.no_kernel_timing
+    lib.psx_profile_enable(1 if timing else 0)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.check_status(dev, "bench")
+    kern = {}
+    if timing:
+        import ctypes
+        buf = ctypes.create_string_buffer(1 << 16)
+        _lib.check(lib.psx_profile_summary(buf, len(buf)), "psx_profile_summary")
+        for line in buf.value.decode().splitlines():
+            nm, cnt, tot = line.split()
+            kern[nm] = (int(cnt), float(tot))
+        lib.psx_profile_enable(0)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # final image gather (RCCL over xGMI), outside the timed region
+    gather_ms = None
+    if world > 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        bucket = [torch.empty_like(fres[1]) for _ in range(world)] if rank == 0 else None
+        td.gather(fres[1], bucket, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - t1) * 1e3
+
+    units = len(DISTANCES)
+    ms_per_step = dt / a.steps * 1e3
+    value = units * N * N * world / (dt / a.steps) / 1e6
+
+    out = {"metric": "Mpixels/s, 4096^2 Fresnel+refraction step", "value": round(value, 1), "unit": "Mpixel/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%dx%d fp32 study grid, 1 membrane position per GPU per step, 4 propagation distances "
+                                  "z={1.6,3.6,5.2,7.2} m: 4 x (Fresnel propagation + refraction), 2-material membrane "
+                                  "transmission fused; 52 keV, dSM/dMO/dOD=140/1.6/3.6 m" % (N, N),
+                      "units_per_step": units, "fresnel_engine": {1: "rocfft", 2: "lds"}[plan.engine],
+                      "parallelism": "positions sharded, 1 per GPU" if world > 1 else "single GPU"}}
+    if gather_ms is not None:
+        out["gather_ms"] = round(gather_ms, 3)
+
+    if rank == 0:
+        P = N + 30
+        nmat = 2
+        # algorithmic bytes per launch of each timed kernel (DESIGN.md "Roofline accounting")
+        alg = {
+            "k_refract_near": (12 + 4 * nmat) * P * P,
+            "rocfft_forward": 32 * P * P,
+            "rocfft_inverse": 32 * P * P,
+            "k_fresnel_rows": 32 * P * P,
+            "k_fresnel_cols": 32 * P * P,
+        }
+        per = {nm: tot / cnt for nm, (cnt, tot) in kern.items()}
+        step_share = {nm: tot / a.steps for nm, (cnt, tot) in kern.items()}
+        out["kernel_ms_per_step"] = {nm: round(v, 4) for nm, v in sorted(step_share.items(), key=lambda kv: -kv[1])}
+        dom = None
+        for nm, v in sorted(step_share.items(), key=lambda kv: -kv[1]):
+            if nm in alg:
+                dom = nm
+                break
+        if dom is not None:
+            ach = alg[dom] / (per[dom] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "ms_per_launch": round(per[dom], 4), "algorithmic_bytes_per_launch": alg[dom]}
+            # whole-step view with the same accounting: 4 x (64 + 12 + 4*nmat) bytes per padded pixel
+            step_bytes = units * (64 + 12 + 4 * nmat) * P * P
+            out["roofline"]["step_achieved"] = round(step_bytes / (dt / a.steps) / 1e9, 1)
+            out["roofline"]["step_frac"] = round(step_bytes / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 4)
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"], out["parity"] = cpu_baseline(N, geo, delta, beta, E, M, pix, I0, fres, refr)
+        print(json.dumps(out))
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+def cpu_baseline(N, geo, delta, beta, E, M, pix, I0, fres, refr):
+    """The oracle (fp64 numpy/pocketfft + scalar C loop, ONE thread = what the reference's numpy.fft + Numba @jit use)
+    timed on this box's host cores for a bounded sample: ONE of the step's 4 units (z = 3.6 m) on the same inputs.
+    Also returns the fp32 error of the GPU images against it."""
+    import torch
+    from oracle import paresis_oracle as orc
+    torch.set_num_threads(1)
+    g64 = geo["membrane"].astype(np.float64)
+    zi = 1
+    z = DISTANCES[zi]
+    t0 = time.perf_counter()
+    w = orc.set_wave(np.full((N, N), np.sqrt(I0) + 0j), g64, delta, beta, E)
+    Fi = np.abs(orc.wave_propagation(w, z, E, M, (N, N), pix)) ** 2
+    t1 = time.perf_counter()
+    I, phi, _ = orc.set_wave_rt(np.full((N, N), I0), g64, delta, beta, E, 0)
+    Ri, _, _ = orc.fast_refraction(I, phi, z, E, M, pix)
+    t2 = time.perf_counter()
+    ef = float(np.max(np.abs(fres[zi].cpu().numpy() - Fi)) / np.max(np.abs(Fi)))
+    er = float(np.max(np.abs(refr[zi].cpu().numpy() - Ri)) / np.max(np.abs(Ri)))
+    cb = {"value": round(N * N / (t2 - t0) / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
+          "sample": "1 of the step's 4 units (z=3.6 m) on the same %dx%d inputs: transmission + Fresnel propagation "
+                    "(%.2f s) + transmission + refraction (%.2f s), fp64, 1 thread" % (N, N, t1 - t0, t2 - t1),
+          "host_cpus": os.cpu_count()}
+    return cb, {"metric": "max|gpu-oracle|/max|oracle|", "fresnel": ef, "refraction": er, "tolerance": 1e-5}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,158 @@
+/*
+ * paresis_hip.h -- C ABI of libparesis_hip.so: the MI355X (gfx950) image-formation hot path of an X-ray
+ * speckle-propagation simulator, drop-in for the numerical kernels behind
+ * Experiment.computeSampleAndReferenceImages_{Fresnel,RT} of quenotl/PARESIS.
+ *
+ * The reference has no FFI layer: its boundary is the Python call surface of CodePython/{Experiment,Sample,
+ * Detector,refractionFileNumba2,refractionFileNumba,getk}.py.  Each entry point below names the reference
+ * function (file:line, relative to CodePython/) whose array work it replaces; the Python modules under paresis_amd/ keep the reference's
+ * names and signatures on top of this ABI (see INTEGRATION.md for the ctypes binding a maintainer would add).
+ *
+ * Conventions
+ *   - every pointer named T/I/wave/phi/out/... is a DEVICE pointer (HBM); "host array" is said explicitly;
+ *   - images are row-major [Nx][Ny] (numpy C order: axis 0 = "x" of the reference), float32 / interleaved complex64;
+ *     the optional explicit phase is float64 (fp32 cannot hold kilo-radian phases to 1e-5);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is asynchronous on it, performs
+ *     no host synchronisation and allocates nothing the caller must free (plans own their work buffers);
+ *   - return value: 0 = ok, <0 = invalid argument (PSX_E_*), >0 = hipError_t or 1000+rocfft_status;
+ *     psx_last_error() returns a thread-local description of the last failure;
+ *   - thread model: one host thread per GPU/process; plans are not shared between threads.
+ *
+ * Materials: an object is a stack of thickness maps T[m] (metres, float32, [Nx][Ny]) with two per-map coefficients,
+ *   cphase[m] (rad/m, added to the phase:  phi += cphase[m]*T[m];  the reference's -k*delta, Sample.py:279,348) and
+ *   catt[m]   (1/m, log-attenuation:       log a += catt[m]*T[m]; -k*beta for a wave, -2*k*beta for an intensity,
+ *   Sample.py:279,347).  Products and sums over m are formed in float64 on the device, then range-reduced.
+ */
+#ifndef PARESIS_HIP_H
+#define PARESIS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSX_MAX_MAT 8
+#define PSX_MAX_DIST 8
+
+#define PSX_E_ARG (-1)      /* bad argument (null pointer, size, count) */
+#define PSX_E_STATE (-2)    /* plan/shape mismatch */
+#define PSX_E_UNSUPPORTED (-3)
+
+/* bits of the device status word (psx_status_*) */
+#define PSX_STATUS_NONFINITE 1u   /* NaN or |v| > 1e50 in a refracted image: refractionFileNumba2.py:81-82 raises */
+
+typedef struct psx_fresnel_plan psx_fresnel_plan;
+typedef struct psx_detector_plan psx_detector_plan;
+
+typedef struct { float re, im; } psx_c64;
+
+/* library / build identification; psx_abi_version() changes when a signature changes */
+int psx_abi_version(void);
+const char *psx_last_error(void);
+/* 1 when the code object for the current device (gfx950) is loadable, else 0 with psx_last_error() set */
+int psx_device_ok(void);
+
+/* ---- K1: AnalyticalSample.setWave (Sample.py:248-282) ------------------------------------------------------
+ * wave_out[p] = amp * wave_in[p] * exp(sum_m catt[m]*T[m][p]) * exp(i * sum_m cphase[m]*T[m][p]),  p < n.
+ * wave_in may be NULL (unit wave).  T is a HOST array of nmat device pointers.  In place (wave_out==wave_in) is ok. */
+int psx_transmit_wave_c64(const psx_c64 *wave_in, float amp, const float *const *T, const double *cphase,
+                          const double *catt, int nmat, psx_c64 *wave_out, int64_t n, void *stream);
+
+/* ---- K2: AnalyticalSample.setWaveRT (Sample.py:285-351, scalar dark field) ------------------------------------
+ * I_out[p] = I0 * I_in[p] * exp(sum_m catt[m]*T[m][p]);   phi_out[p] = phi_in[p] + sum_m cphase[m]*T[m][p].
+ * I_in may be NULL (ones); phi_in may be NULL (zeros); phi_out may be NULL (phase not wanted); I_out may be NULL. */
+int psx_transmit_rt_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,
+                        int nmat, float *I_out, const double *phi_in, double *phi_out, int64_t n, void *stream);
+
+/* acc[p] (+)= scale * img[p] * exp(sum_m catt[m]*T[m][p])  -- plate attenuation + energy accumulation
+ * (Experiment.py:351-358, 478-483).  accumulate: 0 store, 1 add.  nmat may be 0. */
+int psx_accumulate_f32(float *acc, const float *img, float scale, const float *const *T, const double *catt, int nmat,
+                       int accumulate, int64_t n, void *stream);
+
+/* ---- K9-K13: fastRefraction (refractionFileNumba2.py:25-86; variant v1: refractionFileNumba.py:11-68) ----------
+ * Source intensity  I_src = I0 * I_in * exp(sum catt*T)          (I_in may be NULL = ones; fused K2)
+ * Phase             phi   = phi_in + sum cphase*T                 (phi_in float64, may be NULL)
+ * Displacement      D     = grad(phi) * dscale, np.gradient(edge_order=2) with unit spacing, i.e. the caller passes
+ *                   dscale = z / k / (h*M) / h  (RF2:54-56);  |D|<1e-12 -> 0;  |Dx|>clamp_x or |Dy|>clamp_y -> I=0,
+ *                   that component = 0 (RF2:59-64: clamp = Nx,Ny for v2, 1e3 for v1).
+ * Output            I_out[Nx][Ny] (+)= out_scale * bilinear scatter of I_src by D on a grid padded by `margin`
+ *                   (15 for v2, 10 for v1), cropped back (RF2:65-78, loop RF2:198-263).
+ * Dx_out/Dy_out     optional [Nx+2*margin][Ny+2*margin] float32 (zero margins), as the reference returns them.
+ * I_mut             optional: the reference zeroes clamped entries of its INPUT intensity in place (RF2:61-62);
+ *                   pass I_in here to reproduce that, NULL otherwise.
+ * status            optional device word; PSX_STATUS_NONFINITE is OR-ed in when the output holds NaN/inf.
+ * workspace         device scratch of psx_refract_workspace_bytes(Nx,Ny) bytes (far-ray list), caller-owned.
+ */
+size_t psx_refract_workspace_bytes(int Nx, int Ny);
+int psx_refract_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,
+                    int nmat, const double *phi_in, float *I_out, float out_scale, int accumulate, float *Dx_out,
+                    float *Dy_out, float *I_mut, int Nx, int Ny, int margin, double dscale, double clamp_x,
+                    double clamp_y, unsigned *status, void *workspace, void *stream);
+
+/* The raw scatter loop on explicit displacement fields: fastloopNumba (refractionFileNumba2.py:198-263).
+ * I, Dx, Dy, I2 are [Nx][Ny]; I2 is accumulated into (float atomics; order-dependent in the last bits). */
+int psx_fastloop_f32(const float *I, const float *Dx, const float *Dy, float *I2, int Nx, int Ny, void *stream);
+
+/* ---- K3-K8: Experiment.wavePropagation (Experiment.py:219-252) ------------------------------------------------
+ * A plan fixes the study grid [Nx][Ny] and the reflect margin (15, EXP:236) and owns the padded work buffers.
+ * engine: 0 = auto, 1 = rocFFT on the padded grid (pad -> FFT2 -> chirp -> IFFT2 -> crop, any size),
+ *         2 = LDS-resident FFT convolution (row pass + column pass, the padded spectrum never touches HBM). */
+#define PSX_ENGINE_AUTO 0
+#define PSX_ENGINE_ROCFFT 1
+#define PSX_ENGINE_LDS 2
+int psx_fresnel_plan_create(int Nx, int Ny, int margin, int max_dist, int engine, psx_fresnel_plan **plan);
+int psx_fresnel_plan_destroy(psx_fresnel_plan *plan);
+/* engine actually selected (PSX_ENGINE_ROCFFT / PSX_ENGINE_LDS) */
+int psx_fresnel_plan_engine(const psx_fresnel_plan *plan);
+/* bytes of device memory the plan owns */
+size_t psx_fresnel_plan_bytes(const psx_fresnel_plan *plan);
+
+/* Propagate ONE input wave to n_dist distances (the forward transform is shared, e.g. EXP:341 and EXP:349).
+ *   input  psi = amp * wave_in * transmission(T, cphase, catt)          (wave_in may be NULL = unit wave; fused K1)
+ *   for d < n_dist:  out_d = exp(i*gphase[d]) * IDFT2( exp(-i*a[d]*(u^2+v^2)) * DFT2(reflect_pad(psi)) ) cropped,
+ *                    u_i = (i - Px/2)*du_x, v_j = (j - Py/2)*du_y  with du = 2*pi/(N*h) from the UN-padded N (EXP:246-247),
+ *                    a[d] = z/(2*k*M), gphase[d] = k*z/M  (EXP:250);  a[d] == 0 means "z == 0": out_d = psi (EXP:233).
+ *   wave_out[d]  (host array of device pointers, entries may be NULL): complex result [Nx][Ny]
+ *   inten_out[d] (host array of device pointers, entries may be NULL): inten_out[d] (+)= inten_scale[d]*|out_d|^2 (K8)
+ */
+int psx_fresnel_propagate(psx_fresnel_plan *plan, const psx_c64 *wave_in, float amp, const float *const *T,
+                          const double *cphase, const double *catt, int nmat, int n_dist, const double *a,
+                          const double *gphase, double du_x, double du_y, psx_c64 *const *wave_out,
+                          float *const *inten_out, const float *inten_scale, int accumulate, void *stream);
+
+/* ---- K14-K19: Detector.detection (Detector.py:79-119), resize (:185-198), create_gaussian_shape (:201-220) -----
+ * reflect-pad 15*ov -> source blur (sigma_src study px, 0 = none) -> ov x ov block SUM -> PSF blur (sigma_psf detector
+ * px, 0 = none) -> crop 15.  All stages are linear and separable; the plan holds the composed banded operators.
+ * out [nx][ny] (+)= ... ; Poisson noise is a separate call (psx_poisson_f32). */
+int psx_detector_plan_create(int Nx, int Ny, int ov, int nx, int ny, int margin, double sigma_src, double sigma_psf,
+                             psx_detector_plan **plan);
+int psx_detector_plan_destroy(psx_detector_plan *plan);
+int psx_detect_f32(psx_detector_plan *plan, const float *img, float *out, void *stream);
+/* Host-only view of one axis of the composed operator (no GPU needed): row r of the [n x N] banded matrix is
+ * weights[r*wcap .. r*wcap+W) applied to study pixels start[r] .. start[r]+W.  *W_out receives the band width;
+ * fails with PSX_E_ARG when it exceeds wcap. */
+int psx_detector_operator_host(int N, int ov, int n, int margin, double sigma_src, double sigma_psf, int *start,
+                               float *weights, int wcap, int *W_out);
+/* out[x][y] = sum of the s x s block of img, s = Nx/sx (Detector.resize, Detector.py:185-198) */
+int psx_resize_f32(const float *img, int Nx, int Ny, float *out, int sx, int sy, void *stream);
+/* out[p] = Poisson(lam[p]) drawn from a counter-based generator keyed by (seed, p)  (Detector.py:113-115;
+ * the reference seeds from the wall clock, so only the distribution is reproducible) */
+int psx_poisson_f32(const float *lam, float *out, int64_t n, uint64_t seed, void *stream);
+
+/* ---- per-kernel timing (bench.py's roofline leg) ----------------------------------------------------------------------
+ * psx_profile_enable(1) clears the log and makes every kernel launch of the library record a HIP event pair on the
+ * stream it is launched on; psx_profile_summary() waits for the recorded events and writes one line per kernel,
+ * "name count total_ms\n".  Off by default (no events, no overhead). */
+int psx_profile_enable(int on);
+int psx_profile_summary(char *buf, size_t cap);
+
+/* ---- status word ------------------------------------------------------------------------------------------------ */
+/* OR PSX_STATUS_NONFINITE into *status when img holds NaN or |v| > 1e50 (float32: inf) */
+int psx_status_scan_f32(const float *img, int64_t n, unsigned *status, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARESIS_HIP_H */

@@ -1,0 +1,426 @@
+"""Experiment orchestration on the MI355X (mirror of CodePython/Experiment.py:25-607).
+
+Same class surface as the reference: Experiment(exp_dict) reads the four XML files, owns mySource / myDetector /
+myMembrane / mySampleofInterest / myAirVolume / myPlate, and exposes computeSampleAndReferenceImages_Fresnel,
+computeSampleAndReferenceImages_RT, wavePropagation, refraction and saveAllParameters.
+
+What is different under the hood (MI355X-first, not a translation):
+  * every array lives in HBM (float32 / complex64 torch tensors); numpy never touches the hot loop;
+  * object transmissions are not separate passes: the thickness maps and their per-energy coefficients are handed to the
+    Fresnel / refraction kernels, which evaluate exp((-ik delta - k beta) T) while loading (K1/K2 fused);
+  * the two propagations that share the membrane exit wave (Experiment.py:341 and :349) are one call (shared forward
+    transform); |.|^2, plate attenuation and the sum over energies happen in the kernels' store phase;
+  * `Experiment.from_objects` builds an experiment from injected objects (no XML), which is how the parity tests feed
+    the same inputs to this class and to the oracle.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import _xml, ops
+from ._lib import PsxError
+from ._tensors import device, is_scalar, to_dev
+from .Detector import Detector
+from .getk import getk, k_refraction
+from .Sample import AnalyticalSample
+from .Source import Source
+
+
+class Experiment:
+    def __init__(self, exp_dict):
+        """Experiment.py:26-137: XML -> objects -> geometry; exp_dict carries experimentName, overSampling,
+        nbExpPoints, simulation_type, filepath (and optionally xmlDir, noise, seed, fresnelEngine)."""
+        self.xmlExperimentFileName = "xmlFiles/Experiment.xml"
+        self._xml_directory = _xml.xml_dir(exp_dict)
+        self.name = exp_dict['experimentName']
+        self.exp_dict = exp_dict
+        ed = self.exp_dict
+        ed['studyPixelSize'] = 0.
+        ed['studyDimensions'] = (0., 0.)
+        ed['inVacuum'] = False
+        ed['meanShotCount'] = 0
+        ed['meanEnergy'] = 0
+        ed['distSourceToMembrane'] = 0
+        ed['distMembraneToObject'] = 0
+        ed['distObjectToDetector'] = 0
+        ed['studyPixelSize_unit'] = "um"
+        ed['studyDimensions_unit'] = "pixels"
+        ed['meanEnergy_unit'] = "keV"
+        ed['distSourceToMembrane_unit'] = "m"
+        ed['distMembraneToObject_unit'] = "m"
+        ed['distObjectToDetector_unit'] = "m"
+        self._init_state()
+
+        self.defineCorrectValues(exp_dict)
+        self.myDetector.defineCorrectValuesDetector()
+        self.mySource.defineCorrectValuesSource()
+        self.mySampleofInterest.defineCorrectValuesSample()
+        self.myAirVolume.defineCorrectValuesSample()
+        self.myAirVolume.myThickness = (ed['distSourceToMembrane'] + ed['distObjectToDetector'] + ed['distMembraneToObject']) * 1e6
+        if self.myPlate is not None:
+            self.myPlate.defineCorrectValuesSample()
+        self.myMembrane.defineCorrectValuesSample()
+
+        ed['magnification'] = (ed['distSourceToMembrane'] + ed['distObjectToDetector'] + ed['distMembraneToObject']) / (ed['distSourceToMembrane'] + ed['distMembraneToObject'])   # EXP:81
+        self.getStudyDimensions()
+        self.mySource.setMySpectrum(self.myDetector.det_param["photonCounting"])
+        dims, pix, ov = ed['studyDimensions'], ed['studyPixelSize'], ed['overSampling']
+        self.myAirVolume.getDeltaBeta(self.mySource.mySpectrum)
+        self.myAirVolume.getMyGeometry(dims, pix, ov)
+        if self.myPlate is not None:
+            self.myPlate.getDeltaBeta(self.mySource.mySpectrum)
+            self.myPlate.getMyGeometry(dims, pix, ov)
+        self.mySampleofInterest.getDeltaBeta(self.mySource.mySpectrum)
+        self.mySampleofInterest.getMyGeometry(dims, pix, ov)
+        self.myMembrane.getDeltaBeta(self.mySource.mySpectrum)
+        self.myMembrane.membranePixelSize = pix * ed['distSourceToMembrane'] / (ed['distSourceToMembrane'] + ed['distMembraneToObject'])   # EXP:96
+        if self.myDetector.det_param['myScintillatorMaterial'] is not None:
+            self.myDetector.getBeta(self.mySource.mySpectrum)
+            self.myDetector.getSpectralEfficiency()
+        if ed['simulation_type'] == "RayT" and ed["overSampling"] < 2:      # EXP:103-105
+            print(f'/!\\/!\\ OVERSAMPLING FACTOR < MIN OVERSAMPLING FOR RAY-T MODEL: {ed["overSampling"]} < 2')
+        print('\nCurrent experiment:', self.name)
+        print("  Magnification :", ed['magnification'])
+        print(f'  Study dimensions: {ed["studyDimensions"]} pixels')
+        print("  Sample pixel size =", ed["studyPixelSize"], "um")
+
+    def _init_state(self):
+        self.mySampleofInterest = None
+        self.mySampleType = ""
+        self.myDetector = None
+        self.mySource = None
+        self.myMembrane = None
+        self.myPlate = None
+        self.myAirVolume = None
+        self.Dxreal = []
+        self.Dyreal = []
+        self.imageSampleBeforeDetection = []
+        self.imageReferenceBeforeDetection = []
+        self.imagePropagBeforeDetection = []
+        self._fresnel_plan = None
+
+    @classmethod
+    def from_objects(cls, exp_dict, source, detector, membrane, sample, air=None, plate=None):
+        """Build an experiment from ready objects instead of XML (the route the parity tests and bench.py use)."""
+        self = object.__new__(cls)
+        self.name = exp_dict.get('experimentName', 'injected')
+        self.exp_dict = exp_dict
+        self._xml_directory = None
+        self._init_state()
+        self.mySource, self.myDetector = source, detector
+        self.myMembrane, self.mySampleofInterest, self.myAirVolume, self.myPlate = membrane, sample, air, plate
+        self.mySampleType = "AnalyticalSample"
+        ed = exp_dict
+        ed.setdefault('meanEnergy', 0)
+        ed.setdefault('inVacuum', air is None)
+        if 'magnification' not in ed:
+            ed['magnification'] = (ed['distSourceToMembrane'] + ed['distObjectToDetector'] + ed['distMembraneToObject']) / (ed['distSourceToMembrane'] + ed['distMembraneToObject'])
+        if 'studyDimensions' not in ed or 'studyPixelSize' not in ed:
+            self.getStudyDimensions()
+        return self
+
+    def defineCorrectValues(self, exp_dict):
+        """Experiment.py:140-197."""
+        self.mySource = Source(self._xml_directory)
+        self.myDetector = Detector(exp_dict, self._xml_directory)
+        doc = _xml.parse(self._xml_directory, "Experiment.xml")
+        node = _xml.find_named(doc, "experiment", self.name)
+        if node is None:
+            raise ValueError("experiment not found in xml file")
+        ed = self.exp_dict
+        ed['distSourceToMembrane'] = float(_xml.child_text(node, "distSourceToMembrane"))
+        ed['distMembraneToObject'] = float(_xml.child_text(node, "distMembraneToObject"))
+        ed['distObjectToDetector'] = float(_xml.child_text(node, "distObjectToDetector"))
+        ed['meanShotCount'] = float(_xml.child_text(node, "meanShotCount"))
+        if _xml.has_child(node, "inVacuum"):
+            ed['inVacuum'] = _xml.child_text(node, "inVacuum") == "True"
+        if _xml.has_child(node, "plateName"):
+            self.myPlate = AnalyticalSample(self._xml_directory)
+            self.myPlate.myName = _xml.child_text(node, "plateName")
+        self.myAirVolume = AnalyticalSample(self._xml_directory)
+        self.myAirVolume.myName = "air_volume"
+        self.mySampleType = _xml.child_text(node, "sampleType")
+        if self.mySampleType != "AnalyticalSample":
+            raise Exception("sample type not defined")
+        self.mySampleofInterest = AnalyticalSample(self._xml_directory)
+        self.myMembrane = AnalyticalSample(self._xml_directory)
+        self.myMembrane.myName = _xml.child_text(node, "membraneName")
+        self.mySampleofInterest.myName = _xml.child_text(node, "sampleName")
+        self.myDetector.myName = _xml.child_text(node, "detectorName")
+        self.mySource.myName = _xml.child_text(node, "sourceName")
+
+    def getText(self, node):
+        return _xml.text(node)
+
+    def getStudyDimensions(self):
+        """Experiment.py:204-216."""
+        ed, dp = self.exp_dict, self.myDetector.det_param
+        self.precision = (dp["myPixelSize"] / ed['overSampling'] / ed['distObjectToDetector'])
+        dims = np.asarray(dp["myDimensions"]) * int(ed['overSampling'])
+        ed['studyDimensions'] = [int(dims[0]), int(dims[1])]
+        ed['studyPixelSize'] = dp["myPixelSize"] / ed['overSampling'] / ed['magnification']
+
+    # ---------------------------------------------------------------------------------------- propagators
+    def _plan(self):
+        Nx, Ny = (int(v) for v in self.exp_dict['studyDimensions'])
+        p = self._fresnel_plan
+        if p is None or (p.Nx, p.Ny) != (Nx, Ny):
+            if p is not None:
+                p.close()
+            p = self._fresnel_plan = ops.FresnelPlan(Nx, Ny, max_dist=2, engine=int(self.exp_dict.get('fresnelEngine', 0)))
+        return p
+
+    def _fresnel_scalars(self, z, Energy, magnification):
+        """a = z/(2kM), global phase kz/M (EXP:250) and the frequency step from the UN-padded grid (EXP:246-247)."""
+        k = getk(Energy * 1000)
+        Nx, Ny = self.exp_dict['studyDimensions']
+        h = self.exp_dict['studyPixelSize'] * 1e-6
+        return z / (2 * k * magnification), k * z / magnification, (2 * np.pi / (Nx * h), 2 * np.pi / (Ny * h))
+
+    def wavePropagation(self, waveToPropagate, propagationDistance, Energy, magnification):
+        """Experiment.py:219-252: Fresnel propagation of a complex wave over `propagationDistance` metres."""
+        if propagationDistance == 0:
+            return waveToPropagate                                                     # EXP:233-234
+        a, g, du = self._fresnel_scalars(propagationDistance, Energy, magnification)
+        return self._plan().propagate([a], [g], du, wave_in=to_dev(waveToPropagate, torch.complex64))[0]
+
+    def refraction(self, intensityRefracted, phi, propagationDistance, Energy, magnification, darkField=0):
+        """Experiment.py:255-277."""
+        from .refractionFileNumba2 import fastRefraction, fastRefractionDF
+        if type(darkField) == int or type(darkField) == float:
+            return fastRefraction(intensityRefracted, phi, propagationDistance, Energy, magnification,
+                                  self.exp_dict["studyPixelSize"])
+        return fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magnification,
+                                self.exp_dict["studyPixelSize"], darkField)
+
+    def computeSampleAndReferenceImages(self, pointNum):
+        """Dispatcher on exp_dict['simulation_type'] (main.py:68-73)."""
+        if self.exp_dict['simulation_type'] == "Fresnel":
+            return self.computeSampleAndReferenceImages_Fresnel(pointNum)
+        if self.exp_dict['simulation_type'] == "RayT":
+            return self.computeSampleAndReferenceImages_RT(pointNum)
+        raise Exception("simulation Type not defined: ", self.exp_dict['simulation_type'])
+
+    # ------------------------------------------------------------------------------------------- helpers
+    def _begin(self, pointNum):
+        """Bin thresholds (EXP:296-305) and output stacks."""
+        dp, spec = self.myDetector.det_param, self.mySource.mySpectrum
+        if pointNum == 0:
+            thr = dp["myBinsThersholds"]
+            if any(e < spec[0][0] for e in thr) or any(e > spec[-1][0] for e in thr):
+                raise Exception(f'At least one of your detector bin threshold is outside your source spectrum. \nYour source spectrum ranges from {spec[0][0]} to {spec[-1][0]}')
+            thr.append(spec[-1][0])
+        nbins = len(dp["myBinsThersholds"])
+        dev = device()
+        n0, n1 = int(dp['myDimensions'][0]), int(dp['myDimensions'][1])
+        stacks = [torch.zeros((nbins, n0, n1), dtype=torch.float32, device=dev) for _ in range(4)]
+        N = tuple(int(v) for v in self.exp_dict['studyDimensions'])
+        accs = [torch.zeros(N, dtype=torch.float32, device=dev) for _ in range(4)]
+        return stacks, accs, N, dev
+
+    def _incident(self, flux, energy, ie):
+        """Scalar incident intensity per study pixel after the source window (EXP:308,320) and the scintillator
+        efficiency (EXP:326-333 / 456-459); air attenuation is returned as a material stack to fuse."""
+        ed = self.exp_dict
+        I = ed['meanShotCount'] / ed['overSampling'] ** 2 * flux
+        det = self.myDetector
+        if det.det_param['myScintillatorMaterial'] is not None:
+            if ed['simulation_type'] == "Fresnel" or not det.mySpectralEfficiency:
+                beta = [b for e, b in det.beta if e == energy][-1]
+                I *= 1 - np.exp(-2 * getk(energy * 1000) * det.det_param['myScintillatorThickness'] * 1e-6 * beta)
+            else:
+                for e, eff in det.mySpectralEfficiency:
+                    if e == energy:
+                        I *= eff
+        return float(I)
+
+    def _effective_source(self):
+        ed = self.exp_dict
+        return self.mySource.source_dict["mySize"] * ed['distObjectToDetector'] / (ed['distSourceToMembrane'] + ed['distMembraneToObject']) / self.myDetector.det_param['myPixelSize'] * ed['overSampling']   # EXP:380
+
+    def _detect_bin(self, ibin, pointNum, stacks, accs):
+        """EXP:378-401 / 501-521: detection of the accumulated images of one energy bin, then reset."""
+        S, R, Pg, W = stacks
+        ess = self._effective_source()
+        det = lambda im: self.myDetector.detection(im, ess, self.exp_dict)
+        S[ibin] = det(accs[0])
+        R[ibin] = det(accs[1])
+        if pointNum == 0:
+            Pg[ibin] = det(accs[2])
+        W[ibin] = det(accs[3])
+        for a in accs:
+            a.zero_()
+
+    # -------------------------------------------------------------------------------------- Fresnel chain
+    def _add_intensity(self, acc, img, plate_att):
+        """acc += img * plate attenuation (EXP:351-358); returns nothing, img is left untouched."""
+        ops.accumulate(acc, img, 1.0, plate_att, add=True)
+
+    def _white(self, white, I_scalar, air_rt, plate_att):
+        """EXP:372-375 / 494-497: the flat-field image of one energy (uniform unless air/plate maps are not)."""
+        att = ops.MaterialStack.concat(air_rt, plate_att)
+        if att.n == 0:
+            white += I_scalar
+        else:
+            white += ops.transmit_rt(None, I_scalar, att, want_phi=False)[0]
+
+    def _finish_mean_energy(self, e_sum, i_sum):
+        """EXP:360-361,403: intensity-weighted mean energy of the reference image (one synchronising read)."""
+        ed = self.exp_dict
+        ed['meanEnergy'] = (ed.get('meanEnergy', 0) + float(e_sum.item())) / float(i_sum.item())
+
+    def computeSampleAndReferenceImages_Fresnel(self, pointNum):
+        """Experiment.py:279-405.  Returns (SampleImage, ReferenceImage, PropagImage, detectedWhite), each
+        [nbins, n, n] float32 in HBM."""
+        ed = self.exp_dict
+        stacks, accs, N, dev = self._begin(pointNum)
+        accS, accR, accP, white = accs
+        plan = self._plan()
+        plate, air = self.myPlate, (None if ed['inVacuum'] else self.myAirVolume)
+        tmp = torch.empty(N, dtype=torch.float32, device=dev)
+        i_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        e_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        dSM, dMO, dOD, M = ed['distSourceToMembrane'], ed['distMembraneToObject'], ed['distObjectToDetector'], ed['magnification']
+        ibin = 0
+        for ie, (currentEnergy, flux) in enumerate(self.mySource.mySpectrum):
+            I0 = self._incident(flux, currentEnergy, ie)
+            amp = float(np.sqrt(I0))                                                      # EXP:334
+            air_w = air.stack_wave(currentEnergy, phase=False) if air is not None else None   # sqrt(exp(-2 k beta T))
+            air_rt = air.stack_rt(currentEnergy, phase=False) if air is not None else None
+            plate_att = plate.stack_rt(currentEnergy, phase=False) if plate is not None else None
+            mem = ops.MaterialStack.concat(air_w, self.myMembrane.stack_wave(currentEnergy))   # EXP:323,338
+            smp = self.mySampleofInterest.stack_wave(currentEnergy)
+            a1, g1, du = self._fresnel_scalars(dMO, currentEnergy, (dSM + dMO) / dSM)     # EXP:340 local magnification
+            a2, g2, _ = self._fresnel_scalars(dOD + dMO, currentEnergy, M)
+            a3, g3, _ = self._fresnel_scalars(dOD, currentEnergy, M)
+            # EXP:341 + EXP:349 in one call: membrane exit wave -> sample plane (complex field) and -> detector (|.|^2)
+            wbs = plan.propagate([a1, a2], [g1, g2], du, amp=amp, mats=mem, want_wave=[True, False],
+                                 inten_out=[None, tmp])[0]
+            self.waveSampleBeforeSample = wbs
+            if plate_att is not None:
+                ops.accumulate(tmp, tmp, 1.0, plate_att, add=False)                       # EXP:355-356
+            ops.accumulate(accR, tmp, 1.0, None, add=True)                                # EXP:358
+            m = tmp.mean(dtype=torch.float64)                                             # EXP:360-361
+            i_sum += m
+            e_sum += currentEnergy * m
+            # EXP:344 + EXP:348: through the sample, on to the detector
+            if plate_att is None:
+                plan.propagate([a3], [g3], du, wave_in=wbs, mats=smp, want_wave=[False], inten_out=[accS], add=True)
+            else:
+                plan.propagate([a3], [g3], du, wave_in=wbs, mats=smp, want_wave=[False], inten_out=[tmp])
+                self._add_intensity(accS, tmp, plate_att)
+            if pointNum == 0:                                                             # EXP:363-375
+                smp0 = ops.MaterialStack.concat(air_w, smp)
+                if plate_att is None:
+                    plan.propagate([a3], [g3], du, amp=amp, mats=smp0, want_wave=[False], inten_out=[accP], add=True)
+                else:
+                    plan.propagate([a3], [g3], du, amp=amp, mats=smp0, want_wave=[False], inten_out=[tmp])
+                    self._add_intensity(accP, tmp, plate_att)
+                self._white(white, I0, air_rt, plate_att)
+            if currentEnergy > self.myDetector.det_param["myBinsThersholds"][ibin] - self.mySource.source_dict["myEnergySampling"] / 2:
+                self._detect_bin(ibin, pointNum, stacks, accs)                            # EXP:378-401
+                ibin += 1
+        self._finish_mean_energy(e_sum, i_sum)
+        return tuple(stacks)
+
+    # ------------------------------------------------------------------------------------------- RT chain
+    def _dscale(self, z, Energy):
+        """D[pixels] = grad(phi)[rad/pixel] * dscale  (RF2:54-56; the RT chain uses the TOTAL magnification on
+        every hop, EXP:466,473,474)."""
+        h = self.exp_dict['studyPixelSize'] * 1e-6
+        return z / k_refraction(Energy) / (h * self.exp_dict['magnification']) / h
+
+    def computeSampleAndReferenceImages_RT(self, pointNum):
+        """Experiment.py:407-526.  Returns (SampleImage, ReferenceImage, PropagImage, detectedWhite, Dxreal, Dyreal,
+        darkFieldPropag); Dxreal/Dyreal are the PADDED [N+30, N+30] maps of the last energy (point 0 only)."""
+        ed = self.exp_dict
+        stacks, accs, N, dev = self._begin(pointNum)
+        accS, accR, accP, white = accs
+        plate, air = self.myPlate, (None if ed['inVacuum'] else self.myAirVolume)
+        Ibs = torch.empty(N, dtype=torch.float32, device=dev)
+        tmp = torch.empty(N, dtype=torch.float32, device=dev)
+        self.darkFieldPropag = torch.zeros(N, dtype=torch.float32, device=dev)            # scalar dark field only
+        i_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        e_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        dMO, dOD = ed['distMembraneToObject'], ed['distObjectToDetector']
+        clamp = (N[0], N[1])                                                              # RF2:61-64
+        ibin = 0
+        for ie, (currentEnergy, flux) in enumerate(self.mySource.mySpectrum):
+            I0 = self._incident(flux, currentEnergy, ie)
+            air_rt = air.stack_rt(currentEnergy, phase=False) if air is not None else None
+            plate_att = plate.stack_rt(currentEnergy, phase=False) if plate is not None else None
+            mem = self.myMembrane.stack_rt(currentEnergy)
+            smp = self.mySampleofInterest.stack_rt(currentEnergy)
+            # EXP:463 + 466: membrane transmission fused into the first refraction
+            ops.refract(N, ops.MaterialStack.concat(air_rt, mem), self._dscale(dMO, currentEnergy), clamp, I0=I0, out=Ibs)
+            self.IntensitySampleBeforeSample = Ibs
+            mem_phase = mem.with_coeffs(catt=[0.0] * mem.n)
+            # EXP:474 reference image: refracted again with the membrane phase only
+            ops.refract(N, mem_phase, self._dscale(dOD, currentEnergy), clamp, I_in=Ibs, out=tmp)
+            if plate_att is not None:
+                ops.accumulate(tmp, tmp, 1.0, plate_att, add=False)                       # EXP:480
+            ops.accumulate(accR, tmp, 1.0, None, add=True)                                # EXP:483
+            m = tmp.mean(dtype=torch.float64)                                             # EXP:485-486
+            i_sum += m
+            e_sum += currentEnergy * m
+            # EXP:469 + 473 sample image: sample attenuation and membrane+sample phase fused into the refraction
+            both = ops.MaterialStack.concat(mem_phase, smp)
+            if plate_att is None:
+                ops.refract(N, both, self._dscale(dOD, currentEnergy), clamp, I_in=Ibs, out=accS, add=True)
+            else:
+                ops.refract(N, both, self._dscale(dOD, currentEnergy), clamp, I_in=Ibs, out=tmp)
+                self._add_intensity(accS, tmp, plate_att)
+            if pointNum == 0:                                                             # EXP:488-498
+                _, self.Dxreal, self.Dyreal = ops.refract(N, ops.MaterialStack.concat(air_rt, smp),
+                                                          self._dscale(dOD, currentEnergy), clamp, I0=I0, out=tmp,
+                                                          want_D=True)
+                self._add_intensity(accP, tmp, plate_att)
+                self._white(white, I0, air_rt, plate_att)
+            if currentEnergy > self.myDetector.det_param["myBinsThersholds"][ibin] - self.mySource.source_dict["myEnergySampling"] / 2:
+                self._detect_bin(ibin, pointNum, stacks, accs)                            # EXP:501-521
+                ibin += 1
+        ops.check_status(dev, "computeSampleAndReferenceImages_RT")                       # RF2:81-82, checked once
+        self._finish_mean_energy(e_sum, i_sum)
+        print("Mean detected energy in reference image", ed['meanEnergy'])
+        return stacks[0], stacks[1], stacks[2], stacks[3], self.Dxreal, self.Dyreal, self.darkFieldPropag
+
+    # ------------------------------------------------------------------------------------------- reporting
+    def saveAllParameters(self, time0, expDict):
+        """Experiment.py:530-607: text dump of every parameter dictionary next to the images."""
+        fileName = expDict['filepath'] + self.name + '_' + str(expDict['expID']) + ".txt"
+        print("file name: ", fileName)
+
+        def dump(f, d):
+            for cle, valeur in d.items():
+                if cle.split('_')[-1] != 'unit':
+                    unit = d.get(cle + "_unit")
+                    f.write(f'\n    {cle}: {valeur} {unit}' if unit is not None else f'\n    {cle}: {valeur}')
+
+        with open(fileName, "w+") as f:
+            f.write("EXPERIMENT PARAMETERS - " + expDict['simulation_type'] + " - " + str(expDict['expID']))
+            dump(f, self.exp_dict)
+            f.write("\n\nEntire computing time: %gs" % (time.time() - time0))
+            f.write("\n\nSource parameters:")
+            f.write("\nSource name: %s" % self.mySource.myName)
+            dump(f, self.mySource.source_dict)
+            f.write("\n\nDetector parameters:")
+            f.write("\nDetector name: %s" % self.myDetector.myName)
+            dump(f, self.myDetector.det_param)
+            f.write("\n\nSample informations")
+            f.write("\nSample name: %s" % self.mySampleofInterest.myName)
+            f.write("\nSample type: %s" % self.mySampleType)
+            f.write("\n    materials: %s" % self.mySampleofInterest.myMaterials)
+            for cle, valeur in (self.mySampleofInterest.geom_parameters or {}).items():
+                f.write(f'\n    {cle}: {valeur[0]} {valeur[1]}')
+            f.write("\n\nMembrane informations:")
+            f.write("\nMembrane name: %s" % self.myMembrane.myName)
+            f.write("\nMembrane type: %s" % self.myMembrane.myType)
+            f.write("\n    materials: %s" % self.myMembrane.myMaterials)
+            f.write("\n    Membrane geometry function: %s" % self.myMembrane.myGeometryFunction)
+            for cle, valeur in (self.myMembrane.geom_parameters or {}).items():
+                f.write(f'\n    {cle}: {valeur[0]} {valeur[1]}')
+            if self.myPlate is not None:
+                f.write("\n\nDetectors protection Plate")
+                f.write("\nPlate thickness: %s" % getattr(self.myPlate, "myThickness", None))
+                f.write("\nPlate Material: %s" % self.myPlate.myMaterials)

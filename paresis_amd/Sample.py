@@ -1,0 +1,158 @@
+"""Physical objects crossed by the beam (mirror of CodePython/Sample.py:22-351).
+
+`AnalyticalSample.setWave` / `setWaveRT` keep the reference signatures and run as HIP kernels on thickness maps held in
+HBM as float32.  The phase k*delta*T reaches 1e2-1e3 rad, which float32 cannot carry to 1e-5, so
+  * setWave forms the phase in float64 on the device, range-reduces, then takes a float32 sincos;
+  * setWaveRT returns the phase as a float64 tensor;
+  * the Experiment chains never materialise the phase at all: they hand the thickness maps and the per-material
+    coefficients (`stack_wave` / `stack_rt`) to the consuming kernel, which fuses the transmission into its load.
+"""
+import numpy as np
+import torch
+
+from . import _xml, geometry, materials, ops
+from ._lib import PsxError
+from ._tensors import device, is_scalar, to_dev
+from .getk import k_sample
+
+
+class Sample:
+    def __init__(self, xml_directory=None):
+        self.xmlSampleFileName = "xmlFiles/Samples.xml"
+        self._xml_directory = xml_directory
+        self.myName = ""
+        self.myType = ""
+        self.myMaterials = []
+        self.myGeometry = []
+        self.geom_parameters = None
+        self.myGeometryFunction = ""
+
+    def defineCorrectValuesSample(self):
+        """Sample.py:33-77: XML -> fields (optional tags depend on the geometry function)."""
+        doc = _xml.parse(self._xml_directory or _xml.xml_dir(), "Samples.xml")
+        node = _xml.find_named(doc, "sample", self.myName)
+        if node is None:
+            print(self.myName)
+            raise ValueError("Sample not found in the xml file")
+        self._node = node
+        self.myType = _xml.child_text(node, "myType")
+        self.myMaterials = list(_xml.child_text(node, "myMaterials").split(","))
+        fn = self.myGeometryFunction = _xml.child_text(node, "myGeometryFunction")
+        if fn == "getMembraneFromFile":
+            self.myPMMAThickness = float(_xml.child_text(node, "myPMMAThickness"))
+            if _xml.has_child(node, "myMembraneFile"):   # the reference never reads it (SAM:53-54 vs SAM:231)
+                self.myMembraneFile = _xml.child_text(node, "myMembraneFile")
+        if fn == "getMembraneSegmentedFromFile":
+            self.myMeanSphereRadius = float(_xml.child_text(node, "myMeanSphereRadius"))
+            self.myNbOfLayers = int(_xml.child_text(node, "myNbOfLayers"))
+            self.myPMMAThickness = float(_xml.child_text(node, "myPMMAThickness"))
+        if fn == "get_my_thickness" and self.myName != "air_volume":
+            self.myThickness = float(_xml.child_text(node, "myThickness"))
+        if fn == "getSampleFromFile":
+            self.mySampleFile = _xml.child_text(node, "mySampleFile")
+        if fn == "loadSampleGeometryFromImages":
+            self.myGeometryFolder = _xml.child_text(node, "myGeometryFolder")
+        for tag in ("myRadius", "myOrientation"):
+            if _xml.has_child(node, tag):
+                setattr(self, tag, float(_xml.child_text(node, tag)))
+
+    def getDeltaBeta(self, sourceSpectrum):
+        """Sample.py:83-152: per material, a list of (energy, value) for every energy of the spectrum."""
+        for material in self.myMaterials:
+            db = [materials.delta_beta(material, e) for e, _ in sourceSpectrum]
+            self.delta.append([(e, d) for (e, _), (d, _) in zip(sourceSpectrum, db)])
+            self.beta.append([(e, b) for (e, _), (_, b) in zip(sourceSpectrum, db)])
+        if len(self.delta) != len(self.myMaterials):
+            raise ValueError("One or more materials have not been found in delta beta tables")
+
+
+class AnalyticalSample(Sample):
+    def __init__(self, xml_directory=None):
+        Sample.__init__(self, xml_directory)
+        self.delta = []
+        self.beta = []
+        self._dev_geometry = None
+        self._dev_src = None
+
+    # ------------------------------------------------------------------------------------------ geometry
+    def getMyGeometry(self, studyDimensions, studyPixelSize, oversamp, pointNum=0, number_of_positions=0):
+        """Sample.py:163-245: thickness maps [material, x, y] in metres."""
+        dimX, dimY = int(studyDimensions[0]), int(studyDimensions[1])
+        fn = self.myGeometryFunction
+        if self.myType == "sample_of_interest":
+            if fn == "getSampleFromFile":
+                self.myGeometry = np.load(self.mySampleFile)
+                return
+            if fn == "CreateSampleCylindre":
+                self.myGeometry, self.geom_parameters = geometry.cylinder(dimX, dimY, studyPixelSize, self.myRadius,
+                                                                          self.myOrientation)
+                return
+            if fn == "CreateSampleSphere":
+                self.myGeometry, self.geom_parameters = geometry.sphere(dimX, dimY, studyPixelSize, self.myRadius)
+                return
+        if self.myType == "membrane" and fn in ("getMembraneSegmentedFromFile", "getMembraneFromFile"):
+            if fn == "getMembraneFromFile" and not hasattr(self, "myMeanSphereRadius"):
+                self.myMeanSphereRadius, self.myNbOfLayers = 25.0, 1
+            self.myGeometry, self.geom_parameters = geometry.membrane(self, dimX, dimY, studyPixelSize, pointNum,
+                                                                      self.myPMMAThickness)
+            return
+        if fn == "get_my_thickness":
+            self.myGeometry = np.full((1, dimX, dimY), self.myThickness * 1e-6, dtype=np.float32)   # SAM:239-243
+            return
+        raise ValueError("Could not define sample geometry")
+
+    def geometry_dev(self):
+        """The thickness stack as a float32 tensor in HBM (uploaded once per myGeometry object)."""
+        g = self.myGeometry
+        if self._dev_geometry is None or self._dev_src is not g:
+            if isinstance(g, (list, tuple)):
+                g = np.asarray(g)
+            ndim = g.dim() if isinstance(g, torch.Tensor) else np.ndim(g)
+            if ndim != 3:
+                raise Exception("Sample Geometry has the wrong nb of dim [material, x, y]")   # SAM:263-264
+            self._dev_geometry = to_dev(g, torch.float32)
+            self._dev_src = self.myGeometry
+        return self._dev_geometry
+
+    # --------------------------------------------------------------------------------------- coefficients
+    def _coeff(self, table, energy):
+        """The reference looks delta/beta up by exact float equality on the energy and keeps 0 when nothing matches
+        (Sample.py:266-277)."""
+        out = np.zeros(len(self.myMaterials))
+        for imat in range(len(self.myMaterials)):
+            for energyData, value in table[imat]:
+                if energyData == energy:
+                    out[imat] = value
+        return out
+
+    def stack_wave(self, energy, phase=True, att=True):
+        """MaterialStack for a complex wave: cphase = -k delta, catt = -k beta (Sample.py:279)."""
+        k = k_sample(energy)
+        d, b = self._coeff(self.delta, energy), self._coeff(self.beta, energy)
+        return ops.MaterialStack(self.geometry_dev(), cphase=(-k * d if phase else 0 * d), catt=(-k * b if att else 0 * b))
+
+    def stack_rt(self, energy, phase=True, att=True):
+        """MaterialStack for intensity + phase: cphase = -k delta, catt = -2 k beta (Sample.py:347-348)."""
+        k = k_sample(energy)
+        d, b = self._coeff(self.delta, energy), self._coeff(self.beta, energy)
+        if self.myType == "sample_of_interest" and ("Lung" in self.myMaterials or self.myName == "cylinder_beeds"):
+            raise PsxError("dark-field sample model (Sample.py:322-344) is not built yet (SURVEY.md section 8f-2)")
+        return ops.MaterialStack(self.geometry_dev(), cphase=(-k * d if phase else 0 * d),
+                                 catt=(-2 * k * b if att else 0 * b))
+
+    # ------------------------------------------------------------------------------------- reference API
+    def setWave(self, incidentWave, energy):
+        """Sample.py:248-282: disturbedWave = prod_m exp((-i k delta_m - k beta_m) T_m) * incidentWave."""
+        stack = self.stack_wave(energy)
+        wave = to_dev(incidentWave, torch.complex64)
+        return ops.transmit_wave(wave, 1.0, stack)
+
+    def setWaveRT(self, incidentIntensity, energy, incidentphi=0, incidentDf=0):
+        """Sample.py:285-351: (I*exp(-2 k beta T), phi - k delta T, newDf); phi is float64; newDf = 0 (int)."""
+        stack = self.stack_rt(energy)
+        I = to_dev(incidentIntensity, torch.float32)
+        phi_in = None if is_scalar(incidentphi) and incidentphi == 0 else (
+            torch.full(I.shape, float(incidentphi), dtype=torch.float64, device=I.device) if is_scalar(incidentphi)
+            else to_dev(incidentphi, torch.float64))
+        I_out, phi_out = ops.transmit_rt(I, 1.0, stack, phi_in)
+        return I_out, phi_out, 0

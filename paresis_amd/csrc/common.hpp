@@ -1,0 +1,104 @@
+// common.hpp -- shared host/device helpers of libparesis_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "paresis_hip.h"
+
+namespace psx {
+
+// ---- thread-local error text behind psx_last_error() --------------------------------------------------------
+char *err_buf();
+int fail(int code, const char *fmt, ...);
+
+#define PSX_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return psx::fail((int)e__, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+#define PSX_REQUIRE(cond, ...)                         \
+    do {                                               \
+        if (!(cond)) return psx::fail(PSX_E_ARG, __VA_ARGS__); \
+    } while (0)
+
+inline int launch_check(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+// ---- a stack of thickness maps with per-map coefficients, passed to kernels by value ---------------------------
+struct Mats {
+    const float *T[PSX_MAX_MAT];
+    double cphase[PSX_MAX_MAT];
+    double catt[PSX_MAX_MAT];
+    int n;
+};
+
+// Validates (T, cphase, catt, nmat) and packs them.  Null coefficient arrays mean zeros.
+int pack_mats(Mats &m, const float *const *T, const double *cphase, const double *catt, int nmat);
+
+// ---- device math ---------------------------------------------------------------------------------------------
+#define PSX_TWO_PI 6.283185307179586476925286766559
+#define PSX_INV_TWO_PI 0.15915494309189533576888376337251
+
+// exp(i*ph) for a float64 phase of any magnitude: reduce to [-pi,pi] in float64, then float32 sincos.
+__device__ __forceinline__ void cis_f64(double ph, float &c, float &s) {
+    const double r = ph - PSX_TWO_PI * rint(ph * PSX_INV_TWO_PI);
+    sincosf((float)r, &s, &c);
+}
+
+// sum_m cphase[m]*T[m][p] and sum_m catt[m]*T[m][p] in float64
+__device__ __forceinline__ void mats_eval(const Mats &m, int64_t p, double &ph, double &la) {
+    ph = 0.0;
+    la = 0.0;
+#pragma unroll
+    for (int i = 0; i < PSX_MAX_MAT; ++i) {
+        if (i < m.n) {
+            const double t = (double)m.T[i][p];
+            ph = fma(m.cphase[i], t, ph);
+            la = fma(m.catt[i], t, la);
+        }
+    }
+}
+
+// ---- optional per-kernel timing with HIP events on the launch stream (psx_profile_*) ---------------------------------
+// Off by default: a ProfScope then costs one branch.  When on, every kernel launch of the library is bracketed by two
+// events recorded on the stream it is launched on; psx_profile_summary() resolves them after the work has drained.
+bool prof_enabled();
+int prof_begin(const char *name, hipStream_t st);
+void prof_end(int handle, hipStream_t st);
+
+struct ProfScope {
+    int h;
+    hipStream_t st;
+    ProfScope(const char *name, hipStream_t s) : h(prof_enabled() ? prof_begin(name, s) : -1), st(s) {}
+    ~ProfScope() {
+        if (h >= 0) prof_end(h, st);
+    }
+};
+
+// launch statement(s) bracketed by a timing scope:  PSX_TIMED("k_name", stream, k_name<<<g, b, 0, stream>>>(args));
+#define PSX_TIMED(name, st, ...)        \
+    do {                                \
+        psx::ProfScope ps__(name, st);  \
+        __VA_ARGS__;                    \
+    } while (0)
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// grid for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8, capped (guide G11)
+inline int ew_grid(int64_t n, int block, int per_thread = 1) {
+    int64_t g = cdiv(n, (int64_t)block * per_thread);
+    if (g > 2048 * 8) g = 2048 * 8;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace psx

@@ -1,0 +1,143 @@
+// core.hip -- error reporting, argument packing, device probe.
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace psx {
+
+char *err_buf() {
+    static thread_local char buf[512] = "";
+    return buf;
+}
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int pack_mats(Mats &m, const float *const *T, const double *cphase, const double *catt, int nmat) {
+    if (nmat < 0 || nmat > PSX_MAX_MAT) return fail(PSX_E_ARG, "nmat=%d outside [0,%d]", nmat, PSX_MAX_MAT);
+    if (nmat > 0 && T == nullptr) return fail(PSX_E_ARG, "T is null with nmat=%d", nmat);
+    m.n = nmat;
+    for (int i = 0; i < PSX_MAX_MAT; ++i) {
+        m.T[i] = nullptr;
+        m.cphase[i] = 0.0;
+        m.catt[i] = 0.0;
+    }
+    for (int i = 0; i < nmat; ++i) {
+        if (T[i] == nullptr) return fail(PSX_E_ARG, "T[%d] is null", i);
+        m.T[i] = T[i];
+        m.cphase[i] = cphase ? cphase[i] : 0.0;
+        m.catt[i] = catt ? catt[i] : 0.0;
+    }
+    return 0;
+}
+
+// ---- per-kernel timing ----------------------------------------------------------------------------------------
+namespace {
+struct ProfRec {
+    hipEvent_t a, b;
+    int name;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_recs;
+std::vector<std::string> g_names;
+std::vector<hipEvent_t> g_pool;
+
+hipEvent_t take_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+bool prof_enabled() { return g_prof_on; }
+
+int prof_begin(const char *name, hipStream_t st) {
+    int id = -1;
+    for (size_t i = 0; i < g_names.size(); ++i)
+        if (g_names[i] == name) id = (int)i;
+    if (id < 0) {
+        g_names.push_back(name);
+        id = (int)g_names.size() - 1;
+    }
+    ProfRec r{take_event(), take_event(), id};
+    (void)hipEventRecord(r.a, st);
+    g_recs.push_back(r);
+    return (int)g_recs.size() - 1;
+}
+
+void prof_end(int handle, hipStream_t st) { (void)hipEventRecord(g_recs[handle].b, st); }
+
+}  // namespace psx
+
+__global__ void psx_probe_kernel(int *out) { *out = 950; }
+
+extern "C" {
+
+int psx_abi_version(void) { return 1; }
+
+const char *psx_last_error(void) { return psx::err_buf(); }
+
+int psx_device_ok(void) {
+    int *d = nullptr;
+    int h = 0;
+    if (hipMalloc(&d, sizeof(int)) != hipSuccess) {
+        psx::fail(1, "hipMalloc failed: no usable HIP device");
+        return 0;
+    }
+    (void)hipMemset(d, 0, sizeof(int));
+    psx_probe_kernel<<<1, 1>>>(d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess || h != 950) {
+        psx::fail((int)e, "gfx950 code object not runnable on this device: %s", hipGetErrorString(e));
+        return 0;
+    }
+    return 1;
+}
+
+int psx_profile_enable(int on) {
+    for (auto &r : psx::g_recs) {
+        psx::g_pool.push_back(r.a);
+        psx::g_pool.push_back(r.b);
+    }
+    psx::g_recs.clear();
+    psx::g_prof_on = on != 0;
+    return 0;
+}
+
+int psx_profile_summary(char *buf, size_t cap) {
+    if (!buf || cap == 0) return psx::fail(PSX_E_ARG, "psx_profile_summary: null buffer");
+    std::vector<double> total(psx::g_names.size(), 0.0);
+    std::vector<int> count(psx::g_names.size(), 0);
+    for (auto &r : psx::g_recs) {
+        hipError_t e = hipEventSynchronize(r.b);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
+        if (e != hipSuccess) return psx::fail((int)e, "psx_profile_summary: %s", hipGetErrorString(e));
+        total[r.name] += ms;
+        count[r.name] += 1;
+    }
+    size_t off = 0;
+    buf[0] = 0;
+    for (size_t i = 0; i < psx::g_names.size(); ++i) {
+        if (!count[i]) continue;
+        int n = snprintf(buf + off, cap - off, "%s %d %.6f\n", psx::g_names[i].c_str(), count[i], total[i]);
+        if (n < 0 || (size_t)n >= cap - off) return psx::fail(PSX_E_ARG, "psx_profile_summary: buffer too small");
+        off += (size_t)n;
+    }
+    return 0;
+}
+
+}  // extern "C"

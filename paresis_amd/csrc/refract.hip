@@ -1,0 +1,332 @@
+// refract.hip -- ray-deflection step: phase gradient -> displacement -> bilinear intensity scatter (K9-K13).
+//
+// Replaces fastRefraction + fastloopNumba (refractionFileNumba2.py:25-86,198-263; v1 refractionFileNumba.py:11-135).
+//
+// The reference scatters in raster order on one CPU thread.  Here the scatter is turned into a per-tile GATHER:
+// a workgroup owns one TH x TW output tile, stages the phase (float64) and the source intensity of the tile plus a halo
+// of H+1 pixels in LDS, re-evaluates the displacement of every source pixel of tile+halo, and deposits only what lands
+// in its own tile with LDS float atomics.  The tile is then written once with plain coalesced stores: no zero-init
+// pass, no global read-modify-write.  Rays displaced by more than the halo ("far" rays, rare) are appended to a
+// compact list by the tile that owns the SOURCE pixel and replayed by a second, tiny kernel with global float atomics
+// that applies the reference's border rules literally.
+//
+// HBM traffic per pixel: 4*nmat (thickness maps) + 4 (intensity, if given) read, 4 written  (BASELINE.md section 4
+// prices the scatter at 12+4*nmat because the reference zero-initialises and read-modify-writes its output).
+#include "common.hpp"
+
+using namespace psx;
+
+namespace {
+
+constexpr int TH = 64;          // tile rows   (axis 0, "x" of the reference)
+constexpr int TW = 64;          // tile cols   (axis 1, contiguous)
+constexpr int H = 4;            // gather halo: rays with floor(D) in [-H, H-1] on both axes are "near"
+constexpr int SR = TH + 2 * H + 2;   // staged rows (one more ring for the gradient stencil)
+constexpr int SC = TW + 2 * H + 2;
+constexpr int NTHREADS = 512;
+constexpr int GR = TH + 2 * H, GC = TW + 2 * H;   // source rows/cols gathered by one tile
+
+struct RefractArgs {
+    const float *I_in;
+    float I0;
+    Mats m;
+    const double *phi_in;
+    float *I_out;
+    float out_scale;
+    int accumulate;
+    float *Dx_out, *Dy_out;
+    float *I_mut;
+    int Nx, Ny, margin;
+    double dscale, clamp_x, clamp_y;
+    unsigned *status;
+    unsigned *far_count;     // workspace[0]
+    int *far_list;           // workspace + 16 B, capacity Nx*Ny
+    int tiles_x, tiles_y;
+};
+
+// One axis of the reference's split (RF2:228-233 + the sign cases of RF2:237-262), in padded coordinates.
+// b = base index, nb = neighbour index, wb/wn their weights.
+__device__ __forceinline__ void axis_split_ref(double d, int p, int &b, int &nb, float &wb, float &wn) {
+    if (fabs(d) > 1.0) {
+        const double f = floor(d);
+        b = p + (int)f;
+        const float w = (float)(d - f);
+        nb = b + 1;
+        wn = w;
+        wb = 1.f - w;
+    } else {
+        b = p;
+        const float w = (float)fabs(d);
+        nb = d >= 0.0 ? p + 1 : p - 1;
+        wn = w;
+        wb = 1.f - w;
+    }
+}
+
+// Displacement of one source pixel from the phase at its stencil neighbours (np.gradient edge_order=2, unit
+// spacing; RF2:54-64).  get(i,j) returns phi at GLOBAL pixel (i,j).  Returns the (possibly zeroed) intensity.
+template <class PhiAt>
+__device__ __forceinline__ float source_eval(const RefractArgs &a, int i, int j, float I, PhiAt get, double &dx,
+                                             double &dy, bool &clamped) {
+    double gx, gy;
+    if (i == 0)
+        gx = -1.5 * get(0, j) + 2.0 * get(1, j) - 0.5 * get(2, j);
+    else if (i == a.Nx - 1)
+        gx = 0.5 * get(i - 2, j) - 2.0 * get(i - 1, j) + 1.5 * get(i, j);
+    else
+        gx = 0.5 * (get(i + 1, j) - get(i - 1, j));
+    if (j == 0)
+        gy = -1.5 * get(i, 0) + 2.0 * get(i, 1) - 0.5 * get(i, 2);
+    else if (j == a.Ny - 1)
+        gy = 0.5 * get(i, j - 2) - 2.0 * get(i, j - 1) + 1.5 * get(i, j);
+    else
+        gy = 0.5 * (get(i, j + 1) - get(i, j - 1));
+    dx = gx * a.dscale;
+    dy = gy * a.dscale;
+    if (fabs(dx) < 1e-12) dx = 0.0;          // RF2:59-60
+    if (fabs(dy) < 1e-12) dy = 0.0;
+    clamped = false;
+    if (fabs(dx) > a.clamp_x) { I = 0.f; dx = 0.0; clamped = true; }   // RF2:61-64
+    if (fabs(dy) > a.clamp_y) { I = 0.f; dy = 0.0; clamped = true; }
+    return I;
+}
+
+__device__ __forceinline__ bool is_near(double dx, double dy) {
+    const double fx = floor(dx), fy = floor(dy);
+    return fx >= -H && fx <= H - 1 && fy >= -H && fy <= H - 1;
+}
+
+// XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2), so give each XCD a contiguous run of tiles;
+// neighbouring tiles then re-read each other's halo rows from the same L2.  Bijective for any tile count.
+__device__ __forceinline__ int xcd_tile(int b, int nt) {
+    const int q = nt >> 3, r = nt & 7, x = b & 7;
+    return x * q + (x < r ? x : r) + (b >> 3);
+}
+
+__global__ __launch_bounds__(NTHREADS) void k_refract_near(RefractArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *sphi = (double *)smem;                               // [SR][SC]
+    float *sI = (float *)(smem + sizeof(double) * SR * SC);      // [GR][GC]
+    float *sacc = sI + GR * GC;                                  // [TH][TW]
+
+    const int nt = a.tiles_x * a.tiles_y;
+    const int tile = xcd_tile(blockIdx.x, nt);
+    const int r0 = (tile / a.tiles_y) * TH, c0 = (tile % a.tiles_y) * TW;
+    const int tid = threadIdx.x;
+
+    // ---- stage phi (float64) and source intensity for rows [r0-H-1, r0+TH+H+1) x cols [c0-H-1, c0+TW+H+1)
+    for (int idx = tid; idx < SR * SC; idx += NTHREADS) {
+        const int sr = idx / SC, sc = idx - sr * SC;
+        const int i = r0 - H - 1 + sr, j = c0 - H - 1 + sc;
+        double ph = 0.0;
+        float I = 0.f;
+        if (i >= 0 && i < a.Nx && j >= 0 && j < a.Ny) {
+            const int64_t p = (int64_t)i * a.Ny + j;
+            double la;
+            mats_eval(a.m, p, ph, la);
+            if (a.phi_in) ph += a.phi_in[p];
+            I = a.I0 * (a.I_in ? a.I_in[p] : 1.f);
+            if (la != 0.0) I *= expf((float)la);
+        }
+        sphi[idx] = ph;
+        if (sr >= 1 && sr <= GR && sc >= 1 && sc <= GC) sI[(sr - 1) * GC + (sc - 1)] = I;
+    }
+    for (int idx = tid; idx < TH * TW; idx += NTHREADS) sacc[idx] = 0.f;
+    __syncthreads();
+
+    auto phi_at = [&](int i, int j) -> double { return sphi[(i - (r0 - H - 1)) * SC + (j - (c0 - H - 1))]; };
+
+    // ---- every source pixel of tile+halo deposits what lands inside this tile
+    bool any_bad = false;
+    constexpr int ITERS = (GR * GC + NTHREADS - 1) / NTHREADS;   // uniform trip count: the loop holds wave ballots
+    for (int it = 0; it < ITERS; ++it) {
+        const int idx = it * NTHREADS + tid;
+        const int gr = idx / GC, gc = idx - gr * GC;
+        const int i = r0 - H + gr, j = c0 - H + gc;
+        const bool inside = idx < GR * GC && i >= 0 && i < a.Nx && j >= 0 && j < a.Ny;
+        const bool core = gr >= H && gr < H + TH && gc >= H && gc < H + TW;
+        bool far = false;
+        if (inside) {
+            float I = sI[idx];
+            double dx, dy;
+            bool clamped;
+            I = source_eval(a, i, j, I, phi_at, dx, dy, clamped);
+            const bool near = is_near(dx, dy);
+            if (core) {
+                if (a.Dx_out) {
+                    const int64_t Py = a.Ny + 2 * a.margin;
+                    const int64_t q = (int64_t)(i + a.margin) * Py + (j + a.margin);
+                    a.Dx_out[q] = (float)dx;
+                    a.Dy_out[q] = (float)dy;
+                }
+                if (clamped && a.I_mut) a.I_mut[(int64_t)i * a.Ny + j] = 0.f;
+                far = !near && I != 0.f;
+            }
+            if (near && I != 0.f) {
+                const double fx = floor(dx), fy = floor(dy);
+                const float wx = (float)(dx - fx), wy = (float)(dy - fy);
+                const int ti = gr - H + (int)fx, tj = gc - H + (int)fy;   // base target, tile-relative
+                const float w00 = (1.f - wx) * (1.f - wy), w10 = wx * (1.f - wy), w01 = (1.f - wx) * wy, w11 = wx * wy;
+                const bool i0 = ti >= 0 && ti < TH, i1 = ti + 1 >= 0 && ti + 1 < TH;
+                const bool j0 = tj >= 0 && tj < TW, j1 = tj + 1 >= 0 && tj + 1 < TW;
+                if (i0 && j0) atomicAdd(&sacc[ti * TW + tj], I * w00);
+                if (i1 && j0 && w10 != 0.f) atomicAdd(&sacc[(ti + 1) * TW + tj], I * w10);
+                if (i0 && j1 && w01 != 0.f) atomicAdd(&sacc[ti * TW + tj + 1], I * w01);
+                if (i1 && j1 && w11 != 0.f) atomicAdd(&sacc[(ti + 1) * TW + tj + 1], I * w11);
+            }
+        }
+        // wave-aggregated append of far rays (one global atomic per wave)
+        const unsigned long long mask = __ballot(far);
+        if (mask) {
+            const int lane = tid & 63;
+            const int leader = __ffsll((long long)mask) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(a.far_count, (unsigned)__popcll(mask));
+            base = __shfl(base, leader);
+            if (far) {
+                const unsigned rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+                a.far_list[base + rank] = i * a.Ny + j;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- write the tile once (coalesced rows of TW floats)
+    for (int idx = tid; idx < TH * TW; idx += NTHREADS) {
+        const int tr = idx / TW, tc = idx - tr * TW;
+        const int i = r0 + tr, j = c0 + tc;
+        if (i < a.Nx && j < a.Ny) {
+            const int64_t p = (int64_t)i * a.Ny + j;
+            float v = a.out_scale * sacc[idx];
+            if (a.accumulate) v += a.I_out[p];
+            any_bad |= !(fabsf(v) <= 3.0e38f);
+            a.I_out[p] = v;
+        }
+    }
+    if (a.status && __any(any_bad) && (tid & 63) == 0) atomicOr(a.status, PSX_STATUS_NONFINITE);
+}
+
+// Replay of the far rays with the reference's literal border rules (RF2:235-262) in padded coordinates.
+__global__ __launch_bounds__(NTHREADS) void k_refract_far(RefractArgs a) {
+    const unsigned n = *a.far_count;
+    const int Px = a.Nx + 2 * a.margin, Py = a.Ny + 2 * a.margin;
+    auto phi_at = [&](int i, int j) -> double {
+        const int64_t p = (int64_t)i * a.Ny + j;
+        double ph, la;
+        mats_eval(a.m, p, ph, la);
+        if (a.phi_in) ph += a.phi_in[p];
+        return ph;
+    };
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const int s = a.far_list[e];
+        const int i = s / a.Ny, j = s - i * a.Ny;
+        const int64_t p = s;
+        double ph, la;
+        mats_eval(a.m, p, ph, la);
+        float I = a.I0 * (a.I_in ? a.I_in[p] : 1.f);
+        if (la != 0.0) I *= expf((float)la);
+        double dx, dy;
+        bool clamped;
+        I = source_eval(a, i, j, I, phi_at, dx, dy, clamped);
+        int bi, ni, bj, nj;
+        float wbi, wni, wbj, wnj;
+        axis_split_ref(dx, i + a.margin, bi, ni, wbi, wni);
+        axis_split_ref(dy, j + a.margin, bj, nj, wbj, wnj);
+        if (bi < 0 || bi >= Px || bj < 0 || bj >= Py) continue;       // RF2:235-236
+        auto deposit = [&](int pi, int pj, float v) {
+            const int ui = pi - a.margin, uj = pj - a.margin;           // crop (RF2:78)
+            if (ui >= 0 && ui < a.Nx && uj >= 0 && uj < a.Ny && v != 0.f) {
+                const float add = a.out_scale * v;
+                if (a.status && !(fabsf(add) <= 3.0e38f)) atomicOr(a.status, PSX_STATUS_NONFINITE);
+                atomicAdd(&a.I_out[(int64_t)ui * a.Ny + uj], add);
+            }
+        };
+        deposit(bi, bj, I * wbi * wbj);
+        if (ni < 0 || ni >= Px || nj < 0 || nj >= Py) continue;       // RF2:238-262: all three or none
+        deposit(ni, bj, I * wni * wbj);
+        deposit(ni, nj, I * wni * wnj);
+        deposit(bi, nj, I * wbi * wnj);
+    }
+}
+
+// fastloopNumba on explicit displacement maps: literal branch structure, global float atomics.
+__global__ __launch_bounds__(NTHREADS) void k_fastloop(const float *__restrict__ I, const float *__restrict__ Dx,
+                                                       const float *__restrict__ Dy, float *I2, int Nx, int Ny) {
+    const int64_t n = (int64_t)Nx * Ny;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(p / Ny), j = (int)(p - (int64_t)i * Ny);
+        const float Iij = I[p];
+        const double dx = Dx[p], dy = Dy[p];
+        if (dx == 0.0 && dy == 0.0) {                                  // RF2:222-224
+            atomicAdd(&I2[p], Iij);
+            continue;
+        }
+        int bi, ni, bj, nj;
+        float wbi, wni, wbj, wnj;
+        axis_split_ref(dx, i, bi, ni, wbi, wni);
+        axis_split_ref(dy, j, bj, nj, wbj, wnj);
+        if (bi < 0 || bi >= Nx || bj < 0 || bj >= Ny) continue;
+        atomicAdd(&I2[(int64_t)bi * Ny + bj], Iij * wbi * wbj);
+        if (ni < 0 || ni >= Nx || nj < 0 || nj >= Ny) continue;
+        atomicAdd(&I2[(int64_t)ni * Ny + bj], Iij * wni * wbj);
+        atomicAdd(&I2[(int64_t)ni * Ny + nj], Iij * wni * wnj);
+        atomicAdd(&I2[(int64_t)bi * Ny + nj], Iij * wbi * wnj);
+    }
+}
+
+constexpr size_t NEAR_LDS = sizeof(double) * SR * SC + sizeof(float) * GR * GC + sizeof(float) * TH * TW;
+
+}  // namespace
+
+extern "C" {
+
+size_t psx_refract_workspace_bytes(int Nx, int Ny) {
+    if (Nx <= 0 || Ny <= 0) return 16;
+    return 16 + sizeof(int) * (size_t)Nx * (size_t)Ny;
+}
+
+int psx_refract_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,
+                    int nmat, const double *phi_in, float *I_out, float out_scale, int accumulate, float *Dx_out,
+                    float *Dy_out, float *I_mut, int Nx, int Ny, int margin, double dscale, double clamp_x,
+                    double clamp_y, unsigned *status, void *workspace, void *stream) {
+    PSX_REQUIRE(I_out != nullptr && workspace != nullptr, "psx_refract_f32: null output or workspace");
+    PSX_REQUIRE(Nx >= 3 && Ny >= 3, "psx_refract_f32: grid %dx%d too small for the edge_order=2 gradient", Nx, Ny);
+    PSX_REQUIRE((int64_t)Nx * Ny < (1ll << 31), "psx_refract_f32: grid %dx%d exceeds int32 pixel indices", Nx, Ny);
+    PSX_REQUIRE(margin >= H && margin <= 4096, "psx_refract_f32: margin %d must be >= %d", margin, H);
+    PSX_REQUIRE((Dx_out == nullptr) == (Dy_out == nullptr), "psx_refract_f32: Dx_out and Dy_out go together");
+    PSX_REQUIRE(nmat > 0 || phi_in != nullptr, "psx_refract_f32: no phase source (nmat=0 and phi_in=NULL)");
+    RefractArgs a;
+    if (int rc = pack_mats(a.m, T, cphase, catt, nmat)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    a.I_in = I_in; a.I0 = I0; a.phi_in = phi_in; a.I_out = I_out; a.out_scale = out_scale; a.accumulate = accumulate;
+    a.Dx_out = Dx_out; a.Dy_out = Dy_out; a.I_mut = I_mut; a.Nx = Nx; a.Ny = Ny; a.margin = margin;
+    a.dscale = dscale; a.clamp_x = clamp_x; a.clamp_y = clamp_y; a.status = status;
+    a.far_count = (unsigned *)workspace;
+    a.far_list = (int *)((char *)workspace + 16);
+    a.tiles_x = (int)cdiv(Nx, TH);
+    a.tiles_y = (int)cdiv(Ny, TW);
+    PSX_HIP(hipMemsetAsync(workspace, 0, 16, st));
+    if (Dx_out) {
+        const size_t padded = sizeof(float) * (size_t)(Nx + 2 * margin) * (size_t)(Ny + 2 * margin);
+        PSX_HIP(hipMemsetAsync(Dx_out, 0, padded, st));     // zero margins (RF2:65-66)
+        PSX_HIP(hipMemsetAsync(Dy_out, 0, padded, st));
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        PSX_HIP(hipFuncSetAttribute((const void *)k_refract_near, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)NEAR_LDS));
+        attr_set = true;
+    }
+    PSX_TIMED("k_refract_near", st, k_refract_near<<<a.tiles_x * a.tiles_y, NTHREADS, NEAR_LDS, st>>>(a));
+    if (int rc = launch_check("k_refract_near")) return rc;
+    PSX_TIMED("k_refract_far", st, k_refract_far<<<512, NTHREADS, 0, st>>>(a));
+    return launch_check("k_refract_far");
+}
+
+int psx_fastloop_f32(const float *I, const float *Dx, const float *Dy, float *I2, int Nx, int Ny, void *stream) {
+    PSX_REQUIRE(I && Dx && Dy && I2 && Nx > 0 && Ny > 0, "psx_fastloop_f32: null pointer or empty grid");
+    PSX_TIMED("k_fastloop", (hipStream_t)stream, k_fastloop<<<ew_grid((int64_t)Nx * Ny, NTHREADS), NTHREADS, 0, (hipStream_t)stream>>>(I, Dx, Dy, I2, Nx, Ny));
+    return launch_check("k_fastloop");
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+// transmit.hip -- object transmission (K1, K2) and attenuated accumulation (K8 tail).
+// Elementwise, HBM-bound: one coalesced pass, 16 B per lane where the layout allows.
+#include "common.hpp"
+
+using namespace psx;
+
+// K1: Sample.py:279  wave <- exp((-i k delta - k beta) T) wave, all materials in one pass.
+__global__ __launch_bounds__(256) void k_transmit_wave(const float2 *__restrict__ win, float amp, Mats m,
+                                                       float2 *__restrict__ wout, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        double ph, la;
+        mats_eval(m, p, ph, la);
+        float c, s;
+        cis_f64(ph, c, s);
+        const float a = amp * expf((float)la);
+        float2 w = win ? win[p] : make_float2(1.f, 0.f);
+        float2 o;
+        o.x = a * (w.x * c - w.y * s);
+        o.y = a * (w.x * s + w.y * c);
+        wout[p] = o;
+    }
+}
+
+// K2: Sample.py:347-348  I <- exp(-2 k beta T) I ; phi <- phi - k delta T
+__global__ __launch_bounds__(256) void k_transmit_rt(const float *__restrict__ Iin, float I0, Mats m,
+                                                     float *__restrict__ Iout, const double *__restrict__ phin,
+                                                     double *__restrict__ phout, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        double ph, la;
+        mats_eval(m, p, ph, la);
+        if (Iout) Iout[p] = I0 * (Iin ? Iin[p] : 1.f) * expf((float)la);
+        if (phout) phout[p] = (phin ? phin[p] : 0.0) + ph;
+    }
+}
+
+// EXP:351-358 / 478-483: acc (+)= scale * img * exp(sum catt T)
+// acc and img may alias (in-place attenuation), so no __restrict__ here
+__global__ __launch_bounds__(256) void k_accumulate(float *acc, const float *img, float scale,
+                                                    Mats m, int accumulate, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        float v = scale * img[p];
+        if (m.n > 0) {
+            double ph, la;
+            mats_eval(m, p, ph, la);
+            v *= expf((float)la);
+        }
+        acc[p] = accumulate ? acc[p] + v : v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_status_scan(const float *__restrict__ img, int64_t n, unsigned *status) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        const float v = img[p];
+        bad |= !(fabsf(v) <= 3.0e38f);   // NaN or inf; float32 cannot hold the reference's 1e50 bound
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, PSX_STATUS_NONFINITE);
+}
+
+extern "C" {
+
+int psx_transmit_wave_c64(const psx_c64 *wave_in, float amp, const float *const *T, const double *cphase,
+                          const double *catt, int nmat, psx_c64 *wave_out, int64_t n, void *stream) {
+    PSX_REQUIRE(wave_out != nullptr && n >= 0, "psx_transmit_wave_c64: null output or negative n");
+    Mats m;
+    if (int rc = pack_mats(m, T, cphase, catt, nmat)) return rc;
+    if (n == 0) return 0;
+    PSX_TIMED("k_transmit_wave", (hipStream_t)stream, k_transmit_wave<<<ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>((const float2 *)wave_in, amp, m,
+                                                                      (float2 *)wave_out, n));
+    return launch_check("k_transmit_wave");
+}
+
+int psx_transmit_rt_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,
+                        int nmat, float *I_out, const double *phi_in, double *phi_out, int64_t n, void *stream) {
+    PSX_REQUIRE(n >= 0 && (I_out || phi_out), "psx_transmit_rt_f32: nothing to write");
+    Mats m;
+    if (int rc = pack_mats(m, T, cphase, catt, nmat)) return rc;
+    if (n == 0) return 0;
+    PSX_TIMED("k_transmit_rt", (hipStream_t)stream, k_transmit_rt<<<ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(I_in, I0, m, I_out, phi_in, phi_out, n));
+    return launch_check("k_transmit_rt");
+}
+
+int psx_accumulate_f32(float *acc, const float *img, float scale, const float *const *T, const double *catt, int nmat,
+                       int accumulate, int64_t n, void *stream) {
+    PSX_REQUIRE(acc && img && n >= 0, "psx_accumulate_f32: null pointer or negative n");
+    Mats m;
+    if (int rc = pack_mats(m, T, nullptr, catt, nmat)) return rc;
+    if (n == 0) return 0;
+    PSX_TIMED("k_accumulate", (hipStream_t)stream, k_accumulate<<<ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(acc, img, scale, m, accumulate, n));
+    return launch_check("k_accumulate");
+}
+
+int psx_status_scan_f32(const float *img, int64_t n, unsigned *status, void *stream) {
+    PSX_REQUIRE(img && status && n >= 0, "psx_status_scan_f32: null pointer or negative n");
+    if (n == 0) return 0;
+    PSX_TIMED("k_status_scan", (hipStream_t)stream, k_status_scan<<<ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(img, n, status));
+    return launch_check("k_status_scan");
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""XML-driven entry point (mirror of CodePython/main.py:20-115).
+
+    python -m paresis_amd.main [--experiment NAME] [--type RayT|Fresnel] [--oversampling N] [--points N]
+                               [--out DIR] [--format .tif|.edf|.npy] [--xml DIR] [--no-noise] [--seed S]
+
+With torchrun (one process per GPU) the membrane positions are strided over the ranks and the detector images are
+gathered on rank 0 over RCCL (paresis_amd/dist.py); results do not depend on the number of GPUs because every position
+has its own seed.
+"""
+import argparse
+import datetime
+import os
+import time
+
+import numpy as np
+
+
+def run(exp_dict, save=True, saving_format=".tif"):
+    from . import dist
+    from .Experiment import Experiment
+    from .InputOutput.pagailleIO import save_image
+
+    time0 = time.time()
+    exp_dict['expID'] = datetime.datetime.now().strftime("%Y%m%d-%H%M%S")
+    rank, world = dist.init()
+    print("\n\nINITIALIZING EXPERIMENT PARAMETERS AND GEOMETRIES")
+    experiment = Experiment(exp_dict)
+    print("\nImages calculation")
+    results = {}
+    for pointNum in dist.my_positions(exp_dict['nbExpPoints'], rank, world):
+        experiment.myMembrane.myGeometry = []
+        experiment.myMembrane.getMyGeometry(experiment.exp_dict['studyDimensions'], experiment.myMembrane.membranePixelSize,
+                                            experiment.exp_dict['overSampling'], pointNum, exp_dict['nbExpPoints'])   # main.py:64-65
+        print("\nCalculations point", pointNum)
+        out = experiment.computeSampleAndReferenceImages(pointNum)
+        results[pointNum] = out
+    gathered = dist.gather_positions(results, exp_dict['nbExpPoints'], rank, world)
+    if rank == 0 and save:
+        sim = exp_dict['simulation_type']
+        root = exp_dict['filepath'] + ('Fresnel_' if sim == "Fresnel" else 'RayTracing_') + str(exp_dict['expID']) + '/'
+        os.makedirs(root, exist_ok=True)
+        thresholds = [experiment.mySource.mySpectrum[0][0]] + list(experiment.myDetector.det_param['myBinsThersholds'])
+        nbin = gathered[0][0].shape[0]
+        paths = []
+        for ibin in range(nbin):                                         # main.py:84-96
+            p = root if nbin == 1 else f'{root}{"%2.2d" % thresholds[ibin]}_{"%2.2d" % thresholds[ibin + 1]}kev/'
+            for sub in ("ref/", "sample/", "propag/"):
+                os.makedirs(p + sub, exist_ok=True)
+            paths.append(p)
+        for pointNum in sorted(gathered):
+            S, R = gathered[pointNum][0], gathered[pointNum][1]
+            txt = '%2.2d' % pointNum
+            for ibin in range(nbin):
+                save_image(S[ibin], paths[ibin] + 'sample/sampleImage_' + str(exp_dict['expID']) + '_' + txt + saving_format)
+                save_image(R[ibin], paths[ibin] + 'ref/ReferenceImage_' + str(exp_dict['expID']) + '_' + txt + saving_format)
+                if pointNum == 0 and len(gathered[0]) > 3:
+                    save_image(gathered[0][2][ibin], paths[ibin] + 'propag/PropagImage_' + str(exp_dict['expID']) + '_' + saving_format)
+                    save_image(gathered[0][3][ibin], paths[ibin] + 'White_' + str(exp_dict['expID']) + '_' + saving_format)
+        experiment.saveAllParameters(time0, exp_dict)
+    dist.finish()
+    print("\nfini")
+    return gathered
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--experiment", default="Fil_Nylon_ID17")
+    ap.add_argument("--type", default="RayT", choices=["RayT", "Fresnel"])
+    ap.add_argument("--oversampling", type=int, default=2)
+    ap.add_argument("--points", type=int, default=1)
+    ap.add_argument("--out", default="Results/")
+    ap.add_argument("--format", default=".tif")
+    ap.add_argument("--xml", default=None)
+    ap.add_argument("--no-noise", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args(argv)
+    exp_dict = {'experimentName': a.experiment, 'filepath': a.out if a.out.endswith('/') else a.out + '/',
+                'overSampling': a.oversampling, 'nbExpPoints': a.points, 'simulation_type': a.type,
+                'noise': not a.no_noise, 'seed': a.seed}
+    if a.xml:
+        exp_dict['xmlDir'] = a.xml
+    os.makedirs(exp_dict['filepath'], exist_ok=True)
+    run(exp_dict, save=True, saving_format=a.format)
+
+
+if __name__ == "__main__":
+    main()

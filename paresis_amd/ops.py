@@ -1,0 +1,353 @@
+"""Tensor-level operators: PyTorch-ROCm tensors in HBM -> libparesis_hip.so (ctypes) on the current HIP stream.
+
+PyTorch is plumbing here (device memory, streams, torch.distributed); all arithmetic on the hot path runs in the
+hand-written HIP kernels behind the C ABI.  Every function checks devices/dtypes/shapes on the host before a kernel is
+launched, and raises PsxError on any failure -- there is no CPU fallback.
+"""
+import ctypes
+from ctypes import c_double, c_float, c_int, c_void_p
+
+import torch
+
+from . import _lib
+from ._lib import PsxError, check, lib
+
+MARGIN_FRESNEL = 15   # Experiment.py:236
+MARGIN_DETECTOR = 15  # Detector.py:92
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(None)
+
+
+def _need(t, dtype, name, shape=None):
+    if not isinstance(t, torch.Tensor):
+        raise PsxError("%s must be a torch.Tensor, got %r" % (name, type(t)))
+    if not t.is_cuda:
+        raise PsxError("%s must live in HBM (cuda/ROCm tensor); got device %s. There is no CPU path." % (name, t.device))
+    if t.dtype != dtype:
+        raise PsxError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise PsxError("%s must be contiguous (row-major [Nx][Ny])" % name)
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise PsxError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    return t
+
+
+class MaterialStack:
+    """Thickness maps [nmat, Nx, Ny] float32 in HBM + per-map coefficients (see include/paresis_hip.h, "Materials")."""
+
+    def __init__(self, T, cphase=None, catt=None):
+        if T is None:
+            self.T, self.n = None, 0
+        else:
+            _need(T, torch.float32, "thickness stack")
+            if T.dim() != 3:
+                raise PsxError("Sample Geometry has the wrong nb of dim [material, x, y]")   # Sample.py:263-264
+            self.T, self.n = T, T.shape[0]
+        if self.n > _lib.PSX_MAX_MAT:
+            raise PsxError("at most %d materials per call, got %d" % (_lib.PSX_MAX_MAT, self.n))
+        self.cphase = [0.0] * self.n if cphase is None else [float(v) for v in cphase]
+        self.catt = [0.0] * self.n if catt is None else [float(v) for v in catt]
+        if len(self.cphase) != self.n or len(self.catt) != self.n:
+            raise PsxError("coefficient lists must have one entry per material")
+
+    @staticmethod
+    def concat(*stacks):
+        """Materials of several objects seen by one kernel (e.g. membrane phase + sample phase, Experiment.py:469)."""
+        stacks = [s for s in stacks if s is not None and s.n > 0]
+        if not stacks:
+            return MaterialStack(None)
+        out = MaterialStack.__new__(MaterialStack)
+        out.T = None
+        out.n = sum(s.n for s in stacks)
+        if out.n > _lib.PSX_MAX_MAT:
+            raise PsxError("at most %d materials per call, got %d" % (_lib.PSX_MAX_MAT, out.n))
+        out.cphase = [c for s in stacks for c in s.cphase]
+        out.catt = [c for s in stacks for c in s.catt]
+        out._maps = [s.map(i) for s in stacks for i in range(s.n)]
+        return out
+
+    def map(self, i):
+        if self.T is not None:
+            return self.T[i]
+        return self._maps[i]
+
+    def with_coeffs(self, cphase=None, catt=None):
+        out = MaterialStack.__new__(MaterialStack)
+        out.T, out.n = self.T, self.n
+        if self.T is None and self.n:
+            out._maps = self._maps
+        out.cphase = list(self.cphase) if cphase is None else [float(v) for v in cphase]
+        out.catt = list(self.catt) if catt is None else [float(v) for v in catt]
+        return out
+
+    def cargs(self, shape=None):
+        """(T** host array, cphase*, catt*, nmat) for the C ABI; keeps the ctypes arrays alive on self."""
+        maps = [self.map(i) for i in range(self.n)]
+        for i, m in enumerate(maps):
+            _need(m, torch.float32, "thickness map %d" % i, shape)
+        self._c = ((c_void_p * max(1, self.n))(*[m.data_ptr() for m in maps]),
+                   (c_double * max(1, self.n))(*self.cphase), (c_double * max(1, self.n))(*self.catt))
+        return self._c[0], self._c[1], self._c[2], self.n
+
+
+_NO_MATS = None
+
+
+def _mats(m):
+    global _NO_MATS
+    if m is None:
+        if _NO_MATS is None:
+            _NO_MATS = MaterialStack(None)
+        return _NO_MATS
+    return m
+
+
+_workspaces = {}
+_status_words = {}
+
+
+def _workspace(device, nbytes):
+    key = (device.index, "ws")
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def status_word(device):
+    """Per-device status word the kernels OR error bits into (PSX_STATUS_*)."""
+    w = _status_words.get(device.index)
+    if w is None:
+        w = torch.zeros(1, dtype=torch.int32, device=device)
+        _status_words[device.index] = w
+    return w
+
+
+def check_status(device, what="refraction"):
+    """Synchronising read of the status word; raises like refractionFileNumba2.py:81-82 and clears it."""
+    w = status_word(device)
+    v = int(w.item())
+    if v:
+        w.zero_()
+        if v & _lib.STATUS_NONFINITE:
+            raise PsxError("The calculated intensity refractive includes some nans or insane values (%s)" % what)
+        raise PsxError("device status %d after %s" % (v, what))
+
+
+# --------------------------------------------------------------------------------------------- transmission
+def transmit_wave(wave_in, amp, mats, out=None):
+    """K1 (Sample.py:279): out = amp * wave_in * exp(sum catt*T) * exp(i sum cphase*T).  wave_in None = unit wave."""
+    mats = _mats(mats)
+    ref = wave_in if wave_in is not None else mats.map(0)
+    shape = tuple(ref.shape)
+    if wave_in is not None:
+        _need(wave_in, torch.complex64, "wave_in")
+    if out is None:
+        out = torch.empty(shape, dtype=torch.complex64, device=ref.device)
+    _need(out, torch.complex64, "wave_out", shape)
+    T, cp, ca, n = mats.cargs(shape)
+    check(lib().psx_transmit_wave_c64(_ptr(wave_in), c_float(amp), T, cp, ca, n, _ptr(out), out.numel(), _stream()),
+          "psx_transmit_wave_c64")
+    return out
+
+
+def transmit_rt(I_in, I0, mats, phi_in=None, want_phi=True, shape=None):
+    """K2 (Sample.py:347-348): I = I0*I_in*exp(sum catt*T); phi = phi_in + sum cphase*T (float64)."""
+    mats = _mats(mats)
+    ref = I_in if I_in is not None else mats.map(0)
+    shape = tuple(ref.shape)
+    if I_in is not None:
+        _need(I_in, torch.float32, "I_in")
+    if phi_in is not None:
+        _need(phi_in, torch.float64, "phi_in", shape)
+    I_out = torch.empty(shape, dtype=torch.float32, device=ref.device)
+    phi_out = torch.empty(shape, dtype=torch.float64, device=ref.device) if want_phi else None
+    T, cp, ca, n = mats.cargs(shape)
+    check(lib().psx_transmit_rt_f32(_ptr(I_in), c_float(I0), T, cp, ca, n, _ptr(I_out), _ptr(phi_in), _ptr(phi_out),
+                                    I_out.numel(), _stream()), "psx_transmit_rt_f32")
+    return I_out, phi_out
+
+
+def accumulate(acc, img, scale=1.0, mats=None, add=True):
+    """acc (+)= scale*img*exp(sum catt*T)  (Experiment.py:351-358, 478-483)."""
+    mats = _mats(mats)
+    _need(acc, torch.float32, "acc")
+    _need(img, torch.float32, "img", acc.shape)
+    T, cp, ca, n = mats.cargs(tuple(acc.shape))
+    check(lib().psx_accumulate_f32(_ptr(acc), _ptr(img), c_float(scale), T, ca, n, 1 if add else 0, acc.numel(),
+                                   _stream()), "psx_accumulate_f32")
+    return acc
+
+
+# ----------------------------------------------------------------------------------------------- refraction
+def refract(shape, mats, dscale, clamp, margin=15, I_in=None, I0=1.0, phi_in=None, out=None, out_scale=1.0, add=False,
+            want_D=False, I_mut=None):
+    """K9-K13 (refractionFileNumba2.py:25-86 + 198-263).  Returns (I_out, Dx|None, Dy|None); Dx,Dy are padded."""
+    mats = _mats(mats)
+    Nx, Ny = int(shape[0]), int(shape[1])
+    dev = (I_in if I_in is not None else (phi_in if phi_in is not None else mats.map(0))).device
+    if I_in is not None:
+        _need(I_in, torch.float32, "I_in", (Nx, Ny))
+    if phi_in is not None:
+        _need(phi_in, torch.float64, "phi_in", (Nx, Ny))
+    if out is None:
+        if add:
+            raise PsxError("add=True needs an existing output image")
+        out = torch.empty((Nx, Ny), dtype=torch.float32, device=dev)
+    _need(out, torch.float32, "I_out", (Nx, Ny))
+    Dx = Dy = None
+    if want_D:
+        Dx = torch.empty((Nx + 2 * margin, Ny + 2 * margin), dtype=torch.float32, device=dev)
+        Dy = torch.empty_like(Dx)
+    if I_mut is not None and (I_in is None or I_mut.data_ptr() != I_in.data_ptr()):
+        raise PsxError("I_mut must alias I_in")
+    ws = _workspace(dev, lib().psx_refract_workspace_bytes(Nx, Ny))
+    T, cp, ca, n = mats.cargs((Nx, Ny))
+    check(lib().psx_refract_f32(_ptr(I_in), c_float(I0), T, cp, ca, n, _ptr(phi_in), _ptr(out), c_float(out_scale),
+                                1 if add else 0, _ptr(Dx), _ptr(Dy), _ptr(I_mut), Nx, Ny, int(margin), c_double(dscale),
+                                c_double(clamp[0]), c_double(clamp[1]), _ptr(status_word(dev)), _ptr(ws), _stream()),
+          "psx_refract_f32")
+    return out, Dx, Dy
+
+
+def fastloop(I, Dx, Dy, I2):
+    """fastloopNumba (refractionFileNumba2.py:198-263) on explicit float32 displacement maps; accumulates into I2."""
+    _need(I, torch.float32, "I")
+    for nm, t in (("Dx", Dx), ("Dy", Dy), ("I2", I2)):
+        _need(t, torch.float32, nm, I.shape)
+    check(lib().psx_fastloop_f32(_ptr(I), _ptr(Dx), _ptr(Dy), _ptr(I2), I.shape[0], I.shape[1], _stream()),
+          "psx_fastloop_f32")
+    return I2
+
+
+# -------------------------------------------------------------------------------------------------- Fresnel
+class FresnelPlan:
+    """psx_fresnel_plan for one study grid (Experiment.wavePropagation, Experiment.py:219-252)."""
+
+    def __init__(self, Nx, Ny, margin=MARGIN_FRESNEL, max_dist=4, engine=_lib.ENGINE_AUTO, device=None):
+        self.Nx, self.Ny, self.margin, self.max_dist = int(Nx), int(Ny), int(margin), int(max_dist)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._h = c_void_p(None)
+        with torch.cuda.device(self.device):
+            check(lib().psx_fresnel_plan_create(self.Nx, self.Ny, self.margin, self.max_dist, int(engine),
+                                                ctypes.byref(self._h)), "psx_fresnel_plan_create")
+        self.engine = lib().psx_fresnel_plan_engine(self._h)
+        self.bytes = lib().psx_fresnel_plan_bytes(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().psx_fresnel_plan_destroy(self._h)
+            self._h = c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def propagate(self, a, gphase, du, wave_in=None, amp=1.0, mats=None, want_wave=None, inten_out=None,
+                  inten_scale=None, add=False):
+        """One input wave -> len(a) distances.  a[d]=z/(2kM), gphase[d]=kz/M, du=(du_x,du_y)=2*pi/(N*h).
+
+        want_wave[d]: return the complex field; inten_out[d]: float32 image that receives inten_scale[d]*|.|^2
+        (added when add=True).  Returns the list of complex outputs (None where not wanted)."""
+        mats = _mats(mats)
+        nd = len(a)
+        shape = (self.Nx, self.Ny)
+        if wave_in is not None:
+            _need(wave_in, torch.complex64, "wave_in", shape)
+        want_wave = [True] * nd if want_wave is None else list(want_wave)
+        inten_out = [None] * nd if inten_out is None else list(inten_out)
+        inten_scale = [1.0] * nd if inten_scale is None else [float(s) for s in inten_scale]
+        waves = [torch.empty(shape, dtype=torch.complex64, device=self.device) if w else None for w in want_wave]
+        for i, t in enumerate(inten_out):
+            if t is not None:
+                _need(t, torch.float32, "inten_out[%d]" % i, shape)
+        T, cp, ca, n = mats.cargs(shape)
+        wo = (c_void_p * nd)(*[w.data_ptr() if w is not None else None for w in waves])
+        io = (c_void_p * nd)(*[t.data_ptr() if t is not None else None for t in inten_out])
+        check(lib().psx_fresnel_propagate(self._h, _ptr(wave_in), c_float(amp), T, cp, ca, n, nd,
+                                          (c_double * nd)(*[float(v) for v in a]),
+                                          (c_double * nd)(*[float(v) for v in gphase]), c_double(du[0]), c_double(du[1]),
+                                          wo, io, (c_float * nd)(*inten_scale), 1 if add else 0, _stream()),
+              "psx_fresnel_propagate")
+        return waves
+
+
+# ------------------------------------------------------------------------------------------------- detector
+class DetectorPlan:
+    """psx_detector_plan: the composed blur/bin/PSF operator of Detector.detection (Detector.py:79-119)."""
+
+    def __init__(self, Nx, Ny, ov, nx, ny, sigma_src, sigma_psf, margin=MARGIN_DETECTOR, device=None):
+        self.Nx, self.Ny, self.nx, self.ny = int(Nx), int(Ny), int(nx), int(ny)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._h = c_void_p(None)
+        with torch.cuda.device(self.device):
+            check(lib().psx_detector_plan_create(self.Nx, self.Ny, int(ov), self.nx, self.ny, int(margin),
+                                                 c_double(sigma_src), c_double(sigma_psf), ctypes.byref(self._h)),
+                  "psx_detector_plan_create")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().psx_detector_plan_destroy(self._h)
+            self._h = c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def detect(self, img, out=None):
+        _need(img, torch.float32, "img", (self.Nx, self.Ny))
+        if out is None:
+            out = torch.empty((self.nx, self.ny), dtype=torch.float32, device=img.device)
+        _need(out, torch.float32, "out", (self.nx, self.ny))
+        check(lib().psx_detect_f32(self._h, _ptr(img), _ptr(out), _stream()), "psx_detect_f32")
+        return out
+
+
+def detector_operator_host(N, ov, n, sigma_src, sigma_psf, margin=MARGIN_DETECTOR):
+    """One axis of the composed detector operator, built on the host (no GPU): (start[n], weights[n][W])."""
+    import numpy as np
+    wcap = 4096
+    start = (c_int * n)()
+    weights = (c_float * (n * wcap))()
+    W = c_int(0)
+    check(lib().psx_detector_operator_host(int(N), int(ov), int(n), int(margin), c_double(sigma_src), c_double(sigma_psf),
+                                           start, weights, wcap, ctypes.byref(W)), "psx_detector_operator_host")
+    w = np.frombuffer(weights, dtype=np.float32).reshape(n, wcap)[:, :W.value].copy()
+    return np.frombuffer(start, dtype=np.int32).copy(), w
+
+
+def resize(img, sx, sy):
+    """Detector.resize (Detector.py:185-198): identity when sizes match, else s x s block sums, s = Nx//sx."""
+    _need(img, torch.float32, "img")
+    if img.shape[0] == sx and img.shape[1] == sy:
+        return img
+    out = torch.empty((sx, sy), dtype=torch.float32, device=img.device)
+    check(lib().psx_resize_f32(_ptr(img), img.shape[0], img.shape[1], _ptr(out), int(sx), int(sy), _stream()),
+          "psx_resize_f32")
+    return out
+
+
+def poisson(lam, seed):
+    """Shot noise (Detector.py:113-115) from a counter-based generator keyed by (seed, pixel)."""
+    _need(lam, torch.float32, "lam")
+    out = torch.empty_like(lam)
+    check(lib().psx_poisson_f32(_ptr(lam), _ptr(out), lam.numel(), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _stream()),
+          "psx_poisson_f32")
+    return out
+
+
+def status_scan(img):
+    _need(img, torch.float32, "img")
+    check(lib().psx_status_scan_f32(_ptr(img), img.numel(), _ptr(status_word(img.device)), _stream()),
+          "psx_status_scan_f32")

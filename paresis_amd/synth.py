@@ -40,7 +40,7 @@ def sphere_membrane(Nx, Ny, pix_m, pointNum=0, coverage=0.5, rmin=3.0, rmax=8.0,
     ox = ox.ravel()[None, :]
     oy = oy.ravel()[None, :]
     out = np.zeros(Nx * Ny, dtype=np.float64)
-    chunk = 20000
+    chunk = max(1, int(2e6 // ox.size))     # bound the scratch arrays to ~2M entries
     for s in range(0, n_s, chunk):
         ix = np.floor(cx[s:s + chunk]).astype(np.int64)[:, None] + ox
         iy = np.floor(cy[s:s + chunk]).astype(np.int64)[:, None] + oy

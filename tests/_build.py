@@ -1,0 +1,41 @@
+"""Build a paresis_amd Experiment from the injected configuration of tests/golden/experiment.npz (no XML)."""
+import numpy as np
+
+
+def build_experiment(cfg, sim, noise=False):
+    from paresis_amd.Detector import Detector
+    from paresis_amd.Experiment import Experiment
+    from paresis_amd.Sample import AnalyticalSample
+    from paresis_amd.Source import Source
+
+    energies = [e for e, _ in cfg["spectrum"]]
+    src = Source()
+    src.myName = "injected"
+    src.mySpectrum = list(cfg["spectrum"])
+    src.source_dict.update(mySize=cfg["source_size_um"], myEnergySampling=cfg["energy_sampling"],
+                           myType="Monochromatic" if len(energies) == 1 else "Polychromatic")
+    det = Detector({})
+    det.myName = "injected"
+    det.det_param.update(myDimensions=np.array(cfg["det_dims"]), myPixelSize=cfg["det_pix_um"], myPSF=cfg["psf"],
+                         myBinsThersholds=list(cfg["bins"]))
+
+    def sample(obj, name, mtype, mats):
+        if obj is None:
+            return None
+        s = AnalyticalSample()
+        s.myName, s.myType, s.myMaterials = name, mtype, list(mats)
+        s.myGeometry = obj.geometry
+        s.delta = [[(e, obj.delta[m][i]) for i, e in enumerate(energies)] for m in range(len(mats))]
+        s.beta = [[(e, obj.beta[m][i]) for i, e in enumerate(energies)] for m in range(len(mats))]
+        return s
+
+    exp_dict = {"experimentName": "injected", "overSampling": cfg["ov"], "nbExpPoints": 2,
+                "simulation_type": "RayT" if sim == "RT" else "Fresnel", "studyPixelSize": cfg["pix_um"],
+                "studyDimensions": list(cfg["N"]), "inVacuum": cfg["inVacuum"], "meanShotCount": cfg["meanShotCount"],
+                "meanEnergy": 0, "distSourceToMembrane": cfg["dSM"], "distMembraneToObject": cfg["dMO"],
+                "distObjectToDetector": cfg["dOD"], "magnification": cfg["M"], "noise": noise}
+    return Experiment.from_objects(exp_dict, src, det,
+                                   sample(cfg["membrane"], "membrane", "membrane", ["CuSn", "PMMA"]),
+                                   sample(cfg["sample"], "sample", "sample_of_interest", ["Nylon"]),
+                                   air=None if cfg["inVacuum"] else sample(cfg["air"], "air_volume", "volume", ["Air"]),
+                                   plate=sample(cfg["plate"], "plate", "thin_film", ["C"]))

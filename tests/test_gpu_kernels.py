@@ -1,0 +1,257 @@
+"""GPU parity of each HIP kernel family (through the C ABI) against the golden vectors and the CPU oracle.
+
+Tolerance: max|out-ref| / max|ref| <= 1e-5 (BASELINE.json north_star, fp32 vs the fp64 reference)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import paresis_oracle as orc
+from tests._golden import load, relmax
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from paresis_amd import ops as _ops
+    from paresis_amd._lib import lib
+    assert lib().psx_device_ok() == 1, lib().psx_last_error()
+    return _ops
+
+
+def dev(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).cuda()
+
+
+def test_transmission_golden(ops):
+    g = load("transmission.npz")
+    T = dev(g["T"], torch.float32)
+    for ie, E in enumerate(g["energies"]):
+        k = orc.k_sample(E)
+        dl, bl = g["delta"][:, ie], g["beta"][:, ie]
+        m = ops.MaterialStack(T, cphase=-k * dl, catt=-k * bl)
+        out = ops.transmit_wave(dev(g["wave_in"], torch.complex64), 1.0, m)
+        assert relmax(out.cpu().numpy(), g["setWave/%d" % ie]) < TOL
+        m2 = ops.MaterialStack(T, cphase=-k * dl, catt=-2 * k * bl)
+        I, phi = ops.transmit_rt(dev(g["I_in"], torch.float32), 1.0, m2, dev(g["phi_in"], torch.float64))
+        assert relmax(I.cpu().numpy(), g["setWaveRT/%d/I" % ie]) < TOL
+        assert relmax(phi.cpu().numpy(), g["setWaveRT/%d/phi" % ie]) < 1e-12   # float64 on the device
+        # unit wave / ones intensity through NULL inputs
+        out1 = ops.transmit_wave(None, 2.0, m)
+        ref1 = orc.set_wave(np.full(T.shape[1:], 2.0 + 0j), g["T"], dl, bl, E)
+        assert relmax(out1.cpu().numpy(), ref1) < TOL
+        # in place
+        w = dev(g["wave_in"], torch.complex64)
+        ops.transmit_wave(w, 1.0, m, out=w)
+        assert relmax(w.cpu().numpy(), g["setWave/%d" % ie]) < TOL
+
+
+def test_accumulate(ops):
+    rng = np.random.default_rng(1)
+    img = rng.uniform(1, 2, (33, 47)); acc0 = rng.uniform(1, 2, (33, 47)); T = rng.uniform(0, 1e-3, (1, 33, 47))
+    acc = dev(acc0, torch.float32)
+    m = ops.MaterialStack(dev(T, torch.float32), catt=[-700.0])
+    ops.accumulate(acc, dev(img, torch.float32), 0.5, m, add=True)
+    ref = acc0 + 0.5 * img * np.exp(-700.0 * T[0].astype(np.float32).astype(np.float64))
+    assert relmax(acc.cpu().numpy(), ref) < 1e-6
+    ops.accumulate(acc, dev(img, torch.float32), 2.0, None, add=False)
+    assert relmax(acc.cpu().numpy(), 2.0 * img) < 1e-6
+
+
+@pytest.mark.parametrize("engine", [1, 0])
+def test_fresnel_golden(ops, engine):
+    g = load("fresnel.npz")
+    worst = 0.0
+    for k in range(int(g["n"])):
+        z, E, M, pix = g["%d/params" % k]
+        w = g["%d/wave" % k]
+        Nx, Ny = w.shape
+        plan = ops.FresnelPlan(Nx, Ny, engine=engine)
+        kk = orc.getk(E * 1000)
+        a = z / (2 * kk * M)
+        du = (2 * np.pi / (Nx * pix * 1e-6), 2 * np.pi / (Ny * pix * 1e-6))
+        inten = torch.zeros((Nx, Ny), dtype=torch.float32, device="cuda")
+        out = plan.propagate([a], [kk * z / M], du, wave_in=dev(w, torch.complex64), inten_out=[inten])[0]
+        err = relmax(out.cpu().numpy(), g["%d/out" % k])
+        worst = max(worst, err)
+        assert err < TOL, (k, err)
+        assert relmax(inten.cpu().numpy(), np.abs(g["%d/out" % k]) ** 2) < TOL
+        plan.close()
+    print("fresnel engine", engine, "worst rel err", worst)
+
+
+@pytest.mark.parametrize("engine", [1, 0])
+def test_fresnel_fused_transmission_and_shared_forward(ops, engine):
+    """K1 fused into the padded load; two distances share one forward transform (EXP:341 and EXP:349)."""
+    g = load("transmission.npz")
+    T64 = g["T"]
+    Nx, Ny = T64.shape[1:]
+    E, pix = 52.0, 2.9
+    k = orc.k_sample(E)
+    dl, bl = g["delta"][:, 0], g["beta"][:, 0]
+    m = ops.MaterialStack(dev(T64, torch.float32), cphase=-k * dl, catt=-k * bl)
+    w0 = orc.set_wave(np.full((Nx, Ny), 86.6 + 0j), T64, dl, bl, E)
+    plan = ops.FresnelPlan(Nx, Ny, engine=engine)
+    zs = [(1.6, 141.6 / 140), (5.2, 145.2 / 141.6), (0.0, 1.0)]
+    kk = orc.getk(E * 1000)
+    du = (2 * np.pi / (Nx * pix * 1e-6), 2 * np.pi / (Ny * pix * 1e-6))
+    acc = [torch.ones((Nx, Ny), dtype=torch.float32, device="cuda") for _ in zs]
+    outs = plan.propagate([z / (2 * kk * M) for z, M in zs], [kk * z / M for z, M in zs], du, amp=86.6, mats=m,
+                          inten_out=acc, inten_scale=[1.0, 0.5, 2.0], add=True)
+    for (z, M), o, ac, sc in zip(zs, outs, acc, [1.0, 0.5, 2.0]):
+        ref = orc.wave_propagation(w0, z, E, M, (Nx, Ny), pix)
+        assert relmax(o.cpu().numpy(), ref) < TOL
+        assert relmax(ac.cpu().numpy(), 1.0 + sc * np.abs(ref) ** 2) < TOL
+    plan.close()
+
+
+def test_fresnel_known_answers(ops):
+    # uniform wave keeps its modulus (reflect pad of a constant is constant: only the DC bin, chirp(0)=1)
+    plan = ops.FresnelPlan(40, 44)
+    w = torch.full((40, 44), 3.0 + 0j, dtype=torch.complex64, device="cuda")
+    out = plan.propagate([1.3e-9], [0.7], (5e4, 4e4), wave_in=w)[0]
+    assert np.allclose(np.abs(out.cpu().numpy()), 3.0, rtol=2e-6)
+
+
+@pytest.mark.parametrize("ver", ["v2", "v1"])
+def test_refraction_golden_phi64(ops, ver):
+    """Signature-faithful path: explicit float64 phase array."""
+    g = load("refraction.npz")
+    margin = 15 if ver == "v2" else 10
+    for k in range(int(g["n"])):
+        z, E, M, pix = g["%d/params" % k]
+        I = g["%d/I" % k]; phi = g["%d/phi" % k]
+        Nx, Ny = I.shape
+        h = pix * 1e-6
+        dscale = z / orc.k_refraction(E) / (h * M) / h
+        clamp = (Nx, Ny) if ver == "v2" else (1e3, 1e3)
+        Iin = dev(I, torch.float32)
+        out, Dx, Dy = ops.refract((Nx, Ny), None, dscale, clamp, margin=margin, I_in=Iin, phi_in=dev(phi, torch.float64),
+                                  want_D=True, I_mut=Iin)
+        ops.check_status(out.device)
+        assert relmax(out.cpu().numpy(), g["%d/%s/out" % (k, ver)]) < TOL, (k, ver)
+        assert relmax(Dx.cpu().numpy(), g["%d/%s/Dx" % (k, ver)]) < 1e-6
+        assert relmax(Dy.cpu().numpy(), g["%d/%s/Dy" % (k, ver)]) < 1e-6
+        assert relmax(Iin.cpu().numpy(), g["%d/%s/I_after" % (k, ver)]) < 1e-6     # clamped rays zeroed in place
+
+
+def test_refraction_from_thickness_maps(ops):
+    """Fused path: phase and attenuation formed on the device from float32 thickness maps (never phi in fp32)."""
+    g = load("refraction.npz")
+    for k in range(int(g["n"])):
+        z, E, M, pix = g["%d/params" % k]
+        T = g["%d/T" % k]
+        Nx, Ny = T.shape
+        kk = orc.k_sample(E)
+        slab = np.full_like(T, 6e-3)
+        geom = np.stack([T, slab])
+        I_ref, phi_ref, _ = orc.set_wave_rt(np.full((Nx, Ny), 7500.0), geom, [6.2e-7, 9.87e-8], [4.0e-9, 4.5e-11], E, 0)
+        ref, Dxr, Dyr = orc.fast_refraction(I_ref.copy(), phi_ref, z, E, M, pix)
+        m = ops.MaterialStack(dev(geom, torch.float32), cphase=[-kk * 6.2e-7, -kk * 9.87e-8],
+                              catt=[-2 * kk * 4.0e-9, -2 * kk * 4.5e-11])
+        h = pix * 1e-6
+        out, Dx, Dy = ops.refract((Nx, Ny), m, z / orc.k_refraction(E) / (h * M) / h, (Nx, Ny), I0=7500.0, want_D=True)
+        assert relmax(out.cpu().numpy(), ref) < TOL, k
+        assert relmax(Dx.cpu().numpy(), Dxr) < 1e-6
+        # accumulate + scale
+        acc = torch.full((Nx, Ny), 3.0, dtype=torch.float32, device="cuda")
+        ops.refract((Nx, Ny), m, z / orc.k_refraction(E) / (h * M) / h, (Nx, Ny), I0=7500.0, out=acc, out_scale=0.5, add=True)
+        assert relmax(acc.cpu().numpy(), 3.0 + 0.5 * ref) < TOL
+
+
+def test_refraction_known_answers(ops):
+    rng = np.random.default_rng(3)
+    Nx, Ny = 70, 131
+    I = rng.uniform(1, 2, (Nx, Ny)).astype(np.float32)
+    # phi = const -> D == 0 -> identity (RF2:222-224)
+    out, _, _ = ops.refract((Nx, Ny), None, 1.0, (Nx, Ny), I_in=dev(I, torch.float32),
+                            phi_in=torch.full((Nx, Ny), 123.456, dtype=torch.float64, device="cuda"))
+    assert np.array_equal(out.cpu().numpy(), I)
+    # phi linear along axis 0 -> uniform integer shift by s pixels
+    s = 3
+    phi = (np.arange(Nx, dtype=np.float64) * s)[:, None] * np.ones((1, Ny))
+    out, Dx, _ = ops.refract((Nx, Ny), None, 1.0, (Nx, Ny), I_in=dev(I, torch.float32), phi_in=dev(phi, torch.float64), want_D=True)
+    o = out.cpu().numpy()
+    assert np.allclose(o[s:], I[:-s], rtol=1e-6) and np.all(o[:s] == 0)
+    assert np.allclose(Dx.cpu().numpy()[15:-15, 15:-15], s)
+    # flux conservation when nothing leaves the grid: shift by a fraction inside a zero border
+    I2 = np.zeros((Nx, Ny), np.float32); I2[20:50, 20:100] = I[20:50, 20:100]
+    phi = 0.37 * np.arange(Nx, dtype=np.float64)[:, None] - 1.6 * np.arange(Ny, dtype=np.float64)[None, :]
+    out, _, _ = ops.refract((Nx, Ny), None, 1.0, (Nx, Ny), I_in=dev(I2, torch.float32), phi_in=dev(phi, torch.float64))
+    assert abs(float(out.sum().item()) / float(I2.sum()) - 1) < 1e-5
+
+
+def test_refraction_far_rays_and_border_rules(ops):
+    """Displacements far beyond the gather halo (and beyond the margin) go through the far-ray replay."""
+    rng = np.random.default_rng(5)
+    Nx, Ny = 150, 97
+    I = rng.uniform(1, 2, (Nx, Ny))
+    phi = np.cumsum(rng.uniform(-30, 30, (Nx, Ny)), axis=0) + np.cumsum(rng.uniform(-30, 30, (Nx, Ny)), axis=1)
+    I32 = I.astype(np.float32).astype(np.float64)
+    ref, Dxr, Dyr = orc.fast_refraction(I32.copy(), phi.copy(), 1.0, 52.0, 1.0, 1.0)   # arbitrary scale
+    k = orc.k_refraction(52.0)
+    dscale = 1.0 / k / (1e-6 * 1.0) / 1e-6
+    out, Dx, Dy = ops.refract((Nx, Ny), None, dscale, (Nx, Ny), I_in=dev(I32, torch.float32), phi_in=dev(phi, torch.float64), want_D=True)
+    assert np.abs(Dxr).max() > 20
+    assert relmax(Dx.cpu().numpy(), Dxr) < 1e-6
+    assert relmax(out.cpu().numpy(), ref) < TOL
+
+
+def test_refraction_status_flag(ops):
+    Nx, Ny = 64, 64
+    I = torch.full((Nx, Ny), float("inf"), dtype=torch.float32, device="cuda")
+    ops.refract((Nx, Ny), None, 1.0, (Nx, Ny), I_in=I, phi_in=torch.zeros((Nx, Ny), dtype=torch.float64, device="cuda"))
+    with pytest.raises(Exception, match="nans or insane"):
+        ops.check_status(I.device)
+    ops.check_status(I.device)   # cleared
+
+
+def test_fastloop_golden(ops):
+    g = load("refraction.npz")
+    I2 = torch.zeros(g["loop/I"].shape, dtype=torch.float32, device="cuda")
+    ops.fastloop(dev(g["loop/I"], torch.float32), dev(g["loop/Dx"], torch.float32), dev(g["loop/Dy"], torch.float32), I2)
+    assert relmax(I2.cpu().numpy(), g["loop/out"]) < TOL
+
+
+def test_detector_golden(ops):
+    g = load("detector.npz")
+    for k in range(int(g["n"])):
+        d0, d1, ov, fwhm, psf = g["%d/params" % k]
+        img = g["%d/in" % k]
+        plan = ops.DetectorPlan(img.shape[0], img.shape[1], int(ov), int(d0), int(d1), fwhm / 2.355, psf)
+        out = plan.detect(dev(img, torch.float32))
+        assert relmax(out.cpu().numpy(), g["%d/out" % k]) < TOL, k
+        plan.close()
+
+
+def test_resize_golden(ops):
+    g = load("scalars.npz")
+    for k in range(int(g["resize/n"])):
+        sx, sy = (int(v) for v in g["resize/%d/size" % k])
+        out = ops.resize(dev(g["resize/%d/in" % k], torch.float32), sx, sy)
+        assert relmax(out.cpu().numpy(), g["resize/%d/out" % k]) < 1e-6
+
+
+def test_poisson_statistics(ops):
+    for lam in (0.5, 4.0, 30.0, 7500.0):
+        x = ops.poisson(torch.full((400, 500), lam, dtype=torch.float32, device="cuda"), seed=1234).cpu().numpy().astype(np.float64)
+        n = x.size
+        assert abs(x.mean() - lam) < 6 * np.sqrt(lam / n), (lam, x.mean())
+        assert abs(x.var() / lam - 1) < 0.02, (lam, x.var())
+        assert np.all(x == np.floor(x)) and x.min() >= 0
+    a = ops.poisson(torch.full((64, 64), 20.0, dtype=torch.float32, device="cuda"), seed=7)
+    b = ops.poisson(torch.full((64, 64), 20.0, dtype=torch.float32, device="cuda"), seed=7)
+    c = ops.poisson(torch.full((64, 64), 20.0, dtype=torch.float32, device="cuda"), seed=8)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_bad_arguments_raise(ops):
+    from paresis_amd._lib import PsxError
+    with pytest.raises(PsxError):
+        ops.transmit_wave(torch.zeros((4, 4), dtype=torch.complex64), 1.0, None)   # CPU tensor: no CPU path
+    with pytest.raises(PsxError):
+        ops.FresnelPlan(8, 8, margin=15)                                           # reflect margin larger than grid
+    with pytest.raises(PsxError):
+        ops.refract((2, 2), None, 1.0, (2, 2), phi_in=torch.zeros((2, 2), dtype=torch.float64, device="cuda"))

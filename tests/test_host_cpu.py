@@ -1,0 +1,147 @@
+"""CPU-side checks (no GPU): the C ABI library loads and exports every symbol include/paresis_hip.h declares, host logic
+(detector operator composition, XML loading, geometry, position sharding, image I/O) behaves like the reference."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import paresis_oracle as orc
+from tests._golden import load, relmax
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "paresis_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(psx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from paresis_amd import _lib
+    lib = _lib.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), name
+        assert name in _lib.PROTOTYPES, "binding missing for " + name
+    assert sorted(_lib.PROTOTYPES) == declared
+    assert lib.psx_abi_version() == _lib.ABI_VERSION
+
+
+def test_bad_arguments_fail_loudly_without_gpu():
+    import ctypes
+    from paresis_amd import _lib
+    lib = _lib.lib()
+    assert lib.psx_refract_workspace_bytes(100, 50) == 16 + 4 * 5000
+    plan = ctypes.c_void_p(None)
+    rc = lib.psx_fresnel_plan_create(8, 8, 15, 1, 0, ctypes.byref(plan))      # margin >= grid
+    assert rc == -1 and b"margin" in lib.psx_last_error()
+    with pytest.raises(_lib.PsxError):
+        _lib.check(rc, "psx_fresnel_plan_create")
+    rc = lib.psx_transmit_wave_c64(None, 1.0, None, None, None, 99, None, 10, None)
+    assert rc == -1
+
+
+def test_no_cpu_fallback():
+    import torch
+    from paresis_amd import ops
+    from paresis_amd._lib import PsxError
+    with pytest.raises(PsxError, match="no CPU path|HBM"):
+        ops.transmit_wave(torch.zeros((4, 4), dtype=torch.complex64), 1.0, None)
+    if not torch.cuda.is_available():
+        from paresis_amd.Detector import resize
+        with pytest.raises(PsxError, match="no CPU fallback"):
+            resize(np.ones((4, 4)), 2, 2)
+
+
+@pytest.mark.parametrize("k", range(7))
+def test_detector_operator_matches_oracle(k):
+    """The composed banded operator (host, float64->float32) applied with numpy reproduces Detector.detection."""
+    from paresis_amd import ops
+    g = load("detector.npz")
+    d0, d1, ov, fwhm, psf = g["%d/params" % k]
+    img = g["%d/in" % k]
+    sig = fwhm / 2.355 if fwhm != 0 else 0.0
+    sx, wx = ops.detector_operator_host(img.shape[0], int(ov), int(d0), sig, psf)
+    sy, wy = ops.detector_operator_host(img.shape[1], int(ov), int(d1), sig, psf)
+
+    def dense(start, w, N):
+        C = np.zeros((len(start), N))
+        for r in range(len(start)):
+            n = min(w.shape[1], N - start[r])
+            C[r, start[r]:start[r] + n] = w[r, :n]
+        return C
+
+    out = dense(sx, wx, img.shape[0]) @ img @ dense(sy, wy, img.shape[1]).T
+    assert relmax(out, g["%d/out" % k]) < 2e-7
+    assert relmax(out, orc.detection(img, fwhm, int(ov), (int(d0), int(d1)), psf)) < 2e-7
+
+
+def test_detector_operator_known_answers():
+    from paresis_amd import ops
+    # uniform image: blur + PSF preserve the level in the interior, binning multiplies by ov^2 (bin SUM, DET:196)
+    s, w = ops.detector_operator_host(64, 4, 16, 1.5, 1.2)
+    assert np.allclose(w.sum(axis=1)[4:-4], 4.0, rtol=1e-6)
+    s, w = ops.detector_operator_host(32, 1, 32, 0.0, 0.0)
+    assert w.shape[1] == 1 and np.all(w == 1) and np.array_equal(s, np.arange(32))
+
+
+def test_xml_experiment_loads_like_the_reference(monkeypatch):
+    """Experiment(exp_dict) parses the four XML files; checked without touching the GPU (geometry stays on the host)."""
+    from paresis_amd.Experiment import Experiment
+    ed = {"experimentName": "Fil_Nylon_ID17", "filepath": "/tmp/", "overSampling": 2, "nbExpPoints": 1,
+          "simulation_type": "RayT"}
+    exp = Experiment(ed)
+    assert ed["distSourceToMembrane"] == 140 and ed["distMembraneToObject"] == 1.6 and ed["distObjectToDetector"] == 3.6
+    assert ed["inVacuum"] is True and ed["meanShotCount"] == 30000
+    assert abs(ed["magnification"] - 145.2 / 141.6) < 1e-15                   # EXP:81
+    assert ed["studyDimensions"] == [400, 400]                                # EXP:213
+    assert abs(ed["studyPixelSize"] - 6 / 2 / (145.2 / 141.6)) < 1e-15        # EXP:216
+    assert exp.mySource.mySpectrum == [(52.0, 1)]                             # SRC:90-93
+    assert exp.myMembrane.myMaterials == ["CuSn", "PMMA"] and exp.mySampleofInterest.myMaterials == ["Nylon"]
+    assert abs(exp.myMembrane.membranePixelSize - ed["studyPixelSize"] * 140 / 141.6) < 1e-15   # EXP:96
+    assert exp.mySampleofInterest.myGeometry.shape == (1, 400, 400)
+    assert exp.myAirVolume.myGeometry.shape == (1, 400, 400)
+    assert abs(float(exp.myAirVolume.myGeometry[0, 0, 0]) - 145.2) < 1e-4
+    exp.myMembrane.getMyGeometry(ed["studyDimensions"], exp.myMembrane.membranePixelSize, 2, 0, 1)
+    g0 = np.array(exp.myMembrane.myGeometry)
+    exp.myMembrane.getMyGeometry(ed["studyDimensions"], exp.myMembrane.membranePixelSize, 2, 1, 1)
+    assert g0.shape == (2, 400, 400) and not np.array_equal(g0, exp.myMembrane.myGeometry)
+    exp.myMembrane.getMyGeometry(ed["studyDimensions"], exp.myMembrane.membranePixelSize, 2, 0, 1)
+    assert np.array_equal(g0, exp.myMembrane.myGeometry)                      # seeded per position
+    with pytest.raises(ValueError, match="experiment not found"):
+        Experiment({"experimentName": "nope", "overSampling": 2, "nbExpPoints": 1, "simulation_type": "RayT"})
+
+
+def test_xml_plate_and_psf_experiment():
+    from paresis_amd.Experiment import Experiment
+    ed = {"experimentName": "Sphere_PMMA_plate", "filepath": "/tmp/", "overSampling": 1, "nbExpPoints": 1,
+          "simulation_type": "Fresnel"}
+    exp = Experiment(ed)
+    assert exp.myPlate is not None and exp.myPlate.myMaterials == ["CarbonFiber"]
+    assert abs(float(exp.myPlate.myGeometry[0, 0, 0]) - 2.5e-3) < 1e-9
+    assert ed["inVacuum"] is False and exp.myDetector.det_param["myPSF"] == 1.2
+    assert ed["studyDimensions"] == [300, 200]
+
+
+def test_image_io_roundtrip(tmp_path):
+    from paresis_amd.InputOutput.pagailleIO import openImage, save_image
+    img = np.random.default_rng(0).uniform(0, 1e4, (37, 53)).astype(np.float32)
+    for ext in (".tif", ".edf", ".npy"):
+        p = str(tmp_path / ("img" + ext))
+        save_image(img, p)
+        assert np.array_equal(openImage(p), img)
+
+
+def test_position_partition():
+    from paresis_amd import dist
+    for world in (1, 2, 3, 8):
+        seen = sorted(p for r in range(world) for p in dist.my_positions(64, r, world))
+        assert seen == list(range(64))
+        assert dist.my_positions(64, 0, world)[0] == 0       # position 0 (Propag/White) stays on rank 0
+    from paresis_amd import synth
+    assert synth.position_seed(5) == 1005
+    a = synth.sphere_membrane(64, 48, 3e-6, 2)
+    assert np.array_equal(a, synth.sphere_membrane(64, 48, 3e-6, 2)) and a.dtype == np.float32
