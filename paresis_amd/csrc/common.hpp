@@ -54,19 +54,37 @@ __device__ __forceinline__ void cis_f64(double ph, float &c, float &s) {
     sincosf((float)r, &s, &c);
 }
 
-// sum_m cphase[m]*T[m][p] and sum_m catt[m]*T[m][p] in float64
+// sum_m cphase[m]*T[m][p] and sum_m catt[m]*T[m][p] in float64.
+// NM is the compile-time material count the kernel was instantiated for (pack_mats pads unused slots with T[0] and zero
+// coefficients), so the NM loads are unconditional and independent: the compiler issues them together and waits once.
+// (A run-time `if (i < n)` around each load makes hipcc wait vmcnt(0) per material -- guide, "register or load" trap.)
+template <int NM>
 __device__ __forceinline__ void mats_eval(const Mats &m, int64_t p, double &ph, double &la) {
+    float t[NM > 0 ? NM : 1];
+#pragma unroll
+    for (int i = 0; i < NM; ++i) t[i] = m.T[i][p];
     ph = 0.0;
     la = 0.0;
 #pragma unroll
-    for (int i = 0; i < PSX_MAX_MAT; ++i) {
-        if (i < m.n) {
-            const double t = (double)m.T[i][p];
-            ph = fma(m.cphase[i], t, ph);
-            la = fma(m.catt[i], t, la);
-        }
+    for (int i = 0; i < NM; ++i) {
+        ph = fma(m.cphase[i], (double)t[i], ph);
+        la = fma(m.catt[i], (double)t[i], la);
     }
 }
+
+// smallest instantiated count >= n
+inline int mats_variant(int n) { return n <= 4 ? n : 8; }
+
+// instantiate the statement for the variant matching n; NM is the compile-time count inside it
+#define PSX_DISPATCH_NMAT(n, ...)                    \
+    switch (psx::mats_variant(n)) {                  \
+        case 0: { constexpr int NM = 0; __VA_ARGS__; } break; \
+        case 1: { constexpr int NM = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int NM = 2; __VA_ARGS__; } break; \
+        case 3: { constexpr int NM = 3; __VA_ARGS__; } break; \
+        case 4: { constexpr int NM = 4; __VA_ARGS__; } break; \
+        default: { constexpr int NM = 8; __VA_ARGS__; } break; \
+    }
 
 // ---- optional per-kernel timing with HIP events on the launch stream (psx_profile_*) ---------------------------------
 // Off by default: a ProfScope then costs one branch.  When on, every kernel launch of the library is bracketed by two

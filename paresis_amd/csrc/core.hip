@@ -34,6 +34,8 @@ int pack_mats(Mats &m, const float *const *T, const double *cphase, const double
         m.cphase[i] = cphase ? cphase[i] : 0.0;
         m.catt[i] = catt ? catt[i] : 0.0;
     }
+    // pad up to the instantiated variant with a valid map and zero coefficients (see mats_eval)
+    for (int i = nmat; i < mats_variant(nmat); ++i) m.T[i] = T[0];
     return 0;
 }
 

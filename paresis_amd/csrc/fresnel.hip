@@ -24,6 +24,7 @@ namespace {
             return psx::fail(1000 + (int)s__, "%s:%d: %s -> rocfft_status %d", __FILE__, __LINE__, #expr, (int)s__); \
     } while (0)
 
+template <int NM>
 __global__ __launch_bounds__(256) void k_pad_transmit(const float2 *__restrict__ wave_in, float amp, Mats m,
                                                       float2 *__restrict__ out, int Nx, int Ny, int margin, int Px,
                                                       int Py) {
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void k_pad_transmit(const float2 *__restrict__
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
         const int pi = (int)(q / Py), pj = (int)(q - (int64_t)pi * Py);
         const int i = reflect_index(pi - margin, Nx), j = reflect_index(pj - margin, Ny);
-        out[q] = source_wave(wave_in, amp, m, (int64_t)i * Ny + j);
+        out[q] = source_wave<NM>(wave_in, amp, m, (int64_t)i * Ny + j);
     }
 }
 
@@ -130,8 +131,8 @@ int rocfft_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
     RocfftEngine *e = p->rf;
     hipStream_t st = a.stream;
     const int64_t npad = (int64_t)p->Px * p->Py, n = (int64_t)p->Nx * p->Ny;
-    PSX_TIMED("k_pad_transmit", st, k_pad_transmit<<<ew_grid(npad, 256), 256, 0, st>>>(a.wave_in, a.amp, a.m, e->spec, p->Nx, p->Ny, p->margin, p->Px,
-                                                      p->Py));
+    PSX_DISPATCH_NMAT(a.m.n, PSX_TIMED("k_pad_transmit", st, k_pad_transmit<NM><<<ew_grid(npad, 256), 256, 0, st>>>(a.wave_in, a.amp, a.m, e->spec, p->Nx, p->Ny, p->margin, p->Px,
+                                                      p->Py)));
     if (int rc = launch_check("k_pad_transmit")) return rc;
     bool need_fft = false;
     for (int d = 0; d < a.n_dist; ++d) {

@@ -55,12 +55,13 @@ void lds_engine_destroy(psx_fresnel_plan *p);
 int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a);
 
 // psi(p) = amp * wave_in * transmission at UN-padded pixel p
+template <int NM>
 __device__ __forceinline__ float2 source_wave(const float2 *__restrict__ wave_in, float amp, const Mats &m, int64_t p) {
     float2 w = wave_in ? wave_in[p] : make_float2(1.f, 0.f);
     float a = amp;
-    if (m.n > 0) {
+    if (NM > 0) {
         double ph, la;
-        mats_eval(m, p, ph, la);
+        mats_eval<NM>(m, p, ph, la);
         float c, s;
         cis_f64(ph, c, s);
         a *= expf((float)la);

@@ -12,6 +12,8 @@
 //
 // HBM traffic per pixel: 4*nmat (thickness maps) + 4 (intensity, if given) read, 4 written  (BASELINE.md section 4
 // prices the scatter at 12+4*nmat because the reference zero-initialises and read-modify-writes its output).
+#include <type_traits>
+
 #include "common.hpp"
 
 using namespace psx;
@@ -24,6 +26,7 @@ constexpr int H = 4;            // gather halo: rays with floor(D) in [-H, H-1] 
 constexpr int SR = TH + 2 * H + 2;   // staged rows (one more ring for the gradient stencil)
 constexpr int SC = TW + 2 * H + 2;
 constexpr int NTHREADS = 512;
+constexpr int FAR_THREADS = 128;
 constexpr int GR = TH + 2 * H, GC = TW + 2 * H;   // source rows/cols gathered by one tile
 
 struct RefractArgs {
@@ -39,8 +42,8 @@ struct RefractArgs {
     int Nx, Ny, margin;
     double dscale, clamp_x, clamp_y;
     unsigned *status;
-    unsigned *far_count;     // workspace[0]
-    int *far_list;           // workspace + 16 B, capacity Nx*Ny
+    unsigned *far_count;     // workspace: [ntiles] far rays found by each tile
+    int *far_list;           // then [ntiles][TH*TW] their source pixels (a tile can never overflow its slot)
     int tiles_x, tiles_y;
 };
 
@@ -103,35 +106,60 @@ __device__ __forceinline__ int xcd_tile(int b, int nt) {
     return x * q + (x < r ? x : r) + (b >> 3);
 }
 
+template <int NM, bool HAS_I, bool HAS_PHI>
 __global__ __launch_bounds__(NTHREADS) void k_refract_near(RefractArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *sphi = (double *)smem;                               // [SR][SC]
     float *sI = (float *)(smem + sizeof(double) * SR * SC);      // [GR][GC]
     float *sacc = sI + GR * GC;                                  // [TH][TW]
+    unsigned *sfar = (unsigned *)(sacc + TH * TW);               // far rays of this tile so far
 
     const int nt = a.tiles_x * a.tiles_y;
     const int tile = xcd_tile(blockIdx.x, nt);
     const int r0 = (tile / a.tiles_y) * TH, c0 = (tile % a.tiles_y) * TW;
     const int tid = threadIdx.x;
 
-    // ---- stage phi (float64) and source intensity for rows [r0-H-1, r0+TH+H+1) x cols [c0-H-1, c0+TW+H+1)
-    for (int idx = tid; idx < SR * SC; idx += NTHREADS) {
-        const int sr = idx / SC, sc = idx - sr * SC;
-        const int i = r0 - H - 1 + sr, j = c0 - H - 1 + sc;
-        double ph = 0.0;
-        float I = 0.f;
-        if (i >= 0 && i < a.Nx && j >= 0 && j < a.Ny) {
-            const int64_t p = (int64_t)i * a.Ny + j;
-            double la;
-            mats_eval(a.m, p, ph, la);
-            if (a.phi_in) ph += a.phi_in[p];
-            I = a.I0 * (a.I_in ? a.I_in[p] : 1.f);
-            if (la != 0.0) I *= expf((float)la);
+    // ---- stage phi (float64) and source intensity for rows [r0-H-1, r0+TH+H+1) x cols [c0-H-1, c0+TW+H+1).
+    // Addresses are clamped into the image so every load is unconditional (they can all be in flight together);
+    // out-of-image entries are zeroed afterwards and never used as sources.
+    constexpr int SITERS = (SR * SC + NTHREADS - 1) / NTHREADS;
+    constexpr int U = 4;   // staged pixels per thread whose loads are issued together
+    for (int it0 = 0; it0 < SITERS; it0 += U) {
+        float t[U][NM > 0 ? NM : 1], Iin[U];
+        double phin[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = (it0 + u) * NTHREADS + tid;
+            const int sr = idx / SC, sc = idx - sr * SC;
+            const int i = r0 - H - 1 + sr, j = c0 - H - 1 + sc;
+            ok[u] = idx < SR * SC && i >= 0 && i < a.Nx && j >= 0 && j < a.Ny;
+            const int64_t p = (int64_t)min(max(i, 0), a.Nx - 1) * a.Ny + min(max(j, 0), a.Ny - 1);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) t[u][m] = a.m.T[m][p];
+            Iin[u] = HAS_I ? a.I_in[p] : 1.f;
+            phin[u] = HAS_PHI ? a.phi_in[p] : 0.0;
         }
-        sphi[idx] = ph;
-        if (sr >= 1 && sr <= GR && sc >= 1 && sc <= GC) sI[(sr - 1) * GC + (sc - 1)] = I;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = (it0 + u) * NTHREADS + tid;
+            const int sr = idx / SC, sc = idx - sr * SC;
+            double ph = phin[u], la = 0.0;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                ph = fma(a.m.cphase[m], (double)t[u][m], ph);
+                la = fma(a.m.catt[m], (double)t[u][m], la);
+            }
+            float I = a.I0 * Iin[u];
+            if (NM > 0) I *= expf((float)la);
+            if (idx < SR * SC) {
+                sphi[idx] = ok[u] ? ph : 0.0;
+                if (sr >= 1 && sr <= GR && sc >= 1 && sc <= GC) sI[(sr - 1) * GC + (sc - 1)] = ok[u] ? I : 0.f;
+            }
+        }
     }
     for (int idx = tid; idx < TH * TW; idx += NTHREADS) sacc[idx] = 0.f;
+    if (tid == 0) *sfar = 0u;
     __syncthreads();
 
     auto phi_at = [&](int i, int j) -> double { return sphi[(i - (r0 - H - 1)) * SC + (j - (c0 - H - 1))]; };
@@ -175,17 +203,18 @@ __global__ __launch_bounds__(NTHREADS) void k_refract_near(RefractArgs a) {
                 if (i1 && j1 && w11 != 0.f) atomicAdd(&sacc[(ti + 1) * TW + tj + 1], I * w11);
             }
         }
-        // wave-aggregated append of far rays (one global atomic per wave)
+        // wave-aggregated append of far rays to this tile's own list: one LDS atomic per wave, no global atomics
+        // (a single global counter saturates at ~90 returning atomics per microsecond on this chip)
         const unsigned long long mask = __ballot(far);
         if (mask) {
             const int lane = tid & 63;
             const int leader = __ffsll((long long)mask) - 1;
             unsigned base = 0;
-            if (lane == leader) base = atomicAdd(a.far_count, (unsigned)__popcll(mask));
+            if (lane == leader) base = atomicAdd(sfar, (unsigned)__popcll(mask));
             base = __shfl(base, leader);
             if (far) {
                 const unsigned rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-                a.far_list[base + rank] = i * a.Ny + j;
+                a.far_list[(size_t)tile * (TH * TW) + base + rank] = i * a.Ny + j;
             }
         }
     }
@@ -204,27 +233,31 @@ __global__ __launch_bounds__(NTHREADS) void k_refract_near(RefractArgs a) {
         }
     }
     if (a.status && __any(any_bad) && (tid & 63) == 0) atomicOr(a.status, PSX_STATUS_NONFINITE);
+    if (tid == 0) a.far_count[tile] = *sfar;     // the barrier above ordered every append before this read
 }
 
 // Replay of the far rays with the reference's literal border rules (RF2:235-262) in padded coordinates.
-__global__ __launch_bounds__(NTHREADS) void k_refract_far(RefractArgs a) {
-    const unsigned n = *a.far_count;
+template <int NM, bool HAS_I, bool HAS_PHI>
+__global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a) {
+    const unsigned n = a.far_count[blockIdx.x];
+    if (n == 0) return;
+    const int *list = a.far_list + (size_t)blockIdx.x * (TH * TW);
     const int Px = a.Nx + 2 * a.margin, Py = a.Ny + 2 * a.margin;
     auto phi_at = [&](int i, int j) -> double {
         const int64_t p = (int64_t)i * a.Ny + j;
         double ph, la;
-        mats_eval(a.m, p, ph, la);
-        if (a.phi_in) ph += a.phi_in[p];
+        mats_eval<NM>(a.m, p, ph, la);
+        if (HAS_PHI) ph += a.phi_in[p];
         return ph;
     };
-    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-        const int s = a.far_list[e];
+    for (unsigned e = threadIdx.x; e < n; e += blockDim.x) {
+        const int s = list[e];
         const int i = s / a.Ny, j = s - i * a.Ny;
         const int64_t p = s;
         double ph, la;
-        mats_eval(a.m, p, ph, la);
-        float I = a.I0 * (a.I_in ? a.I_in[p] : 1.f);
-        if (la != 0.0) I *= expf((float)la);
+        mats_eval<NM>(a.m, p, ph, la);
+        float I = a.I0 * (HAS_I ? a.I_in[p] : 1.f);
+        if (NM > 0) I *= expf((float)la);
         double dx, dy;
         bool clamped;
         I = source_eval(a, i, j, I, phi_at, dx, dy, clamped);
@@ -274,7 +307,7 @@ __global__ __launch_bounds__(NTHREADS) void k_fastloop(const float *__restrict__
     }
 }
 
-constexpr size_t NEAR_LDS = sizeof(double) * SR * SC + sizeof(float) * GR * GC + sizeof(float) * TH * TW;
+constexpr size_t NEAR_LDS = sizeof(double) * SR * SC + sizeof(float) * GR * GC + sizeof(float) * TH * TW + 16;
 
 }  // namespace
 
@@ -282,7 +315,8 @@ extern "C" {
 
 size_t psx_refract_workspace_bytes(int Nx, int Ny) {
     if (Nx <= 0 || Ny <= 0) return 16;
-    return 16 + sizeof(int) * (size_t)Nx * (size_t)Ny;
+    const size_t nt = (size_t)cdiv(Nx, TH) * (size_t)cdiv(Ny, TW);
+    return sizeof(unsigned) * nt + sizeof(int) * nt * TH * TW;
 }
 
 int psx_refract_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,
@@ -301,25 +335,39 @@ int psx_refract_f32(const float *I_in, float I0, const float *const *T, const do
     a.I_in = I_in; a.I0 = I0; a.phi_in = phi_in; a.I_out = I_out; a.out_scale = out_scale; a.accumulate = accumulate;
     a.Dx_out = Dx_out; a.Dy_out = Dy_out; a.I_mut = I_mut; a.Nx = Nx; a.Ny = Ny; a.margin = margin;
     a.dscale = dscale; a.clamp_x = clamp_x; a.clamp_y = clamp_y; a.status = status;
-    a.far_count = (unsigned *)workspace;
-    a.far_list = (int *)((char *)workspace + 16);
     a.tiles_x = (int)cdiv(Nx, TH);
     a.tiles_y = (int)cdiv(Ny, TW);
-    PSX_HIP(hipMemsetAsync(workspace, 0, 16, st));
+    a.far_count = (unsigned *)workspace;
+    a.far_list = (int *)((char *)workspace + sizeof(unsigned) * (size_t)a.tiles_x * a.tiles_y);
     if (Dx_out) {
         const size_t padded = sizeof(float) * (size_t)(Nx + 2 * margin) * (size_t)(Ny + 2 * margin);
         PSX_HIP(hipMemsetAsync(Dx_out, 0, padded, st));     // zero margins (RF2:65-66)
         PSX_HIP(hipMemsetAsync(Dy_out, 0, padded, st));
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        PSX_HIP(hipFuncSetAttribute((const void *)k_refract_near, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)NEAR_LDS));
-        attr_set = true;
-    }
-    PSX_TIMED("k_refract_near", st, k_refract_near<<<a.tiles_x * a.tiles_y, NTHREADS, NEAR_LDS, st>>>(a));
-    if (int rc = launch_check("k_refract_near")) return rc;
-    PSX_TIMED("k_refract_far", st, k_refract_far<<<512, NTHREADS, 0, st>>>(a));
+    int rc_launch = 0;
+    auto launch = [&](auto nm, auto hi, auto hp) -> int {
+        constexpr int NM = decltype(nm)::value;
+        constexpr bool HI = decltype(hi)::value, HP = decltype(hp)::value;
+        static bool attr_set = false;
+        if (!attr_set) {
+            PSX_HIP(hipFuncSetAttribute((const void *)k_refract_near<NM, HI, HP>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)NEAR_LDS));
+            attr_set = true;
+        }
+        PSX_TIMED("k_refract_near", st,
+                  k_refract_near<NM, HI, HP><<<a.tiles_x * a.tiles_y, NTHREADS, NEAR_LDS, st>>>(a));
+        if (int rc = launch_check("k_refract_near")) return rc;
+        PSX_TIMED("k_refract_far", st, k_refract_far<NM, HI, HP><<<a.tiles_x * a.tiles_y, FAR_THREADS, 0, st>>>(a));
+        return 0;
+    };
+    PSX_DISPATCH_NMAT(nmat, {
+        using N_ = std::integral_constant<int, NM>;
+        if (I_in && phi_in) rc_launch = launch(N_{}, std::true_type{}, std::true_type{});
+        else if (I_in) rc_launch = launch(N_{}, std::true_type{}, std::false_type{});
+        else if (phi_in) rc_launch = launch(N_{}, std::false_type{}, std::true_type{});
+        else rc_launch = launch(N_{}, std::false_type{}, std::false_type{});
+    });
+    if (rc_launch) return rc_launch;
     return launch_check("k_refract_far");
 }
 

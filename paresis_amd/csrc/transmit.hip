@@ -5,12 +5,13 @@
 using namespace psx;
 
 // K1: Sample.py:279  wave <- exp((-i k delta - k beta) T) wave, all materials in one pass.
+template <int NM>
 __global__ __launch_bounds__(256) void k_transmit_wave(const float2 *__restrict__ win, float amp, Mats m,
                                                        float2 *__restrict__ wout, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         double ph, la;
-        mats_eval(m, p, ph, la);
+        mats_eval<NM>(m, p, ph, la);
         float c, s;
         cis_f64(ph, c, s);
         const float a = amp * expf((float)la);
@@ -23,13 +24,14 @@ __global__ __launch_bounds__(256) void k_transmit_wave(const float2 *__restrict_
 }
 
 // K2: Sample.py:347-348  I <- exp(-2 k beta T) I ; phi <- phi - k delta T
+template <int NM>
 __global__ __launch_bounds__(256) void k_transmit_rt(const float *__restrict__ Iin, float I0, Mats m,
                                                      float *__restrict__ Iout, const double *__restrict__ phin,
                                                      double *__restrict__ phout, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         double ph, la;
-        mats_eval(m, p, ph, la);
+        mats_eval<NM>(m, p, ph, la);
         if (Iout) Iout[p] = I0 * (Iin ? Iin[p] : 1.f) * expf((float)la);
         if (phout) phout[p] = (phin ? phin[p] : 0.0) + ph;
     }
@@ -37,14 +39,15 @@ __global__ __launch_bounds__(256) void k_transmit_rt(const float *__restrict__ I
 
 // EXP:351-358 / 478-483: acc (+)= scale * img * exp(sum catt T)
 // acc and img may alias (in-place attenuation), so no __restrict__ here
+template <int NM>
 __global__ __launch_bounds__(256) void k_accumulate(float *acc, const float *img, float scale,
                                                     Mats m, int accumulate, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         float v = scale * img[p];
-        if (m.n > 0) {
+        if (NM > 0) {
             double ph, la;
-            mats_eval(m, p, ph, la);
+            mats_eval<NM>(m, p, ph, la);
             v *= expf((float)la);
         }
         acc[p] = accumulate ? acc[p] + v : v;
@@ -69,8 +72,8 @@ int psx_transmit_wave_c64(const psx_c64 *wave_in, float amp, const float *const 
     Mats m;
     if (int rc = pack_mats(m, T, cphase, catt, nmat)) return rc;
     if (n == 0) return 0;
-    PSX_TIMED("k_transmit_wave", (hipStream_t)stream, k_transmit_wave<<<ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>((const float2 *)wave_in, amp, m,
-                                                                      (float2 *)wave_out, n));
+    PSX_DISPATCH_NMAT(nmat, PSX_TIMED("k_transmit_wave", (hipStream_t)stream, k_transmit_wave<NM><<<ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>((const float2 *)wave_in, amp, m,
+                                                                      (float2 *)wave_out, n)));
     return launch_check("k_transmit_wave");
 }
 
@@ -80,7 +83,7 @@ int psx_transmit_rt_f32(const float *I_in, float I0, const float *const *T, cons
     Mats m;
     if (int rc = pack_mats(m, T, cphase, catt, nmat)) return rc;
     if (n == 0) return 0;
-    PSX_TIMED("k_transmit_rt", (hipStream_t)stream, k_transmit_rt<<<ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(I_in, I0, m, I_out, phi_in, phi_out, n));
+    PSX_DISPATCH_NMAT(nmat, PSX_TIMED("k_transmit_rt", (hipStream_t)stream, k_transmit_rt<NM><<<ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(I_in, I0, m, I_out, phi_in, phi_out, n)));
     return launch_check("k_transmit_rt");
 }
 
@@ -90,7 +93,7 @@ int psx_accumulate_f32(float *acc, const float *img, float scale, const float *c
     Mats m;
     if (int rc = pack_mats(m, T, nullptr, catt, nmat)) return rc;
     if (n == 0) return 0;
-    PSX_TIMED("k_accumulate", (hipStream_t)stream, k_accumulate<<<ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(acc, img, scale, m, accumulate, n));
+    PSX_DISPATCH_NMAT(nmat, PSX_TIMED("k_accumulate", (hipStream_t)stream, k_accumulate<NM><<<ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(acc, img, scale, m, accumulate, n)));
     return launch_check("k_accumulate");
 }
 
