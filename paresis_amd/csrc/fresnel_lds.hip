@@ -27,7 +27,9 @@ using namespace psx;
 
 namespace {
 
-constexpr int T = 384;        // threads per workgroup (6 waves)
+// One 12-wave workgroup per CU owns the whole LDS: 3 waves per SIMD are needed to keep the vector pipes issuing (a
+// 6-wave workgroup with two butterflies per thread measured 334 us per 4096^2 pass: VALU busy only a third of it).
+constexpr int T = 768;        // threads per workgroup = radix-24 butterflies per stage
 constexpr int TOT = 18432;    // complex points resident in LDS per workgroup = LINES * M
 constexpr int RAD = 24;       // radix of the two big stages
 
@@ -40,7 +42,7 @@ struct LineArgs {
     int N, nlines, margin, P, L;
     int64_t in_stride;      // sample i of line l is pixel i*in_stride + l
     int64_t out_ld;         // output sample i of line l goes to l*out_ld + i
-    const float2 *twA, *twB;
+    const float2 *twA, *twB;   // [n][24] stage twiddles
     int n_dist;
     const float2 *H[PSX_MAX_DIST];
     float2 *wave_out[PSX_MAX_DIST];
@@ -58,8 +60,10 @@ __device__ __forceinline__ int xcd_group(int b, int ng) {
 template <int R3, int NM, bool MULTI>
 __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     constexpr int M = 576 * R3, LINES = TOT / M, S1 = M / RAD, MP = M + M / 32;
-    constexpr int SLAB = 16, NSLAB = TOT / SLAB / T;   // 16 contiguous points per thread in the middle stage
-    static_assert(R3 <= 16 && SLAB % R3 == 0 && TOT % (SLAB * T) == 0, "unsupported last radix");
+    constexpr int SLAB = 16, NSLABS = TOT / SLAB;       // 16 contiguous points per slab in the middle stage
+    constexpr int NSLAB = (NSLABS + T - 1) / T;          // slabs per thread (the last round may be partly idle)
+    constexpr int BPT = TOT / RAD / T;                   // radix-24 butterflies per thread per stage
+    static_assert(R3 <= 16 && SLAB % R3 == 0 && TOT % (RAD * T) == 0, "unsupported geometry");
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
     const int ngroups = (a.nlines + LINES - 1) / LINES;
@@ -84,36 +88,60 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     }
     __syncthreads();
 
+    // LDS index of butterfly element j: with S1 a multiple of 32 (and R3 | 32) the pad term of phys() is affine in j, so
+    // every element is one base register + a compile-time offset (ds_read/ds_write immediate offsets)
+    constexpr bool AFF = (S1 % 32 == 0);
+    auto idxA = [&](int n, int j) __attribute__((always_inline)) {
+        return AFF ? phys(n) + j * (S1 + S1 / 32) : phys(n + j * S1);
+    };
+    auto idxB = [&](int p0, int j) __attribute__((always_inline)) {      // p0 = q1*S1 + n,  n < R3
+        return AFF ? phys(p0) + j * R3 + ((j * R3) >> 5) : phys(p0 + j * R3);
+    };
+    // the 24 twiddles of butterfly n: 12 x 16-byte loads from one base
+    auto load_tw = [&](const float2 *tw, int n, float2(&w)[RAD]) __attribute__((always_inline)) {
+        const float4 *t4 = reinterpret_cast<const float4 *>(tw + (size_t)n * RAD);
+#pragma unroll
+        for (int q = 0; q < RAD / 2; ++q) {
+            const float4 x = t4[q];
+            w[2 * q] = make_float2(x.x, x.y);
+            w[2 * q + 1] = make_float2(x.z, x.w);
+        }
+    };
+
     // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}
 #pragma unroll 1
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < BPT; ++u) {
         const int e = tid + T * u, line = e / S1, n = e % S1;
         float2 *base = lds + line * MP;
-        float2 v[RAD];
+        float2 v[RAD], w[RAD];
 #pragma unroll
-        for (int j = 0; j < RAD; ++j) v[j] = base[phys(n + j * S1)];
+        for (int j = 0; j < RAD; ++j) v[j] = base[idxA(n, j)];
         Dft<RAD, false>::run(v);
+        __builtin_amdgcn_sched_barrier(0);   // keep the twiddle loads below the butterfly: 48 fewer live VGPRs
+        load_tw(a.twA, n, w);
 #pragma unroll
-        for (int q = 1; q < RAD; ++q) v[q] = cmul(v[q], a.twA[(q - 1) * S1 + n]);
+        for (int q = 1; q < RAD; ++q) v[q] = cmul(v[q], w[q]);
 #pragma unroll
-        for (int q = 0; q < RAD; ++q) base[phys(n + q * S1)] = v[q];
+        for (int q = 0; q < RAD; ++q) base[idxA(n, q)] = v[q];
     }
     __syncthreads();
 
     // ---- 3. forward stage B: radix 24 inside each block of S1, stride R3, twiddle w_S1^{n q}
 #pragma unroll 1
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < BPT; ++u) {
         const int e = tid + T * u, line = e / S1, rem = e % S1, q1 = rem / R3, n = rem % R3;
-        float2 *base = lds + line * MP + 0;
+        float2 *base = lds + line * MP;
         const int p0 = q1 * S1 + n;
-        float2 v[RAD];
+        float2 v[RAD], w[RAD];
 #pragma unroll
-        for (int j = 0; j < RAD; ++j) v[j] = base[phys(p0 + j * R3)];
+        for (int j = 0; j < RAD; ++j) v[j] = base[idxB(p0, j)];
         Dft<RAD, false>::run(v);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tw(a.twB, n, w);
 #pragma unroll
-        for (int q = 1; q < RAD; ++q) v[q] = cmul(v[q], a.twB[(q - 1) * R3 + n]);
+        for (int q = 1; q < RAD; ++q) v[q] = cmul(v[q], w[q]);
 #pragma unroll
-        for (int q = 0; q < RAD; ++q) base[phys(p0 + q * R3)] = v[q];
+        for (int q = 0; q < RAD; ++q) base[idxB(p0, q)] = v[q];
     }
     __syncthreads();
 
@@ -122,10 +150,10 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     constexpr int NF = MULTI ? NSLAB : 1;
     float2 F[NF][SLAB];
     auto load_slab = [&](int r, float2(&f)[SLAB]) __attribute__((always_inline)) {
-        const int s = tid + T * r, line = s / (M / SLAB), p0 = (s % (M / SLAB)) * SLAB;
+        const int s = min(tid + T * r, NSLABS - 1), line = s / (M / SLAB), p0 = (s % (M / SLAB)) * SLAB;
         const float2 *base = lds + line * MP;
 #pragma unroll
-        for (int j = 0; j < SLAB; ++j) f[j] = base[phys(p0 + j)];
+        for (int j = 0; j < SLAB; ++j) f[j] = base[phys(p0) + j];   // p0 % 16 == 0: no pad slot inside a slab
 #pragma unroll
         for (int c = 0; c < SLAB / R3; ++c) {
             float2 w[R3];
@@ -148,6 +176,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 #pragma unroll
         for (int r = 0; r < NSLAB; ++r) {
             const int s = tid + T * r, line = s / (M / SLAB), p0 = (s % (M / SLAB)) * SLAB;
+            if (NSLABS % T != 0 && s >= NSLABS) break;      // idle tail of the last slab round
             float2 *base = lds + line * MP;
             if (!MULTI) load_slab(r, F[0]);
             float2(&f)[SLAB] = F[MULTI ? r : 0];
@@ -166,25 +195,31 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 for (int j = 0; j < R3; ++j) w[j] = g[c * R3 + j];
                 Dft<R3, true>::run(w);
 #pragma unroll
-                for (int j = 0; j < R3; ++j) base[phys(p0 + c * R3 + j)] = w[j];
+                for (int j = 0; j < R3; ++j) base[phys(p0) + c * R3 + j] = w[j];
             }
         }
         __syncthreads();
 
+        // The inverse stages use the same twiddles as the forward ones; launder the pointers so that the compiler
+        // reloads them (L2-resident) instead of keeping 92 VGPRs alive across the whole kernel and spilling.
+        const float2 *twA_i = a.twA, *twB_i = a.twB;
+        asm volatile("" : "+s"(twA_i), "+s"(twB_i));
         // ---- 6. inverse stage B: conjugate twiddle on the inputs, then the inverse radix-24 butterfly
 #pragma unroll 1
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < BPT; ++u) {
             const int e = tid + T * u, line = e / S1, rem = e % S1, q1 = rem / R3, n = rem % R3;
             float2 *base = lds + line * MP;
             const int p0 = q1 * S1 + n;
-            float2 v[RAD];
+            float2 v[RAD], w[RAD];
+            load_tw(twB_i, n, w);
 #pragma unroll
-            for (int q = 0; q < RAD; ++q) v[q] = base[phys(p0 + q * R3)];
+            for (int q = 0; q < RAD; ++q) v[q] = base[idxB(p0, q)];
 #pragma unroll
-            for (int q = 1; q < RAD; ++q) v[q] = cmulc(v[q], a.twB[(q - 1) * R3 + n]);
+            for (int q = 1; q < RAD; ++q) v[q] = cmulc(v[q], w[q]);
+            __builtin_amdgcn_sched_barrier(0);
             Dft<RAD, true>::run(v);
 #pragma unroll
-            for (int j = 0; j < RAD; ++j) base[phys(p0 + j * R3)] = v[j];
+            for (int j = 0; j < RAD; ++j) base[idxB(p0, j)] = v[j];
         }
         __syncthreads();
 
@@ -195,14 +230,16 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         const float sc = a.scale[d];
         const float2 gp = a.gph[d];
 #pragma unroll 1
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < BPT; ++u) {
             const int e = tid + T * u, line = e / S1, n = e % S1;
             const float2 *base = lds + line * MP;
-            float2 v[RAD];
+            float2 v[RAD], w[RAD];
+            load_tw(twA_i, n, w);
 #pragma unroll
-            for (int q = 0; q < RAD; ++q) v[q] = base[phys(n + q * S1)];
+            for (int q = 0; q < RAD; ++q) v[q] = base[idxA(n, q)];
 #pragma unroll
-            for (int q = 1; q < RAD; ++q) v[q] = cmulc(v[q], a.twA[(q - 1) * S1 + n]);
+            for (int q = 1; q < RAD; ++q) v[q] = cmulc(v[q], w[q]);
+            __builtin_amdgcn_sched_barrier(0);
             Dft<RAD, true>::run(v);
             if (l0 + line < a.nlines) {
                 const int64_t ob = (int64_t)(l0 + line) * a.out_ld;
@@ -301,14 +338,16 @@ __global__ void k_kern_perm(const double2 *Hh, float2 *out, int M, int R3) {
 __global__ void k_stage_twiddles(float2 *twA, float2 *twB, int M, int R3) {
     const int S1 = M / RAD;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (RAD - 1) * S1) {
-        const int q = idx / S1 + 1, n = idx % S1;
+    // layout [n][24]: the 24 twiddles of one butterfly are contiguous (192 B), so a thread fetches them with 16-byte
+    // loads at immediate offsets from ONE address register
+    if (idx < RAD * S1) {
+        const int n = idx / RAD, q = idx % RAD;
         double s, c;
         sincospi(-2.0 * (double)(((long long)n * q) % M) / (double)M, &s, &c);
         twA[idx] = make_float2((float)c, (float)s);
     }
-    if (idx < (RAD - 1) * R3) {
-        const int q = idx / R3 + 1, n = idx % R3;
+    if (idx < RAD * R3) {
+        const int n = idx / RAD, q = idx % RAD;
         double s, c;
         sincospi(-2.0 * (double)((n * q) % S1) / (double)S1, &s, &c);
         twB[idx] = make_float2((float)c, (float)s);
@@ -357,10 +396,10 @@ static int make_axis(AxisTables &t, int N, int margin, size_t &bytes) {
     t.R3 = pick_r3(N, margin);
     t.M = 576 * t.R3;
     const int S1 = t.M / RAD;
-    PSX_HIP(hipMalloc((void **)&t.twA, sizeof(float2) * (RAD - 1) * S1));
-    PSX_HIP(hipMalloc((void **)&t.twB, sizeof(float2) * (RAD - 1) * t.R3));
-    bytes += sizeof(float2) * (RAD - 1) * (S1 + t.R3);
-    k_stage_twiddles<<<(int)cdiv((RAD - 1) * S1, 256), 256>>>(t.twA, t.twB, t.M, t.R3);
+    PSX_HIP(hipMalloc((void **)&t.twA, sizeof(float2) * RAD * S1));
+    PSX_HIP(hipMalloc((void **)&t.twB, sizeof(float2) * RAD * t.R3));
+    bytes += sizeof(float2) * RAD * (S1 + t.R3);
+    k_stage_twiddles<<<(int)cdiv(RAD * S1, 256), 256>>>(t.twA, t.twB, t.M, t.R3);
     return launch_check("k_stage_twiddles");
 }
 
