@@ -148,6 +148,10 @@ int psx_poisson_f32(const float *lam, float *out, int64_t n, uint64_t seed, void
 int psx_profile_enable(int on);
 int psx_profile_summary(char *buf, size_t cap);
 
+/* Diagnostics: device buffer of 16 x uint64 per workgroup receiving the phase timestamps (100 MHz wall clock) of the
+ * row pass of the LDS Fresnel engine; NULL (default) switches it off.  Never enabled in timed runs. */
+int psx_debug_stamps(void *buf);
+
 /* ---- status word ------------------------------------------------------------------------------------------------ */
 /* OR PSX_STATUS_NONFINITE into *status when img holds NaN or |v| > 1e50 (float32: inf) */
 int psx_status_scan_f32(const float *img, int64_t n, unsigned *status, void *stream);

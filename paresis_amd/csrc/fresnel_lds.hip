@@ -50,7 +50,14 @@ struct LineArgs {
     float scale[PSX_MAX_DIST];
     float2 gph[PSX_MAX_DIST];
     int accumulate;
+    unsigned long long *stamps;   // optional diagnostics: 16 phase timestamps per workgroup (psx_debug_stamps)
 };
+
+// phase timestamp of wave 0 (diagnostic runs only; a null buffer costs one scalar branch)
+#define PSX_STAMP(k)                                                             \
+    do {                                                                         \
+        if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); \
+    } while (0)
 
 __device__ __forceinline__ int xcd_group(int b, int ng) {
     const int q = ng >> 3, r = ng & 7, x = b & 7;
@@ -70,23 +77,40 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     const int l0 = xcd_group(blockIdx.x, ngroups) * LINES;
     const int N = a.N, mg = a.margin;
 
+    PSX_STAMP(0);
     // ---- 1. samples -> LDS.  s[j] = x_per[j - (N+mg-1)], j in [0, L);  zeros in [L, M).
     for (int idx = tid; idx < LINES * (M - a.L); idx += T) {
         const int line = idx / (M - a.L), j = a.L + idx % (M - a.L);
         lds[line * MP + phys(j)] = make_float2(0.f, 0.f);
     }
-#pragma unroll 4
-    for (int idx = tid; idx < LINES * N; idx += T) {
-        const int line = idx % LINES, i = idx / LINES;
-        float2 x = make_float2(0.f, 0.f);
-        if (l0 + line < a.nlines) x = source_wave<NM>(a.src, a.amp, a.m, (int64_t)i * a.in_stride + (l0 + line));
-        float2 *base = lds + line * MP;
-        base[phys(i + N + 2 * mg - 1)] = x;                            // t = i+mg (first period)
-        if (i >= 1) base[phys(i - 1)] = x;                             // same sample one period earlier
-        if (i >= 1 && i <= mg) base[phys(N + 2 * mg - 1 - i)] = x;     // left mirror  (reflect: no edge repeat)
-        if (i >= N - 1 - mg && i <= N - 2) base[phys(2 * N - 3 - i)] = x;   // right mirror, one period earlier
+    // every thread owns up to NLD samples; their (strided) global loads are issued back to back so that one memory
+    // latency covers all of them, then the values are spread to their periodic / mirrored positions
+    constexpr int NLDMAX = 12;
+    for (int k0 = 0; k0 * T < LINES * N; k0 += NLDMAX) {
+        float2 xs[NLDMAX];
+#pragma unroll
+        for (int k = 0; k < NLDMAX; ++k) {
+            const int idx = tid + (k0 + k) * T, line = idx % LINES, i = idx / LINES;
+            xs[k] = make_float2(0.f, 0.f);
+            if (idx < LINES * N && l0 + line < a.nlines)
+                xs[k] = source_wave<NM>(a.src, a.amp, a.m, (int64_t)i * a.in_stride + (l0 + line));
+        }
+#pragma unroll
+        for (int k = 0; k < NLDMAX; ++k) {
+            const int idx = tid + (k0 + k) * T, line = idx % LINES, i = idx / LINES;
+            if (idx < LINES * N) {
+                const float2 x = xs[k];
+                float2 *base = lds + line * MP;
+                base[phys(i + N + 2 * mg - 1)] = x;                            // t = i+mg (first period)
+                if (i >= 1) base[phys(i - 1)] = x;                             // same sample one period earlier
+                if (i >= 1 && i <= mg) base[phys(N + 2 * mg - 1 - i)] = x;     // left mirror (reflect: no edge repeat)
+                if (i >= N - 1 - mg && i <= N - 2) base[phys(2 * N - 3 - i)] = x;   // right mirror, one period earlier
+            }
+        }
     }
+    PSX_STAMP(1);
     __syncthreads();
+    PSX_STAMP(2);
 
     // LDS index of butterfly element j: with S1 a multiple of 32 (and R3 | 32) the pad term of phys() is affine in j, so
     // every element is one base register + a compile-time offset (ds_read/ds_write immediate offsets)
@@ -124,7 +148,9 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 #pragma unroll
         for (int q = 0; q < RAD; ++q) base[idxA(n, q)] = v[q];
     }
+    PSX_STAMP(3);
     __syncthreads();
+    PSX_STAMP(4);
 
     // ---- 3. forward stage B: radix 24 inside each block of S1, stride R3, twiddle w_S1^{n q}
 #pragma unroll 1
@@ -143,7 +169,9 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 #pragma unroll
         for (int q = 0; q < RAD; ++q) base[idxB(p0, q)] = v[q];
     }
+    PSX_STAMP(5);
     __syncthreads();
+    PSX_STAMP(6);
 
     // ---- 4. forward stage C (radix R3 on contiguous chunks).  MULTI: the spectrum stays in registers while every
     // distance's kernel is applied to it; otherwise it is consumed slab by slab (far fewer live registers).
@@ -178,15 +206,17 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             const int s = tid + T * r, line = s / (M / SLAB), p0 = (s % (M / SLAB)) * SLAB;
             if (NSLABS % T != 0 && s >= NSLABS) break;      // idle tail of the last slab round
             float2 *base = lds + line * MP;
+            float4 hh[SLAB / 2];                     // kernel spectrum of this slab: issued before the LDS reads
+            const float4 *h4 = reinterpret_cast<const float4 *>(Hd + p0);
+#pragma unroll
+            for (int j = 0; j < SLAB / 2; ++j) hh[j] = h4[j];
             if (!MULTI) load_slab(r, F[0]);
             float2(&f)[SLAB] = F[MULTI ? r : 0];
             float2 g[SLAB];
-            const float4 *h4 = reinterpret_cast<const float4 *>(Hd + p0);
 #pragma unroll
             for (int j = 0; j < SLAB / 2; ++j) {
-                const float4 hh = h4[j];
-                g[2 * j] = cmul(f[2 * j], make_float2(hh.x, hh.y));
-                g[2 * j + 1] = cmul(f[2 * j + 1], make_float2(hh.z, hh.w));
+                g[2 * j] = cmul(f[2 * j], make_float2(hh[j].x, hh[j].y));
+                g[2 * j + 1] = cmul(f[2 * j + 1], make_float2(hh[j].z, hh[j].w));
             }
 #pragma unroll
             for (int c = 0; c < SLAB / R3; ++c) {
@@ -198,7 +228,9 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 for (int j = 0; j < R3; ++j) base[phys(p0) + c * R3 + j] = w[j];
             }
         }
+        PSX_STAMP(7);
         __syncthreads();
+        PSX_STAMP(8);
 
         // The inverse stages use the same twiddles as the forward ones; launder the pointers so that the compiler
         // reloads them (L2-resident) instead of keeping 92 VGPRs alive across the whole kernel and spilling.
@@ -221,7 +253,9 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 #pragma unroll
             for (int j = 0; j < RAD; ++j) base[idxB(p0, j)] = v[j];
         }
+        PSX_STAMP(9);
         __syncthreads();
+        PSX_STAMP(10);
 
         // ---- 7. inverse stage A; the wanted outputs y[n + P - 1] leave for HBM straight from the registers
         const int jout = N + 2 * mg - 1;      // LDS position of output sample 0
@@ -257,6 +291,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             }
         }
     }
+    PSX_STAMP(11);
 }
 
 // z == 0 (EXP:233-234): out = psi, |psi|^2
@@ -364,6 +399,8 @@ int pick_r3(int N, int margin) {
 }  // namespace
 
 namespace psx {
+
+unsigned long long *g_stamps = nullptr;
 
 struct AxisTables {
     int N = 0, R3 = 0, M = 0;
@@ -561,7 +598,7 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
     la.N = p->Nx; la.nlines = p->Ny; la.margin = p->margin; la.P = p->Px; la.L = p->Nx + p->Px - 1;
     la.in_stride = p->Ny; la.out_ld = p->Nx;
     la.twA = e->ax[0].twA; la.twB = e->ax[0].twB;
-    la.n_dist = nnz; la.accumulate = 0;
+    la.n_dist = nnz; la.accumulate = 0; la.stamps = nullptr;
     for (int i = 0; i < nnz; ++i) {
         if (int rc = kernel_spectrum(p, e->ax[0], a.a[nz[i]], a.du_x, st, &la.H[i])) return rc;
         la.wave_out[i] = e->inter + (size_t)i * npix;
@@ -588,7 +625,7 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         lb.N = p->Ny; lb.nlines = p->Nx; lb.margin = p->margin; lb.P = p->Py; lb.L = p->Ny + p->Py - 1;
         lb.in_stride = p->Nx; lb.out_ld = p->Ny;
         lb.twA = e->ax[1].twA; lb.twB = e->ax[1].twB;
-        lb.n_dist = 1; lb.accumulate = a.accumulate;
+        lb.n_dist = 1; lb.accumulate = a.accumulate; lb.stamps = g_stamps;
         if (int rc2 = kernel_spectrum(p, e->ax[1], a.a[d], a.du_y, st, &lb.H[0])) return rc2;
         lb.wave_out[0] = a.wave_out ? a.wave_out[d] : nullptr;
         lb.inten_out[0] = a.inten_out ? a.inten_out[d] : nullptr;
@@ -601,3 +638,8 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
 }
 
 }  // namespace psx
+
+extern "C" int psx_debug_stamps(void *buf) {
+    psx::g_stamps = (unsigned long long *)buf;
+    return 0;
+}
