@@ -5,10 +5,18 @@
 // The reference scatters in raster order on one CPU thread.  Here the scatter is turned into a per-tile GATHER:
 // a workgroup owns one TH x TW output tile, stages the phase (float64) and the source intensity of the tile plus a halo
 // of H+1 pixels in LDS, re-evaluates the displacement of every source pixel of tile+halo, and deposits only what lands
-// in its own tile with LDS float atomics.  The tile is then written once with plain coalesced stores: no zero-init
-// pass, no global read-modify-write.  Rays displaced by more than the halo ("far" rays, rare) are appended to a
-// compact list by the tile that owns the SOURCE pixel and replayed by a second, tiny kernel with global float atomics
-// that applies the reference's border rules literally.
+// in its own tile into an LDS accumulator.  The tile is then written once with plain coalesced stores: no zero-init
+// pass, no global read-modify-write.
+//
+// The LDS accumulator is 64-bit FIXED POINT, not float: on gfx950 an LDS float atomic (ds_add_f32) retires one lane
+// per ~3 clocks (194 clocks per wave instruction, tools/lds_atomic_bench.hip) and made this kernel LDS-bound, while
+// ds_add_u64 takes ~8 clocks per wave instruction.  Each tile scales its deposits by a power of two chosen from the
+// largest staged source intensity (2^-40 of it is one unit; 2^23 of headroom for sums), so the quantisation is far
+// below float32 resolution and the tile sums do not depend on the order of the atomics (bitwise reproducible).
+//
+// Rays displaced by more than the halo ("far" rays) are written, already evaluated, to a per-tile list by the tile that
+// owns the SOURCE pixel and replayed by a second kernel with global float atomics that applies the reference's border
+// rules literally (RF2:235-262).
 //
 // HBM traffic per pixel: 4*nmat (thickness maps) + 4 (intensity, if given) read, 4 written  (BASELINE.md section 4
 // prices the scatter at 12+4*nmat because the reference zero-initialises and read-modify-writes its output).
@@ -20,14 +28,24 @@ using namespace psx;
 
 namespace {
 
-constexpr int TH = 64;          // tile rows   (axis 0, "x" of the reference)
-constexpr int TW = 64;          // tile cols   (axis 1, contiguous)
-constexpr int H = 4;            // gather halo: rays with floor(D) in [-H, H-1] on both axes are "near"
-constexpr int SR = TH + 2 * H + 2;   // staged rows (one more ring for the gradient stencil)
-constexpr int SC = TW + 2 * H + 2;
-constexpr int NTHREADS = 512;
+// Tile geometry.  H is the gather halo: rays with floor(D) in [-H, H-1] on both axes are "near".
+template <int TH_, int TW_, int H_, int NT_>
+struct Geo {
+    static constexpr int TH = TH_, TW = TW_, H = H_, NT = NT_;
+    static constexpr int SR = TH + 2 * H + 2, SC = TW + 2 * H + 2;   // staged phase (one more ring for the stencil)
+    static constexpr int GR = TH + 2 * H, GC = TW + 2 * H;           // source pixels gathered by one tile
+    static constexpr size_t LDS = sizeof(double) * SR * SC + sizeof(float) * GR * GC + sizeof(long long) * TH * TW + 16;
+};
+using GeoSmall = Geo<56, 56, 4, 512>;    // 76 KiB of LDS: two workgroups per CU; 1.31 source evaluations per pixel
+using GeoWide = Geo<96, 48, 8, 1024>;    // 126 KiB: one 16-wave workgroup per CU; 1.56 evaluations, 4x the reach
 constexpr int FAR_THREADS = 128;
-constexpr int GR = TH + 2 * H, GC = TW + 2 * H;   // source rows/cols gathered by one tile
+
+// a far ray, already evaluated by the tile that owns its source pixel
+struct FarRay {
+    double dx, dy;
+    float I;
+    int src;
+};
 
 struct RefractArgs {
     const float *I_in;
@@ -43,8 +61,8 @@ struct RefractArgs {
     double dscale, clamp_x, clamp_y;
     unsigned *status;
     unsigned *far_count;     // workspace: [ntiles] far rays found by each tile
-    int *far_list;           // then [ntiles][TH*TW] their source pixels (a tile can never overflow its slot)
-    int tiles_x, tiles_y;
+    FarRay *far_list;        // then [ntiles][TH*TW] records (a tile can never overflow its slot)
+    int tiles_x, tiles_y, tile_cap;
 };
 
 // One axis of the reference's split (RF2:228-233 + the sign cases of RF2:237-262), in padded coordinates.
@@ -94,6 +112,7 @@ __device__ __forceinline__ float source_eval(const RefractArgs &a, int i, int j,
     return I;
 }
 
+template <int H>
 __device__ __forceinline__ bool is_near(double dx, double dy) {
     const double fx = floor(dx), fy = floor(dy);
     return fx >= -H && fx <= H - 1 && fy >= -H && fy <= H - 1;
@@ -106,13 +125,15 @@ __device__ __forceinline__ int xcd_tile(int b, int nt) {
     return x * q + (x < r ? x : r) + (b >> 3);
 }
 
-template <int NM, bool HAS_I, bool HAS_PHI>
-__global__ __launch_bounds__(NTHREADS) void k_refract_near(RefractArgs a) {
+template <class G, int NM, bool HAS_I, bool HAS_PHI>
+__global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
+    constexpr int TH = G::TH, TW = G::TW, H = G::H, SR = G::SR, SC = G::SC, GR = G::GR, GC = G::GC, NTHREADS = G::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *sphi = (double *)smem;                               // [SR][SC]
-    float *sI = (float *)(smem + sizeof(double) * SR * SC);      // [GR][GC]
-    float *sacc = sI + GR * GC;                                  // [TH][TW]
-    unsigned *sfar = (unsigned *)(sacc + TH * TW);               // far rays of this tile so far
+    double *sphi = (double *)smem;                                        // [SR][SC]
+    long long *sacc = (long long *)(smem + sizeof(double) * SR * SC);     // [TH][TW] fixed point
+    float *sI = (float *)(sacc + TH * TW);                                // [GR][GC]
+    unsigned *sfar = (unsigned *)(sI + GR * GC);                          // far rays of this tile so far
+    unsigned *smax = sfar + 1;                                            // largest |source intensity| (float bits)
 
     const int nt = a.tiles_x * a.tiles_y;
     const int tile = xcd_tile(blockIdx.x, nt);
@@ -123,6 +144,12 @@ __global__ __launch_bounds__(NTHREADS) void k_refract_near(RefractArgs a) {
     // Addresses are clamped into the image so every load is unconditional (they can all be in flight together);
     // out-of-image entries are zeroed afterwards and never used as sources.
     constexpr int SITERS = (SR * SC + NTHREADS - 1) / NTHREADS;
+    unsigned imax = 0u;
+    if (tid == 0) {
+        *sfar = 0u;
+        *smax = 0u;
+    }
+    __syncthreads();
     constexpr int U = 4;   // staged pixels per thread whose loads are issued together
     for (int it0 = 0; it0 < SITERS; it0 += U) {
         float t[U][NM > 0 ? NM : 1], Iin[U];
@@ -154,13 +181,22 @@ __global__ __launch_bounds__(NTHREADS) void k_refract_near(RefractArgs a) {
             if (NM > 0) I *= expf((float)la);
             if (idx < SR * SC) {
                 sphi[idx] = ok[u] ? ph : 0.0;
-                if (sr >= 1 && sr <= GR && sc >= 1 && sc <= GC) sI[(sr - 1) * GC + (sc - 1)] = ok[u] ? I : 0.f;
+                if (sr >= 1 && sr <= GR && sc >= 1 && sc <= GC) {
+                    sI[(sr - 1) * GC + (sc - 1)] = ok[u] ? I : 0.f;
+                    if (ok[u]) imax = max(imax, __float_as_uint(fabsf(I)));   // NaN/inf sort above every finite value
+                }
             }
         }
     }
-    for (int idx = tid; idx < TH * TW; idx += NTHREADS) sacc[idx] = 0.f;
-    if (tid == 0) *sfar = 0u;
+    for (int idx = tid; idx < TH * TW; idx += NTHREADS) sacc[idx] = 0ll;
+    for (int o = 32; o > 0; o >>= 1) imax = max(imax, (unsigned)__shfl_xor((int)imax, o));
+    if ((tid & 63) == 0) atomicMax(smax, imax);
     __syncthreads();
+    // fixed-point scale of this tile: one unit = 2^-40 of (the power of two above) the largest staged intensity
+    const unsigned mbits = *smax;
+    const bool finite_in = mbits < 0x7f800000u;
+    const int sexp = 40 - (mbits ? ilogbf(__uint_as_float(mbits)) + 1 : 0);
+    const double fscale = finite_in ? ldexp(1.0, sexp) : 0.0, finv = finite_in ? ldexp(1.0, -sexp) : 0.0;
 
     auto phi_at = [&](int i, int j) -> double { return sphi[(i - (r0 - H - 1)) * SC + (j - (c0 - H - 1))]; };
 
@@ -174,12 +210,17 @@ __global__ __launch_bounds__(NTHREADS) void k_refract_near(RefractArgs a) {
         const bool inside = idx < GR * GC && i >= 0 && i < a.Nx && j >= 0 && j < a.Ny;
         const bool core = gr >= H && gr < H + TH && gc >= H && gc < H + TW;
         bool far = false;
+        double Dxs = 0.0, Dys = 0.0;
+        float Is = 0.f;
         if (inside) {
             float I = sI[idx];
             double dx, dy;
             bool clamped;
             I = source_eval(a, i, j, I, phi_at, dx, dy, clamped);
-            const bool near = is_near(dx, dy);
+            const bool near = is_near<H>(dx, dy);
+            Dxs = dx;
+            Dys = dy;
+            Is = I;
             if (core) {
                 if (a.Dx_out) {
                     const int64_t Py = a.Ny + 2 * a.margin;
@@ -197,10 +238,13 @@ __global__ __launch_bounds__(NTHREADS) void k_refract_near(RefractArgs a) {
                 const float w00 = (1.f - wx) * (1.f - wy), w10 = wx * (1.f - wy), w01 = (1.f - wx) * wy, w11 = wx * wy;
                 const bool i0 = ti >= 0 && ti < TH, i1 = ti + 1 >= 0 && ti + 1 < TH;
                 const bool j0 = tj >= 0 && tj < TW, j1 = tj + 1 >= 0 && tj + 1 < TW;
-                if (i0 && j0) atomicAdd(&sacc[ti * TW + tj], I * w00);
-                if (i1 && j0 && w10 != 0.f) atomicAdd(&sacc[(ti + 1) * TW + tj], I * w10);
-                if (i0 && j1 && w01 != 0.f) atomicAdd(&sacc[ti * TW + tj + 1], I * w01);
-                if (i1 && j1 && w11 != 0.f) atomicAdd(&sacc[(ti + 1) * TW + tj + 1], I * w11);
+                auto dep = [&](int t, float v) __attribute__((always_inline)) {
+                    atomicAdd((unsigned long long *)&sacc[t], (unsigned long long)__double2ll_rn((double)v * fscale));
+                };
+                if (i0 && j0) dep(ti * TW + tj, I * w00);
+                if (i1 && j0 && w10 != 0.f) dep((ti + 1) * TW + tj, I * w10);
+                if (i0 && j1 && w01 != 0.f) dep(ti * TW + tj + 1, I * w01);
+                if (i1 && j1 && w11 != 0.f) dep((ti + 1) * TW + tj + 1, I * w11);
             }
         }
         // wave-aggregated append of far rays to this tile's own list: one LDS atomic per wave, no global atomics
@@ -214,7 +258,9 @@ __global__ __launch_bounds__(NTHREADS) void k_refract_near(RefractArgs a) {
             base = __shfl(base, leader);
             if (far) {
                 const unsigned rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-                a.far_list[(size_t)tile * (TH * TW) + base + rank] = i * a.Ny + j;
+                FarRay fr;
+                fr.dx = Dxs; fr.dy = Dys; fr.I = Is; fr.src = i * a.Ny + j;
+                a.far_list[(size_t)tile * (TH * TW) + base + rank] = fr;
             }
         }
     }
@@ -226,7 +272,7 @@ __global__ __launch_bounds__(NTHREADS) void k_refract_near(RefractArgs a) {
         const int i = r0 + tr, j = c0 + tc;
         if (i < a.Nx && j < a.Ny) {
             const int64_t p = (int64_t)i * a.Ny + j;
-            float v = a.out_scale * sacc[idx];
+            float v = finite_in ? a.out_scale * (float)((double)sacc[idx] * finv) : __uint_as_float(0x7fc00000u);
             if (a.accumulate) v += a.I_out[p];
             any_bad |= !(fabsf(v) <= 3.0e38f);
             a.I_out[p] = v;
@@ -237,34 +283,19 @@ __global__ __launch_bounds__(NTHREADS) void k_refract_near(RefractArgs a) {
 }
 
 // Replay of the far rays with the reference's literal border rules (RF2:235-262) in padded coordinates.
-template <int NM, bool HAS_I, bool HAS_PHI>
 __global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a) {
     const unsigned n = a.far_count[blockIdx.x];
     if (n == 0) return;
-    const int *list = a.far_list + (size_t)blockIdx.x * (TH * TW);
+    const FarRay *list = a.far_list + (size_t)blockIdx.x * a.tile_cap;
     const int Px = a.Nx + 2 * a.margin, Py = a.Ny + 2 * a.margin;
-    auto phi_at = [&](int i, int j) -> double {
-        const int64_t p = (int64_t)i * a.Ny + j;
-        double ph, la;
-        mats_eval<NM>(a.m, p, ph, la);
-        if (HAS_PHI) ph += a.phi_in[p];
-        return ph;
-    };
     for (unsigned e = threadIdx.x; e < n; e += blockDim.x) {
-        const int s = list[e];
-        const int i = s / a.Ny, j = s - i * a.Ny;
-        const int64_t p = s;
-        double ph, la;
-        mats_eval<NM>(a.m, p, ph, la);
-        float I = a.I0 * (HAS_I ? a.I_in[p] : 1.f);
-        if (NM > 0) I *= expf((float)la);
-        double dx, dy;
-        bool clamped;
-        I = source_eval(a, i, j, I, phi_at, dx, dy, clamped);
+        const FarRay fr = list[e];
+        const int i = fr.src / a.Ny, j = fr.src - i * a.Ny;
+        const float I = fr.I;
         int bi, ni, bj, nj;
         float wbi, wni, wbj, wnj;
-        axis_split_ref(dx, i + a.margin, bi, ni, wbi, wni);
-        axis_split_ref(dy, j + a.margin, bj, nj, wbj, wnj);
+        axis_split_ref(fr.dx, i + a.margin, bi, ni, wbi, wni);
+        axis_split_ref(fr.dy, j + a.margin, bj, nj, wbj, wnj);
         if (bi < 0 || bi >= Px || bj < 0 || bj >= Py) continue;       // RF2:235-236
         auto deposit = [&](int pi, int pj, float v) {
             const int ui = pi - a.margin, uj = pj - a.margin;           // crop (RF2:78)
@@ -283,7 +314,7 @@ __global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a) {
 }
 
 // fastloopNumba on explicit displacement maps: literal branch structure, global float atomics.
-__global__ __launch_bounds__(NTHREADS) void k_fastloop(const float *__restrict__ I, const float *__restrict__ Dx,
+__global__ __launch_bounds__(256) void k_fastloop(const float *__restrict__ I, const float *__restrict__ Dx,
                                                        const float *__restrict__ Dy, float *I2, int Nx, int Ny) {
     const int64_t n = (int64_t)Nx * Ny;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
@@ -307,57 +338,37 @@ __global__ __launch_bounds__(NTHREADS) void k_fastloop(const float *__restrict__
     }
 }
 
-constexpr size_t NEAR_LDS = sizeof(double) * SR * SC + sizeof(float) * GR * GC + sizeof(float) * TH * TW + 16;
+// Which geometry a call uses.  The wide halo costs ~20 % more source evaluations but keeps rays displaced by up to
+// 8 pixels inside the LDS gather; the far replay (scattered global float atomics, ~0.1 TB/s) is what it avoids.
+int g_refract_geometry = 1;   // 0: GeoSmall (H=4), 1: GeoWide (H=8)
 
-}  // namespace
-
-extern "C" {
-
-size_t psx_refract_workspace_bytes(int Nx, int Ny) {
-    if (Nx <= 0 || Ny <= 0) return 16;
-    const size_t nt = (size_t)cdiv(Nx, TH) * (size_t)cdiv(Ny, TW);
-    return sizeof(unsigned) * nt + sizeof(int) * nt * TH * TW;
+template <class G>
+size_t workspace_for(int Nx, int Ny) {
+    const size_t nt = (size_t)cdiv(Nx, G::TH) * (size_t)cdiv(Ny, G::TW);
+    return 16 * ((sizeof(unsigned) * nt + 15) / 16) + sizeof(FarRay) * nt * G::TH * G::TW;
 }
 
-int psx_refract_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,
-                    int nmat, const double *phi_in, float *I_out, float out_scale, int accumulate, float *Dx_out,
-                    float *Dy_out, float *I_mut, int Nx, int Ny, int margin, double dscale, double clamp_x,
-                    double clamp_y, unsigned *status, void *workspace, void *stream) {
-    PSX_REQUIRE(I_out != nullptr && workspace != nullptr, "psx_refract_f32: null output or workspace");
-    PSX_REQUIRE(Nx >= 3 && Ny >= 3, "psx_refract_f32: grid %dx%d too small for the edge_order=2 gradient", Nx, Ny);
-    PSX_REQUIRE((int64_t)Nx * Ny < (1ll << 31), "psx_refract_f32: grid %dx%d exceeds int32 pixel indices", Nx, Ny);
-    PSX_REQUIRE(margin >= H && margin <= 4096, "psx_refract_f32: margin %d must be >= %d", margin, H);
-    PSX_REQUIRE((Dx_out == nullptr) == (Dy_out == nullptr), "psx_refract_f32: Dx_out and Dy_out go together");
-    PSX_REQUIRE(nmat > 0 || phi_in != nullptr, "psx_refract_f32: no phase source (nmat=0 and phi_in=NULL)");
-    RefractArgs a;
-    if (int rc = pack_mats(a.m, T, cphase, catt, nmat)) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    a.I_in = I_in; a.I0 = I0; a.phi_in = phi_in; a.I_out = I_out; a.out_scale = out_scale; a.accumulate = accumulate;
-    a.Dx_out = Dx_out; a.Dy_out = Dy_out; a.I_mut = I_mut; a.Nx = Nx; a.Ny = Ny; a.margin = margin;
-    a.dscale = dscale; a.clamp_x = clamp_x; a.clamp_y = clamp_y; a.status = status;
-    a.tiles_x = (int)cdiv(Nx, TH);
-    a.tiles_y = (int)cdiv(Ny, TW);
+template <class G>
+int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int nmat, void *workspace, hipStream_t st) {
+    a.tiles_x = (int)cdiv(a.Nx, G::TH);
+    a.tiles_y = (int)cdiv(a.Ny, G::TW);
+    a.tile_cap = G::TH * G::TW;
     a.far_count = (unsigned *)workspace;
-    a.far_list = (int *)((char *)workspace + sizeof(unsigned) * (size_t)a.tiles_x * a.tiles_y);
-    if (Dx_out) {
-        const size_t padded = sizeof(float) * (size_t)(Nx + 2 * margin) * (size_t)(Ny + 2 * margin);
-        PSX_HIP(hipMemsetAsync(Dx_out, 0, padded, st));     // zero margins (RF2:65-66)
-        PSX_HIP(hipMemsetAsync(Dy_out, 0, padded, st));
-    }
+    a.far_list = (FarRay *)((char *)workspace + 16 * ((sizeof(unsigned) * (size_t)a.tiles_x * a.tiles_y + 15) / 16));
     int rc_launch = 0;
     auto launch = [&](auto nm, auto hi, auto hp) -> int {
         constexpr int NM = decltype(nm)::value;
         constexpr bool HI = decltype(hi)::value, HP = decltype(hp)::value;
         static bool attr_set = false;
         if (!attr_set) {
-            PSX_HIP(hipFuncSetAttribute((const void *)k_refract_near<NM, HI, HP>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)NEAR_LDS));
+            PSX_HIP(hipFuncSetAttribute((const void *)k_refract_near<G, NM, HI, HP>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
             attr_set = true;
         }
         PSX_TIMED("k_refract_near", st,
-                  k_refract_near<NM, HI, HP><<<a.tiles_x * a.tiles_y, NTHREADS, NEAR_LDS, st>>>(a));
+                  k_refract_near<G, NM, HI, HP><<<a.tiles_x * a.tiles_y, G::NT, G::LDS, st>>>(a));
         if (int rc = launch_check("k_refract_near")) return rc;
-        PSX_TIMED("k_refract_far", st, k_refract_far<NM, HI, HP><<<a.tiles_x * a.tiles_y, FAR_THREADS, 0, st>>>(a));
+        PSX_TIMED("k_refract_far", st, k_refract_far<<<a.tiles_x * a.tiles_y, FAR_THREADS, 0, st>>>(a));
         return 0;
     };
     PSX_DISPATCH_NMAT(nmat, {
@@ -371,9 +382,50 @@ int psx_refract_f32(const float *I_in, float I0, const float *const *T, const do
     return launch_check("k_refract_far");
 }
 
+}  // namespace
+
+extern "C" {
+
+size_t psx_refract_workspace_bytes(int Nx, int Ny) {
+    if (Nx <= 0 || Ny <= 0) return 16;
+    const size_t a = workspace_for<GeoSmall>(Nx, Ny), b = workspace_for<GeoWide>(Nx, Ny);
+    return a > b ? a : b;
+}
+
+int psx_refract_set_halo(int halo) {
+    PSX_REQUIRE(halo == 4 || halo == 8, "psx_refract_set_halo: halo must be 4 or 8, got %d", halo);
+    g_refract_geometry = halo == 8 ? 1 : 0;
+    return 0;
+}
+
+int psx_refract_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,
+                    int nmat, const double *phi_in, float *I_out, float out_scale, int accumulate, float *Dx_out,
+                    float *Dy_out, float *I_mut, int Nx, int Ny, int margin, double dscale, double clamp_x,
+                    double clamp_y, unsigned *status, void *workspace, void *stream) {
+    PSX_REQUIRE(I_out != nullptr && workspace != nullptr, "psx_refract_f32: null output or workspace");
+    PSX_REQUIRE(Nx >= 3 && Ny >= 3, "psx_refract_f32: grid %dx%d too small for the edge_order=2 gradient", Nx, Ny);
+    PSX_REQUIRE((int64_t)Nx * Ny < (1ll << 31), "psx_refract_f32: grid %dx%d exceeds int32 pixel indices", Nx, Ny);
+    PSX_REQUIRE(margin >= 8 && margin <= 4096, "psx_refract_f32: margin %d must be >= 8 (the widest gather halo)", margin);
+    PSX_REQUIRE((Dx_out == nullptr) == (Dy_out == nullptr), "psx_refract_f32: Dx_out and Dy_out go together");
+    PSX_REQUIRE(nmat > 0 || phi_in != nullptr, "psx_refract_f32: no phase source (nmat=0 and phi_in=NULL)");
+    RefractArgs a;
+    if (int rc = pack_mats(a.m, T, cphase, catt, nmat)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    a.I_in = I_in; a.I0 = I0; a.phi_in = phi_in; a.I_out = I_out; a.out_scale = out_scale; a.accumulate = accumulate;
+    a.Dx_out = Dx_out; a.Dy_out = Dy_out; a.I_mut = I_mut; a.Nx = Nx; a.Ny = Ny; a.margin = margin;
+    a.dscale = dscale; a.clamp_x = clamp_x; a.clamp_y = clamp_y; a.status = status;
+    if (Dx_out) {
+        const size_t padded = sizeof(float) * (size_t)(Nx + 2 * margin) * (size_t)(Ny + 2 * margin);
+        PSX_HIP(hipMemsetAsync(Dx_out, 0, padded, st));     // zero margins (RF2:65-66)
+        PSX_HIP(hipMemsetAsync(Dy_out, 0, padded, st));
+    }
+    return g_refract_geometry ? launch_refract<GeoWide>(a, I_in, phi_in, nmat, workspace, st)
+                              : launch_refract<GeoSmall>(a, I_in, phi_in, nmat, workspace, st);
+}
+
 int psx_fastloop_f32(const float *I, const float *Dx, const float *Dy, float *I2, int Nx, int Ny, void *stream) {
     PSX_REQUIRE(I && Dx && Dy && I2 && Nx > 0 && Ny > 0, "psx_fastloop_f32: null pointer or empty grid");
-    PSX_TIMED("k_fastloop", (hipStream_t)stream, k_fastloop<<<ew_grid((int64_t)Nx * Ny, NTHREADS), NTHREADS, 0, (hipStream_t)stream>>>(I, Dx, Dy, I2, Nx, Ny));
+    PSX_TIMED("k_fastloop", (hipStream_t)stream, k_fastloop<<<ew_grid((int64_t)Nx * Ny, 256), 256, 0, (hipStream_t)stream>>>(I, Dx, Dy, I2, Nx, Ny));
     return launch_check("k_fastloop");
 }
 

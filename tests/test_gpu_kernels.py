@@ -199,6 +199,33 @@ def test_refraction_far_rays_and_border_rules(ops):
     assert relmax(out.cpu().numpy(), ref) < TOL
 
 
+@pytest.mark.parametrize("halo", [4, 8])
+def test_refraction_both_tile_geometries(ops, halo):
+    """The gather halo (4 or 8 pixels) is a pure speed knob: every golden case passes with either."""
+    from paresis_amd._lib import lib
+    g = load("refraction.npz")
+    try:
+        assert lib().psx_refract_set_halo(halo) == 0
+        for k in range(int(g["n"])):
+            z, E, M, pix = g["%d/params" % k]
+            I = g["%d/I" % k]; phi = g["%d/phi" % k]
+            Nx, Ny = I.shape
+            h = pix * 1e-6
+            out, Dx, Dy = ops.refract((Nx, Ny), None, z / orc.k_refraction(E) / (h * M) / h, (Nx, Ny),
+                                      I_in=dev(I, torch.float32), phi_in=dev(phi, torch.float64), want_D=True)
+            assert relmax(out.cpu().numpy(), g["%d/v2/out" % k]) < TOL, (halo, k)
+        # bitwise reproducible when no ray is far (fixed-point tile sums do not depend on the atomics' order)
+        z, E, M, pix = g["0/params"]
+        I = dev(g["0/I"], torch.float32); phi = dev(g["0/phi"] * 0.2, torch.float64)
+        h = pix * 1e-6
+        a1, _, _ = ops.refract(I.shape, None, z / orc.k_refraction(E) / (h * M) / h, I.shape, I_in=I, phi_in=phi)
+        a2, _, _ = ops.refract(I.shape, None, z / orc.k_refraction(E) / (h * M) / h, I.shape, I_in=I, phi_in=phi)
+        assert torch.equal(a1, a2)
+    finally:
+        lib().psx_refract_set_halo(8)
+    assert lib().psx_refract_set_halo(5) != 0
+
+
 def test_refraction_status_flag(ops):
     Nx, Ny = 64, 64
     I = torch.full((Nx, Ny), float("inf"), dtype=torch.float32, device="cuda")
