@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--engine", default="auto", choices=["auto", "rocfft", "lds"])
+    ap.add_argument("--halo", type=int, default=8, choices=[4, 8], help="refraction gather halo (speed knob)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -59,6 +60,7 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
     lib = _lib.lib()
     assert lib.psx_device_ok() == 1, lib.psx_last_error()
+    _lib.check(lib.psx_refract_set_halo(a.halo), "psx_refract_set_halo")
 
     N = a.size
     E = 52.0
