@@ -39,3 +39,27 @@ def build_experiment(cfg, sim, noise=False):
                                    sample(cfg["sample"], "sample", "sample_of_interest", ["Nylon"]),
                                    air=None if cfg["inVacuum"] else sample(cfg["air"], "air_volume", "volume", ["Air"]),
                                    plate=sample(cfg["plate"], "plate", "thin_film", ["C"]))
+
+
+def cfg_from_experiment(exp, Obj):
+    """Oracle configuration holding exactly what an XML-built paresis_amd Experiment holds (same XML -> both sides)."""
+    import numpy as np
+    ed = exp.exp_dict
+    energies = [e for e, _ in exp.mySource.mySpectrum]
+
+    def obj(s):
+        if s is None:
+            return None
+        geom = np.asarray(s.myGeometry, dtype=np.float64)
+        return Obj(geom, [[v for _, v in l] for l in s.delta], [[v for _, v in l] for l in s.beta])
+
+    return dict(dSM=ed["distSourceToMembrane"], dMO=ed["distMembraneToObject"], dOD=ed["distObjectToDetector"],
+                meanShotCount=ed["meanShotCount"], ov=ed["overSampling"], pix_um=ed["studyPixelSize"],
+                M=ed["magnification"], inVacuum=ed["inVacuum"], N=tuple(ed["studyDimensions"]),
+                spectrum=list(exp.mySource.mySpectrum), source_size_um=exp.mySource.source_dict["mySize"],
+                energy_sampling=exp.mySource.source_dict["myEnergySampling"],
+                det_dims=tuple(int(v) for v in exp.myDetector.det_param["myDimensions"]),
+                det_pix_um=exp.myDetector.det_param["myPixelSize"], psf=exp.myDetector.det_param["myPSF"],
+                bins=list(exp.myDetector.det_param["myBinsThersholds"]),
+                membrane=obj(exp.myMembrane), sample=obj(exp.mySampleofInterest),
+                air=None if ed["inVacuum"] else obj(exp.myAirVolume), plate=obj(exp.myPlate))

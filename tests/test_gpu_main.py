@@ -1,0 +1,55 @@
+"""XML-driven entry (paresis_amd/main.py, mirror of CodePython/main.py) on the GPU, and parity of the XML-built chains
+with the oracle fed from the SAME XML-derived configuration."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import paresis_oracle as orc
+from tests._build import cfg_from_experiment
+from tests._golden import relmax
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("sim,name,ov", [("RayT", "Fil_Nylon_ID17", 2), ("Fresnel", "Fil_Nylon_ID17", 2),
+                                         ("Fresnel", "Sphere_PMMA_plate", 1), ("RayT", "Sphere_PMMA_plate", 2)])
+def test_xml_experiment_matches_oracle(sim, name, ov):
+    from paresis_amd.Experiment import Experiment
+    ed = {"experimentName": name, "filepath": "/tmp/", "overSampling": ov, "nbExpPoints": 2, "simulation_type": sim,
+          "noise": False}
+    exp = Experiment(ed)
+    for point in (0, 1):
+        exp.myMembrane.myGeometry = []
+        exp.myMembrane.getMyGeometry(ed["studyDimensions"], exp.myMembrane.membranePixelSize, ov, point, 2)   # main.py:64-65
+        cfg = cfg_from_experiment(exp, orc.Obj)
+        ed["meanEnergy"] = 0
+        out = exp.computeSampleAndReferenceImages(point)
+        if sim == "RayT":
+            ref = orc.compute_rt(cfg, point)
+            refs, mE = ref[:4], ref[6]
+        else:
+            ref = orc.compute_fresnel(cfg, point)
+            refs, mE = ref[:4], ref[4]
+        for nm, a, r in zip(("Sample", "Reference", "Propag", "White"), out[:4], refs):
+            err = relmax(a.cpu().numpy(), r)
+            assert err < 1e-5, (sim, name, point, nm, err)
+        assert abs(ed["meanEnergy"] - mE) < 1e-4
+
+
+def test_main_writes_images(tmp_path):
+    from paresis_amd import main
+    from paresis_amd.InputOutput.pagailleIO import openImage
+    for sim, fmt in (("RayT", ".tif"), ("Fresnel", ".edf")):
+        ed = {"experimentName": "Fil_Nylon_ID17", "filepath": str(tmp_path) + "/" + sim + "/", "overSampling": 2,
+              "nbExpPoints": 2, "simulation_type": sim, "noise": True, "seed": 5}
+        os.makedirs(ed["filepath"])
+        res = main.run(ed, save=True, saving_format=fmt)
+        assert sorted(res) == [0, 1] and res[0][0].shape == (1, 200, 200)
+        files = glob.glob(ed["filepath"] + "*/sample/*" + fmt)
+        assert len(files) == 2
+        img = openImage(files[0])
+        assert img.shape == (200, 200) and np.all(img == np.floor(img)) and img.mean() > 1000    # Poisson counts
+        assert glob.glob(ed["filepath"] + "*/ref/*" + fmt) and glob.glob(ed["filepath"] + "*/propag/*" + fmt)
+        assert glob.glob(ed["filepath"] + "*.txt")                                                  # saveAllParameters
