@@ -86,6 +86,9 @@ inline int mats_variant(int n) { return n <= 4 ? n : 8; }
         default: { constexpr int NM = 8; __VA_ARGS__; } break; \
     }
 
+// diagnostic phase-timestamp buffer (psx_debug_stamps); null in every timed run
+extern unsigned long long *g_stamps;
+
 // ---- optional per-kernel timing with HIP events on the launch stream (psx_profile_*) ---------------------------------
 // Off by default: a ProfScope then costs one branch.  When on, every kernel launch of the library is bracketed by two
 // events recorded on the stream it is launched on; psx_profile_summary() resolves them after the work has drained.

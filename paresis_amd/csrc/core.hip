@@ -62,6 +62,8 @@ hipEvent_t take_event() {
 }
 }  // namespace
 
+unsigned long long *g_stamps = nullptr;
+
 bool prof_enabled() { return g_prof_on; }
 
 int prof_begin(const char *name, hipStream_t st) {
@@ -107,6 +109,11 @@ int psx_device_ok(void) {
         return 0;
     }
     return 1;
+}
+
+int psx_debug_stamps(void *buf) {
+    psx::g_stamps = (unsigned long long *)buf;
+    return 0;
 }
 
 int psx_profile_enable(int on) {

@@ -400,8 +400,6 @@ int pick_r3(int N, int margin) {
 
 namespace psx {
 
-unsigned long long *g_stamps = nullptr;
-
 struct AxisTables {
     int N = 0, R3 = 0, M = 0;
     float2 *twA = nullptr, *twB = nullptr;
@@ -639,7 +637,3 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
 
 }  // namespace psx
 
-extern "C" int psx_debug_stamps(void *buf) {
-    psx::g_stamps = (unsigned long long *)buf;
-    return 0;
-}

