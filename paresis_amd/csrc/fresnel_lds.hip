@@ -18,6 +18,7 @@
 // TRANSPOSED, pass 2 runs along the transposed axis 0 (= original rows) and writes the final image: every global store
 // of both passes is a contiguous line.  Several distances share pass 1's forward transform (its spectrum stays in
 // registers while each distance's kernel is applied), e.g. Experiment.py:341 and :349.
+#include <cstdlib>
 #include <vector>
 
 #include "fft_regs.hpp"
@@ -132,6 +133,26 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         }
     };
 
+    // v[q] *= conj(tw[n][q]); with the spectrum F resident (MULTI) the twiddles come in two batches of 12 so that only
+    // 24 instead of 48 VGPRs hold them at a time
+    auto mul_tw_conj = [&](const float2 *tw, int n, float2(&v)[RAD]) __attribute__((always_inline)) {
+        const float4 *t4 = reinterpret_cast<const float4 *>(tw + (size_t)n * RAD);
+        constexpr int NB = MULTI ? 2 : 1, PER = RAD / 2 / NB;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float4 x[PER];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) x[q] = t4[b * PER + q];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int k = 2 * (b * PER + q);
+                if (k > 0) v[k] = cmulc(v[k], make_float2(x[q].x, x[q].y));
+                v[k + 1] = cmulc(v[k + 1], make_float2(x[q].z, x[q].w));
+            }
+            if (MULTI) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}
 #pragma unroll 1
     for (int u = 0; u < BPT; ++u) {
@@ -206,17 +227,33 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             const int s = tid + T * r, line = s / (M / SLAB), p0 = (s % (M / SLAB)) * SLAB;
             if (NSLABS % T != 0 && s >= NSLABS) break;      // idle tail of the last slab round
             float2 *base = lds + line * MP;
-            float4 hh[SLAB / 2];                     // kernel spectrum of this slab: issued before the LDS reads
             const float4 *h4 = reinterpret_cast<const float4 *>(Hd + p0);
-#pragma unroll
-            for (int j = 0; j < SLAB / 2; ++j) hh[j] = h4[j];
-            if (!MULTI) load_slab(r, F[0]);
-            float2(&f)[SLAB] = F[MULTI ? r : 0];
             float2 g[SLAB];
+            if (!MULTI) {
+                float4 hh[SLAB / 2];                 // kernel spectrum of this slab: issued before the LDS reads
 #pragma unroll
-            for (int j = 0; j < SLAB / 2; ++j) {
-                g[2 * j] = cmul(f[2 * j], make_float2(hh[j].x, hh[j].y));
-                g[2 * j + 1] = cmul(f[2 * j + 1], make_float2(hh[j].z, hh[j].w));
+                for (int j = 0; j < SLAB / 2; ++j) hh[j] = h4[j];
+                load_slab(r, F[0]);
+#pragma unroll
+                for (int j = 0; j < SLAB / 2; ++j) {
+                    g[2 * j] = cmul(F[0][2 * j], make_float2(hh[j].x, hh[j].y));
+                    g[2 * j + 1] = cmul(F[0][2 * j + 1], make_float2(hh[j].z, hh[j].w));
+                }
+            } else {                                 // resident spectrum: two batches keep the live set small
+                float2(&f)[SLAB] = F[r];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float4 hh[SLAB / 4];
+#pragma unroll
+                    for (int j = 0; j < SLAB / 4; ++j) hh[j] = h4[b * (SLAB / 4) + j];
+#pragma unroll
+                    for (int j = 0; j < SLAB / 4; ++j) {
+                        const int k = 2 * (b * (SLAB / 4) + j);
+                        g[k] = cmul(f[k], make_float2(hh[j].x, hh[j].y));
+                        g[k + 1] = cmul(f[k + 1], make_float2(hh[j].z, hh[j].w));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
 #pragma unroll
             for (int c = 0; c < SLAB / R3; ++c) {
@@ -242,12 +279,10 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             const int e = tid + T * u, line = e / S1, rem = e % S1, q1 = rem / R3, n = rem % R3;
             float2 *base = lds + line * MP;
             const int p0 = q1 * S1 + n;
-            float2 v[RAD], w[RAD];
-            load_tw(twB_i, n, w);
+            float2 v[RAD];
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = base[idxB(p0, q)];
-#pragma unroll
-            for (int q = 1; q < RAD; ++q) v[q] = cmulc(v[q], w[q]);
+            mul_tw_conj(twB_i, n, v);
             __builtin_amdgcn_sched_barrier(0);
             Dft<RAD, true>::run(v);
 #pragma unroll
@@ -267,12 +302,10 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         for (int u = 0; u < BPT; ++u) {
             const int e = tid + T * u, line = e / S1, n = e % S1;
             const float2 *base = lds + line * MP;
-            float2 v[RAD], w[RAD];
-            load_tw(twA_i, n, w);
+            float2 v[RAD];
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = base[idxA(n, q)];
-#pragma unroll
-            for (int q = 1; q < RAD; ++q) v[q] = cmulc(v[q], w[q]);
+            mul_tw_conj(twA_i, n, v);
             __builtin_amdgcn_sched_barrier(0);
             Dft<RAD, true>::run(v);
             if (l0 + line < a.nlines) {
@@ -596,7 +629,8 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
     la.N = p->Nx; la.nlines = p->Ny; la.margin = p->margin; la.P = p->Px; la.L = p->Nx + p->Px - 1;
     la.in_stride = p->Ny; la.out_ld = p->Nx;
     la.twA = e->ax[0].twA; la.twB = e->ax[0].twB;
-    la.n_dist = nnz; la.accumulate = 0; la.stamps = nullptr;
+    static const bool stamp_pass1 = getenv("PSX_STAMP_PASS1") != nullptr;   // diagnostics only
+    la.n_dist = nnz; la.accumulate = 0; la.stamps = stamp_pass1 ? g_stamps : nullptr;
     for (int i = 0; i < nnz; ++i) {
         if (int rc = kernel_spectrum(p, e->ax[0], a.a[nz[i]], a.du_x, st, &la.H[i])) return rc;
         la.wave_out[i] = e->inter + (size_t)i * npix;
@@ -623,7 +657,7 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         lb.N = p->Ny; lb.nlines = p->Nx; lb.margin = p->margin; lb.P = p->Py; lb.L = p->Ny + p->Py - 1;
         lb.in_stride = p->Nx; lb.out_ld = p->Ny;
         lb.twA = e->ax[1].twA; lb.twB = e->ax[1].twB;
-        lb.n_dist = 1; lb.accumulate = a.accumulate; lb.stamps = g_stamps;
+        lb.n_dist = 1; lb.accumulate = a.accumulate; lb.stamps = stamp_pass1 ? nullptr : g_stamps;
         if (int rc2 = kernel_spectrum(p, e->ax[1], a.a[d], a.du_y, st, &lb.H[0])) return rc2;
         lb.wave_out[0] = a.wave_out ? a.wave_out[d] : nullptr;
         lb.inten_out[0] = a.inten_out ? a.inten_out[d] : nullptr;

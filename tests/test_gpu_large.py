@@ -1,0 +1,148 @@
+"""BASELINE.json's full sizes on the GPU, checked through size-independent properties (the oracle would take minutes):
+2048^2 / 4096^2 on the LDS Fresnel engine, 16384^2 on the rocFFT engine, plus an oracle spot check at 1024^2."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import paresis_oracle as orc
+from tests._golden import relmax
+
+pytestmark = pytest.mark.gpu
+
+
+def _membrane(N, seed=0):
+    from paresis_amd import synth
+    g = synth.bench_geometry(N, pointNum=seed)
+    return g, torch.from_numpy(g["membrane"]).cuda()
+
+
+def _stacks(ops, T, E=52.0):
+    from paresis_amd import synth
+    from paresis_amd.getk import k_sample
+    k = k_sample(E)
+    d = [synth.DELTA_BETA_52KEV[m] for m in ("CuSn", "PMMA")]
+    wave = ops.MaterialStack(T, cphase=[-k * x[0] for x in d], catt=[-k * x[1] for x in d])
+    rt = ops.MaterialStack(T, cphase=[-k * x[0] for x in d], catt=[-2 * k * x[1] for x in d])
+    return wave, rt
+
+
+@pytest.mark.parametrize("N,engine", [(2048, 2), (4096, 2), (4096, 1)])
+def test_fresnel_properties_full_size(N, engine):
+    from paresis_amd import ops
+    from paresis_amd.getk import getk
+    g, T = _membrane(N)
+    wave, _ = _stacks(ops, T)
+    plan = ops.FresnelPlan(N, N, max_dist=2, engine=engine)
+    assert plan.engine == engine
+    kk = getk(52000.0)
+    h = g["pix_um"] * 1e-6
+    du = (2 * np.pi / (N * h),) * 2
+    a = [3.6 / (2 * kk * g["M"]), 7.2 / (2 * kk * g["M"])]
+    # (1) uniform wave keeps its modulus
+    u = torch.full((N, N), 2.0 + 1.0j, dtype=torch.complex64, device="cuda")
+    out = plan.propagate(a[:1], [0.3], du, wave_in=u)[0]
+    assert float((out.abs() - abs(2 + 1j)).abs().max()) < 2e-5
+    # (2) linearity: P(alpha*w1 + w2) == alpha*P(w1) + P(w2)
+    w1 = ops.transmit_wave(None, 50.0, wave)
+    w2 = torch.roll(w1, (37, -111), (0, 1)).contiguous()
+    p1, p2 = plan.propagate(a[:1], [0.0], du, wave_in=w1)[0], plan.propagate(a[:1], [0.0], du, wave_in=w2)[0]
+    p12 = plan.propagate(a[:1], [0.0], du, wave_in=(0.5 * w1 + w2).contiguous())[0]
+    assert float((p12 - (0.5 * p1 + p2)).abs().max() / p1.abs().max()) < 2e-5
+    # (3) fused transmission == separate transmission; two distances in one call == one by one; |.|^2 output
+    f2 = plan.propagate(a, [0.0, 0.0], du, amp=50.0, mats=wave)
+    assert float((f2[0] - p1).abs().max() / p1.abs().max()) < 2e-6
+    inten = torch.zeros((N, N), dtype=torch.float32, device="cuda")
+    plan.propagate(a[1:], [0.0], du, wave_in=w1, want_wave=[False], inten_out=[inten])
+    assert float((inten - f2[1].abs() ** 2).abs().max() / inten.max()) < 2e-6
+    # (4) composition of the periodic operator: propagating by a then by a equals propagating by 2a away from the frame
+    #     (the crop/re-pad between the two hops only touches a band near the border)
+    q = plan.propagate(a[:1], [0.0], du, wave_in=p1)[0]
+    m = 600
+    err = (q - f2[1])[m:-m, m:-m].abs().max() / f2[1].abs().max()
+    assert float(err) < 5e-3
+    plan.close()
+
+
+def test_both_engines_agree_4096():
+    from paresis_amd import ops
+    from paresis_amd.getk import getk
+    N = 4096
+    g, T = _membrane(N, 1)
+    wave, _ = _stacks(ops, T)
+    kk = getk(52000.0)
+    h = g["pix_um"] * 1e-6
+    du = (2 * np.pi / (N * h),) * 2
+    a = [1.6 / (2 * kk * 141.6 / 140)]
+    outs = []
+    for eng in (1, 2):
+        plan = ops.FresnelPlan(N, N, engine=eng)
+        outs.append(plan.propagate(a, [kk * 1.6 / (141.6 / 140)], du, amp=86.6, mats=wave)[0])
+        plan.close()
+    assert float((outs[0] - outs[1]).abs().max() / outs[0].abs().max()) < 3e-6
+
+
+@pytest.mark.parametrize("N", [1024])
+def test_oracle_spot_check(N):
+    from paresis_amd import ops, synth
+    from paresis_amd.getk import getk, k_refraction
+    g, T = _membrane(N, 2)
+    wave, rt = _stacks(ops, T)
+    d = [synth.DELTA_BETA_52KEV[m] for m in ("CuSn", "PMMA")]
+    delta, beta = [x[0] for x in d], [x[1] for x in d]
+    g64 = g["membrane"].astype(np.float64)
+    kk = getk(52000.0)
+    h = g["pix_um"] * 1e-6
+    plan = ops.FresnelPlan(N, N)
+    out = plan.propagate([3.6 / (2 * kk * g["M"])], [kk * 3.6 / g["M"]], (2 * np.pi / (N * h),) * 2, amp=86.6, mats=wave)[0]
+    ref = orc.wave_propagation(orc.set_wave(np.full((N, N), 86.6 + 0j), g64, delta, beta, 52.0), 3.6, 52.0, g["M"], (N, N), g["pix_um"])
+    assert relmax(out.cpu().numpy(), ref) < 1e-5
+    I, phi, _ = orc.set_wave_rt(np.full((N, N), 7500.0), g64, delta, beta, 52.0, 0)
+    r_ref, _, _ = orc.fast_refraction(I, phi, 7.2, 52.0, g["M"], g["pix_um"])
+    r, _, _ = ops.refract((N, N), rt, 7.2 / k_refraction(52.0) / (h * g["M"]) / h, (N, N), I0=7500.0)
+    ops.check_status(r.device)
+    assert relmax(r.cpu().numpy(), r_ref) < 1e-5
+
+
+def test_refraction_flux_and_halos_4096():
+    """Flux that stays on the grid is conserved; both gather halos give the same image at full size."""
+    from paresis_amd import ops
+    from paresis_amd._lib import lib
+    from paresis_amd.getk import k_refraction
+    N = 4096
+    g, T = _membrane(N, 3)
+    _, rt = _stacks(ops, T)
+    h = g["pix_um"] * 1e-6
+    dsc = 5.2 / k_refraction(52.0) / (h * g["M"]) / h
+    outs = []
+    try:
+        for halo in (4, 8):
+            lib().psx_refract_set_halo(halo)
+            out, _, _ = ops.refract((N, N), rt, dsc, (N, N), I0=7500.0)
+            outs.append(out)
+    finally:
+        lib().psx_refract_set_halo(8)
+    assert float((outs[0] - outs[1]).abs().max() / outs[0].max()) < 2e-6
+    I_in, _ = ops.transmit_rt(None, 7500.0, rt, want_phi=False)
+    m = 64   # rays near the frame may leave; compare the bulk
+    lost = abs(float(outs[1][m:-m, m:-m].sum(dtype=torch.float64) / I_in[m:-m, m:-m].sum(dtype=torch.float64)) - 1)
+    assert lost < 1e-3
+
+
+def test_16384_rocfft_engine_and_detector():
+    """Config 5: 16384^2 study grid (detector 4096^2 x oversampling 4, PSF 1.2 px, 10 um source) resident in HBM."""
+    from paresis_amd import ops
+    N, ov, n = 16384, 4, 4096
+    plan = ops.FresnelPlan(N, N, max_dist=1)
+    assert plan.engine == 1                      # a 32797-point line does not fit LDS: rocFFT engine
+    u = torch.full((N, N), 1.5 + 0j, dtype=torch.complex64, device="cuda")
+    inten = torch.zeros((N, N), dtype=torch.float32, device="cuda")
+    plan.propagate([2e-12], [0.1], (3e5, 3e5), wave_in=u, want_wave=[False], inten_out=[inten])
+    assert float((inten - 2.25).abs().max()) < 1e-4
+    del u
+    plan.close()
+    det = ops.DetectorPlan(N, N, ov, n, n, 10 * 3.6 / 141.6 / 6 * ov / 2.355, 1.2)
+    img = det.detect(inten)
+    assert img.shape == (n, n)
+    assert float((img[40:-40, 40:-40] - 2.25 * ov * ov).abs().max()) < 1e-3     # bin SUM of a uniform image
+    noisy = ops.poisson(img * 100, seed=11)
+    assert abs(float(noisy.mean()) / (225.0 * ov * ov) - 1) < 1e-3
