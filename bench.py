@@ -168,7 +168,7 @@ def main():
         if dom is not None:
             ach = alg[dom] / (per[dom] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, N),
                                "ms_per_launch": round(per[dom], 4), "algorithmic_bytes_per_launch": alg[dom]}
             # whole-step view with the same accounting: 4 x (64 + 12 + 4*nmat) bytes per padded pixel
             step_bytes = units * (64 + 12 + 4 * nmat) * P * P
@@ -180,6 +180,21 @@ def main():
     if world > 1:
         td.barrier()
         td.destroy_process_group()
+
+
+def pmc_traffic(kernel, N):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_summary.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950).  Only valid for the configuration it was collected on (N = 4096); None otherwise."""
+    if N != 4096:
+        return None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    key = {"k_fresnel_rows": "k_fresnel_lines<16, 0, false>", "k_fresnel_cols": "k_fresnel_lines<16, 2, false>",
+           "k_refract_near": "k_refract_near<"}.get(kernel)
+    return prof.get(key, {}).get("hbm_bytes_per_launch") if key else None
 
 
 def cpu_baseline(N, geo, delta, beta, E, M, pix, I0, fres, refr):

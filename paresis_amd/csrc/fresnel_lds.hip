@@ -623,29 +623,36 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
     }
     if (nnz == 0) return launch_check("k_source_out");
 
-    // ---- pass 1: lines along axis 0 (columns), all distances share the forward transform, output transposed
-    LineArgs la;
-    la.src = src; la.amp = amp; la.m = m;
-    la.N = p->Nx; la.nlines = p->Ny; la.margin = p->margin; la.P = p->Px; la.L = p->Nx + p->Px - 1;
-    la.in_stride = p->Ny; la.out_ld = p->Nx;
-    la.twA = e->ax[0].twA; la.twB = e->ax[0].twB;
+    // ---- pass 1: lines along axis 0 (columns), output transposed.  One launch per distance: keeping the forward spectrum
+    // in registers across distances (the MULTI variant) needs 64 more VGPRs than the 168 a 12-wave workgroup has, and its
+    // spills cost more HBM traffic (3.9 GB per 4-distance launch, rocprof) than re-running the forward stages.
     static const bool stamp_pass1 = getenv("PSX_STAMP_PASS1") != nullptr;   // diagnostics only
-    la.n_dist = nnz; la.accumulate = 0; la.stamps = stamp_pass1 ? g_stamps : nullptr;
-    for (int i = 0; i < nnz; ++i) {
-        if (int rc = kernel_spectrum(p, e->ax[0], a.a[nz[i]], a.du_x, st, &la.H[i])) return rc;
-        la.wave_out[i] = e->inter + (size_t)i * npix;
-        la.inten_out[i] = nullptr;
-        la.scale[i] = 1.f;
-        la.gph[i] = make_float2(1.f, 0.f);
+    static const bool share_fwd = getenv("PSX_FRESNEL_SHARE_FORWARD") != nullptr;
+    const int launches = share_fwd ? 1 : nnz;
+    for (int li = 0; li < launches; ++li) {
+        LineArgs la;
+        la.src = src; la.amp = amp; la.m = m;
+        la.N = p->Nx; la.nlines = p->Ny; la.margin = p->margin; la.P = p->Px; la.L = p->Nx + p->Px - 1;
+        la.in_stride = p->Ny; la.out_ld = p->Nx;
+        la.twA = e->ax[0].twA; la.twB = e->ax[0].twB;
+        la.n_dist = share_fwd ? nnz : 1; la.accumulate = 0; la.stamps = stamp_pass1 ? g_stamps : nullptr;
+        for (int k = 0; k < la.n_dist; ++k) {
+            const int i = share_fwd ? k : li;
+            if (int rc = kernel_spectrum(p, e->ax[0], a.a[nz[i]], a.du_x, st, &la.H[k])) return rc;
+            la.wave_out[k] = e->inter + (size_t)i * npix;
+            la.inten_out[k] = nullptr;
+            la.scale[k] = 1.f;
+            la.gph[k] = make_float2(1.f, 0.f);
+        }
+        int rc = 0;
+        switch (m.n) {
+            case 0: rc = launch_lines_r3<0>(e->ax[0].R3, la, st, "k_fresnel_cols"); break;
+            case 1: rc = launch_lines_r3<1>(e->ax[0].R3, la, st, "k_fresnel_cols"); break;
+            case 2: rc = launch_lines_r3<2>(e->ax[0].R3, la, st, "k_fresnel_cols"); break;
+            default: rc = launch_lines_r3<3>(e->ax[0].R3, la, st, "k_fresnel_cols"); break;
+        }
+        if (rc) return rc;
     }
-    int rc = 0;
-    switch (m.n) {
-        case 0: rc = launch_lines_r3<0>(e->ax[0].R3, la, st, "k_fresnel_cols"); break;
-        case 1: rc = launch_lines_r3<1>(e->ax[0].R3, la, st, "k_fresnel_cols"); break;
-        case 2: rc = launch_lines_r3<2>(e->ax[0].R3, la, st, "k_fresnel_cols"); break;
-        default: rc = launch_lines_r3<3>(e->ax[0].R3, la, st, "k_fresnel_cols"); break;
-    }
-    if (rc) return rc;
 
     // ---- pass 2: lines along axis 1 of the original image (= axis 0 of the transposed intermediate)
     Mats none;

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 outputs under gpurun_out/fin_{stats,fetch,write,sq}/ into the committed summaries in profiles/."""
+import collections, csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+os.makedirs("profiles", exist_ok=True)
+newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1]
+shutil.copy(newest("gpurun_out/fin_stats/runc/*kernel_stats.csv"), "profiles/%s_kernel_stats.csv" % tag)
+
+
+def agg(d):
+    rows = list(csv.DictReader(open(newest("gpurun_out/%s/runc/*counter_collection.csv" % d))))
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in rows:
+        name = r["Kernel_Name"]
+        if "anonymous" not in name:
+            continue
+        short = name.split("::")[1].split("(")[0]
+        out[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in out.items()}
+
+
+fetch, write, sq = agg("fin_fetch"), agg("fin_write"), agg("fin_sq")
+summary = {}
+for k in sorted(set(fetch) | set(write) | set(sq)):
+    if not (k.startswith("k_fresnel") or k.startswith("k_refract")):
+        continue
+    e = {}
+    if k in fetch:
+        e["FETCH_SIZE_KB"] = fetch[k]["FETCH_SIZE"]
+    if k in write:
+        e["WRITE_SIZE_KB"] = write[k]["WRITE_SIZE"]
+    if k in fetch and k in write:
+        e["hbm_bytes_per_launch"] = int((2 * fetch[k]["FETCH_SIZE"] + write[k]["WRITE_SIZE"]) * 1024)
+    e.update(sq.get(k, {}))
+    summary[k] = e
+json.dump({"note": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ counters each in its own run) of "
+                   "`python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing` on one MI355X; averages per "
+                   "launch.  hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE reads half of a wide "
+                   "coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section), WRITE_SIZE is exact.",
+           "kernels": summary}, open("profiles/%s_pmc_summary.json" % tag, "w"), indent=1)
+for k, e in summary.items():
+    print(k, {a: ("%.4g" % b if isinstance(b, float) else b) for a, b in e.items()})
