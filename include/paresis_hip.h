@@ -144,6 +144,14 @@ int psx_resize_f32(const float *img, int Nx, int Ny, float *out, int sx, int sy,
  * the reference seeds from the wall clock, so only the distribution is reproducible) */
 int psx_poisson_f32(const float *lam, float *out, int64_t n, uint64_t seed, void *stream);
 
+/* ---- membrane thickness synthesis (next row of the scope table) -----------------------------
+ * getMembraneSegmentedFromFile's sphere splat (Samples/getMembraneFromFile.py:143-159) for ONE layer:
+ * out[i][j] (+)= scale * sum over spheres of 2*sqrt(r^2 - dist^2) on the cropped grid, with the reference's window and
+ * placement rules.  xf, yf, rad are HOST arrays (pixels of the margin-extended grid: they come from a host-side list);
+ * out is a DEVICE image.  Unlike the rest of the ABI this call synchronises the stream once (host staging buffers). */
+int psx_membrane_f32(const double *xf, const double *yf, const double *rad, int64_t n, int dimX, int dimY, int margin,
+                     int margin2, double scale, int accumulate, float *out, void *stream);
+
 /* ---- per-kernel timing (bench.py's roofline leg) ----------------------------------------------------------------------
  * psx_profile_enable(1) clears the log and makes every kernel launch of the library record a HIP event pair on the
  * stream it is launched on; psx_profile_summary() waits for the recorded events and writes one line per kernel,

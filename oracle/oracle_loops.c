@@ -72,3 +72,25 @@ void oracle_resize(int64_t Nx, int64_t Ny, const double *img, int64_t sizeX, int
         }
     }
 }
+
+/* Sphere splat of getMembraneSegmentedFromFile (Samples/getMembraneFromFile.py:143-159) for one layer.
+ * membrane is [Mx][My] (study grid + margin on every side); xf, yf, rad are in pixels of that grid.
+ * A sphere is drawn when margin2 < round(x) < dimX+margin+margin2 (same in y); its window is
+ * [x-radInt, x+radInt) x [y-radInt, y+radInt) with radInt = floor(rad)+1 -- note the half-open upper end. */
+void oracle_membrane_splat(int64_t n, const double *xf, const double *yf, const double *rad, int64_t dimX, int64_t dimY,
+                           int64_t margin, int64_t margin2, double *membrane)
+{
+    const int64_t My = dimY + 2 * margin;
+    for (int64_t i = 0; i < n; ++i) {
+        const double r = rad[i];
+        const int64_t radInt = (int64_t)floor(r) + 1;
+        const int64_t x = (int64_t)rint(xf[i]), y = (int64_t)rint(yf[i]);    /* np.round: half to even */
+        if (!(margin2 < x && x < dimX + margin + margin2 && margin2 < y && y < dimY + margin + margin2)) continue;
+        for (int64_t ii = -radInt; ii < radInt; ++ii)
+            for (int64_t jj = -radInt; jj < radInt; ++jj) {
+                const double dx = (double)(ii + x) - xf[i], dy = (double)(jj + y) - yf[i];
+                const double dist = sqrt(dx * dx + dy * dy);
+                if (dist < r) membrane[(x + ii) * My + (y + jj)] += 2.0 * sqrt(r * r - dist * dist);
+            }
+    }
+}

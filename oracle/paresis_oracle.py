@@ -32,6 +32,9 @@ def _lib():
         lib.oracle_fastloop.restype = None
         lib.oracle_resize.argtypes = [ctypes.c_int64, ctypes.c_int64, dp, ctypes.c_int64, ctypes.c_int64, dp]
         lib.oracle_resize.restype = None
+        lib.oracle_membrane_splat.argtypes = [ctypes.c_int64, dp, dp, dp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                              ctypes.c_int64, dp]
+        lib.oracle_membrane_splat.restype = None
         _LIB = lib
     return _LIB
 
@@ -315,3 +318,52 @@ def compute_rt(cfg, point, variant="v2"):
             accS = np.zeros((N0, N1)); accR = np.zeros((N0, N1)); accP = np.zeros((N0, N1)); white = np.zeros((N0, N1))
             ibin += 1
     return S, R, Pg, W, Dxreal, Dyreal, meanE / sumI
+
+
+# ------------------------------------------------------------------------------------- membrane synthesis
+def membrane_sphere_layers(sphere_list, dimX, dimY, pix_um, mean_radius_um, n_layers, rand_state):
+    """Host part of getMembraneSegmentedFromFile (Samples/getMembraneFromFile.py:79-142): scale the sphere list to the
+    requested mean radius, move the origin to the top-left corner, stitch copies until the list covers the study grid,
+    draw one random offset per layer.  Returns (margin, margin2, [(xfloat, yfloat, radFloat) per layer]) in pixels of the
+    margin-extended grid.  `rand_state` is a numpy RandomState: the reference uses the unseeded global one (:139-140)."""
+    margin = int(np.ceil(10 * mean_radius_um / pix_um))                      # :80
+    margin2 = int(np.floor(margin / 2))                                      # :81
+    corr = mean_radius_um / 12.8                                             # :85
+    size_x = int(np.floor(8102)) * corr + mean_radius_um                     # :86
+    size_y = int(np.floor(9740)) * corr + mean_radius_um                     # :87
+    par = np.asarray(sphere_list, dtype=np.float64) * corr                   # :93-94
+    par[:, 1] += size_x / 2                                                  # :97-98
+    par[:, 0] += size_y / 2
+    par0, sx0, sy0 = par.copy(), size_x, size_y
+    while size_x / pix_um - dimX < 0:                                        # :107-113 stitching along x
+        st = par0.copy()
+        st[:, 1] += size_x
+        par = np.concatenate((par, st), axis=0)
+        size_x += sx0
+    par0 = par.copy()
+    while size_y / pix_um - dimY < 0:                                        # :115-122 stitching along y
+        st = par0.copy()
+        st[:, 0] += size_y
+        par = np.concatenate((par, st), axis=0)
+        size_y += sy0
+    layers = []
+    for _ in range(n_layers):                                                # :135-142
+        max_ox = size_x / pix_um - dimX
+        max_oy = size_y / pix_um - dimY
+        ox = rand_state.randint(margin2, max_ox - margin2)
+        oy = rand_state.randint(margin2, max_oy - margin2)
+        layers.append((par[:, 1] / pix_um - ox, par[:, 0] / pix_um - oy, par[:, 2] / pix_um))
+    return margin, margin2, layers
+
+
+def membrane_segmented(sphere_list, dimX, dimY, pix_um, mean_radius_um, n_layers, support_um, seed):
+    """getMembraneSegmentedFromFile, Samples/getMembraneFromFile.py:60-171, with np.random.seed(seed) semantics.
+    Returns [membrane_m, support_m] (float64)."""
+    margin, margin2, layers = membrane_sphere_layers(sphere_list, dimX, dimY, pix_um, mean_radius_um, n_layers,
+                                                     np.random.RandomState(seed))
+    mem = np.zeros((dimX + 2 * margin, dimY + 2 * margin))
+    for xf, yf, rad in layers:
+        xf = np.ascontiguousarray(xf); yf = np.ascontiguousarray(yf); rad = np.ascontiguousarray(rad)
+        _lib().oracle_membrane_splat(len(rad), _dp(xf), _dp(yf), _dp(rad), dimX, dimY, margin, margin2, _dp(mem))
+    mem = mem[margin:-margin, margin:-margin]                                # :161
+    return [mem * pix_um * 1e-6, np.ones(mem.shape) * support_um * 1e-6]     # :167-169

@@ -90,12 +90,19 @@ class AnalyticalSample(Sample):
             if fn == "CreateSampleSphere":
                 self.myGeometry, self.geom_parameters = geometry.sphere(dimX, dimY, studyPixelSize, self.myRadius)
                 return
-        if self.myType == "membrane" and fn in ("getMembraneSegmentedFromFile", "getMembraneFromFile"):
-            if fn == "getMembraneFromFile" and not hasattr(self, "myMeanSphereRadius"):
-                self.myMeanSphereRadius, self.myNbOfLayers = 25.0, 1
-            self.myGeometry, self.geom_parameters = geometry.membrane(self, dimX, dimY, studyPixelSize, pointNum,
-                                                                      self.myPMMAThickness)
-            return
+        if self.myType == "membrane":
+            if fn == "getMembraneFromFile":                                   # SAM:230-233
+                from .Samples.getMembraneFromFile import getMembraneFromFile
+                geom, self.geom_parameters = getMembraneFromFile(self.myMembraneFile, studyDimensions, pointNum,
+                                                                 self.myPMMAThickness)
+                self.myGeometry = np.asarray(geom)
+                return
+            if fn == "getMembraneSegmentedFromFile":                          # SAM:234-237, sphere splat on the GPU
+                from .Samples.getMembraneFromFile import getMembraneSegmentedFromFile
+                geom, self.geom_parameters = getMembraneSegmentedFromFile(self, dimX, dimY, studyPixelSize, pointNum,
+                                                                          self.myPMMAThickness)
+                self.myGeometry = torch.stack(geom)
+                return
         if fn == "get_my_thickness":
             self.myGeometry = np.full((1, dimX, dimY), self.myThickness * 1e-6, dtype=np.float32)   # SAM:239-243
             return

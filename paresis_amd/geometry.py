@@ -2,11 +2,10 @@
 
 Input synthesis is outside the hot path: the reference's generators need cv2/imutils/skimage and a
 sphere list that is not shipped.  These analytic versions keep the parameters of the XML files (radius, orientation,
-mean sphere radius, number of layers, support thickness) and are seeded per membrane position.
+mean sphere radius, number of layers, support thickness).  Membranes are synthesised on the GPU
+(paresis_amd/Samples/getMembraneFromFile.py).
 """
 import numpy as np
-
-from . import synth
 
 
 def sphere(dimX, dimY, pix_um, radius_um):
@@ -30,18 +29,3 @@ def cylinder(dimX, dimY, pix_um, radius_um, orientation_deg):
     t = 2 * np.sqrt(np.clip(r * r - d * d, 0, None))
     return (t * pix_um * 1e-6)[None].astype(np.float32), {"Cylinder_radius": (radius_um, "um"),
                                                            "Cylinder_orientation": (orientation_deg, "degree")}
-
-
-def membrane(sample, dimX, dimY, pix_um, pointNum, support_um):
-    """getMembraneFromFile.py:60-171: layers of randomly placed spheres of mean radius myMeanSphereRadius on a support.
-    The sphere list (Samples/Membranes/CuSn.txt) is not shipped; radii are drawn around the requested mean and the
-    layer offsets are seeded by the position so that results do not depend on how positions are sharded."""
-    rmean = sample.myMeanSphereRadius / pix_um
-    layers = max(1, int(getattr(sample, "myNbOfLayers", 1)))
-    t = np.zeros((dimX, dimY), dtype=np.float64)
-    for layer in range(layers):
-        t += synth.sphere_membrane(dimX, dimY, pix_um * 1e-6, pointNum * 131 + layer, coverage=0.35,
-                                   rmin=0.55 * rmean, rmax=1.45 * rmean, dtype=np.float64)
-    geom = np.stack([t, np.full((dimX, dimY), support_um * 1e-6)]).astype(np.float32)
-    return geom, {"Average sphere radius": (sample.myMeanSphereRadius, "um"), "Number of layers": (layers, ""),
-                  "Support total thickness": (support_um, "um")}

@@ -78,3 +78,23 @@ def bench_geometry(N, pointNum=0, ov=2, det_pix_um=6.0, dSM=140.0, dMO=1.6, dOD=
     return dict(M=M, pix_um=pix_um, membrane=membrane, sample=sample,
                 membrane_materials=["CuSn", "PMMA"], sample_materials=["Nylon"],
                 dSM=dSM, dMO=dMO, dOD=dOD, energy_keV=52.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Stand-in for the reference's sphere list Samples/Membranes/CuSn.txt (.MISSING_LARGE_BLOBS): same JSON layout, a list of
+# [y, x, r] in "file units" centred on the origin, for a membrane of 9740 x 8102 units with mean sphere radius 12.8
+# (getMembraneFromFile.py:84-87).  Seeded, so every run and every rank sees the same file.
+SPHERE_FILE_SIZE_X = 8102
+SPHERE_FILE_SIZE_Y = 9740
+SPHERE_FILE_MEAN_RADIUS = 12.8
+
+
+def sphere_list(seed=20211011, coverage=0.45, n_max=None):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = int(coverage * SPHERE_FILE_SIZE_X * SPHERE_FILE_SIZE_Y / (np.pi * SPHERE_FILE_MEAN_RADIUS ** 2))
+    if n_max is not None:
+        n = min(n, int(n_max))
+    y = rng.uniform(-SPHERE_FILE_SIZE_Y / 2, SPHERE_FILE_SIZE_Y / 2, n)
+    x = rng.uniform(-SPHERE_FILE_SIZE_X / 2, SPHERE_FILE_SIZE_X / 2, n)
+    r = np.clip(rng.normal(SPHERE_FILE_MEAN_RADIUS, 3.0, n), 4.0, 24.0)
+    return np.stack([y, x, r], axis=1)

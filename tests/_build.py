@@ -50,7 +50,8 @@ def cfg_from_experiment(exp, Obj):
     def obj(s):
         if s is None:
             return None
-        geom = np.asarray(s.myGeometry, dtype=np.float64)
+        g = s.myGeometry
+        geom = np.asarray(g.cpu().numpy() if hasattr(g, "cpu") else g, dtype=np.float64)
         return Obj(geom, [[v for _, v in l] for l in s.delta], [[v for _, v in l] for l in s.beta])
 
     return dict(dSM=ed["distSourceToMembrane"], dMO=ed["distMembraneToObject"], dOD=ed["distObjectToDetector"],

@@ -373,6 +373,39 @@ def gold_experiment():
     save("experiment.npz", d)
 
 
+def gold_membrane():
+    """getMembraneSegmentedFromFile (Samples/getMembraneFromFile.py:60-171) on a synthetic sphere list written as
+    Samples/Membranes/CuSn.txt in a scratch directory (the real file is not distributed); numpy's global generator is
+    seeded so that the layer offsets (getMembraneFromFile.py:139-140) are reproducible."""
+    import json
+    import tempfile
+    import Samples.getMembraneFromFile as GM
+    d = {}
+    cases = [  # tag, dimX, dimY, pixSize_um, meanRadius_um, layers, support_um, n_spheres, seed
+        ("plain", 72, 64, 3.0, 12.0, 2, 6000.0, None, 7),
+        ("stitch", 60, 52, 40.0, 60.0, 1, 4000.0, 3000, 8),
+    ]
+    here = os.getcwd()
+    for tag, dimX, dimY, pix, meanR, layers, support, nmax, seed in cases:
+        lst = synth.sphere_list(n_max=nmax)
+        with tempfile.TemporaryDirectory() as tmp:
+            os.makedirs(os.path.join(tmp, "Samples", "Membranes"))
+            with open(os.path.join(tmp, "Samples", "Membranes", "CuSn.txt"), "w") as f:
+                json.dump(lst.tolist(), f)
+            os.chdir(tmp)
+            try:
+                smp = types.SimpleNamespace(myMeanSphereRadius=meanR, myNbOfLayers=layers)
+                np.random.seed(seed)
+                geom, params = GM.getMembraneSegmentedFromFile(smp, dimX, dimY, pix, 0, support)
+            finally:
+                os.chdir(here)
+        d[tag + "/params"] = np.array([dimX, dimY, pix, meanR, layers, support, -1 if nmax is None else nmax, seed], dtype=np.float64)
+        d[tag + "/membrane"] = np.asarray(geom[0], dtype=np.float64)
+        d[tag + "/support"] = np.asarray(geom[1], dtype=np.float64)
+        print("membrane", tag, "max thickness", d[tag + "/membrane"].max(), "coverage", (d[tag + "/membrane"] > 0).mean())
+    save("membrane.npz", d)
+
+
 if __name__ == "__main__":
     gold_scalars()
     gold_transmission()
@@ -380,4 +413,5 @@ if __name__ == "__main__":
     gold_refraction()
     gold_detector()
     gold_experiment()
+    gold_membrane()
     os.chdir(_cwd)

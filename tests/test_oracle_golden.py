@@ -133,3 +133,14 @@ def test_full_chain_fresnel(tag):
         for nm, a in (("Sample", S), ("Reference", R), ("Propag", Pg), ("White", W)):
             assert relmax(a, g[t + nm]) < TOL, (tag, point, nm)
         assert abs(mE - float(g[t + "meanEnergy"])) < 1e-9
+
+
+def test_membrane_synthesis():
+    from paresis_amd import synth
+    g = load("membrane.npz")
+    for tag in ("plain", "stitch"):
+        dimX, dimY, pix, meanR, layers, support, nmax, seed = g[tag + "/params"]
+        lst = synth.sphere_list(n_max=None if nmax < 0 else int(nmax))
+        geom = orc.membrane_segmented(lst, int(dimX), int(dimY), pix, meanR, int(layers), support, int(seed))
+        assert relmax(geom[0], g[tag + "/membrane"]) < TOL, tag
+        assert relmax(geom[1], g[tag + "/support"]) < TOL
