@@ -144,6 +144,15 @@ int psx_resize_f32(const float *img, int Nx, int Ny, float *out, int sx, int sy,
  * the reference seeds from the wall clock, so only the distribution is reproducible) */
 int psx_poisson_f32(const float *lam, float *out, int64_t n, uint64_t seed, void *stream);
 
+/* ---- dark-field refraction, second half: the per-pixel variable-width Gaussian re-splat of
+ * fastRefractionDF (refractionFileNumba2.py:168-186).  I2DF: refracted dark-field intensity, DF: dark-field width in
+ * pixels at each TARGET pixel (0 = no spreading), I2: refracted non-dark-field intensity added at the end (may be NULL),
+ * all [Nx][Ny] on the cropped grid; R >= round(1.5*max DF) is the largest patch half-size.  workspace:
+ * psx_darkfield_workspace_bytes(Nx,Ny) bytes. */
+size_t psx_darkfield_workspace_bytes(int Nx, int Ny);
+int psx_darkfield_blur_f32(const float *I2DF, const float *DF, const float *I2, float *out, int Nx, int Ny, int R,
+                           void *workspace, void *stream);
+
 /* ---- membrane thickness synthesis (next row of the scope table) -----------------------------
  * getMembraneSegmentedFromFile's sphere splat (Samples/getMembraneFromFile.py:143-159) for ONE layer:
  * out[i][j] (+)= scale * sum over spheres of 2*sqrt(r^2 - dist^2) on the cropped grid, with the reference's window and

@@ -78,14 +78,28 @@ def set_wave(wave, geometry, delta, beta, energy_keV):
     return out
 
 
-def set_wave_rt(intensity, geometry, delta, beta, energy_keV, phi=0):
-    """AnalyticalSample.setWaveRT, Sample.py:285-351 (without the Lung / cylinder_beeds dark-field branch)."""
+def set_wave_rt(intensity, geometry, delta, beta, energy_keV, phi=0, materials=None, my_type=None, name=None):
+    """AnalyticalSample.setWaveRT, Sample.py:285-351.  `materials`, `my_type`, `name` switch on the dark-field sample
+    model (Sample.py:322-344): a "Lung" material of a sample_of_interest, or any material of the sample named
+    'cylinder_beeds', scatters: newDf = 2 delta sqrt(N_s) sqrt(ln(2/delta)+1) and the thickness is scaled by the
+    sphere volume fraction.  newDf is overwritten (not accumulated) per material, like the reference."""
     k = k_sample(energy_keV)
     I = intensity
-    for m in range(np.asarray(geometry).shape[0]):
-        I = np.exp(-2 * k * beta[m] * geometry[m]) * I        # SAM:347
-        phi = phi - k * delta[m] * geometry[m]                # SAM:348
-    return I, phi, 0
+    new_df = 0
+    geometry = np.asarray(geometry)
+    for m in range(geometry.shape[0]):
+        geom = geometry[m]
+        if my_type == "sample_of_interest":
+            for hit, radius, fraction in ((materials is not None and materials[m] == "Lung", 47, 0.5),       # SAM:324-333
+                                          (name == "cylinder_beeds", 15, 0.6)):                               # SAM:335-343
+                if hit:
+                    n_vol = fraction * 3 / 4 / np.pi / (radius ** 3)
+                    n_sphere = n_vol ** (1 / 3) * (geometry[m] * 1e6)
+                    new_df = 2 * delta[m] * (n_sphere) ** (1 / 2) * np.sqrt(np.log(2 / delta[m]) + 1)
+                    geom = geom * fraction
+        I = np.exp(-2 * k * beta[m] * geom) * I               # SAM:347
+        phi = phi - k * delta[m] * geom                       # SAM:348
+    return I, phi, new_df
 
 
 # ------------------------------------------------------------------------------------------------- Fresnel
@@ -153,6 +167,50 @@ def fast_refraction(intensity, phi, z, energy_keV, magnification, pix_um, varian
     return I2, Dx, Dy
 
 
+def fast_refraction_df(intensity, phi, z, energy_keV, magnification, pix_um, dark_field):
+    """fastRefractionDF, refractionFileNumba2.py:88-196 (without its matplotlib pop-ups).  Mutates `intensity` and
+    `dark_field` in place like the reference.  Returns (I3[N,N], Dx, Dy) with Dx, Dy padded by ceil(6*max DF)."""
+    k = k_refraction(energy_keV)
+    Nx, Ny = intensity.shape
+    h = pix_um * 1e-6
+    dark_field = dark_field * z / (h * magnification)                          # RF2:114 (rad -> pixels)
+    max_df = np.max(dark_field)
+    margin2 = int(np.ceil(max_df * 6))                                         # RF2:117
+    dphix, dphiy = np.gradient(phi, h, edge_order=2)
+    Dx = dphix * z / k / (h * magnification)
+    Dy = dphiy * z / k / (h * magnification)
+    Dx[abs(Dx) < 1e-12] = 0
+    Dy[abs(Dy) < 1e-12] = 0
+    intensity[abs(Dx) > Nx] = 0
+    intensity[abs(Dy) > Ny] = 0
+    Dx[abs(Dx) > Nx] = 0
+    Dy[abs(Dy) > Ny] = 0
+    Dx = np.pad(Dx, margin2, mode="constant")
+    Dy = np.pad(Dy, margin2, mode="constant")
+    dark_field[dark_field > Nx / 4] = 0                                        # RF2:135
+    dark_field = np.pad(dark_field, margin2, mode="constant")
+    Ipad = np.pad(intensity, margin2, mode="constant")
+    I_nodf = np.copy(Ipad); I_nodf[dark_field != 0] = 0                        # RF2:147-150
+    I_df = np.copy(Ipad); I_df[dark_field == 0] = 0
+    I2 = fastloop(I_nodf, Dx, Dy)
+    I2df = fastloop(I_df, Dx, Dy)
+    I3 = np.zeros_like(I2)
+    for i in range(margin2, Nx + margin2):                                     # RF2:171-184
+        for j in range(margin2, Ny + margin2):
+            if I2df[i, j] != 0:
+                if dark_field[i, j] != 0:
+                    patch = create_gaussian_shape(dark_field[i, j] / 2)
+                    s2 = patch.shape[0] // 2
+                    I3[i - s2:i + s2 + 1, j - s2:j + s2 + 1] += patch * I2df[i, j]
+                else:
+                    I3[i, j] += I2df[i, j]
+    I3 += I2
+    I3 = I3[margin2:Nx + margin2, margin2:Ny + margin2]
+    if np.any(abs(I3) > 1e50) or np.isnan(I3).any():
+        raise Exception("The calculated intensity refractive includes some nans or insane values")
+    return I3, Dx, Dy
+
+
 # ------------------------------------------------------------------------------------------------ detector
 def py_round(x):
     """Python 3 round(): round-half-to-even, as used at Detector.py:212 / refractionFileNumba2.py:15."""
@@ -196,10 +254,11 @@ def detection(img, eff_source_fwhm_px, over_sampling, det_dims, psf_sigma_px):
 class Obj:
     """A thickness stack with its per-energy index decrements: geometry [nmat,Nx,Ny] (m), delta/beta [nmat][nE]."""
 
-    def __init__(self, geometry, delta, beta):
+    def __init__(self, geometry, delta, beta, materials=None, my_type=None, name=None):
         self.geometry = np.asarray(geometry, dtype=np.float64)
         self.delta = np.asarray(delta, dtype=np.float64)
         self.beta = np.asarray(beta, dtype=np.float64)
+        self.materials, self.my_type, self.name = materials, my_type, name
 
 
 def _bins(cfg, point):
@@ -285,15 +344,20 @@ def compute_rt(cfg, point, variant="v2"):
     sumI = 0.0; meanE = 0.0; ibin = 0
     Dxreal = []; Dyreal = []
     mem, smp, air, plate = cfg["membrane"], cfg["sample"], cfg["air"], cfg["plate"]
-    refr = lambda I, phi, z, E: fast_refraction(abs(I), phi, z, E, cfg["M"], cfg["pix_um"], variant)
+    def refr(I, phi, z, E, df=0):                                              # Experiment.refraction, EXP:255-277
+        if type(df) == int or type(df) == float:
+            return fast_refraction(abs(I), phi, z, E, cfg["M"], cfg["pix_um"], variant)
+        return fast_refraction_df(abs(I), phi, z, E, cfg["M"], cfg["pix_um"], df)
+    dfp = np.zeros((N0, N1))
+    sm = dict(materials=getattr(smp, "materials", None), my_type=getattr(smp, "my_type", None), name=getattr(smp, "name", None))
     for ie, (E, flux) in enumerate(cfg["spectrum"]):
         I = I0 * flux                                                          # EXP:451
         if not cfg["inVacuum"]:
             I, _, _ = set_wave_rt(I, air.geometry, air.delta[:, ie], air.beta[:, ie], E)
         Im, phim, _ = set_wave_rt(I, mem.geometry, mem.delta[:, ie], mem.beta[:, ie], E, phi0)   # EXP:463
         Ibs, _, _ = refr(Im, phim, cfg["dMO"], E)                              # EXP:466 (total magnification!)
-        Ias, phis, _ = set_wave_rt(Ibs, smp.geometry, smp.delta[:, ie], smp.beta[:, ie], E, phim)  # EXP:469
-        IS, _, _ = refr(Ias, phis, cfg["dOD"], E)                              # EXP:473
+        Ias, phis, DF = set_wave_rt(Ibs, smp.geometry, smp.delta[:, ie], smp.beta[:, ie], E, phim, **sm)  # EXP:469
+        IS, _, _ = refr(Ias, phis, cfg["dOD"], E, DF)                          # EXP:473
         IR, _, _ = refr(Ibs, phim, cfg["dOD"], E)                              # EXP:474
         if plate is not None:                                                  # EXP:478-480
             IS, _, _ = set_wave_rt(IS, plate.geometry, plate.delta[:, ie], plate.beta[:, ie], E)
@@ -301,8 +365,9 @@ def compute_rt(cfg, point, variant="v2"):
         accS += IS; accR += IR
         sumI += np.mean(IR); meanE += E * np.mean(IR)
         if point == 0:                                                         # EXP:488-498
-            Ip, phip, _ = set_wave_rt(I, smp.geometry, smp.delta[:, ie], smp.beta[:, ie], E, phi0)
-            IP, Dxreal, Dyreal = refr(Ip, phip, cfg["dOD"], E)
+            Ip, phip, DFp = set_wave_rt(I, smp.geometry, smp.delta[:, ie], smp.beta[:, ie], E, phi0, **sm)
+            dfp = dfp + DFp * flux                                             # EXP:491
+            IP, Dxreal, Dyreal = refr(Ip, phip, cfg["dOD"], E, DFp)
             if plate is not None:
                 IP, _, _ = set_wave_rt(IP, plate.geometry, plate.delta[:, ie], plate.beta[:, ie], E)
                 I, _, _ = set_wave_rt(I, plate.geometry, plate.delta[:, ie], plate.beta[:, ie], E)
@@ -317,6 +382,7 @@ def compute_rt(cfg, point, variant="v2"):
             W[ibin] = det(white)
             accS = np.zeros((N0, N1)); accR = np.zeros((N0, N1)); accP = np.zeros((N0, N1)); white = np.zeros((N0, N1))
             ibin += 1
+    cfg["_darkFieldPropag"] = dfp
     return S, R, Pg, W, Dxreal, Dyreal, meanE / sumI
 
 

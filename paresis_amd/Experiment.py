@@ -366,16 +366,28 @@ class Experiment:
             e_sum += currentEnergy * m
             # EXP:469 + 473 sample image: sample attenuation and membrane+sample phase fused into the refraction
             both = ops.MaterialStack.concat(mem_phase, smp)
-            if plate_att is None:
+            scattering = self.mySampleofInterest.has_dark_field()
+            if scattering:                                       # Lung / cylinder_beeds: fastRefractionDF (EXP:272-275)
+                DF = self.mySampleofInterest.dark_field(currentEnergy)
+                Ias, phis = ops.transmit_rt(Ibs, 1.0, both)
+                img, _, _ = self.refraction(Ias, phis, dOD, currentEnergy, ed['magnification'], DF)
+                self._add_intensity(accS, img, plate_att)
+            elif plate_att is None:
                 ops.refract(N, both, self._dscale(dOD, currentEnergy), clamp, I_in=Ibs, out=accS, add=True)
             else:
                 ops.refract(N, both, self._dscale(dOD, currentEnergy), clamp, I_in=Ibs, out=tmp)
                 self._add_intensity(accS, tmp, plate_att)
             if pointNum == 0:                                                             # EXP:488-498
-                _, self.Dxreal, self.Dyreal = ops.refract(N, ops.MaterialStack.concat(air_rt, smp),
-                                                          self._dscale(dOD, currentEnergy), clamp, I0=I0, out=tmp,
-                                                          want_D=True)
-                self._add_intensity(accP, tmp, plate_att)
+                if scattering:
+                    Ip, phip = ops.transmit_rt(None, I0, ops.MaterialStack.concat(air_rt, smp))
+                    self.darkFieldPropag += (DF * flux).to(torch.float32)                 # EXP:491
+                    img, self.Dxreal, self.Dyreal = self.refraction(Ip, phip, dOD, currentEnergy, ed['magnification'], DF)
+                    self._add_intensity(accP, img, plate_att)
+                else:
+                    _, self.Dxreal, self.Dyreal = ops.refract(N, ops.MaterialStack.concat(air_rt, smp),
+                                                              self._dscale(dOD, currentEnergy), clamp, I0=I0, out=tmp,
+                                                              want_D=True)
+                    self._add_intensity(accP, tmp, plate_att)
                 self._white(white, I0, air_rt, plate_att)
             if currentEnergy > self.myDetector.det_param["myBinsThersholds"][ibin] - self.mySource.source_dict["myEnergySampling"] / 2:
                 self._detect_bin(ibin, pointNum, stacks, accs)                            # EXP:501-521

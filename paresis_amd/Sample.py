@@ -138,14 +138,44 @@ class AnalyticalSample(Sample):
         d, b = self._coeff(self.delta, energy), self._coeff(self.beta, energy)
         return ops.MaterialStack(self.geometry_dev(), cphase=(-k * d if phase else 0 * d), catt=(-k * b if att else 0 * b))
 
+    def _df_model(self, imat):
+        """(alveoli radius um, sphere volume fraction) when material `imat` scatters (Sample.py:322-344), else None.
+        'cylinder_beeds' wins over "Lung" because the reference tests it second and overwrites."""
+        if self.myType != "sample_of_interest":
+            return None
+        if self.myName == 'cylinder_beeds':
+            return 15, 0.6
+        if self.myMaterials[imat] == "Lung":
+            return 47, 0.5
+        return None
+
+    def has_dark_field(self):
+        return any(self._df_model(i) is not None for i in range(len(self.myMaterials)))
+
     def stack_rt(self, energy, phase=True, att=True):
-        """MaterialStack for intensity + phase: cphase = -k delta, catt = -2 k beta (Sample.py:347-348)."""
+        """MaterialStack for intensity + phase: cphase = -k delta, catt = -2 k beta (Sample.py:347-348).  Scattering
+        materials enter with their thickness scaled by the sphere volume fraction (Sample.py:332,343), which is the same
+        as scaling their two coefficients."""
         k = k_sample(energy)
         d, b = self._coeff(self.delta, energy), self._coeff(self.beta, energy)
-        if self.myType == "sample_of_interest" and ("Lung" in self.myMaterials or self.myName == "cylinder_beeds"):
-            raise PsxError("dark-field sample model (Sample.py:322-344) is not built yet (SURVEY.md section 8f-2)")
-        return ops.MaterialStack(self.geometry_dev(), cphase=(-k * d if phase else 0 * d),
-                                 catt=(-2 * k * b if att else 0 * b))
+        frac = np.array([1.0 if self._df_model(i) is None else self._df_model(i)[1] for i in range(len(self.myMaterials))])
+        return ops.MaterialStack(self.geometry_dev(), cphase=(-k * d * frac if phase else 0 * d),
+                                 catt=(-2 * k * b * frac if att else 0 * b))
+
+    def dark_field(self, energy):
+        """newDf of setWaveRT (Sample.py:322-344): 2 delta sqrt(N_s) sqrt(ln(2/delta)+1) of the LAST scattering
+        material (the reference overwrites, it does not accumulate); int 0 when nothing scatters."""
+        d = self._coeff(self.delta, energy)
+        newDf = 0
+        for imat in range(len(self.myMaterials)):
+            model = self._df_model(imat)
+            if model is None:
+                continue
+            radius, fraction = model
+            NsphereVol = fraction * 3 / 4 / np.pi / (radius ** 3)
+            geom = self.geometry_dev()[imat].to(torch.float64) * 1e6
+            newDf = (2 * d[imat] * np.sqrt(np.log(2 / d[imat]) + 1)) * torch.sqrt(NsphereVol ** (1 / 3) * geom)
+        return newDf
 
     # ------------------------------------------------------------------------------------- reference API
     def setWave(self, incidentWave, energy):
@@ -155,11 +185,12 @@ class AnalyticalSample(Sample):
         return ops.transmit_wave(wave, 1.0, stack)
 
     def setWaveRT(self, incidentIntensity, energy, incidentphi=0, incidentDf=0):
-        """Sample.py:285-351: (I*exp(-2 k beta T), phi - k delta T, newDf); phi is float64; newDf = 0 (int)."""
+        """Sample.py:285-351: (I*exp(-2 k beta T), phi - k delta T, newDf); phi is float64; newDf is int 0
+        unless a material scatters (then a float64 tensor of angles in rad)."""
         stack = self.stack_rt(energy)
         I = to_dev(incidentIntensity, torch.float32)
         phi_in = None if is_scalar(incidentphi) and incidentphi == 0 else (
             torch.full(I.shape, float(incidentphi), dtype=torch.float64, device=I.device) if is_scalar(incidentphi)
             else to_dev(incidentphi, torch.float64))
         I_out, phi_out = ops.transmit_rt(I, 1.0, stack, phi_in)
-        return I_out, phi_out, 0
+        return I_out, phi_out, self.dark_field(energy)

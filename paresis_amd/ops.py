@@ -217,6 +217,21 @@ def refract(shape, mats, dscale, clamp, margin=15, I_in=None, I0=1.0, phi_in=Non
     return out, Dx, Dy
 
 
+def darkfield_blur(I2DF, DF, I2, R):
+    """Variable-width Gaussian re-splat of fastRefractionDF (refractionFileNumba2.py:168-186): returns
+    I2 + sum_s I2DF[s] * gaussian_shape(DF[s]/2) centred on s.  DF in pixels at the target pixels; R = max half-size."""
+    _need(I2DF, torch.float32, "I2DF")
+    _need(DF, torch.float32, "DF", I2DF.shape)
+    if I2 is not None:
+        _need(I2, torch.float32, "I2", I2DF.shape)
+    out = torch.empty_like(I2DF)
+    Nx, Ny = I2DF.shape
+    ws = torch.empty(lib().psx_darkfield_workspace_bytes(Nx, Ny), dtype=torch.uint8, device=I2DF.device)
+    check(lib().psx_darkfield_blur_f32(_ptr(I2DF), _ptr(DF), _ptr(I2), _ptr(out), Nx, Ny, int(R), _ptr(ws), _stream()),
+          "psx_darkfield_blur_f32")
+    return out
+
+
 def fastloop(I, Dx, Dy, I2):
     """fastloopNumba (refractionFileNumba2.py:198-263) on explicit float32 displacement maps; accumulates into I2."""
     _need(I, torch.float32, "I")

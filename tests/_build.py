@@ -2,7 +2,7 @@
 import numpy as np
 
 
-def build_experiment(cfg, sim, noise=False):
+def build_experiment(cfg, sim, noise=False, sample_materials=("Nylon",), sample_name="sample"):
     from paresis_amd.Detector import Detector
     from paresis_amd.Experiment import Experiment
     from paresis_amd.Sample import AnalyticalSample
@@ -36,7 +36,7 @@ def build_experiment(cfg, sim, noise=False):
                 "distObjectToDetector": cfg["dOD"], "magnification": cfg["M"], "noise": noise}
     return Experiment.from_objects(exp_dict, src, det,
                                    sample(cfg["membrane"], "membrane", "membrane", ["CuSn", "PMMA"]),
-                                   sample(cfg["sample"], "sample", "sample_of_interest", ["Nylon"]),
+                                   sample(cfg["sample"], sample_name, "sample_of_interest", list(sample_materials)),
                                    air=None if cfg["inVacuum"] else sample(cfg["air"], "air_volume", "volume", ["Air"]),
                                    plate=sample(cfg["plate"], "plate", "thin_film", ["C"]))
 

@@ -373,6 +373,60 @@ def gold_experiment():
     save("experiment.npz", d)
 
 
+def gold_darkfield():
+    """Dark-field branch: AnalyticalSample.setWaveRT with a "Lung" material (Sample.py:322-344), fastRefractionDF
+    (refractionFileNumba2.py:88-196) and the RT chain that routes through them (Experiment.py:469-473, 490-492)."""
+    d = {}
+    Nx, Ny = 48, 40
+    pix_um = 6.0 / 2 / (145.2 / 141.6)
+    M = 145.2 / 141.6
+    E = 52.0
+    I, phi, T = refraction_inputs(Nx, Ny, pix_um, 21)
+    # dark-field angle map (rad): a cylinder-shaped region, zero elsewhere
+    yy = np.arange(Ny, dtype=np.float64) - Ny / 2 + 0.5
+    prof = np.sqrt(np.clip(12.0 ** 2 - yy ** 2, 0, None)) / 12.0
+    for k, (z, amp) in enumerate([(3.6, 2.5e-6), (1.6, 0.6e-6), (3.6, 0.0)]):
+        df = np.broadcast_to(amp * prof[None, :], (Nx, Ny)).copy()
+        Iin = I.copy()
+        out, Dx, Dy = RF2.fastRefractionDF(Iin, phi.copy(), z, E, M, pix_um, df.copy())
+        d["rf/%d/params" % k] = np.array([z, E, M, pix_um])
+        d["rf/%d/df" % k] = df
+        d["rf/%d/out" % k] = out
+        d["rf/%d/Dx" % k] = Dx
+        d["rf/%d/Dy" % k] = Dy
+        print("fastRefractionDF case", k, "max DF px", (df * z / (pix_um * 1e-6 * M)).max(), "Dx shape", Dx.shape)
+    d["rf/I"] = I
+    d["rf/phi"] = phi
+    d["rf/n"] = np.array(3)
+    # Lung sample through setWaveRT
+    geom = np.stack([synth.cylinder_sample(Nx, Ny, pix_um * 1e-6).astype(np.float64), T])
+    s = make_sample("lungs", "sample_of_interest", ["Lung", "PMMA"], geom, [E], [[3.1e-7], [9.87e-8]], [[1.6e-10], [4.5e-11]])
+    I1, phi1, df1 = s.setWaveRT(I.copy(), E, phi.copy())
+    d["lung/geometry"] = geom
+    d["lung/I"] = I1
+    d["lung/phi"] = phi1
+    d["lung/df"] = np.asarray(df1, dtype=np.float64)
+    s2 = make_sample("cylinder_beeds", "sample_of_interest", ["PMMA"], geom[:1], [E], [[9.87e-8]], [[4.5e-11]])
+    I2, phi2, df2 = s2.setWaveRT(I.copy(), E, phi.copy())
+    d["beeds/I"] = I2
+    d["beeds/phi"] = phi2
+    d["beeds/df"] = np.asarray(df2, dtype=np.float64)
+    # full RT chain with a Lung sample (mono-energetic, points 0 and 1)
+    exp, membrane_geom = build_experiment((24, 20), 2, [(52.0, 1)], [], 1, 0.0, 10.0, True, False, 60)
+    Ns = exp.exp_dict["studyDimensions"]
+    lung = synth.cylinder_sample(Ns[0], Ns[1], exp.exp_dict["studyPixelSize"] * 1e-6, radius_frac=0.3).astype(np.float64)[None]
+    exp.mySampleofInterest = make_sample("lungs", "sample_of_interest", ["Lung"], lung, [52.0], [[3.1e-7]], [[1.6e-10]])
+    record_inputs(d, "chain", exp)
+    for point in (0, 1):
+        exp.myMembrane.myGeometry = membrane_geom(point)
+        d["chain/p%d/membrane" % point] = exp.myMembrane.myGeometry
+        exp.exp_dict["meanEnergy"] = 0
+        S, R, Pg, W, Dx, Dy, DF = exp.computeSampleAndReferenceImages_RT(point)
+        for nm, a in (("Sample", S), ("Reference", R), ("Propag", Pg), ("White", W), ("Dx", Dx), ("Dy", Dy), ("DF", DF)):
+            d["chain/p%d/%s" % (point, nm)] = np.asarray(a, dtype=np.float64)
+    save("darkfield.npz", d)
+
+
 def gold_membrane():
     """getMembraneSegmentedFromFile (Samples/getMembraneFromFile.py:60-171) on a synthetic sphere list written as
     Samples/Membranes/CuSn.txt in a scratch directory (the real file is not distributed); numpy's global generator is
@@ -414,4 +468,5 @@ if __name__ == "__main__":
     gold_detector()
     gold_experiment()
     gold_membrane()
+    gold_darkfield()
     os.chdir(_cwd)

@@ -123,3 +123,47 @@ def test_experiment_wave_propagation_and_refraction_methods():
     exp.exp_dict["studyPixelSize"] = pix
     out, Dx, Dy = exp.refraction(r["1/I"].copy(), r["1/phi"], z, E, M)
     assert relmax(out.cpu().numpy(), r["1/v2/out"]) < TOL
+
+
+def test_darkfield_refraction_and_sample_model():
+    """Dark-field branch: setWaveRT's scattering model, fastRefractionDF, and the RT chain."""
+    from paresis_amd import refractionFileNumba2 as RF2
+    from paresis_amd.Sample import AnalyticalSample
+    g = load("darkfield.npz")
+    for k in range(int(g["rf/n"])):
+        z, E, M, pix = g["rf/%d/params" % k]
+        I = g["rf/I"].astype(np.float32)
+        out, Dx, Dy = RF2.fastRefractionDF(I, g["rf/phi"], z, E, M, pix, g["rf/%d/df" % k])
+        assert tuple(Dx.shape) == g["rf/%d/Dx" % k].shape                 # padded by ceil(6*max DF)
+        assert relmax(out.cpu().numpy(), g["rf/%d/out" % k]) < TOL, k
+        assert relmax(Dx.cpu().numpy(), g["rf/%d/Dx" % k]) < 1e-6
+    s = AnalyticalSample()
+    s.myName, s.myType, s.myMaterials, s.myGeometry = "lungs", "sample_of_interest", ["Lung", "PMMA"], g["lung/geometry"]
+    s.delta, s.beta = [[(52.0, 3.1e-7)], [(52.0, 9.87e-8)]], [[(52.0, 1.6e-10)], [(52.0, 4.5e-11)]]
+    I1, phi1, df1 = s.setWaveRT(g["rf/I"], 52.0, g["rf/phi"])
+    assert relmax(I1.cpu().numpy(), g["lung/I"]) < TOL
+    assert relmax(phi1.cpu().numpy(), g["lung/phi"]) < 1e-7       # thickness maps are float32 on the device
+    assert relmax(df1.cpu().numpy(), g["lung/df"]) < 1e-6
+    s2 = AnalyticalSample()
+    s2.myName, s2.myType, s2.myMaterials, s2.myGeometry = "cylinder_beeds", "sample_of_interest", ["PMMA"], g["lung/geometry"][:1]
+    s2.delta, s2.beta = [[(52.0, 9.87e-8)]], [[(52.0, 4.5e-11)]]
+    I2, phi2, df2 = s2.setWaveRT(g["rf/I"], 52.0, g["rf/phi"])
+    assert relmax(I2.cpu().numpy(), g["beeds/I"]) < TOL and relmax(df2.cpu().numpy(), g["beeds/df"]) < 1e-6
+
+
+def test_darkfield_chain():
+    g = load("darkfield.npz")
+    cfg = experiment_cfg(g, "chain", orc.Obj)
+    exp = build_experiment(cfg, "RT", sample_materials=("Lung",), sample_name="lungs")
+    for point in (0, 1):
+        exp.myMembrane.myGeometry = g["chain/p%d/membrane" % point]
+        exp.exp_dict["meanEnergy"] = 0
+        S, R, Pg, W, Dx, Dy, DF = exp.computeSampleAndReferenceImages_RT(point)
+        t = "chain/p%d/" % point
+        for nm, a in (("Sample", S), ("Reference", R), ("Propag", Pg), ("White", W)):
+            err = relmax(a.cpu().numpy(), g[t + nm])
+            assert err < TOL, (point, nm, err)
+        if point == 0:
+            assert tuple(Dx.shape) == g[t + "Dx"].shape
+            assert relmax(Dx.cpu().numpy(), g[t + "Dx"]) < 1e-6
+            assert relmax(DF.cpu().numpy(), g[t + "DF"]) < 1e-6

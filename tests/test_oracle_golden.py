@@ -144,3 +144,36 @@ def test_membrane_synthesis():
         geom = orc.membrane_segmented(lst, int(dimX), int(dimY), pix, meanR, int(layers), support, int(seed))
         assert relmax(geom[0], g[tag + "/membrane"]) < TOL, tag
         assert relmax(geom[1], g[tag + "/support"]) < TOL
+
+
+def test_darkfield_sample_model_and_refraction():
+    g = load("darkfield.npz")
+    I, phi = g["rf/I"], g["rf/phi"]
+    for k in range(int(g["rf/n"])):
+        z, E, M, pix = g["rf/%d/params" % k]
+        out, Dx, Dy = orc.fast_refraction_df(I.copy(), phi.copy(), z, E, M, pix, g["rf/%d/df" % k].copy())
+        assert Dx.shape == g["rf/%d/Dx" % k].shape
+        assert relmax(out, g["rf/%d/out" % k]) < TOL, k
+        assert relmax(Dx, g["rf/%d/Dx" % k]) < TOL and relmax(Dy, g["rf/%d/Dy" % k]) < TOL
+    geom = g["lung/geometry"]
+    I1, phi1, df1 = orc.set_wave_rt(I.copy(), geom, [3.1e-7, 9.87e-8], [1.6e-10, 4.5e-11], 52.0, phi.copy(),
+                                    materials=["Lung", "PMMA"], my_type="sample_of_interest", name="lungs")
+    assert relmax(I1, g["lung/I"]) < TOL and relmax(phi1, g["lung/phi"]) < TOL and relmax(df1, g["lung/df"]) < TOL
+    I2, phi2, df2 = orc.set_wave_rt(I.copy(), geom[:1], [9.87e-8], [4.5e-11], 52.0, phi.copy(), materials=["PMMA"],
+                                    my_type="sample_of_interest", name="cylinder_beeds")
+    assert relmax(I2, g["beeds/I"]) < TOL and relmax(phi2, g["beeds/phi"]) < TOL and relmax(df2, g["beeds/df"]) < TOL
+
+
+def test_darkfield_chain():
+    g = load("darkfield.npz")
+    cfg = experiment_cfg(g, "chain", orc.Obj)
+    cfg["sample"].materials, cfg["sample"].my_type, cfg["sample"].name = ["Lung"], "sample_of_interest", "lungs"
+    for point in (0, 1):
+        cfg["membrane"] = orc.Obj(g["chain/p%d/membrane" % point], cfg["membrane"].delta, cfg["membrane"].beta)
+        S, R, Pg, W, Dx, Dy, mE = orc.compute_rt(cfg, point)
+        t = "chain/p%d/" % point
+        for nm, a in (("Sample", S), ("Reference", R), ("Propag", Pg), ("White", W)):
+            assert relmax(a, g[t + nm]) < TOL, (point, nm)
+        if point == 0:
+            assert relmax(Dx, g[t + "Dx"]) < TOL
+            assert relmax(cfg["_darkFieldPropag"], g[t + "DF"]) < TOL
