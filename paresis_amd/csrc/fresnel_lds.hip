@@ -65,7 +65,7 @@ __device__ __forceinline__ int xcd_group(int b, int ng) {
     return x * q + (x < r ? x : r) + (b >> 3);
 }
 
-template <int R3, int NM, bool MULTI>
+template <int R3, int NM>
 __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     constexpr int M = 576 * R3, LINES = TOT / M, S1 = M / RAD, MP = M + M / 32;
     constexpr int SLAB = 16, NSLABS = TOT / SLAB;       // 16 contiguous points per slab in the middle stage
@@ -133,11 +133,10 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         }
     };
 
-    // v[q] *= conj(tw[n][q]); with the spectrum F resident (MULTI) the twiddles come in two batches of 12 so that only
-    // 24 instead of 48 VGPRs hold them at a time
+    // v[q] *= conj(tw[n][q])
     auto mul_tw_conj = [&](const float2 *tw, int n, float2(&v)[RAD]) __attribute__((always_inline)) {
         const float4 *t4 = reinterpret_cast<const float4 *>(tw + (size_t)n * RAD);
-        constexpr int NB = MULTI ? 2 : 1, PER = RAD / 2 / NB;
+        constexpr int NB = 1, PER = RAD / 2 / NB;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             float4 x[PER];
@@ -149,7 +148,6 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 if (k > 0) v[k] = cmulc(v[k], make_float2(x[q].x, x[q].y));
                 v[k + 1] = cmulc(v[k + 1], make_float2(x[q].z, x[q].w));
             }
-            if (MULTI) __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -194,66 +192,36 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     __syncthreads();
     PSX_STAMP(6);
 
-    // ---- 4. forward stage C (radix R3 on contiguous chunks).  MULTI: the spectrum stays in registers while every
-    // distance's kernel is applied to it; otherwise it is consumed slab by slab (far fewer live registers).
-    constexpr int NF = MULTI ? NSLAB : 1;
-    float2 F[NF][SLAB];
-    auto load_slab = [&](int r, float2(&f)[SLAB]) __attribute__((always_inline)) {
-        const int s = min(tid + T * r, NSLABS - 1), line = s / (M / SLAB), p0 = (s % (M / SLAB)) * SLAB;
-        const float2 *base = lds + line * MP;
-#pragma unroll
-        for (int j = 0; j < SLAB; ++j) f[j] = base[phys(p0) + j];   // p0 % 16 == 0: no pad slot inside a slab
-#pragma unroll
-        for (int c = 0; c < SLAB / R3; ++c) {
-            float2 w[R3];
-#pragma unroll
-            for (int j = 0; j < R3; ++j) w[j] = f[c * R3 + j];
-            Dft<R3, false>::run(w);
-#pragma unroll
-            for (int j = 0; j < R3; ++j) f[c * R3 + j] = w[j];
-        }
-    };
-    if (MULTI) {
-#pragma unroll
-        for (int r = 0; r < NSLAB; ++r) load_slab(r, F[r]);
-    }
-
+    // ---- 4+5. middle stage, slab by slab: forward radix R3 on contiguous chunks, x FFT_M(h_d), inverse radix R3, back to
+    // LDS.  Each thread rewrites exactly the slabs it read, so no barrier separates the two halves.
     for (int d = 0; d < a.n_dist; ++d) {
-        // ---- 5. x FFT_M(h_d), inverse stage C, back to LDS (each thread rewrites exactly the slabs it read)
-        if (MULTI) __syncthreads();   // the previous distance's inverse stage A has finished reading LDS
+        if (d > 0) __syncthreads();   // the previous distance's inverse stage A has finished reading LDS
         const float2 *Hd = a.H[d];
 #pragma unroll
         for (int r = 0; r < NSLAB; ++r) {
             const int s = tid + T * r, line = s / (M / SLAB), p0 = (s % (M / SLAB)) * SLAB;
             if (NSLABS % T != 0 && s >= NSLABS) break;      // idle tail of the last slab round
-            float2 *base = lds + line * MP;
+            float2 *base = lds + line * MP + phys(p0);      // p0 % 16 == 0: no pad slot inside a slab
+            float4 hh[SLAB / 2];                            // kernel spectrum of this slab: issued before the LDS reads
             const float4 *h4 = reinterpret_cast<const float4 *>(Hd + p0);
-            float2 g[SLAB];
-            if (!MULTI) {
-                float4 hh[SLAB / 2];                 // kernel spectrum of this slab: issued before the LDS reads
 #pragma unroll
-                for (int j = 0; j < SLAB / 2; ++j) hh[j] = h4[j];
-                load_slab(r, F[0]);
+            for (int j = 0; j < SLAB / 2; ++j) hh[j] = h4[j];
+            float2 f[SLAB], g[SLAB];
 #pragma unroll
-                for (int j = 0; j < SLAB / 2; ++j) {
-                    g[2 * j] = cmul(F[0][2 * j], make_float2(hh[j].x, hh[j].y));
-                    g[2 * j + 1] = cmul(F[0][2 * j + 1], make_float2(hh[j].z, hh[j].w));
-                }
-            } else {                                 // resident spectrum: two batches keep the live set small
-                float2(&f)[SLAB] = F[r];
+            for (int j = 0; j < SLAB; ++j) f[j] = base[j];
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    float4 hh[SLAB / 4];
+            for (int c = 0; c < SLAB / R3; ++c) {
+                float2 w[R3];
 #pragma unroll
-                    for (int j = 0; j < SLAB / 4; ++j) hh[j] = h4[b * (SLAB / 4) + j];
+                for (int j = 0; j < R3; ++j) w[j] = f[c * R3 + j];
+                Dft<R3, false>::run(w);
 #pragma unroll
-                    for (int j = 0; j < SLAB / 4; ++j) {
-                        const int k = 2 * (b * (SLAB / 4) + j);
-                        g[k] = cmul(f[k], make_float2(hh[j].x, hh[j].y));
-                        g[k + 1] = cmul(f[k + 1], make_float2(hh[j].z, hh[j].w));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int j = 0; j < R3; ++j) f[c * R3 + j] = w[j];
+            }
+#pragma unroll
+            for (int j = 0; j < SLAB / 2; ++j) {
+                g[2 * j] = cmul(f[2 * j], make_float2(hh[j].x, hh[j].y));
+                g[2 * j + 1] = cmul(f[2 * j + 1], make_float2(hh[j].z, hh[j].w));
             }
 #pragma unroll
             for (int c = 0; c < SLAB / R3; ++c) {
@@ -262,7 +230,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 for (int j = 0; j < R3; ++j) w[j] = g[c * R3 + j];
                 Dft<R3, true>::run(w);
 #pragma unroll
-                for (int j = 0; j < R3; ++j) base[phys(p0) + c * R3 + j] = w[j];
+                for (int j = 0; j < R3; ++j) base[c * R3 + j] = w[j];
             }
         }
         PSX_STAMP(7);
@@ -554,36 +522,28 @@ static int kernel_spectrum(psx_fresnel_plan *p, const AxisTables &t, double a, d
     return 0;
 }
 
-template <int R3, int NM, bool MULTI>
+template <int R3, int NM>
 static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
     constexpr int M = 576 * R3, LINES = TOT / M;
     constexpr size_t lds_bytes = sizeof(float2) * (size_t)LINES * (M + M / 32);
     static bool attr_set = false;
     if (!attr_set) {
-        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, NM, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, NM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_bytes));
         attr_set = true;
     }
     const int ngroups = (la.nlines + LINES - 1) / LINES;
-    PSX_TIMED(name, st, k_fresnel_lines<R3, NM, MULTI><<<ngroups, T, lds_bytes, st>>>(la));
+    PSX_TIMED(name, st, k_fresnel_lines<R3, NM><<<ngroups, T, lds_bytes, st>>>(la));
     return launch_check(name);
 }
 
 template <int NM>
 static int launch_lines_r3(int R3, const LineArgs &la, hipStream_t st, const char *name) {
-    if (la.n_dist > 1) {
-        switch (R3) {
-            case 2: return launch_lines<2, NM, true>(la, st, name);
-            case 4: return launch_lines<4, NM, true>(la, st, name);
-            case 8: return launch_lines<8, NM, true>(la, st, name);
-            case 16: return launch_lines<16, NM, true>(la, st, name);
-        }
-    }
     switch (R3) {
-        case 2: return launch_lines<2, NM, false>(la, st, name);
-        case 4: return launch_lines<4, NM, false>(la, st, name);
-        case 8: return launch_lines<8, NM, false>(la, st, name);
-        case 16: return launch_lines<16, NM, false>(la, st, name);
+        case 2: return launch_lines<2, NM>(la, st, name);
+        case 4: return launch_lines<4, NM>(la, st, name);
+        case 8: return launch_lines<8, NM>(la, st, name);
+        case 16: return launch_lines<16, NM>(la, st, name);
     }
     return fail(PSX_E_UNSUPPORTED, "LDS engine: unsupported line length");
 }
@@ -624,26 +584,21 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
     if (nnz == 0) return launch_check("k_source_out");
 
     // ---- pass 1: lines along axis 0 (columns), output transposed.  One launch per distance: keeping the forward spectrum
-    // in registers across distances (the MULTI variant) needs 64 more VGPRs than the 168 a 12-wave workgroup has, and its
-    // spills cost more HBM traffic (3.9 GB per 4-distance launch, rocprof) than re-running the forward stages.
+    // in registers across distances needs 64 more VGPRs than the 168 a 12-wave workgroup has, and the spills of that
+    // variant cost 3.9 GB of HBM traffic per 4-distance launch (rocprof) -- no faster than re-running the forward stages.
     static const bool stamp_pass1 = getenv("PSX_STAMP_PASS1") != nullptr;   // diagnostics only
-    static const bool share_fwd = getenv("PSX_FRESNEL_SHARE_FORWARD") != nullptr;
-    const int launches = share_fwd ? 1 : nnz;
-    for (int li = 0; li < launches; ++li) {
+    for (int i = 0; i < nnz; ++i) {
         LineArgs la;
         la.src = src; la.amp = amp; la.m = m;
         la.N = p->Nx; la.nlines = p->Ny; la.margin = p->margin; la.P = p->Px; la.L = p->Nx + p->Px - 1;
         la.in_stride = p->Ny; la.out_ld = p->Nx;
         la.twA = e->ax[0].twA; la.twB = e->ax[0].twB;
-        la.n_dist = share_fwd ? nnz : 1; la.accumulate = 0; la.stamps = stamp_pass1 ? g_stamps : nullptr;
-        for (int k = 0; k < la.n_dist; ++k) {
-            const int i = share_fwd ? k : li;
-            if (int rc = kernel_spectrum(p, e->ax[0], a.a[nz[i]], a.du_x, st, &la.H[k])) return rc;
-            la.wave_out[k] = e->inter + (size_t)i * npix;
-            la.inten_out[k] = nullptr;
-            la.scale[k] = 1.f;
-            la.gph[k] = make_float2(1.f, 0.f);
-        }
+        la.n_dist = 1; la.accumulate = 0; la.stamps = stamp_pass1 ? g_stamps : nullptr;
+        if (int rc = kernel_spectrum(p, e->ax[0], a.a[nz[i]], a.du_x, st, &la.H[0])) return rc;
+        la.wave_out[0] = e->inter + (size_t)i * npix;
+        la.inten_out[0] = nullptr;
+        la.scale[0] = 1.f;
+        la.gph[0] = make_float2(1.f, 0.f);
         int rc = 0;
         switch (m.n) {
             case 0: rc = launch_lines_r3<0>(e->ax[0].R3, la, st, "k_fresnel_cols"); break;
