@@ -60,6 +60,14 @@ struct LineArgs {
         if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); \
     } while (0)
 
+// orders the LDS traffic of ONE wave (cross-lane exchange through LDS without a workgroup barrier): no instruction is
+// emitted beyond the wait the fence implies; the compiler may not move LDS accesses across it
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int xcd_group(int b, int ng) {
     const int q = ng >> 3, r = ng & 7, x = b & 7;
     return x * q + (x < r ? x : r) + (b >> 3);
@@ -69,9 +77,11 @@ template <int R3, int NM>
 __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     constexpr int M = 576 * R3, LINES = TOT / M, S1 = M / RAD, MP = M + M / 32;
     constexpr int SLAB = 16, NSLABS = TOT / SLAB;       // 16 contiguous points per slab in the middle stage
-    constexpr int NSLAB = (NSLABS + T - 1) / T;          // slabs per thread (the last round may be partly idle)
+    constexpr int WSLABS = 64 * RAD / SLAB;              // slabs inside the 1536 points one wave owns between barriers
+    constexpr int NSLAB = (WSLABS + 63) / 64;            // slab rounds per lane (the last one is partly idle)
     constexpr int BPT = TOT / RAD / T;                   // radix-24 butterflies per thread per stage
-    static_assert(R3 <= 16 && SLAB % R3 == 0 && TOT % (RAD * T) == 0, "unsupported geometry");
+    static_assert(R3 <= 16 && SLAB % R3 == 0 && TOT == RAD * T && 64 % R3 == 0 && NSLABS == (T / 64) * WSLABS,
+                  "unsupported geometry");
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
     const int ngroups = (a.nlines + LINES - 1) / LINES;
@@ -84,29 +94,53 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         const int line = idx / (M - a.L), j = a.L + idx % (M - a.L);
         lds[line * MP + phys(j)] = make_float2(0.f, 0.f);
     }
-    // every thread owns up to NLD samples; their (strided) global loads are issued back to back so that one memory
-    // latency covers all of them, then the values are spread to their periodic / mirrored positions
-    constexpr int NLDMAX = 12;
-    for (int k0 = 0; k0 * T < LINES * N; k0 += NLDMAX) {
-        float2 xs[NLDMAX];
+    // Every thread owns the samples i0 + STEP*k (k < 12) of ONE line: their global loads are issued back to back so that
+    // one memory latency covers all of them.  STEP is a multiple of 32 (R3 >= 4), so the padded LDS index of sample k is
+    // the index of sample 0 plus a compile-time offset: two address registers serve all 24 stores.
+    constexpr int STEP = T / LINES, NLD = TOT / (2 * T), PSTEP = STEP + STEP / 32;
+    static_assert(T % LINES == 0 && NLD * STEP >= (576 * R3 + 1) / 2, "sample ownership does not cover the longest line");
+    constexpr bool AFFL = (STEP % 32 == 0);
+    {
+        const int line = tid % LINES, i0 = tid / LINES;
+        const bool line_ok = l0 + line < a.nlines;
+        const int64_t pix0 = (int64_t)i0 * a.in_stride + (l0 + line), pstep = (int64_t)STEP * a.in_stride;
+        float2 xs[NLD], xm = make_float2(0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < NLDMAX; ++k) {
-            const int idx = tid + (k0 + k) * T, line = idx % LINES, i = idx / LINES;
+        for (int k = 0; k < NLD; ++k) {
             xs[k] = make_float2(0.f, 0.f);
-            if (idx < LINES * N && l0 + line < a.nlines)
-                xs[k] = source_wave<NM>(a.src, a.amp, a.m, (int64_t)i * a.in_stride + (l0 + line));
+            if (line_ok && i0 + STEP * k < N) xs[k] = source_wave<NM>(a.src, a.amp, a.m, pix0 + pstep * k);
         }
+        // mirror duty (np.pad 'reflect', EXP:237): thread t < LINES*2*mg re-reads one of the 2*mg samples next to an edge
+        const int nmir = LINES * 2 * mg;
+        int im = -1, jm = 0;
+        if (tid < nmir) {
+            const int r = tid / LINES;
+            im = r < mg ? r + 1 : N - 1 - 2 * mg + r;                   // 1..mg   |   N-1-mg..N-2
+            jm = r < mg ? N + 2 * mg - 1 - im : 2 * N - 3 - im;         // left mirror | right mirror one period earlier
+            if (line_ok) xm = source_wave<NM>(a.src, a.amp, a.m, (int64_t)im * a.in_stride + (l0 + line));
+        }
+        float2 *base = lds + line * MP;
+        const int ja = i0 + N + 2 * mg - 1, jb = i0 - 1;                 // first period | one period earlier (i >= 1)
+        const int oa = phys(ja), ob = phys(jb);   // jb = -1 (sample 0 has no earlier image) -> -2: affine like the rest, unused at k = 0
 #pragma unroll
-        for (int k = 0; k < NLDMAX; ++k) {
-            const int idx = tid + (k0 + k) * T, line = idx % LINES, i = idx / LINES;
-            if (idx < LINES * N) {
-                const float2 x = xs[k];
-                float2 *base = lds + line * MP;
-                base[phys(i + N + 2 * mg - 1)] = x;                            // t = i+mg (first period)
-                if (i >= 1) base[phys(i - 1)] = x;                             // same sample one period earlier
-                if (i >= 1 && i <= mg) base[phys(N + 2 * mg - 1 - i)] = x;     // left mirror (reflect: no edge repeat)
-                if (i >= N - 1 - mg && i <= N - 2) base[phys(2 * N - 3 - i)] = x;   // right mirror, one period earlier
+        for (int k = 0; k < NLD; ++k) {
+            if (i0 + STEP * k < N) {
+                if (AFFL) {
+                    base[oa + k * PSTEP] = xs[k];
+                    if (k > 0 || jb >= 0) base[ob + k * PSTEP] = xs[k];
+                } else {
+                    base[phys(ja + STEP * k)] = xs[k];
+                    if (k > 0 || jb >= 0) base[phys(jb + STEP * k)] = xs[k];
+                }
             }
+        }
+        if (im >= 0) base[phys(jm)] = xm;
+        for (int t = tid + T; t < nmir; t += T) {                        // margins beyond T/(2*LINES): rare
+            const int ln = t % LINES, r = t / LINES;
+            const int i2 = r < mg ? r + 1 : N - 1 - 2 * mg + r, j2 = r < mg ? N + 2 * mg - 1 - i2 : 2 * N - 3 - i2;
+            float2 x2 = make_float2(0.f, 0.f);
+            if (l0 + ln < a.nlines) x2 = source_wave<NM>(a.src, a.amp, a.m, (int64_t)i2 * a.in_stride + (l0 + ln));
+            lds[ln * MP + phys(j2)] = x2;
         }
     }
     PSX_STAMP(1);
@@ -189,7 +223,11 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         for (int q = 0; q < RAD; ++q) base[idxB(p0, q)] = v[q];
     }
     PSX_STAMP(5);
-    __syncthreads();
+    // From here to the end of inverse stage B every wave works on LDS points that only IT touches: its 64 radix-24
+    // butterflies of stage B cover 64/R3 whole blocks of S1 points = the 1536 consecutive points [1536 w, 1536 (w+1)),
+    // and the middle stage below takes its slabs from the same range.  A wave's LDS operations execute in order, so no
+    // workgroup barrier is needed -- the waves drift apart and overlap each other's LDS and VALU phases.
+    wave_sync();
     PSX_STAMP(6);
 
     // ---- 4+5. middle stage, slab by slab: forward radix R3 on contiguous chunks, x FFT_M(h_d), inverse radix R3, back to
@@ -199,8 +237,10 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         const float2 *Hd = a.H[d];
 #pragma unroll
         for (int r = 0; r < NSLAB; ++r) {
-            const int s = tid + T * r, line = s / (M / SLAB), p0 = (s % (M / SLAB)) * SLAB;
-            if (NSLABS % T != 0 && s >= NSLABS) break;      // idle tail of the last slab round
+            // slab r of this lane inside the wave's own 96 slabs (the second round keeps 32 lanes busy)
+            const int sw = (tid & 63) + 64 * r;
+            if (sw >= WSLABS) break;
+            const int s = (tid >> 6) * WSLABS + sw, line = s / (M / SLAB), p0 = (s % (M / SLAB)) * SLAB;
             float2 *base = lds + line * MP + phys(p0);      // p0 % 16 == 0: no pad slot inside a slab
             float4 hh[SLAB / 2];                            // kernel spectrum of this slab: issued before the LDS reads
             const float4 *h4 = reinterpret_cast<const float4 *>(Hd + p0);
@@ -234,7 +274,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             }
         }
         PSX_STAMP(7);
-        __syncthreads();
+        wave_sync();
         PSX_STAMP(8);
 
         // The inverse stages use the same twiddles as the forward ones; launder the pointers so that the compiler
