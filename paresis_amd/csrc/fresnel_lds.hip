@@ -28,36 +28,38 @@ using namespace psx;
 
 namespace {
 
-// One 12-wave workgroup per CU owns the whole LDS: 3 waves per SIMD are needed to keep the vector pipes issuing (a
-// 6-wave workgroup with two butterflies per thread measured 334 us per 4096^2 pass: VALU busy only a third of it).
-constexpr int T = 768;        // threads per workgroup = radix-24 butterflies per stage
+// One 16-wave workgroup per CU owns the whole LDS.  Waves 0..11 (TC threads) are the butterfly engine -- 3 per SIMD are
+// needed to keep the vector pipes issuing -- and waves 12..15 (TL threads, one per SIMD) only move samples: they fetch
+// the NEXT line group from HBM while the engine transforms the current one, and spread it into LDS in the shadow of the
+// last butterfly + store.  Four waves per SIMD cap every wave at 128 VGPRs.  The workgroups are persistent (one per CU,
+// a strided list of line groups each), so the exposed fetch latency is paid once per launch instead of once per group.
+constexpr int TC = 768;       // engine threads = radix-24 butterflies per stage
+constexpr int TL = 256;       // loader threads
+constexpr int T = TC + TL;
 constexpr int TOT = 18432;    // complex points resident in LDS per workgroup = LINES * M
 constexpr int RAD = 24;       // radix of the two big stages
 
 __host__ __device__ constexpr int phys(int p) { return p + (p >> 5); }   // one pad slot per 32: conflict-free slabs
 
 struct LineArgs {
-    const float2 *src;      // input wave (may be null: unit wave)
-    float amp;
-    Mats m;
+    const float2 *src;      // input wave
     int N, nlines, margin, P, L;
-    int64_t in_stride;      // sample i of line l is pixel i*in_stride + l
+    int64_t in_si, in_sl;   // sample i of line l is element i*in_si + l*in_sl of src
     int64_t out_ld;         // output sample i of line l goes to l*out_ld + i
     const float2 *twA, *twB;   // [n][24] stage twiddles
-    int n_dist;
-    const float2 *H[PSX_MAX_DIST];
-    float2 *wave_out[PSX_MAX_DIST];
-    float *inten_out[PSX_MAX_DIST];
-    float scale[PSX_MAX_DIST];
-    float2 gph[PSX_MAX_DIST];
+    const float2 *H;        // kernel spectrum FFT_M(h) of this distance, digit-reversed, 1/M folded in
+    float2 *wave_out;       // complex result (pass 1: the transposed intermediate) or null
+    float *inten_out;       // scale * |result|^2 or null
+    float scale;
+    float2 gph;             // global phase factor exp(i k z / M) of the complex result
     int accumulate;
-    unsigned long long *stamps;   // optional diagnostics: 16 phase timestamps per workgroup (psx_debug_stamps)
+    unsigned long long *stamps;   // optional diagnostics: 32 phase timestamps per workgroup (psx_debug_stamps)
 };
 
-// phase timestamp of wave 0 (diagnostic runs only; a null buffer costs one scalar branch)
+// phase timestamp of wave 0 for the SECOND line group of each workgroup, a steady-state round (diagnostic runs only)
 #define PSX_STAMP(k)                                                             \
     do {                                                                         \
-        if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); \
+        if (a.stamps && tid == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + (k)] = wall_clock64(); \
     } while (0)
 
 // orders the LDS traffic of ONE wave (cross-lane exchange through LDS without a workgroup barrier): no instruction is
@@ -68,84 +70,35 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ int xcd_group(int b, int ng) {
-    const int q = ng >> 3, r = ng & 7, x = b & 7;
-    return x * q + (x < r ? x : r) + (b >> 3);
+// workgroup barrier that orders LDS traffic only: a loader wave passes it with its global loads still in flight
+// (__syncthreads() would wait vmcnt(0) and stall the engine behind an HBM round trip)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <int R3, int NM>
+// CONTIG: the samples of a line are adjacent in memory (in_si == 1) -- the lanes of a loader wave then walk along the line;
+// otherwise they walk across the LINES lines of the group (adjacent columns of a row-major image).
+template <int R3, bool CONTIG>
 __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     constexpr int M = 576 * R3, LINES = TOT / M, S1 = M / RAD, MP = M + M / 32;
     constexpr int SLAB = 16, NSLABS = TOT / SLAB;       // 16 contiguous points per slab in the middle stage
     constexpr int WSLABS = 64 * RAD / SLAB;              // slabs inside the 1536 points one wave owns between barriers
     constexpr int NSLAB = (WSLABS + 63) / 64;            // slab rounds per lane (the last one is partly idle)
-    constexpr int BPT = TOT / RAD / T;                   // radix-24 butterflies per thread per stage
-    static_assert(R3 <= 16 && SLAB % R3 == 0 && TOT == RAD * T && 64 % R3 == 0 && NSLABS == (T / 64) * WSLABS,
+    static_assert(R3 <= 16 && SLAB % R3 == 0 && TOT == RAD * TC && 64 % R3 == 0 && NSLABS == (TC / 64) * WSLABS,
                   "unsupported geometry");
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
-    const int ngroups = (a.nlines + LINES - 1) / LINES;
-    const int l0 = xcd_group(blockIdx.x, ngroups) * LINES;
     const int N = a.N, mg = a.margin;
 
-    PSX_STAMP(0);
-    // ---- 1. samples -> LDS.  s[j] = x_per[j - (N+mg-1)], j in [0, L);  zeros in [L, M).
-    for (int idx = tid; idx < LINES * (M - a.L); idx += T) {
-        const int line = idx / (M - a.L), j = a.L + idx % (M - a.L);
-        lds[line * MP + phys(j)] = make_float2(0.f, 0.f);
-    }
-    // Every thread owns the samples i0 + STEP*k (k < 12) of ONE line: their global loads are issued back to back so that
-    // one memory latency covers all of them.  STEP is a multiple of 32 (R3 >= 4), so the padded LDS index of sample k is
-    // the index of sample 0 plus a compile-time offset: two address registers serve all 24 stores.
-    constexpr int STEP = T / LINES, NLD = TOT / (2 * T), PSTEP = STEP + STEP / 32;
-    static_assert(T % LINES == 0 && NLD * STEP >= (576 * R3 + 1) / 2, "sample ownership does not cover the longest line");
-    constexpr bool AFFL = (STEP % 32 == 0);
-    {
-        const int line = tid % LINES, i0 = tid / LINES;
-        const bool line_ok = l0 + line < a.nlines;
-        const int64_t pix0 = (int64_t)i0 * a.in_stride + (l0 + line), pstep = (int64_t)STEP * a.in_stride;
-        float2 xs[NLD], xm = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            xs[k] = make_float2(0.f, 0.f);
-            if (line_ok && i0 + STEP * k < N) xs[k] = source_wave<NM>(a.src, a.amp, a.m, pix0 + pstep * k);
-        }
-        // mirror duty (np.pad 'reflect', EXP:237): thread t < LINES*2*mg re-reads one of the 2*mg samples next to an edge
-        const int nmir = LINES * 2 * mg;
-        int im = -1, jm = 0;
-        if (tid < nmir) {
-            const int r = tid / LINES;
-            im = r < mg ? r + 1 : N - 1 - 2 * mg + r;                   // 1..mg   |   N-1-mg..N-2
-            jm = r < mg ? N + 2 * mg - 1 - im : 2 * N - 3 - im;         // left mirror | right mirror one period earlier
-            if (line_ok) xm = source_wave<NM>(a.src, a.amp, a.m, (int64_t)im * a.in_stride + (l0 + line));
-        }
-        float2 *base = lds + line * MP;
-        const int ja = i0 + N + 2 * mg - 1, jb = i0 - 1;                 // first period | one period earlier (i >= 1)
-        const int oa = phys(ja), ob = phys(jb);   // jb = -1 (sample 0 has no earlier image) -> -2: affine like the rest, unused at k = 0
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            if (i0 + STEP * k < N) {
-                if (AFFL) {
-                    base[oa + k * PSTEP] = xs[k];
-                    if (k > 0 || jb >= 0) base[ob + k * PSTEP] = xs[k];
-                } else {
-                    base[phys(ja + STEP * k)] = xs[k];
-                    if (k > 0 || jb >= 0) base[phys(jb + STEP * k)] = xs[k];
-                }
-            }
-        }
-        if (im >= 0) base[phys(jm)] = xm;
-        for (int t = tid + T; t < nmir; t += T) {                        // margins beyond T/(2*LINES): rare
-            const int ln = t % LINES, r = t / LINES;
-            const int i2 = r < mg ? r + 1 : N - 1 - 2 * mg + r, j2 = r < mg ? N + 2 * mg - 1 - i2 : 2 * N - 3 - i2;
-            float2 x2 = make_float2(0.f, 0.f);
-            if (l0 + ln < a.nlines) x2 = source_wave<NM>(a.src, a.amp, a.m, (int64_t)i2 * a.in_stride + (l0 + ln));
-            lds[ln * MP + phys(j2)] = x2;
-        }
-    }
-    PSX_STAMP(1);
-    __syncthreads();
-    PSX_STAMP(2);
+    // ---- line groups of this workgroup: XCD x = blockIdx % 8 owns a contiguous chunk of groups (its 32 CUs then read
+    // neighbouring columns at the same time: the 128-byte lines of the strided source are shared in that XCD's L2)
+    const int ngroups = (a.nlines + LINES - 1) / LINES;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int cq = ngroups >> 3, cr = ngroups & 7;
+    const int cstart = xcd * cq + (xcd < cr ? xcd : cr), clen = cq + (xcd < cr ? 1 : 0);
+    const int nj = slot < clen ? (clen - slot + nslot - 1) / nslot : 0;   // groups cstart + slot + j*nslot, j < nj
 
     // LDS index of butterfly element j: with S1 a multiple of 32 (and R3 | 32) the pad term of phys() is affine in j, so
     // every element is one base register + a compile-time offset (ds_read/ds_write immediate offsets)
@@ -156,21 +109,103 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     auto idxB = [&](int p0, int j) __attribute__((always_inline)) {      // p0 = q1*S1 + n,  n < R3
         return AFF ? phys(p0) + j * R3 + ((j * R3) >> 5) : phys(p0 + j * R3);
     };
-    // the 24 twiddles of butterfly n: 12 x 16-byte loads from one base
-    auto load_tw = [&](const float2 *tw, int n, float2(&w)[RAD]) __attribute__((always_inline)) {
-        const float4 *t4 = reinterpret_cast<const float4 *>(tw + (size_t)n * RAD);
-#pragma unroll
-        for (int q = 0; q < RAD / 2; ++q) {
-            const float4 x = t4[q];
-            w[2 * q] = make_float2(x.x, x.y);
-            w[2 * q + 1] = make_float2(x.z, x.w);
-        }
-    };
 
-    // v[q] *= conj(tw[n][q])
-    auto mul_tw_conj = [&](const float2 *tw, int n, float2(&v)[RAD]) __attribute__((always_inline)) {
+    if (tid >= TC) {
+        // =============================== loader waves =====================================================================
+        // Thread lt owns the samples i0 + STEP*k (k < NLD) of ONE line.  STEP is a multiple of 32 (R3 >= 4), so the padded
+        // LDS index of sample k is the index of sample 0 plus a compile-time offset.
+        const int lt = tid - TC;
+        constexpr int STEP = TL / LINES, NLD = TOT / (2 * TL), PSTEP = STEP + STEP / 32;
+        static_assert(TL % LINES == 0 && NLD * STEP >= (576 * R3 + 1) / 2, "sample ownership does not cover the longest line");
+        constexpr bool AFFL = (STEP % 32 == 0);
+        const int line = CONTIG ? lt / STEP : lt % LINES, i0 = CONTIG ? lt % STEP : lt / LINES;
+        // mirror duty (np.pad 'reflect', EXP:237): thread t < LINES*2*mg re-reads one of the 2*mg samples next to an edge
+        const int nmir = LINES * 2 * mg;
+        const int lm = lt % LINES;
+        int im = -1, jm = 0;
+        if (lt < nmir) {
+            const int r = lt / LINES;
+            im = r < mg ? r + 1 : N - 1 - 2 * mg + r;                   // 1..mg   |   N-1-mg..N-2
+            jm = r < mg ? N + 2 * mg - 1 - im : 2 * N - 3 - im;         // left mirror | right mirror one period earlier
+        }
+        float2 *base = lds + line * MP;
+        const int ja = i0 + N + 2 * mg - 1, jb = i0 - 1;                 // first period | one period earlier (i >= 1)
+        const int oa = phys(ja), ob = phys(jb);   // jb = -1 (sample 0 has no earlier image) -> -2: affine, unused at k = 0
+        const int64_t pstep = (int64_t)STEP * a.in_si;
+
+        float2 xs[NLD], xm = make_float2(0.f, 0.f);
+        auto fetch = [&](int g) __attribute__((always_inline)) {        // issue every load of group g, wait for none
+            const int l0 = g * LINES;
+            const bool line_ok = l0 + line < a.nlines;
+            const int64_t pix0 = (int64_t)i0 * a.in_si + (int64_t)(l0 + line) * a.in_sl;
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                // out-of-range samples re-read element 0 (always valid): unconditional loads issue back to back
+                const bool ok = line_ok && i0 + STEP * k < N;
+                xs[k] = a.src[ok ? pix0 + pstep * k : (int64_t)0];
+            }
+            xm = a.src[(im >= 0 && l0 + lm < a.nlines) ? (int64_t)im * a.in_si + (int64_t)(l0 + lm) * a.in_sl : (int64_t)0];
+        };
+        auto spread = [&](int g) __attribute__((always_inline)) {       // periodic / mirrored images -> LDS
+            const int l0 = g * LINES;
+            const bool line_ok = l0 + line < a.nlines;
+            for (int idx = lt; idx < LINES * (M - a.L); idx += TL) {    // zeros in [L, M)
+                const int ln = idx / (M - a.L), jz = a.L + idx % (M - a.L);
+                lds[ln * MP + phys(jz)] = make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                if (i0 + STEP * k < N) {
+                    const float2 x = line_ok ? xs[k] : make_float2(0.f, 0.f);
+                    if (AFFL) {
+                        base[oa + k * PSTEP] = x;
+                        if (k > 0 || jb >= 0) base[ob + k * PSTEP] = x;
+                    } else {
+                        base[phys(ja + STEP * k)] = x;
+                        if (k > 0 || jb >= 0) base[phys(jb + STEP * k)] = x;
+                    }
+                }
+            }
+            if (im >= 0) lds[lm * MP + phys(jm)] = l0 + lm < a.nlines ? xm : make_float2(0.f, 0.f);
+            for (int t = lt + TL; t < nmir; t += TL) {                   // margins beyond TL/(2*LINES): rare
+                const int ln = t % LINES, r = t / LINES;
+                const int i2 = r < mg ? r + 1 : N - 1 - 2 * mg + r, j2 = r < mg ? N + 2 * mg - 1 - i2 : 2 * N - 3 - i2;
+                float2 x2 = make_float2(0.f, 0.f);
+                if (l0 + ln < a.nlines) x2 = a.src[(int64_t)i2 * a.in_si + (int64_t)(l0 + ln) * a.in_sl];
+                lds[ln * MP + phys(j2)] = x2;
+            }
+        };
+
+        if (nj > 0) {
+            fetch(cstart + slot);
+            spread(cstart + slot);
+        }
+        lds_barrier();                                   // (0) first group is in LDS
+        for (int j = 0; j < nj; ++j) {
+            const bool more = j + 1 < nj;
+            lds_barrier();                               // (1) engine: forward stage A done
+            // Issued after barrier (1), not before: issuing strided loads stalls for ~5 us (the texture path hands out one
+            // 128-byte line per lane pair) and forward stage A lasts only 3 us -- the engine would wait for the loaders.
+            if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 16] = wall_clock64();
+            if (more) fetch(cstart + slot + (j + 1) * nslot);
+            if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 17] = wall_clock64();
+            lds_barrier();                               // (2) engine: wave-private stages done
+            lds_barrier();                               // (3) engine: inverse stage A holds all of LDS in registers
+            if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 18] = wall_clock64();
+            if (more) spread(cstart + slot + (j + 1) * nslot);
+            if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 19] = wall_clock64();
+            lds_barrier();                               // (4) next group is in LDS
+            if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 20] = wall_clock64();
+        }
+        return;
+    }
+
+    // =================================== engine waves =========================================================================
+    // the 24 twiddles of butterfly n: 16-byte loads from one base, HALF of them in flight at a time (128-VGPR budget)
+    auto mul_tw = [&](const float2 *tw, int n, float2(&v)[RAD], auto conj_tag) __attribute__((always_inline)) {
+        constexpr bool CONJ = decltype(conj_tag)::value;
         const float4 *t4 = reinterpret_cast<const float4 *>(tw + (size_t)n * RAD);
-        constexpr int NB = 1, PER = RAD / 2 / NB;
+        constexpr int NB = 2, PER = RAD / 2 / NB;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             float4 x[PER];
@@ -179,98 +214,95 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
                 const int k = 2 * (b * PER + q);
-                if (k > 0) v[k] = cmulc(v[k], make_float2(x[q].x, x[q].y));
-                v[k + 1] = cmulc(v[k + 1], make_float2(x[q].z, x[q].w));
+                if (k > 0) v[k] = CONJ ? cmulc(v[k], make_float2(x[q].x, x[q].y)) : cmul(v[k], make_float2(x[q].x, x[q].y));
+                v[k + 1] = CONJ ? cmulc(v[k + 1], make_float2(x[q].z, x[q].w)) : cmul(v[k + 1], make_float2(x[q].z, x[q].w));
             }
         }
     };
 
-    // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}
-#pragma unroll 1
-    for (int u = 0; u < BPT; ++u) {
-        const int e = tid + T * u, line = e / S1, n = e % S1;
-        float2 *base = lds + line * MP;
-        float2 v[RAD], w[RAD];
-#pragma unroll
-        for (int j = 0; j < RAD; ++j) v[j] = base[idxA(n, j)];
-        Dft<RAD, false>::run(v);
-        __builtin_amdgcn_sched_barrier(0);   // keep the twiddle loads below the butterfly: 48 fewer live VGPRs
-        load_tw(a.twA, n, w);
-#pragma unroll
-        for (int q = 1; q < RAD; ++q) v[q] = cmul(v[q], w[q]);
-#pragma unroll
-        for (int q = 0; q < RAD; ++q) base[idxA(n, q)] = v[q];
-    }
-    PSX_STAMP(3);
-    __syncthreads();
-    PSX_STAMP(4);
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 0] = wall_clock64();
+    lds_barrier();                                       // (0) first group is in LDS
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 1] = wall_clock64();
+    for (int j = 0; j < nj; ++j) {
+        const int l0 = (cstart + slot + j * nslot) * LINES;
+        PSX_STAMP(2);
+        // stage A and B thread mapping (one butterfly per thread per stage)
+        const int lineA = tid / S1, nA = tid % S1;
+        const int remB = tid % S1, q1B = remB / R3, nB = remB % R3, p0B = q1B * S1 + nB;
+        float2 *baseA = lds + lineA * MP;
 
-    // ---- 3. forward stage B: radix 24 inside each block of S1, stride R3, twiddle w_S1^{n q}
-#pragma unroll 1
-    for (int u = 0; u < BPT; ++u) {
-        const int e = tid + T * u, line = e / S1, rem = e % S1, q1 = rem / R3, n = rem % R3;
-        float2 *base = lds + line * MP;
-        const int p0 = q1 * S1 + n;
-        float2 v[RAD], w[RAD];
+        // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}
+        {
+            float2 v[RAD];
 #pragma unroll
-        for (int j = 0; j < RAD; ++j) v[j] = base[idxB(p0, j)];
-        Dft<RAD, false>::run(v);
-        __builtin_amdgcn_sched_barrier(0);
-        load_tw(a.twB, n, w);
+            for (int q = 0; q < RAD; ++q) v[q] = baseA[idxA(nA, q)];
+            Dft<RAD, false>::run(v);
+            __builtin_amdgcn_sched_barrier(0);   // keep the twiddle loads below the butterfly
+            mul_tw(a.twA, nA, v, std::false_type{});
 #pragma unroll
-        for (int q = 1; q < RAD; ++q) v[q] = cmul(v[q], w[q]);
+            for (int q = 0; q < RAD; ++q) baseA[idxA(nA, q)] = v[q];
+        }
+        PSX_STAMP(3);
+        lds_barrier();                               // (1)
+        PSX_STAMP(4);
+        // ---- 3. forward stage B: radix 24 inside each block of S1, stride R3, twiddle w_S1^{n q}
+        {
+            float2 v[RAD];
 #pragma unroll
-        for (int q = 0; q < RAD; ++q) base[idxB(p0, q)] = v[q];
-    }
-    PSX_STAMP(5);
-    // From here to the end of inverse stage B every wave works on LDS points that only IT touches: its 64 radix-24
-    // butterflies of stage B cover 64/R3 whole blocks of S1 points = the 1536 consecutive points [1536 w, 1536 (w+1)),
-    // and the middle stage below takes its slabs from the same range.  A wave's LDS operations execute in order, so no
-    // workgroup barrier is needed -- the waves drift apart and overlap each other's LDS and VALU phases.
-    wave_sync();
-    PSX_STAMP(6);
+            for (int q = 0; q < RAD; ++q) v[q] = baseA[idxB(p0B, q)];
+            Dft<RAD, false>::run(v);
+            __builtin_amdgcn_sched_barrier(0);
+            mul_tw(a.twB, nB, v, std::false_type{});
+#pragma unroll
+            for (int q = 0; q < RAD; ++q) baseA[idxB(p0B, q)] = v[q];
+        }
+        PSX_STAMP(5);
+        // From here to the end of inverse stage B every wave works on LDS points that only IT touches: its 64
+        // radix-24 butterflies of stage B cover 64/R3 whole blocks of S1 points = the 1536 consecutive points
+        // [1536 w, 1536 (w+1)), and the middle stage takes its slabs from the same range.  A wave's LDS operations
+        // execute in order, so no workgroup barrier is needed -- the waves drift apart and overlap each other's LDS
+        // and VALU phases.
+        wave_sync();
+        PSX_STAMP(6);
 
-    // ---- 4+5. middle stage, slab by slab: forward radix R3 on contiguous chunks, x FFT_M(h_d), inverse radix R3, back to
-    // LDS.  Each thread rewrites exactly the slabs it read, so no barrier separates the two halves.
-    for (int d = 0; d < a.n_dist; ++d) {
-        if (d > 0) __syncthreads();   // the previous distance's inverse stage A has finished reading LDS
-        const float2 *Hd = a.H[d];
+        // ---- 4+5. middle stage, slab by slab: forward radix R3 on contiguous chunks, x FFT_M(h_d), inverse radix R3,
+        // back to LDS.  Each thread rewrites exactly the slabs it read.
+        const float2 *Hd = a.H;
 #pragma unroll
         for (int r = 0; r < NSLAB; ++r) {
-            // slab r of this lane inside the wave's own 96 slabs (the second round keeps 32 lanes busy)
-            const int sw = (tid & 63) + 64 * r;
+            const int sw = (tid & 63) + 64 * r;     // slab of this lane inside the wave's own 96 (round 2: 32 lanes)
             if (sw >= WSLABS) break;
             const int s = (tid >> 6) * WSLABS + sw, line = s / (M / SLAB), p0 = (s % (M / SLAB)) * SLAB;
             float2 *base = lds + line * MP + phys(p0);      // p0 % 16 == 0: no pad slot inside a slab
             float4 hh[SLAB / 2];                            // kernel spectrum of this slab: issued before the LDS reads
             const float4 *h4 = reinterpret_cast<const float4 *>(Hd + p0);
 #pragma unroll
-            for (int j = 0; j < SLAB / 2; ++j) hh[j] = h4[j];
-            float2 f[SLAB], g[SLAB];
+            for (int q = 0; q < SLAB / 2; ++q) hh[q] = h4[q];
+            float2 f[SLAB];
 #pragma unroll
-            for (int j = 0; j < SLAB; ++j) f[j] = base[j];
+            for (int q = 0; q < SLAB; ++q) f[q] = base[q];
 #pragma unroll
             for (int c = 0; c < SLAB / R3; ++c) {
                 float2 w[R3];
 #pragma unroll
-                for (int j = 0; j < R3; ++j) w[j] = f[c * R3 + j];
+                for (int q = 0; q < R3; ++q) w[q] = f[c * R3 + q];
                 Dft<R3, false>::run(w);
 #pragma unroll
-                for (int j = 0; j < R3; ++j) f[c * R3 + j] = w[j];
+                for (int q = 0; q < R3; ++q) f[c * R3 + q] = w[q];
             }
 #pragma unroll
-            for (int j = 0; j < SLAB / 2; ++j) {
-                g[2 * j] = cmul(f[2 * j], make_float2(hh[j].x, hh[j].y));
-                g[2 * j + 1] = cmul(f[2 * j + 1], make_float2(hh[j].z, hh[j].w));
+            for (int q = 0; q < SLAB / 2; ++q) {
+                f[2 * q] = cmul(f[2 * q], make_float2(hh[q].x, hh[q].y));
+                f[2 * q + 1] = cmul(f[2 * q + 1], make_float2(hh[q].z, hh[q].w));
             }
 #pragma unroll
             for (int c = 0; c < SLAB / R3; ++c) {
                 float2 w[R3];
 #pragma unroll
-                for (int j = 0; j < R3; ++j) w[j] = g[c * R3 + j];
+                for (int q = 0; q < R3; ++q) w[q] = f[c * R3 + q];
                 Dft<R3, true>::run(w);
 #pragma unroll
-                for (int j = 0; j < R3; ++j) base[c * R3 + j] = w[j];
+                for (int q = 0; q < R3; ++q) base[c * R3 + q] = w[q];
             }
         }
         PSX_STAMP(7);
@@ -278,61 +310,65 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         PSX_STAMP(8);
 
         // The inverse stages use the same twiddles as the forward ones; launder the pointers so that the compiler
-        // reloads them (L2-resident) instead of keeping 92 VGPRs alive across the whole kernel and spilling.
+        // reloads them (L2-resident) instead of keeping them alive across the whole kernel.
         const float2 *twA_i = a.twA, *twB_i = a.twB;
         asm volatile("" : "+s"(twA_i), "+s"(twB_i));
         // ---- 6. inverse stage B: conjugate twiddle on the inputs, then the inverse radix-24 butterfly
-#pragma unroll 1
-        for (int u = 0; u < BPT; ++u) {
-            const int e = tid + T * u, line = e / S1, rem = e % S1, q1 = rem / R3, n = rem % R3;
-            float2 *base = lds + line * MP;
-            const int p0 = q1 * S1 + n;
+        {
             float2 v[RAD];
 #pragma unroll
-            for (int q = 0; q < RAD; ++q) v[q] = base[idxB(p0, q)];
-            mul_tw_conj(twB_i, n, v);
+            for (int q = 0; q < RAD; ++q) v[q] = baseA[idxB(p0B, q)];
+            mul_tw(twB_i, nB, v, std::true_type{});
             __builtin_amdgcn_sched_barrier(0);
             Dft<RAD, true>::run(v);
 #pragma unroll
-            for (int j = 0; j < RAD; ++j) base[idxB(p0, j)] = v[j];
+            for (int q = 0; q < RAD; ++q) baseA[idxB(p0B, q)] = v[q];
         }
         PSX_STAMP(9);
-        __syncthreads();
+        lds_barrier();                               // (2)
         PSX_STAMP(10);
 
-        // ---- 7. inverse stage A; the wanted outputs y[n + P - 1] leave for HBM straight from the registers
-        const int jout = N + 2 * mg - 1;      // LDS position of output sample 0
-        float2 *wo = a.wave_out[d];
-        float *io = a.inten_out[d];
-        const float sc = a.scale[d];
-        const float2 gp = a.gph[d];
-#pragma unroll 1
-        for (int u = 0; u < BPT; ++u) {
-            const int e = tid + T * u, line = e / S1, n = e % S1;
-            const float2 *base = lds + line * MP;
+        // ---- 7. inverse stage A; the wanted outputs y[n + P - 1] leave for HBM straight from the registers.  Once
+        // every engine thread holds its 24 inputs LDS is free: the loaders fill it with the next group meanwhile.
+        {
             float2 v[RAD];
 #pragma unroll
-            for (int q = 0; q < RAD; ++q) v[q] = base[idxA(n, q)];
-            mul_tw_conj(twA_i, n, v);
+            for (int q = 0; q < RAD; ++q) v[q] = baseA[idxA(nA, q)];
+            lds_barrier();                           // (3)
+            PSX_STAMP(11);
+            mul_tw(twA_i, nA, v, std::true_type{});
             __builtin_amdgcn_sched_barrier(0);
             Dft<RAD, true>::run(v);
-            if (l0 + line < a.nlines) {
-                const int64_t ob = (int64_t)(l0 + line) * a.out_ld;
+            // output sample i = nA + q*S1 - jout (jout = LDS position of output sample 0).  The first index is made opaque
+            // so that the 48 per-q addresses are formed here from ONE pointer, not hoisted out of the group loop (they
+            // would occupy 96 VGPRs there and spill).
+            int ifirst = nA - (N + 2 * mg - 1);
+            asm volatile("" : "+v"(ifirst));
+            float2 *wo = a.wave_out;
+            float *io = a.inten_out;
+            const float sc = a.scale;
+            const float2 gp = a.gph;
+            if (l0 + lineA < a.nlines) {
+                const int64_t ob = (int64_t)(l0 + lineA) * a.out_ld + ifirst;
+                if (wo) wo += ob;
+                if (io) io += ob;
 #pragma unroll
-                for (int j = 0; j < RAD; ++j) {
-                    const int i = n + j * S1 - jout;
+                for (int q = 0; q < RAD; ++q) {
+                    const int i = ifirst + q * S1;
                     if (i >= 0 && i < N) {
-                        if (wo) wo[ob + i] = cmul(v[j], gp);
+                        if (wo) wo[q * S1] = cmul(v[q], gp);
                         if (io) {
-                            const float I = sc * (v[j].x * v[j].x + v[j].y * v[j].y);
-                            io[ob + i] = a.accumulate ? io[ob + i] + I : I;
+                            const float I = sc * (v[q].x * v[q].x + v[q].y * v[q].y);
+                            io[q * S1] = a.accumulate ? io[q * S1] + I : I;
                         }
                     }
                 }
             }
         }
+        PSX_STAMP(12);
+        lds_barrier();                               // (4)
+        PSX_STAMP(13);
     }
-    PSX_STAMP(11);
 }
 
 // z == 0 (EXP:233-234): out = psi, |psi|^2
@@ -347,6 +383,34 @@ __global__ __launch_bounds__(256) void k_source_out(const float2 *__restrict__ s
             const float I = scale * (v.x * v.x + v.y * v.y);
             inten_out[p] = accumulate ? inten_out[p] + I : I;
         }
+    }
+}
+
+// Transmitted source wave, written TRANSPOSED: out[y*Nx + x] = source_wave(x*Ny + y)  (K1 = SAM:248-282 fused with the
+// first of the two transposes a two-pass separable transform needs).  One evaluation per propagate call serves all its
+// distances, and pass 1 of the line engine then reads whole lines contiguously.  64x64 tiles through LDS: the thickness
+// maps are read along y (their fast axis), the wave is written along x.
+template <int NM>
+__global__ __launch_bounds__(256) void k_source_transposed(const float2 *__restrict__ src, float amp, Mats m,
+                                                           float2 *__restrict__ out, int Nx, int Ny) {
+    __shared__ float2 tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int ntx = (Ny + 63) / 64;                       // tiles along y
+    const int y0 = (blockIdx.x % ntx) * 64, x0 = (blockIdx.x / ntx) * 64;
+    float2 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int x = x0 + ty + 4 * r, y = y0 + tx;
+        const bool ok = x < Nx && y < Ny;
+        v[r] = source_wave<NM>(src, amp, m, ok ? (int64_t)x * Ny + y : (int64_t)0);   // clamped: loads stay unconditional
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[ty + 4 * r][tx] = v[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int y = y0 + ty + 4 * r, x = x0 + tx;
+        if (x < Nx && y < Ny) out[(int64_t)y * Nx + x] = tile[tx][ty + 4 * r];
     }
 }
 
@@ -562,28 +626,38 @@ static int kernel_spectrum(psx_fresnel_plan *p, const AxisTables &t, double a, d
     return 0;
 }
 
-template <int R3, int NM>
+template <int R3, bool CONTIG>
 static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
     constexpr int M = 576 * R3, LINES = TOT / M;
     constexpr size_t lds_bytes = sizeof(float2) * (size_t)LINES * (M + M / 32);
     static bool attr_set = false;
     if (!attr_set) {
-        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, NM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_bytes));
         attr_set = true;
     }
+    // persistent workgroups: one per CU (the LDS footprint allows no more), a multiple of the 8 XCDs
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        PSX_HIP(hipGetDevice(&dev));
+        PSX_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (n_cu < 8) n_cu = 8;
+    }
     const int ngroups = (la.nlines + LINES - 1) / LINES;
-    PSX_TIMED(name, st, k_fresnel_lines<R3, NM><<<ngroups, T, lds_bytes, st>>>(la));
+    int nslot = n_cu / 8;
+    if (nslot > (ngroups + 7) / 8) nslot = (ngroups + 7) / 8;
+    PSX_TIMED(name, st, k_fresnel_lines<R3, CONTIG><<<8 * nslot, T, lds_bytes, st>>>(la));
     return launch_check(name);
 }
 
-template <int NM>
+template <bool CONTIG>
 static int launch_lines_r3(int R3, const LineArgs &la, hipStream_t st, const char *name) {
     switch (R3) {
-        case 2: return launch_lines<2, NM>(la, st, name);
-        case 4: return launch_lines<4, NM>(la, st, name);
-        case 8: return launch_lines<8, NM>(la, st, name);
-        case 16: return launch_lines<16, NM>(la, st, name);
+        case 2: return launch_lines<2, CONTIG>(la, st, name);
+        case 4: return launch_lines<4, CONTIG>(la, st, name);
+        case 8: return launch_lines<8, CONTIG>(la, st, name);
+        case 16: return launch_lines<16, CONTIG>(la, st, name);
     }
     return fail(PSX_E_UNSUPPORTED, "LDS engine: unsupported line length");
 }
@@ -592,22 +666,6 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
     LdsEngine *e = p->lds;
     hipStream_t st = a.stream;
     const int64_t npix = (int64_t)p->Nx * p->Ny;
-    const float2 *src = a.wave_in;
-    float amp = a.amp;
-    Mats m = a.m;
-    if (m.n > 3) {   // only 0..3 materials are fused into the line kernel: pre-transmit the rest in one pass
-        if (!e->pre) {
-            PSX_HIP(hipMalloc((void **)&e->pre, sizeof(float2) * npix));
-            p->bytes += sizeof(float2) * npix;
-        }
-        PSX_DISPATCH_NMAT(m.n, PSX_TIMED("k_source_out", st, k_source_out<NM><<<ew_grid(npix, 256), 256, 0, st>>>(
-                                                                 src, amp, m, e->pre, nullptr, 1.f, 0, npix)));
-        src = e->pre;
-        amp = 1.f;
-        Mats none;
-        if (int rc = pack_mats(none, nullptr, nullptr, nullptr, 0)) return rc;
-        m = none;
-    }
     // z == 0 distances return the input field (EXP:233-234)
     int nz[PSX_MAX_DIST], nnz = 0;
     for (int d = 0; d < a.n_dist; ++d) {
@@ -615,58 +673,62 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
             nz[nnz++] = d;
             continue;
         }
-        PSX_DISPATCH_NMAT(m.n, PSX_TIMED("k_source_out", st, k_source_out<NM><<<ew_grid(npix, 256), 256, 0, st>>>(
-                                                                 src, amp, m, a.wave_out ? a.wave_out[d] : nullptr,
-                                                                 a.inten_out ? a.inten_out[d] : nullptr,
-                                                                 a.inten_scale ? a.inten_scale[d] : 1.f, a.accumulate,
-                                                                 npix)));
+        PSX_DISPATCH_NMAT(a.m.n, PSX_TIMED("k_source_out", st, k_source_out<NM><<<ew_grid(npix, 256), 256, 0, st>>>(
+                                                                   a.wave_in, a.amp, a.m, a.wave_out ? a.wave_out[d] : nullptr,
+                                                                   a.inten_out ? a.inten_out[d] : nullptr,
+                                                                   a.inten_scale ? a.inten_scale[d] : 1.f, a.accumulate,
+                                                                   npix)));
     }
     if (nnz == 0) return launch_check("k_source_out");
 
-    // ---- pass 1: lines along axis 0 (columns), output transposed.  One launch per distance: keeping the forward spectrum
-    // in registers across distances needs 64 more VGPRs than the 168 a 12-wave workgroup has, and the spills of that
-    // variant cost 3.9 GB of HBM traffic per 4-distance launch (rocprof) -- no faster than re-running the forward stages.
+    // ---- pass 0: the transmitted source wave (K1), evaluated once for all distances and stored transposed [Ny][Nx]
+    if (!e->pre) {
+        PSX_HIP(hipMalloc((void **)&e->pre, sizeof(float2) * npix));
+        p->bytes += sizeof(float2) * npix;
+    }
+    {
+        const int ntiles = (int)(cdiv(p->Nx, 64) * cdiv(p->Ny, 64));
+        PSX_DISPATCH_NMAT(a.m.n, PSX_TIMED("k_source_transposed", st, k_source_transposed<NM><<<ntiles, 256, 0, st>>>(
+                                                                           a.wave_in, a.amp, a.m, e->pre, p->Nx, p->Ny)));
+        if (int rc = launch_check("k_source_transposed")) return rc;
+    }
+
+    // ---- pass 1: lines along axis 0 of the image = rows of the transposed source (contiguous reads); line y writes row
+    // y of the intermediate [Ny][Nx].  One launch per distance: the in-place middle stage consumes the forward spectrum
+    // (keeping it in registers across distances needs 64 VGPRs the engine waves do not have).
     static const bool stamp_pass1 = getenv("PSX_STAMP_PASS1") != nullptr;   // diagnostics only
     for (int i = 0; i < nnz; ++i) {
         LineArgs la;
-        la.src = src; la.amp = amp; la.m = m;
+        la.src = e->pre;
         la.N = p->Nx; la.nlines = p->Ny; la.margin = p->margin; la.P = p->Px; la.L = p->Nx + p->Px - 1;
-        la.in_stride = p->Ny; la.out_ld = p->Nx;
+        la.in_si = 1; la.in_sl = p->Nx; la.out_ld = p->Nx;
         la.twA = e->ax[0].twA; la.twB = e->ax[0].twB;
-        la.n_dist = 1; la.accumulate = 0; la.stamps = stamp_pass1 ? g_stamps : nullptr;
-        if (int rc = kernel_spectrum(p, e->ax[0], a.a[nz[i]], a.du_x, st, &la.H[0])) return rc;
-        la.wave_out[0] = e->inter + (size_t)i * npix;
-        la.inten_out[0] = nullptr;
-        la.scale[0] = 1.f;
-        la.gph[0] = make_float2(1.f, 0.f);
-        int rc = 0;
-        switch (m.n) {
-            case 0: rc = launch_lines_r3<0>(e->ax[0].R3, la, st, "k_fresnel_cols"); break;
-            case 1: rc = launch_lines_r3<1>(e->ax[0].R3, la, st, "k_fresnel_cols"); break;
-            case 2: rc = launch_lines_r3<2>(e->ax[0].R3, la, st, "k_fresnel_cols"); break;
-            default: rc = launch_lines_r3<3>(e->ax[0].R3, la, st, "k_fresnel_cols"); break;
-        }
-        if (rc) return rc;
+        la.accumulate = 0; la.stamps = stamp_pass1 ? g_stamps : nullptr;
+        if (int rc = kernel_spectrum(p, e->ax[0], a.a[nz[i]], a.du_x, st, &la.H)) return rc;
+        la.wave_out = e->inter + (size_t)i * npix;
+        la.inten_out = nullptr;
+        la.scale = 1.f;
+        la.gph = make_float2(1.f, 0.f);
+        if (int rc = launch_lines_r3<true>(e->ax[0].R3, la, st, "k_fresnel_cols")) return rc;
     }
 
-    // ---- pass 2: lines along axis 1 of the original image (= axis 0 of the transposed intermediate)
-    Mats none;
-    if (int rc2 = pack_mats(none, nullptr, nullptr, nullptr, 0)) return rc2;
+    // ---- pass 2: lines along axis 1 of the image = columns of the intermediate (strided reads: the second transpose);
+    // line x writes row x of the result
     for (int i = 0; i < nnz; ++i) {
         const int d = nz[i];
         LineArgs lb;
-        lb.src = e->inter + (size_t)i * npix; lb.amp = 1.f; lb.m = none;
+        lb.src = e->inter + (size_t)i * npix;
         lb.N = p->Ny; lb.nlines = p->Nx; lb.margin = p->margin; lb.P = p->Py; lb.L = p->Ny + p->Py - 1;
-        lb.in_stride = p->Nx; lb.out_ld = p->Ny;
+        lb.in_si = p->Nx; lb.in_sl = 1; lb.out_ld = p->Ny;
         lb.twA = e->ax[1].twA; lb.twB = e->ax[1].twB;
-        lb.n_dist = 1; lb.accumulate = a.accumulate; lb.stamps = stamp_pass1 ? nullptr : g_stamps;
-        if (int rc2 = kernel_spectrum(p, e->ax[1], a.a[d], a.du_y, st, &lb.H[0])) return rc2;
-        lb.wave_out[0] = a.wave_out ? a.wave_out[d] : nullptr;
-        lb.inten_out[0] = a.inten_out ? a.inten_out[d] : nullptr;
-        lb.scale[0] = a.inten_scale ? a.inten_scale[d] : 1.f;
+        lb.accumulate = a.accumulate; lb.stamps = stamp_pass1 ? nullptr : g_stamps;
+        if (int rc2 = kernel_spectrum(p, e->ax[1], a.a[d], a.du_y, st, &lb.H)) return rc2;
+        lb.wave_out = a.wave_out ? a.wave_out[d] : nullptr;
+        lb.inten_out = a.inten_out ? a.inten_out[d] : nullptr;
+        lb.scale = a.inten_scale ? a.inten_scale[d] : 1.f;
         const double g = a.gphase ? a.gphase[d] : 0.0;
-        lb.gph[0] = make_float2((float)std::cos(g), (float)std::sin(g));   // exact reduction of ~1e11 rad (EXP:250)
-        if (int rc2 = launch_lines_r3<0>(e->ax[1].R3, lb, st, "k_fresnel_rows")) return rc2;
+        lb.gph = make_float2((float)std::cos(g), (float)std::sin(g));   // exact reduction of ~1e11 rad (EXP:250)
+        if (int rc2 = launch_lines_r3<false>(e->ax[1].R3, lb, st, "k_fresnel_rows")) return rc2;
     }
     return 0;
 }

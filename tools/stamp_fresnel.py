@@ -21,17 +21,24 @@ def run():
 for _ in range(3):
     run()
 nblk = N
-buf = torch.zeros((nblk, 16), dtype=torch.int64, device="cuda")
+buf = torch.zeros((nblk, 32), dtype=torch.int64, device="cuda")
 lib.psx_debug_stamps(ctypes.c_void_p(buf.data_ptr()))
 run()
 torch.cuda.synchronize()
 lib.psx_debug_stamps(None)
 s = buf.cpu().numpy().astype(np.float64)
-s = s[s[:, 11] > 0]
-names = ["load+spread", "barrier", "fwd A", "barrier", "fwd B", "barrier", "C + xH + invC", "barrier", "inv B", "barrier", "inv A + store (last dist; earlier ones fold in here)"]
-d = np.diff(s[:, :12], axis=1) * 10.0   # 100 MHz ticks -> ns
-print("workgroups:", len(s), " mean total %.2f us" % (d.sum(1).mean() / 1e3))
+s = s[s[:, 13] > 0]
+names = ["prologue: first fetch + spread (once per launch)", "-> round 2 start (round 1 not stamped)", "fwd A", "barrier 1", "fwd B", "wave sync",
+         "C + xH + invC", "wave sync", "inv B", "barrier 2", "inv A: LDS reads + barrier 3", "twiddle, butterfly, stores",
+         "barrier 4 (next group spread by the loaders)"]
+d = np.diff(s[:, :14], axis=1) * 10.0   # 100 MHz ticks -> ns
+rnd = d[:, 2:].sum(1).mean()
+print("workgroups:", len(s), " steady-state round %.2f us" % (rnd / 1e3))
 for n, v in zip(names, d.mean(0)):
-    print("  %-16s %7.2f us  %5.1f %%" % (n, v / 1e3, 100 * v / d.sum(1).mean()))
-span = (s[:, 11].max() - s[:, 0].min()) * 10.0 / 1e3
-print("kernel span %.1f us; sum of workgroup times / 256 CUs = %.1f us" % (span, d.sum() / 1e3 / 256))
+    print("  %-52s %7.2f us  %5.1f %%" % (n, v / 1e3, 100 * v / rnd))
+ld = s[:, 16:21]
+base = s[:, 4:5]      # engine passed barrier 1
+print("loader wave 12 (relative to the engine leaving barrier 1):")
+for n, c in zip(["fetch start", "fetch issued", "spread start (barrier 3 passed)", "spread done", "barrier 4 passed"], range(5)):
+    print("  %-34s %7.2f us" % (n, ((ld[:, c:c+1] - base) * 10.0).mean() / 1e3))
+print("engine: barrier 2 passed %.2f, barrier 3 passed %.2f, stores issued %.2f, barrier 4 passed %.2f us" % tuple(((s[:, c:c+1] - base) * 10.0).mean() / 1e3 for c in (10, 11, 12, 13)))
