@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include "fft_pk.hpp"
 #include "fft_regs.hpp"
 #include "fresnel_plan.hpp"
 
@@ -192,7 +193,12 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             lds_barrier();                               // (2) engine: wave-private stages done
             lds_barrier();                               // (3) engine: inverse stage A holds all of LDS in registers
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 18] = wall_clock64();
+            // the spread sits between two barriers the engine waits at: it goes first on its SIMD (a loader wave would
+            // otherwise get every fourth issue slot).  The fetch keeps normal priority: hurrying the strided loads only
+            // queues the engine's twiddle loads behind them.
+            __builtin_amdgcn_s_setprio(3);
             if (more) spread(cstart + slot + (j + 1) * nslot);
+            __builtin_amdgcn_s_setprio(0);
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 19] = wall_clock64();
             lds_barrier();                               // (4) next group is in LDS
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 20] = wall_clock64();
@@ -201,24 +207,28 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     }
 
     // =================================== engine waves =========================================================================
-    // the 24 twiddles of butterfly n: 16-byte loads from one base, HALF of them in flight at a time (128-VGPR budget)
-    auto mul_tw = [&](const float2 *tw, int n, float2(&v)[RAD], auto conj_tag) __attribute__((always_inline)) {
-        constexpr bool CONJ = decltype(conj_tag)::value;
+    // The 24 twiddles of butterfly n are 12 x 16-byte loads from one base (layout [n][24]).  The engine has 128 VGPRs: an
+    // inverse stage (twiddle BEFORE the butterfly) issues all 12 together with its LDS reads, one latency; a forward
+    // stage (twiddle AFTER the butterfly) issues the first half before the butterfly, the second half after it.
+    auto tw_load = [&](const float2 *tw, int n, auto &x, auto first_tag) __attribute__((always_inline)) {
+        constexpr int Q0 = decltype(first_tag)::value;
         const float4 *t4 = reinterpret_cast<const float4 *>(tw + (size_t)n * RAD);
-        constexpr int NB = 2, PER = RAD / 2 / NB;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            float4 x[PER];
+        for (int q = 0; q < (int)(sizeof(x) / sizeof(float4)); ++q) x[q] = t4[Q0 + q];
+    };
+    auto tw_apply = [&](const auto &x, v2f(&v)[RAD], auto first_tag, auto conj_tag) __attribute__((always_inline)) {
+        constexpr int Q0 = decltype(first_tag)::value;
+        constexpr bool CONJ = decltype(conj_tag)::value;
 #pragma unroll
-            for (int q = 0; q < PER; ++q) x[q] = t4[b * PER + q];
-#pragma unroll
-            for (int q = 0; q < PER; ++q) {
-                const int k = 2 * (b * PER + q);
-                if (k > 0) v[k] = CONJ ? cmulc(v[k], make_float2(x[q].x, x[q].y)) : cmul(v[k], make_float2(x[q].x, x[q].y));
-                v[k + 1] = CONJ ? cmulc(v[k + 1], make_float2(x[q].z, x[q].w)) : cmul(v[k + 1], make_float2(x[q].z, x[q].w));
-            }
+        for (int q = 0; q < (int)(sizeof(x) / sizeof(float4)); ++q) {
+            const int k = 2 * (Q0 + q);
+            const v2f w0 = (v2f){x[q].x, x[q].y}, w1 = (v2f){x[q].z, x[q].w};
+            if (k > 0) v[k] = CONJ ? pk_cmulc(v[k], w0) : pk_cmul(v[k], w0);
+            v[k + 1] = CONJ ? pk_cmulc(v[k + 1], w1) : pk_cmul(v[k + 1], w1);
         }
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I6 = std::integral_constant<int, 6>;
 
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 0] = wall_clock64();
     lds_barrier();                                       // (0) first group is in LDS
@@ -229,16 +239,21 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         // stage A and B thread mapping (one butterfly per thread per stage)
         const int lineA = tid / S1, nA = tid % S1;
         const int remB = tid % S1, q1B = remB / R3, nB = remB % R3, p0B = q1B * S1 + nB;
-        float2 *baseA = lds + lineA * MP;
+        v2f *baseA = reinterpret_cast<v2f *>(lds) + lineA * MP;
 
         // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}
         {
-            float2 v[RAD];
+            v2f v[RAD];
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = baseA[idxA(nA, q)];
-            Dft<RAD, false>::run(v);
-            __builtin_amdgcn_sched_barrier(0);   // keep the twiddle loads below the butterfly
-            mul_tw(a.twA, nA, v, std::false_type{});
+            float4 xa[6], xb[6];
+            tw_load(a.twA, nA, xa, I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            DftPk<RAD, false>::run(v);
+            __builtin_amdgcn_sched_barrier(0);
+            tw_load(a.twA, nA, xb, I6{});
+            tw_apply(xa, v, I0{}, std::false_type{});
+            tw_apply(xb, v, I6{}, std::false_type{});
 #pragma unroll
             for (int q = 0; q < RAD; ++q) baseA[idxA(nA, q)] = v[q];
         }
@@ -247,12 +262,17 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         PSX_STAMP(4);
         // ---- 3. forward stage B: radix 24 inside each block of S1, stride R3, twiddle w_S1^{n q}
         {
-            float2 v[RAD];
+            v2f v[RAD];
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = baseA[idxB(p0B, q)];
-            Dft<RAD, false>::run(v);
+            float4 xa[6], xb[6];
+            tw_load(a.twB, nB, xa, I0{});
             __builtin_amdgcn_sched_barrier(0);
-            mul_tw(a.twB, nB, v, std::false_type{});
+            DftPk<RAD, false>::run(v);
+            __builtin_amdgcn_sched_barrier(0);
+            tw_load(a.twB, nB, xb, I6{});
+            tw_apply(xa, v, I0{}, std::false_type{});
+            tw_apply(xb, v, I6{}, std::false_type{});
 #pragma unroll
             for (int q = 0; q < RAD; ++q) baseA[idxB(p0B, q)] = v[q];
         }
@@ -273,34 +293,34 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             const int sw = (tid & 63) + 64 * r;     // slab of this lane inside the wave's own 96 (round 2: 32 lanes)
             if (sw >= WSLABS) break;
             const int s = (tid >> 6) * WSLABS + sw, line = s / (M / SLAB), p0 = (s % (M / SLAB)) * SLAB;
-            float2 *base = lds + line * MP + phys(p0);      // p0 % 16 == 0: no pad slot inside a slab
+            v2f *base = reinterpret_cast<v2f *>(lds) + line * MP + phys(p0);   // p0 % 16 == 0: no pad slot inside a slab
             float4 hh[SLAB / 2];                            // kernel spectrum of this slab: issued before the LDS reads
             const float4 *h4 = reinterpret_cast<const float4 *>(Hd + p0);
 #pragma unroll
             for (int q = 0; q < SLAB / 2; ++q) hh[q] = h4[q];
-            float2 f[SLAB];
+            v2f f[SLAB];
 #pragma unroll
             for (int q = 0; q < SLAB; ++q) f[q] = base[q];
 #pragma unroll
             for (int c = 0; c < SLAB / R3; ++c) {
-                float2 w[R3];
+                v2f w[R3];
 #pragma unroll
                 for (int q = 0; q < R3; ++q) w[q] = f[c * R3 + q];
-                Dft<R3, false>::run(w);
+                DftPk<R3, false>::run(w);
 #pragma unroll
                 for (int q = 0; q < R3; ++q) f[c * R3 + q] = w[q];
             }
 #pragma unroll
             for (int q = 0; q < SLAB / 2; ++q) {
-                f[2 * q] = cmul(f[2 * q], make_float2(hh[q].x, hh[q].y));
-                f[2 * q + 1] = cmul(f[2 * q + 1], make_float2(hh[q].z, hh[q].w));
+                f[2 * q] = pk_cmul(f[2 * q], (v2f){hh[q].x, hh[q].y});
+                f[2 * q + 1] = pk_cmul(f[2 * q + 1], (v2f){hh[q].z, hh[q].w});
             }
 #pragma unroll
             for (int c = 0; c < SLAB / R3; ++c) {
-                float2 w[R3];
+                v2f w[R3];
 #pragma unroll
                 for (int q = 0; q < R3; ++q) w[q] = f[c * R3 + q];
-                Dft<R3, true>::run(w);
+                DftPk<R3, true>::run(w);
 #pragma unroll
                 for (int q = 0; q < R3; ++q) base[c * R3 + q] = w[q];
             }
@@ -315,12 +335,14 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         asm volatile("" : "+s"(twA_i), "+s"(twB_i));
         // ---- 6. inverse stage B: conjugate twiddle on the inputs, then the inverse radix-24 butterfly
         {
-            float2 v[RAD];
+            v2f v[RAD];
+            float4 x[12];
+            tw_load(twB_i, nB, x, I0{});
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = baseA[idxB(p0B, q)];
-            mul_tw(twB_i, nB, v, std::true_type{});
+            tw_apply(x, v, I0{}, std::true_type{});
             __builtin_amdgcn_sched_barrier(0);
-            Dft<RAD, true>::run(v);
+            DftPk<RAD, true>::run(v);
 #pragma unroll
             for (int q = 0; q < RAD; ++q) baseA[idxB(p0B, q)] = v[q];
         }
@@ -331,23 +353,25 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         // ---- 7. inverse stage A; the wanted outputs y[n + P - 1] leave for HBM straight from the registers.  Once
         // every engine thread holds its 24 inputs LDS is free: the loaders fill it with the next group meanwhile.
         {
-            float2 v[RAD];
+            v2f v[RAD];
+            float4 x[12];
+            tw_load(twA_i, nA, x, I0{});
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = baseA[idxA(nA, q)];
             lds_barrier();                           // (3)
             PSX_STAMP(11);
-            mul_tw(twA_i, nA, v, std::true_type{});
+            tw_apply(x, v, I0{}, std::true_type{});
             __builtin_amdgcn_sched_barrier(0);
-            Dft<RAD, true>::run(v);
+            DftPk<RAD, true>::run(v);
             // output sample i = nA + q*S1 - jout (jout = LDS position of output sample 0).  The first index is made opaque
             // so that the 48 per-q addresses are formed here from ONE pointer, not hoisted out of the group loop (they
             // would occupy 96 VGPRs there and spill).
             int ifirst = nA - (N + 2 * mg - 1);
             asm volatile("" : "+v"(ifirst));
-            float2 *wo = a.wave_out;
+            v2f *wo = reinterpret_cast<v2f *>(a.wave_out);
             float *io = a.inten_out;
             const float sc = a.scale;
-            const float2 gp = a.gph;
+            const v2f gp = (v2f){a.gph.x, a.gph.y};
             if (l0 + lineA < a.nlines) {
                 const int64_t ob = (int64_t)(l0 + lineA) * a.out_ld + ifirst;
                 if (wo) wo += ob;
@@ -356,7 +380,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 for (int q = 0; q < RAD; ++q) {
                     const int i = ifirst + q * S1;
                     if (i >= 0 && i < N) {
-                        if (wo) wo[q * S1] = cmul(v[q], gp);
+                        if (wo) wo[q * S1] = pk_cmul_s(v[q], gp);
                         if (io) {
                             const float I = sc * (v[q].x * v[q].x + v[q].y * v[q].y);
                             io[q * S1] = a.accumulate ? io[q * S1] + I : I;
