@@ -230,29 +230,33 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     using I0 = std::integral_constant<int, 0>;
     using I6 = std::integral_constant<int, 6>;
 
+    // stage A and B thread mapping (one butterfly per thread per stage)
+    const int lineA = tid / S1, nA = tid % S1;
+    const int remB = tid % S1, q1B = remB / R3, nB = remB % R3, p0B = q1B * S1 + nB;
+    v2f *baseA = reinterpret_cast<v2f *>(lds) + lineA * MP;
+    // Table loads are issued one barrier EARLY wherever registers are idle (while a stage's results drain to LDS): they
+    // are in flight during the barrier wait instead of after it.  xfa: first half of forward A's twiddles.
+    float4 xfa[6];
+    tw_load(a.twA, nA, xfa, I0{});
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 0] = wall_clock64();
     lds_barrier();                                       // (0) first group is in LDS
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 1] = wall_clock64();
     for (int j = 0; j < nj; ++j) {
         const int l0 = (cstart + slot + j * nslot) * LINES;
         PSX_STAMP(2);
-        // stage A and B thread mapping (one butterfly per thread per stage)
-        const int lineA = tid / S1, nA = tid % S1;
-        const int remB = tid % S1, q1B = remB / R3, nB = remB % R3, p0B = q1B * S1 + nB;
-        v2f *baseA = reinterpret_cast<v2f *>(lds) + lineA * MP;
 
         // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}
+        float4 xfb[6];
         {
             v2f v[RAD];
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = baseA[idxA(nA, q)];
-            float4 xa[6], xb[6];
-            tw_load(a.twA, nA, xa, I0{});
-            __builtin_amdgcn_sched_barrier(0);
+            float4 xb[6];
             DftPk<RAD, false>::run(v);
             __builtin_amdgcn_sched_barrier(0);
             tw_load(a.twA, nA, xb, I6{});
-            tw_apply(xa, v, I0{}, std::false_type{});
+            tw_apply(xfa, v, I0{}, std::false_type{});
+            tw_load(a.twB, nB, xfb, I0{});               // forward B's first half: in flight across barrier (1)
             tw_apply(xb, v, I6{}, std::false_type{});
 #pragma unroll
             for (int q = 0; q < RAD; ++q) baseA[idxA(nA, q)] = v[q];
@@ -265,13 +269,11 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             v2f v[RAD];
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = baseA[idxB(p0B, q)];
-            float4 xa[6], xb[6];
-            tw_load(a.twB, nB, xa, I0{});
-            __builtin_amdgcn_sched_barrier(0);
+            float4 xb[6];
             DftPk<RAD, false>::run(v);
             __builtin_amdgcn_sched_barrier(0);
             tw_load(a.twB, nB, xb, I6{});
-            tw_apply(xa, v, I0{}, std::false_type{});
+            tw_apply(xfb, v, I0{}, std::false_type{});
             tw_apply(xb, v, I6{}, std::false_type{});
 #pragma unroll
             for (int q = 0; q < RAD; ++q) baseA[idxB(p0B, q)] = v[q];
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         const float2 *twA_i = a.twA, *twB_i = a.twB;
         asm volatile("" : "+s"(twA_i), "+s"(twB_i));
         // ---- 6. inverse stage B: conjugate twiddle on the inputs, then the inverse radix-24 butterfly
+        float4 xia[12];
         {
             v2f v[RAD];
             float4 x[12];
@@ -343,6 +346,8 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             tw_apply(x, v, I0{}, std::true_type{});
             __builtin_amdgcn_sched_barrier(0);
             DftPk<RAD, true>::run(v);
+            __builtin_amdgcn_sched_barrier(0);
+            tw_load(twA_i, nA, xia, I0{});               // inverse A's twiddles: in flight across barriers (2) and (3)
 #pragma unroll
             for (int q = 0; q < RAD; ++q) baseA[idxB(p0B, q)] = v[q];
         }
@@ -354,13 +359,11 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         // every engine thread holds its 24 inputs LDS is free: the loaders fill it with the next group meanwhile.
         {
             v2f v[RAD];
-            float4 x[12];
-            tw_load(twA_i, nA, x, I0{});
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = baseA[idxA(nA, q)];
             lds_barrier();                           // (3)
             PSX_STAMP(11);
-            tw_apply(x, v, I0{}, std::true_type{});
+            tw_apply(xia, v, I0{}, std::true_type{});
             __builtin_amdgcn_sched_barrier(0);
             DftPk<RAD, true>::run(v);
             // output sample i = nA + q*S1 - jout (jout = LDS position of output sample 0).  The first index is made opaque
@@ -389,6 +392,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 }
             }
         }
+        tw_load(a.twA, nA, xfa, I0{});               // next group's forward A, first half: in flight across barrier (4)
         PSX_STAMP(12);
         lds_barrier();                               // (4)
         PSX_STAMP(13);
