@@ -112,7 +112,8 @@ int psx_fresnel_plan_engine(const psx_fresnel_plan *plan);
 /* bytes of device memory the plan owns */
 size_t psx_fresnel_plan_bytes(const psx_fresnel_plan *plan);
 
-/* Propagate ONE input wave to n_dist distances (the forward transform is shared, e.g. EXP:341 and EXP:349).
+/* Propagate ONE input wave to n_dist distances, e.g. EXP:341 and EXP:349 (shared across the distances: the transmitted
+ * source wave in the LDS engine, the forward 2-D transform as well in the rocFFT engine).
  *   input  psi = amp * wave_in * transmission(T, cphase, catt)          (wave_in may be NULL = unit wave; fused K1)
  *   for d < n_dist:  out_d = exp(i*gphase[d]) * IDFT2( exp(-i*a[d]*(u^2+v^2)) * DFT2(reflect_pad(psi)) ) cropped,
  *                    u_i = (i - Px/2)*du_x, v_j = (j - Py/2)*du_y  with du = 2*pi/(N*h) from the UN-padded N (EXP:246-247),
@@ -168,8 +169,9 @@ int psx_membrane_f32(const double *xf, const double *yf, const double *rad, int6
 int psx_profile_enable(int on);
 int psx_profile_summary(char *buf, size_t cap);
 
-/* Diagnostics: device buffer of 16 x uint64 per workgroup receiving the phase timestamps (100 MHz wall clock) of the
- * row pass of the LDS Fresnel engine; NULL (default) switches it off.  Never enabled in timed runs. */
+/* Diagnostics: device buffer receiving phase timestamps (100 MHz wall clock): 32 x uint64 per workgroup from the line
+ * kernels of the LDS Fresnel engine, 16 x uint64 per workgroup from the refraction kernel (tools/stamp_*.py).
+ * NULL (default) switches it off.  Never enabled in timed runs. */
 int psx_debug_stamps(void *buf);
 
 /* ---- status word ------------------------------------------------------------------------------------------------ */

@@ -1,4 +1,4 @@
-// fresnel_lds.hip -- LDS-resident FFT-convolution engine for the Fresnel propagator (K1 + K3..K8 in two kernels).
+// fresnel_lds.hip -- LDS-resident FFT-convolution engine for the Fresnel propagator (K1 + K3..K8 in three kernels).
 //
 // Replaces Experiment.wavePropagation (Experiment.py:219-252) without ever forming the padded 2-D spectrum in HBM.
 //
@@ -7,17 +7,22 @@
 //     out[n] = sum_{d<P} h[d] * x_per[n + margin - d],   h = IDFT_P(c),   x_per = periodic extension of the reflect pad,
 // is evaluated exactly as a linear convolution through a power-friendly FFT of size M >= N+P-1 (M = 576*R3,
 // R3 in {2,4,8,16}: 9216 for N = 4096) that lives entirely in the 160 KiB LDS of one CU:
-//     line samples (transmission evaluated while loading) -> periodic/reflected images written to LDS ->
+//     line samples -> periodic/reflected images written to LDS ->
 //     in-place DIF stages radix 24, 24, R3 -> multiply by FFT_M(h) (digit-reversed table, 1/M folded in) ->
 //     in-place inverse stages R3, 24, 24 -> the N wanted outputs go straight from registers to HBM.
 // P = 4126 = 2*2063 forces Bluestein in a library FFT (two length-8192+ transforms per 1-D DFT, forward AND inverse);
 // here one forward + one inverse length-9216 transform per line does the whole forward-chirp-inverse of that axis, so a
 // propagation costs 2 passes x (8 B read + 8 B written) per pixel instead of 4 padded FFT passes.
 //
-// Pass 1 runs along axis 0 (lines = columns, strided reads of the thickness maps / input wave) and writes its result
-// TRANSPOSED, pass 2 runs along the transposed axis 0 (= original rows) and writes the final image: every global store
-// of both passes is a contiguous line.  Several distances share pass 1's forward transform (its spectrum stays in
-// registers while each distance's kernel is applied), e.g. Experiment.py:341 and :349.
+// A two-pass separable transform with contiguous stores needs two transposes.  The first is a tiled pre-pass
+// (k_source_transposed) that also evaluates the transmitted source wave (K1) -- once per call, for all distances; pass 1
+// (k_fresnel_cols: lines along axis 0) then reads whole lines and writes row y of the intermediate [Ny][Nx]; pass 2
+// (k_fresnel_rows: lines along axis 1) reads the intermediate's columns (the second transpose, 16-byte pieces) and
+// writes the final image.  Pass 1 runs once per distance: the in-place middle stage consumes the forward spectrum.
+//
+// Each CU runs ONE persistent 16-wave workgroup: 12 engine waves own the butterflies (packed-fp32 arithmetic,
+// fft_pk.hpp), 4 loader waves fetch the next line group from HBM during the transform and spread it into LDS while the
+// engine finishes the last butterfly and its stores.
 #include <cstdlib>
 #include <vector>
 
