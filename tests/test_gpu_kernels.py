@@ -107,6 +107,31 @@ def test_fresnel_fused_transmission_and_shared_forward(ops, engine):
     plan.close()
 
 
+@pytest.mark.parametrize("shape", [(16, 40), (97, 131), (131, 97), (33, 1000), (4593, 33), (600, 34)])
+def test_fresnel_lds_engine_edge_geometries(ops, shape):
+    """Ragged line groups, every line length class (M = 1152 ... 9216, incl. the longest line the engine takes), lines
+    straddling the last group, an input wave AND four materials through the transposing pre-pass."""
+    Nx, Ny = shape
+    rng = np.random.default_rng(7 + Nx)
+    E, pix, z, M = 52.0, 2.9, 2.3, 1.02
+    T64 = rng.uniform(0.0, 3e-5, size=(4, Nx, Ny))
+    dl = np.array([6.2e-7, 9.9e-8, 3e-7, 1e-7])
+    bl = np.array([4e-9, 4.5e-11, 1e-9, 2e-10])
+    w_in = rng.normal(size=(Nx, Ny)) + 1j * rng.normal(size=(Nx, Ny))
+    k = orc.k_sample(E)
+    m = ops.MaterialStack(dev(T64, torch.float32), cphase=-k * dl, catt=-k * bl)
+    T32 = T64.astype(np.float32).astype(np.float64)          # both sides see the fp32 thickness values
+    w0 = orc.set_wave(0.75 * w_in.astype(np.complex64).astype(np.complex128), T32, dl, bl, E)
+    ref = orc.wave_propagation(w0, z, E, M, (Nx, Ny), pix)
+    plan = ops.FresnelPlan(Nx, Ny, engine=2)
+    assert plan.engine == 2, "the LDS engine must take this geometry"
+    kk = orc.getk(E * 1000)
+    du = (2 * np.pi / (Nx * pix * 1e-6), 2 * np.pi / (Ny * pix * 1e-6))
+    out = plan.propagate([z / (2 * kk * M)], [kk * z / M], du, wave_in=dev(w_in, torch.complex64), amp=0.75, mats=m)[0]
+    assert relmax(out.cpu().numpy(), ref) < TOL
+    plan.close()
+
+
 def test_fresnel_known_answers(ops):
     # uniform wave keeps its modulus (reflect pad of a constant is constant: only the DC bin, chirp(0)=1)
     plan = ops.FresnelPlan(40, 44)
