@@ -44,14 +44,20 @@ constexpr int TL = 256;       // loader threads
 constexpr int T = TC + TL;
 constexpr int TOT = 18432;    // complex points resident in LDS per workgroup = LINES * M
 constexpr int RAD = 24;       // radix of the two big stages
+// The intermediate between the two passes is stored in blocks of IB samples of a pass-1 line: [Nx/IB][Ny][IB].  Pass 1
+// still writes whole 128-byte lines (2 image rows x 8 samples), and the 16-byte pieces a pass-2 workgroup reads (two
+// adjacent pass-2 lines) sit 64 bytes apart instead of a whole image row: half the cache lines per wave load.
+constexpr int IB = 8;
 
 __host__ __device__ constexpr int phys(int p) { return p + (p >> 5); }   // one pad slot per 32: conflict-free slabs
 
 struct LineArgs {
     const float2 *src;      // input wave
     int N, nlines, margin, P, L;
-    int64_t in_si, in_sl;   // sample i of line l is element i*in_si + l*in_sl of src
-    int64_t out_ld;         // output sample i of line l goes to l*out_ld + i
+    int64_t in_si, in_sl;   // sample i of line l is element i*in_si + l*in_sl of src ...
+    int in_blocked;         // ... or, blocked: element ((l / IB)*N + i)*IB + l % IB  (the intermediate, see IB)
+    int64_t out_ld;         // output sample i of line l goes to l*out_ld + i ...
+    int out_blocked;        // ... or, blocked: element ((i / IB)*nlines + l)*IB + i % IB
     const float2 *twA, *twB;   // [n][24] stage twiddles
     const float2 *H;        // kernel spectrum FFT_M(h) of this distance, digit-reversed, 1/M folded in
     float2 *wave_out;       // complex result (pass 1: the transposed intermediate) or null
@@ -74,6 +80,13 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One ds_read_b64 per value.  Left alone, the compiler pairs neighbouring reads into ds_read2_b64, which moves the same
+// 16 bytes per lane in 8 LDS cycles instead of 2 x 2 (MI355X_MICROARCH.md, LDS table); a volatile access is not paired.
+__device__ __forceinline__ v2f lds_read(const v2f *p) {
+    typedef const volatile __attribute__((address_space(3))) v2f *lds_ptr;   // explicit: a volatile generic load is a flat load
+    return *(lds_ptr)p;
 }
 
 // workgroup barrier that orders LDS traffic only: a loader wave passes it with its global loads still in flight
@@ -137,20 +150,24 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         float2 *base = lds + line * MP;
         const int ja = i0 + N + 2 * mg - 1, jb = i0 - 1;                 // first period | one period earlier (i >= 1)
         const int oa = phys(ja), ob = phys(jb);   // jb = -1 (sample 0 has no earlier image) -> -2: affine, unused at k = 0
-        const int64_t pstep = (int64_t)STEP * a.in_si;
+        const int64_t pstep = (int64_t)STEP * (a.in_blocked ? (int64_t)IB : a.in_si);
 
         float2 xs[NLD], xm = make_float2(0.f, 0.f);
         auto fetch = [&](int g) __attribute__((always_inline)) {        // issue every load of group g, wait for none
             const int l0 = g * LINES;
             const bool line_ok = l0 + line < a.nlines;
-            const int64_t pix0 = (int64_t)i0 * a.in_si + (int64_t)(l0 + line) * a.in_sl;
+            const int64_t pix0 = a.in_blocked
+                                     ? ((int64_t)((l0 + line) / IB) * N + i0) * IB + (l0 + line) % IB
+                                     : (int64_t)i0 * a.in_si + (int64_t)(l0 + line) * a.in_sl;
 #pragma unroll
             for (int k = 0; k < NLD; ++k) {
                 // out-of-range samples re-read element 0 (always valid): unconditional loads issue back to back
                 const bool ok = line_ok && i0 + STEP * k < N;
                 xs[k] = a.src[ok ? pix0 + pstep * k : (int64_t)0];
             }
-            xm = a.src[(im >= 0 && l0 + lm < a.nlines) ? (int64_t)im * a.in_si + (int64_t)(l0 + lm) * a.in_sl : (int64_t)0];
+            const int64_t pixm = a.in_blocked ? ((int64_t)((l0 + lm) / IB) * N + im) * IB + (l0 + lm) % IB
+                                              : (int64_t)im * a.in_si + (int64_t)(l0 + lm) * a.in_sl;
+            xm = a.src[(im >= 0 && l0 + lm < a.nlines) ? pixm : (int64_t)0];
         };
         auto spread = [&](int g) __attribute__((always_inline)) {       // periodic / mirrored images -> LDS
             const int l0 = g * LINES;
@@ -177,7 +194,9 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 const int ln = t % LINES, r = t / LINES;
                 const int i2 = r < mg ? r + 1 : N - 1 - 2 * mg + r, j2 = r < mg ? N + 2 * mg - 1 - i2 : 2 * N - 3 - i2;
                 float2 x2 = make_float2(0.f, 0.f);
-                if (l0 + ln < a.nlines) x2 = a.src[(int64_t)i2 * a.in_si + (int64_t)(l0 + ln) * a.in_sl];
+                if (l0 + ln < a.nlines)
+                    x2 = a.src[a.in_blocked ? ((int64_t)((l0 + ln) / IB) * N + i2) * IB + (l0 + ln) % IB
+                                            : (int64_t)i2 * a.in_si + (int64_t)(l0 + ln) * a.in_sl];
                 lds[ln * MP + phys(j2)] = x2;
             }
         };
@@ -273,7 +292,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         {
             v2f v[RAD];
 #pragma unroll
-            for (int q = 0; q < RAD; ++q) v[q] = baseA[idxB(p0B, q)];
+            for (int q = 0; q < RAD; ++q) v[q] = lds_read(baseA + idxB(p0B, q));
             float4 xb[6];
             DftPk<RAD, false>::run(v);
             __builtin_amdgcn_sched_barrier(0);
@@ -307,7 +326,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             for (int q = 0; q < SLAB / 2; ++q) hh[q] = h4[q];
             v2f f[SLAB];
 #pragma unroll
-            for (int q = 0; q < SLAB; ++q) f[q] = base[q];
+            for (int q = 0; q < SLAB; ++q) f[q] = lds_read(base + q);
 #pragma unroll
             for (int c = 0; c < SLAB / R3; ++c) {
                 v2f w[R3];
@@ -338,8 +357,11 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 
         // The inverse stages use the same twiddles as the forward ones; launder the pointers so that the compiler
         // reloads them (L2-resident) instead of keeping them alive across the whole kernel.
-        const float2 *twA_i = a.twA, *twB_i = a.twB;
-        asm volatile("" : "+s"(twA_i), "+s"(twB_i));
+        // (An opaque zero OFFSET, not an opaque pointer: a pointer that went through the asm is a generic one, and its
+        // loads become flat_load, which also count against the LDS counter.)
+        size_t opaque0 = 0;
+        asm volatile("" : "+s"(opaque0));
+        const float2 *twA_i = a.twA + opaque0, *twB_i = a.twB + opaque0;
         // ---- 6. inverse stage B: conjugate twiddle on the inputs, then the inverse radix-24 butterfly
         float4 xia[12];
         {
@@ -347,7 +369,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             float4 x[12];
             tw_load(twB_i, nB, x, I0{});
 #pragma unroll
-            for (int q = 0; q < RAD; ++q) v[q] = baseA[idxB(p0B, q)];
+            for (int q = 0; q < RAD; ++q) v[q] = lds_read(baseA + idxB(p0B, q));
             tw_apply(x, v, I0{}, std::true_type{});
             __builtin_amdgcn_sched_barrier(0);
             DftPk<RAD, true>::run(v);
@@ -381,17 +403,21 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             const float sc = a.scale;
             const v2f gp = (v2f){a.gph.x, a.gph.y};
             if (l0 + lineA < a.nlines) {
-                const int64_t ob = (int64_t)(l0 + lineA) * a.out_ld + ifirst;
+                // S1 is a multiple of IB: in the blocked layout too the 24 outputs of a thread are one pointer + q * stride
+                static_assert(S1 % IB == 0, "blocked output stride");
+                const int64_t ob = a.out_blocked ? ((int64_t)(ifirst >> 3) * a.nlines + (l0 + lineA)) * IB + (ifirst & (IB - 1))
+                                                 : (int64_t)(l0 + lineA) * a.out_ld + ifirst;
+                const int64_t oq = a.out_blocked ? (int64_t)(S1 / IB) * a.nlines * IB : (int64_t)S1;
                 if (wo) wo += ob;
                 if (io) io += ob;
 #pragma unroll
                 for (int q = 0; q < RAD; ++q) {
                     const int i = ifirst + q * S1;
                     if (i >= 0 && i < N) {
-                        if (wo) wo[q * S1] = pk_cmul_s(v[q], gp);
+                        if (wo) wo[q * oq] = pk_cmul_s(v[q], gp);
                         if (io) {
                             const float I = sc * (v[q].x * v[q].x + v[q].y * v[q].y);
-                            io[q * S1] = a.accumulate ? io[q * S1] + I : I;
+                            io[q * oq] = a.accumulate ? io[q * oq] + I : I;
                         }
                     }
                 }
@@ -552,7 +578,8 @@ struct KernEntry {
 
 struct LdsEngine {
     AxisTables ax[2];            // [0]: lines along axis 0 (length Nx), [1]: along axis 1 (length Ny)
-    float2 *inter = nullptr;     // [max_dist][Ny][Nx] transposed intermediates
+    float2 *inter = nullptr;     // [max_dist][Nx/IB][Ny][IB] intermediates (pass-1 line y, sample x)
+    size_t inter_elems = 0;
     float2 *pre = nullptr;       // [Nx][Ny] pre-transmitted wave when nmat exceeds the fused variants
     double2 *wH = nullptr, *wh = nullptr, *wHh = nullptr, *twP = nullptr, *twM = nullptr;
     int twP_n = 0, twM_n = 0;
@@ -581,7 +608,8 @@ int lds_engine_create(psx_fresnel_plan *p) {
     p->lds = e;
     if (int rc = make_axis(e->ax[0], p->Nx, p->margin, p->bytes)) return rc;
     if (int rc = make_axis(e->ax[1], p->Ny, p->margin, p->bytes)) return rc;
-    const size_t img = sizeof(float2) * (size_t)p->Nx * (size_t)p->Ny;
+    e->inter_elems = (size_t)cdiv(p->Nx, IB) * IB * (size_t)p->Ny;   // blocked layout [Nx/IB][Ny][IB]
+    const size_t img = sizeof(float2) * e->inter_elems;
     PSX_HIP(hipMalloc((void **)&e->inter, img * p->max_dist));
     p->bytes += img * p->max_dist;
     const int Pm = (p->Nx > p->Ny ? p->Nx : p->Ny) + 2 * p->margin;
@@ -734,11 +762,11 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         LineArgs la;
         la.src = e->pre;
         la.N = p->Nx; la.nlines = p->Ny; la.margin = p->margin; la.P = p->Px; la.L = p->Nx + p->Px - 1;
-        la.in_si = 1; la.in_sl = p->Nx; la.out_ld = p->Nx;
+        la.in_si = 1; la.in_sl = p->Nx; la.in_blocked = 0; la.out_ld = 0; la.out_blocked = 1;
         la.twA = e->ax[0].twA; la.twB = e->ax[0].twB;
         la.accumulate = 0; la.stamps = stamp_pass1 ? g_stamps : nullptr;
         if (int rc = kernel_spectrum(p, e->ax[0], a.a[nz[i]], a.du_x, st, &la.H)) return rc;
-        la.wave_out = e->inter + (size_t)i * npix;
+        la.wave_out = e->inter + (size_t)i * e->inter_elems;
         la.inten_out = nullptr;
         la.scale = 1.f;
         la.gph = make_float2(1.f, 0.f);
@@ -750,9 +778,9 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
     for (int i = 0; i < nnz; ++i) {
         const int d = nz[i];
         LineArgs lb;
-        lb.src = e->inter + (size_t)i * npix;
+        lb.src = e->inter + (size_t)i * e->inter_elems;
         lb.N = p->Ny; lb.nlines = p->Nx; lb.margin = p->margin; lb.P = p->Py; lb.L = p->Ny + p->Py - 1;
-        lb.in_si = p->Nx; lb.in_sl = 1; lb.out_ld = p->Ny;
+        lb.in_si = 0; lb.in_sl = 0; lb.in_blocked = 1; lb.out_ld = p->Ny; lb.out_blocked = 0;
         lb.twA = e->ax[1].twA; lb.twB = e->ax[1].twB;
         lb.accumulate = a.accumulate; lb.stamps = stamp_pass1 ? nullptr : g_stamps;
         if (int rc2 = kernel_spectrum(p, e->ax[1], a.a[d], a.du_y, st, &lb.H)) return rc2;
