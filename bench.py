@@ -154,8 +154,9 @@ def main():
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "%dx%d fp32 study grid, 1 membrane position per GPU per step, 4 propagation distances "
-                                  "z={1.6,3.6,5.2,7.2} m: 4 x (Fresnel propagation + refraction), 2-material membrane "
-                                  "transmission fused; 52 keV, dSM/dMO/dOD=140/1.6/3.6 m" % (N, N),
+                                  "z={1.6,3.6,5.2,7.2} m: 4 x (Fresnel propagation + refraction) from the 2-material "
+                                  "membrane thickness maps (transmission evaluated inside the step); 52 keV, "
+                                  "dSM/dMO/dOD=140/1.6/3.6 m" % (N, N),
                       "units_per_step": units, "fresnel_engine": {1: "rocfft", 2: "lds"}[plan.engine],
                       "parallelism": "positions sharded, 1 per GPU" if world > 1 else "single GPU"}}
     if gather_ms is not None:
@@ -208,9 +209,15 @@ def pmc_traffic(kernel, N):
         prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["kernels"]
     except (OSError, ValueError, KeyError):
         return None
-    key = {"k_fresnel_rows": "k_fresnel_lines<16, 0, false>", "k_fresnel_cols": "k_fresnel_lines<16, 2, false>",
+    # pass 2 (k_fresnel_rows) is the <16, false> instance of the line kernel (strided reads), pass 1 the <16, true> one
+    key = {"k_fresnel_rows": "k_fresnel_lines<16, false>", "k_fresnel_cols": "k_fresnel_lines<16, true>",
            "k_refract_near": "k_refract_near<"}.get(kernel)
-    return prof.get(key, {}).get("hbm_bytes_per_launch") if key else None
+    if not key:
+        return None
+    for name, e in prof.items():
+        if name.startswith(key):
+            return e.get("hbm_bytes_per_launch")
+    return None
 
 
 def cpu_baseline(N, geo, delta, beta, E, M, pix, I0, fres, refr):

@@ -4,7 +4,7 @@ import collections, csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 os.makedirs("profiles", exist_ok=True)
-newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1]
+newest = lambda pat: sorted(glob.glob(pat) + glob.glob(pat.replace("/runc/*", "/runc_")), key=os.path.getmtime)[-1]
 shutil.copy(newest("gpurun_out/fin_stats/runc/*kernel_stats.csv"), "profiles/%s_kernel_stats.csv" % tag)
 
 
@@ -23,7 +23,7 @@ def agg(d):
 fetch, write, sq = agg("fin_fetch"), agg("fin_write"), agg("fin_sq")
 summary = {}
 for k in sorted(set(fetch) | set(write) | set(sq)):
-    if not (k.startswith("k_fresnel") or k.startswith("k_refract")):
+    if not (k.startswith("k_fresnel") or k.startswith("k_refract") or k.startswith("k_source")):
         continue
     e = {}
     if k in fetch:
