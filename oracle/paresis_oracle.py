@@ -279,10 +279,11 @@ def _eff_source(cfg):
 
 
 def compute_fresnel(cfg, point):
-    """Experiment.computeSampleAndReferenceImages_Fresnel, Experiment.py:279-405 (scintillator branch omitted).
+    """Experiment.computeSampleAndReferenceImages_Fresnel, Experiment.py:279-405.
 
     cfg keys: dSM,dMO,dOD,meanShotCount,ov,pix_um,M,inVacuum,N(2),spectrum[(E,w)],source_size_um,energy_sampling,
-    det_dims(2),det_pix_um,psf,bins(list, mutated at point 0 like the reference),membrane/sample/air/plate (Obj|None).
+    det_dims(2),det_pix_um,psf,bins(list, mutated at point 0 like the reference),membrane/sample/air/plate (Obj|None),
+    optional scintillator = (thickness_um, [(E, beta)]).
     """
     thr = _bins(cfg, point)
     nb = len(thr)
@@ -298,6 +299,12 @@ def compute_fresnel(cfg, point):
         I = I0 * flux                                                          # EXP:320
         if not cfg["inVacuum"]:
             I, _, _ = set_wave_rt(I, air.geometry, air.delta[:, ie], air.beta[:, ie], E)     # EXP:323
+        if cfg.get("scintillator") is not None:                                # EXP:326-332: beta matched by energy equality
+            thick, betas = cfg["scintillator"]
+            for e_data, b_en in betas:
+                if e_data == E:
+                    sc_beta = b_en
+            I = I * (1 - np.exp(-2 * getk(E * 1000) * thick * 1e-6 * sc_beta))
         w0 = np.sqrt(I)                                                        # EXP:334
         wm = set_wave(w0, mem.geometry, mem.delta[:, ie], mem.beta[:, ie], E)  # EXP:338
         magMemObj = (cfg["dSM"] + cfg["dMO"]) / cfg["dSM"]                     # EXP:340
@@ -354,6 +361,10 @@ def compute_rt(cfg, point, variant="v2"):
         I = I0 * flux                                                          # EXP:451
         if not cfg["inVacuum"]:
             I, _, _ = set_wave_rt(I, air.geometry, air.delta[:, ie], air.beta[:, ie], E)
+        if cfg.get("scintillator") is not None:                                # EXP:456-459: tabulated efficiency
+            for e_data, eff in spectral_efficiency(cfg["scintillator"][1], cfg["scintillator"][0]):
+                if e_data == E:
+                    I = I * eff
         Im, phim, _ = set_wave_rt(I, mem.geometry, mem.delta[:, ie], mem.beta[:, ie], E, phi0)   # EXP:463
         Ibs, _, _ = refr(Im, phim, cfg["dMO"], E)                              # EXP:466 (total magnification!)
         Ias, phis, DF = set_wave_rt(Ibs, smp.geometry, smp.delta[:, ie], smp.beta[:, ie], E, phim, **sm)  # EXP:469
@@ -433,3 +444,87 @@ def membrane_segmented(sphere_list, dimX, dimY, pix_um, mean_radius_um, n_layers
         _lib().oracle_membrane_splat(len(rad), _dp(xf), _dp(yf), _dp(rad), dimX, dimY, margin, margin2, _dp(mem))
     mem = mem[margin:-margin, margin:-margin]                                # :161
     return [mem * pix_um * 1e-6, np.ones(mem.shape) * support_um * 1e-6]     # :167-169
+
+
+# ------------------------------------------------------------------------- polychromatic front-end
+def table_walk(spectrum, table_E_eV, table_delta, table_beta):
+    """The delta/beta table walk of Sample.getDeltaBeta (Sample.py:112-148) and Detector.getBeta (Detector.py:139-158)
+    for ONE material column: table rows (E_eV, delta, beta) ascending, spectrum [(E_keV, w)] ascending.  The row
+    pointer is NOT reset between energies (:121 before the loop), energies under the current row give (0, 1) (:125-129),
+    otherwise linear interpolation between the bracketing rows (:131-144).  Returns ([(E, delta)], [(E, beta)])."""
+    row = 0
+    delta, beta = [], []
+    for energy, _ in spectrum:
+        cur = table_E_eV[row]
+        if energy * 1000 < cur:
+            delta.append((energy, 0))
+            beta.append((energy, 1))
+            continue
+        nxt = table_E_eV[row + 1]
+        while nxt < energy * 1e3:
+            row += 1
+            cur = table_E_eV[row]
+            nxt = table_E_eV[row + 1]
+        step = nxt - cur
+        d = abs(nxt - energy * 1e3) / step * table_delta[row] + abs(cur - energy * 1e3) / step * table_delta[row + 1]
+        b = abs(nxt - energy * 1e3) / step * table_beta[row] + abs(cur - energy * 1e3) / step * table_beta[row + 1]
+        delta.append((energy, d))
+        beta.append((energy, b))
+    return delta, beta
+
+
+def spectral_efficiency(beta, thickness_um):
+    """Detector.getSpectralEfficiency, Detector.py:161-170."""
+    return [(e, 1 - np.exp(-2 * getk(e * 1000) * thickness_um * 1e-6 * b)) for e, b in beta]
+
+
+def tube_spectrum(energies, fluence):
+    """Source.setMySpectrum, generated-spectrum branch after the spekpy call (Source.py:108-123): NaN -> 0,
+    normalise by the total, keep the bins above 1e-4."""
+    fluence = np.where(np.isnan(fluence), 0.0, np.asarray(fluence, dtype=np.float64))
+    fl = 0
+    for v in fluence:
+        fl += v
+    return [(energies[i], fluence[i] / fl) for i in range(len(energies)) if fluence[i] / fl > 0.0001]
+
+
+def xls_spectrum(rows_E, rows_fluence, unit_scale, sampling):
+    """Source.setMySpectrum, tabulated branch (Source.py:132-233): rows in file units (scaled by unit_scale to keV),
+    re-binned to `sampling` keV.  Kept quirks: the bin width counter advances by the step of the FIRST two rows (:194),
+    only Nbin-1 full bins are formed and the rest is one tail bin (:200-222), the normalisation total does not include
+    the tail bin (:213 vs :215-222), bins at or under 0.001 are dropped (:228)."""
+    spectrum = [[e * unit_scale, f] for e, f in zip(rows_E, rows_fluence)]
+    den = spectrum[1][0] - spectrum[0][0]
+    n_en = len(spectrum)
+    n_bin = int((spectrum[-1][0] - spectrum[0][0]) // sampling)
+    energyplot, weightplot = [], []
+    n = 0
+    tot_weight = 0
+    for _ in range(n_bin - 1):
+        curr = 0
+        w = 0
+        eb = 0
+        while curr < sampling:
+            w += spectrum[n][1]
+            eb += spectrum[n][1] * spectrum[n][0]
+            n += 1
+            curr = curr + den
+        if w != 0:
+            energyplot.append(eb / w)
+            weightplot.append(w)
+        tot_weight += w
+    w = 0
+    eb = 0
+    while n < n_en:
+        w += spectrum[n][1]
+        eb += spectrum[n][1] * spectrum[n][0]
+        n += 1
+    if w != 0:
+        energyplot.append(eb / w)
+        weightplot.append(w)
+    out = []
+    for i in range(len(energyplot)):
+        flux = weightplot[i] / tot_weight
+        if flux > 0.001:
+            out.append((energyplot[i], flux))
+    return out

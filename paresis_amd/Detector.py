@@ -76,9 +76,14 @@ class Detector:
         return out
 
     def getBeta(self, sourceSpectrum):
-        """Detector.py:131-160 reads CsI beta from an .xls table; here it comes from the material registry."""
-        from .materials import delta_beta
-        self.beta = [(e, delta_beta(self.det_param["myScintillatorMaterial"], e)[1]) for e, _ in sourceSpectrum]
+        """Detector.py:131-160 reads the scintillator's beta from an .xls table; here from a registered table (same walk and
+        interpolation) or from the material registry."""
+        from . import materials
+        name = self.det_param["myScintillatorMaterial"]
+        if materials.has_table(name):                    # Detector.py:139-158: the same table walk, beta column
+            self.beta = materials.table_walk(name, sourceSpectrum)[1]
+            return
+        self.beta = [(e, materials.delta_beta(name, e)[1]) for e, _ in sourceSpectrum]
 
     def getSpectralEfficiency(self):
         """Detector.py:163-172: 1 - exp(-2 k beta t) per energy."""

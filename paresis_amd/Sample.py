@@ -59,6 +59,11 @@ class Sample:
     def getDeltaBeta(self, sourceSpectrum):
         """Sample.py:83-152: per material, a list of (energy, value) for every energy of the spectrum."""
         for material in self.myMaterials:
+            if materials.has_table(material):            # TablesDeltaBeta branch, Sample.py:112-148
+                delta, beta = materials.table_walk(material, sourceSpectrum)
+                self.delta.append(delta)
+                self.beta.append(beta)
+                continue
             db = [materials.delta_beta(material, e) for e, _ in sourceSpectrum]
             self.delta.append([(e, d) for (e, _), (d, _) in zip(sourceSpectrum, db)])
             self.beta.append([(e, b) for (e, _), (_, b) in zip(sourceSpectrum, db)])

@@ -1,8 +1,10 @@
 """Source model: XML -> source_dict -> spectrum [(E_keV, weight)]  (mirror of CodePython/Source.py:18-249).
 
-Only the monochromatic branch (Source.py:90-93) is exact.  Tube spectra need spekpy or an .xls reader, neither of which
-exists in this image; a polychromatic source therefore takes an injected spectrum (`source_dict['spectrum']` or
-`Source.spectrum_provider`) and otherwise falls back to a documented Kramers-law stand-in (out of the hot path).
+Tube spectra need spekpy or an .xls reader, neither of which exists in this image, so a polychromatic source takes its
+raw data injected and applies the reference's own processing to it: `source_dict['spectrum']` (or
+`Source.spectrum_provider`) stands for spekpy's output (NaN -> 0, normalise, 1e-4 threshold: Source.py:108-123);
+`source_dict['xlsRows']` with `spectrumFromXls` stands for the sheet rows (unit scaling, re-binning, 1e-3 threshold:
+Source.py:132-233).  Without either, a documented Kramers-law stand-in is used (out of the hot path).
 """
 import numpy as np
 
@@ -60,8 +62,12 @@ class Source:
             self.mySpectrum.append((sd["Energy"], 1))       # SRC:90-93
             return
         if sd["myType"] == "Polychromatic":
+            if self.spectrumFromXls and "xlsRows" in sd:
+                self.mySpectrum.extend(self._from_table_rows(sd))
+                return
             if "spectrum" in sd:
-                spec = [(float(e), float(w)) for e, w in sd["spectrum"]]
+                # NaN bins count as zero (Source.py:111-113)
+                spec = [(float(e), 0.0 if np.isnan(w) else float(w)) for e, w in sd["spectrum"]]
             elif Source.spectrum_provider is not None:
                 spec = list(Source.spectrum_provider(sd, flu_fluEn))
             else:
@@ -72,6 +78,42 @@ class Source:
             self.mySpectrum.extend((e, w / tot) for e, w in spec if w / tot > 0.0001)
             return
         raise ValueError("unknown source type %r" % sd["myType"])
+
+    @staticmethod
+    def _from_table_rows(sd):
+        """Tabulated spectrum, Source.py:132-233 after the sheet has been read: `xlsRows` = [(energy, fluence)] in
+        `energyUnit`, re-binned to `myEnergySampling` keV.  The reference's arithmetic is kept as is: the bin-width
+        counter advances by the step of the first two rows, Nbin-1 full bins + one tail bin, the normalisation total
+        leaves the tail bin out, bins at or under 0.001 are dropped (pinned by tests/golden/frontend.npz)."""
+        scale = {"eV": 0.001, "MeV": 1000}.get(sd.get("energyUnit"), 1)
+        spectrum = [[float(e) * scale, float(f)] for e, f in sd["xlsRows"]]
+        sampling = sd["myEnergySampling"]
+        den = spectrum[1][0] - spectrum[0][0]
+        n_en = len(spectrum)
+        n_bin = int((spectrum[-1][0] - spectrum[0][0]) // sampling)
+        energies, weights = [], []
+        n = 0
+        tot = 0
+        for _ in range(n_bin - 1):
+            curr, w, eb = 0, 0, 0
+            while curr < sampling:
+                w += spectrum[n][1]
+                eb += spectrum[n][1] * spectrum[n][0]
+                n += 1
+                curr = curr + den
+            if w != 0:
+                energies.append(eb / w)
+                weights.append(w)
+            tot += w
+        w, eb = 0, 0
+        while n < n_en:
+            w += spectrum[n][1]
+            eb += spectrum[n][1] * spectrum[n][0]
+            n += 1
+        if w != 0:
+            energies.append(eb / w)
+            weights.append(w)
+        return [(e, wt / tot) for e, wt in zip(energies, weights) if wt / tot > 0.001]
 
     @staticmethod
     def _kramers(sd):

@@ -4,6 +4,9 @@ The reference reads refractive-index decrements from xraylib (Materials.csv) or 
 (CodePython/Sample.py:83-152).  Neither library nor a readable table exists in this image, and the lookup is host-side
 O(#energies) work outside the hot path, so the build takes delta/beta as numbers:
 
+  * `register_table(name, E_eV, delta, beta)` installs the three columns of a TablesDeltaBeta-style table; spectra are
+    then resolved by `table_walk`, the reference's own row walk + linear interpolation (Sample.py:112-148,
+    Detector.py:139-158), quirks included (pinned by tests/golden/frontend.npz);
   * `register_material(name, fn)` installs fn(energy_keV) -> (delta, beta);
   * when `xraylib` is importable, materials listed in a Materials.csv-style table resolve through it like the reference;
   * otherwise the few materials of the shipped XML experiments fall back to SYNTHETIC order-of-magnitude values scaled
@@ -32,6 +35,46 @@ def _synthetic(name):
 for _n, _alias in (("CuSn", "CuSn"), ("PMMA", "PMMA"), ("Nylon", "Nylon"), ("Air", "air"), ("air", "air"),
                    ("CarbonFiber", "C"), ("Cu", "CuSn"), ("Fe", "CuSn")):
     register_material(_n, _synthetic(_alias), "synthetic (SURVEY.md 8d)")
+
+
+_TABLES = {}
+
+
+def register_table(name, energies_eV, delta, beta):
+    """Columns of one material of a TablesDeltaBeta-style table: energies in eV (ascending), delta, beta."""
+    E = [float(v) for v in energies_eV]
+    if len(E) < 2 or any(b <= a for a, b in zip(E, E[1:])) or not (len(E) == len(delta) == len(beta)):
+        raise ValueError("a delta/beta table needs >= 2 rows of strictly ascending energies and equal-length columns")
+    _TABLES[name] = (E, [float(v) for v in delta], [float(v) for v in beta])
+    _PROVENANCE[name] = "table"
+
+
+def has_table(name):
+    return name in _TABLES
+
+
+def table_walk(name, sourceSpectrum):
+    """([(E_keV, delta)], [(E_keV, beta)]) for every energy of the spectrum, like the table branch of
+    Sample.getDeltaBeta (Sample.py:112-148): the row pointer walks forward through the spectrum and is not reset,
+    an energy under the current row gives delta = 0, beta = 1, otherwise the two bracketing rows are interpolated
+    linearly.  An energy beyond the last row raises IndexError, as the reference does."""
+    E, D, B = _TABLES[name]
+    row = 0
+    delta, beta = [], []
+    for energy, _ in sourceSpectrum:
+        eV = energy * 1e3
+        if energy * 1000 < E[row]:
+            delta.append((energy, 0))
+            beta.append((energy, 1))
+            continue
+        while E[row + 1] < eV:
+            row += 1
+        lo, hi = E[row], E[row + 1]
+        step = hi - lo
+        wl, wh = abs(hi - eV) / step, abs(lo - eV) / step
+        delta.append((energy, wl * D[row] + wh * D[row + 1]))
+        beta.append((energy, wl * B[row] + wh * B[row + 1]))
+    return delta, beta
 
 
 def delta_beta(name, energy_keV):

@@ -19,6 +19,11 @@ def build_experiment(cfg, sim, noise=False, sample_materials=("Nylon",), sample_
     det.det_param.update(myDimensions=np.array(cfg["det_dims"]), myPixelSize=cfg["det_pix_um"], myPSF=cfg["psf"],
                          myBinsThersholds=list(cfg["bins"]))
 
+    if cfg.get("scintillator") is not None:
+        det.det_param.update(myScintillatorMaterial="injected", myScintillatorThickness=cfg["scintillator"][0])
+        det.beta = list(cfg["scintillator"][1])
+        det.getSpectralEfficiency()
+
     def sample(obj, name, mtype, mats):
         if obj is None:
             return None

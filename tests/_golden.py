@@ -33,7 +33,10 @@ def experiment_cfg(g, tag, Obj):
             return None
         return Obj(g[key], g["%s/%s/delta" % (tag, nm)], g["%s/%s/beta" % (tag, nm)])
 
-    return dict(dSM=float(e[0]), dMO=float(e[1]), dOD=float(e[2]), meanShotCount=float(e[3]), ov=int(e[4]),
+    scint = None
+    if tag + "/scint_beta" in g.files:
+        scint = (float(g["scint/thickness_um"]), [(float(a), float(b)) for a, b in g[tag + "/scint_beta"]])
+    return dict(scintillator=scint, dSM=float(e[0]), dMO=float(e[1]), dOD=float(e[2]), meanShotCount=float(e[3]), ov=int(e[4]),
                 pix_um=float(e[5]), M=float(e[6]), inVacuum=bool(g[tag + "/inVacuum"]),
                 N=tuple(int(v) for v in g[tag + "/studyDimensions"]),
                 spectrum=[(float(a), float(b)) for a, b in g[tag + "/spectrum"]],

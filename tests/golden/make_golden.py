@@ -460,6 +460,184 @@ def gold_membrane():
     save("membrane.npz", d)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Polychromatic front-end: the reference's table walks and spectrum resampling, run on SYNTHETIC
+# tables.  xlrd and spekpy are absent, so the two readers are replaced by in-memory stand-ins that only SERVE data
+# (sheet.cell(r, c).value / Spek.get_spectrum()); every line of parsing, interpolation, thresholding and resampling
+# that is recorded below is the reference's own (Sample.py:83-152, Detector.py:131-158, Source.py:79-240).
+class _Cell:
+    def __init__(self, v):
+        self.value = v
+
+
+class _Sheet:
+    def __init__(self, grid):
+        self.grid = grid
+        self.nrows = len(grid)
+        self.ncols = max(len(r) for r in grid)
+
+    def cell(self, r, c):
+        row = self.grid[r]
+        return _Cell(row[c] if c < len(row) else "")
+
+
+class _Workbook:
+    def __init__(self, sheets):
+        self._sheets = sheets
+
+    def sheets(self):
+        return self._sheets
+
+
+def _fake_xlrd(books):
+    m = types.ModuleType("xlrd")
+    m.open_workbook = lambda path: _Workbook([_Sheet(g) for g in books[path]])
+    return m
+
+
+def _table_sheet(tables):
+    """TablesDeltaBeta.xls layout: per material 3 columns (E_eV, delta, beta), name in row 0, data from row 3."""
+    nrows = 3 + max(len(t[1]) for t in tables)
+    grid = [["" for _ in range(3 * len(tables))] for _ in range(nrows)]
+    for m, (name, E, dl, bt) in enumerate(tables):
+        grid[0][3 * m] = name
+        grid[1][3 * m], grid[1][3 * m + 1], grid[1][3 * m + 2] = "Energy", "delta", "beta"
+        grid[2][3 * m] = "eV"
+        for r in range(len(E)):
+            grid[3 + r][3 * m], grid[3 + r][3 * m + 1], grid[3 + r][3 * m + 2] = float(E[r]), float(dl[r]), float(bt[r])
+    return grid
+
+
+def gold_frontend():
+    d = {}
+    # ---- delta/beta tables: two materials on different (irregular) energy grids
+    E1 = np.concatenate([np.arange(8000.0, 30000.0, 1500.0), np.arange(30000.0, 130001.0, 5000.0)])
+    E2 = np.geomspace(12000.0, 150000.0, 37)
+    tabs = [("SynthNylon", E1, 2.4e-7 * (25000.0 / E1) ** 2, 9e-11 * (25000.0 / E1) ** 3.1),
+            ("SynthGadox", E2, 1.9e-6 * (25000.0 / E2) ** 2, 6e-8 * (25000.0 / E2) ** 2.7)]
+    for m, (name, E, dl, bt) in enumerate(tabs):
+        d["tab/%d/E_eV" % m], d["tab/%d/delta" % m], d["tab/%d/beta" % m] = E, dl, bt
+    d["tab/names"] = np.array([t[0] for t in tabs])
+    books = {"Samples/DeltaBeta/TablesDeltaBeta.xls": [_table_sheet(tabs)]}
+    spectrum = [(7.5, 0.02), (9.0, 0.05), (12.0, 0.1), (17.3, 0.2), (25.0, 0.25), (31.0, 0.18), (52.0, 0.12), (88.8, 0.06),
+                (129.9, 0.02)]
+    d["spectrum"] = np.array(spectrum)
+    SAM.xlrd = _fake_xlrd(books)
+    smp = object.__new__(SAM.AnalyticalSample)
+    smp.myMaterials = ["SynthNylon", "SynthGadox"]
+    smp.delta, smp.beta = [], []
+    smp.getDeltaBeta(spectrum)                                    # Sample.py:83-152, table branch
+    d["sample/delta"] = np.array(smp.delta)                       # [nmat][nE][2]
+    d["sample/beta"] = np.array(smp.beta)
+    DET.xlrd = _fake_xlrd(books)
+    det = object.__new__(DET.Detector)
+    det.det_param = {"myScintillatorMaterial": "SynthGadox", "myScintillatorThickness": 150.0}
+    det.beta, det.mySpectralEfficiency = [], []
+    det.getBeta(spectrum)                                         # Detector.py:131-158
+    det.getSpectralEfficiency()                                   # Detector.py:161-170
+    d["det/beta"] = np.array(det.beta)
+    d["det/efficiency"] = np.array(det.mySpectralEfficiency)
+
+    # ---- tube spectrum through the spekpy branch (Source.py:98-130): NaN bins, 1e-4 threshold
+    Es = np.arange(10.0, 80.5, 0.5)
+    flu = np.maximum(80.0 / Es - 1.0, 0.0) * np.exp(-((12.0 / Es) ** 3)) * 1e6
+    flu[[3, 40]] = np.nan
+    flu[100:] *= 1e-4
+
+    class _Spek:
+        def __init__(self, kvp, th, targ, dk):
+            d["spek/args"] = np.array([kvp, th, dk])
+
+        def filter(self, mat, thick):
+            d["spek/filter_thickness"] = np.array(thick)
+
+        def get_spectrum(self, flu=True):
+            return [Es.copy(), globals_flu.copy()]
+
+    globals_flu = flu
+    fake_sp = types.ModuleType("spekpy")
+    fake_sp.Spek = _Spek
+    SRC.sp = fake_sp
+    src = object.__new__(SRC.Source)
+    src.mySpectrum = []
+    src.spectrumFromXls = False
+    src.source_dict = {"myType": "Polychromatic", "myVoltage": 80.0, "myEnergySampling": 0.5, "filterMaterial": "Al",
+                       "filterThickness": 1.5}
+    src.setMySpectrum()
+    d["spek/E"], d["spek/fluence"] = Es, flu
+    d["spek/out"] = np.array(src.mySpectrum)
+
+    # ---- tabulated spectrum through the xls branch (Source.py:132-233): unit scaling, re-binning, 1e-3 threshold
+    for case, (unit, E0, step, n, sampling) in enumerate([("keV", 10.0, 0.5, 141, 2.0), ("eV", 8000.0, 250.0, 200, 1.0),
+                                                          ("keV", 15.0, 1.0, 60, 5.0)]):
+        Ex = E0 + step * np.arange(n)
+        scale = {"keV": 1.0, "eV": 0.001}[unit]
+        fx = np.maximum((Ex * scale)[-1] * 1.02 / (Ex * scale) - 1.0, 0.0) * np.exp(-((14.0 / (Ex * scale)) ** 3)) * 3e5
+        grid = [["comment", "", ""], ["E", "N", "other"]] + [[float(a), float(b), 0.0] for a, b in zip(Ex, fx)]
+        SRC.xlrd = _fake_xlrd({"spectrum.xls": [grid]})
+        src = object.__new__(SRC.Source)
+        src.mySpectrum = []
+        src.spectrumFromXls = True
+        src.source_dict = {"myType": "Polychromatic", "myEnergySampling": sampling, "energyUnit": unit,
+                           "pathXlsSpectrum": "spectrum.xls", "energyColumnKey": "E", "fluenceColumnKey": "N",
+                           "filterMaterial": None}
+        src.setMySpectrum()
+        d["xls/%d/E" % case], d["xls/%d/fluence" % case] = Ex, fx
+        d["xls/%d/unit_is_eV" % case] = np.array(unit == "eV")
+        d["xls/%d/sampling" % case] = np.array(sampling)
+        d["xls/%d/out" % case] = np.array(src.mySpectrum)
+    d["xls/n"] = np.array(3)
+    save("frontend.npz", d)
+
+
+def gold_frontend_chain():
+    """Both chains with everything the polychromatic front-end produces going through the reference's own code: the
+    spectrum from the tabulated branch of Source.setMySpectrum, the sample's delta/beta and the scintillator's beta from
+    the table walks, the scintillator efficiency (Experiment.py:326-332 / :456-459), air, plate, two energy bins."""
+    g = np.load(os.path.join(HERE, "frontend.npz"))
+    tabs = [(str(n), g["tab/%d/E_eV" % m], g["tab/%d/delta" % m], g["tab/%d/beta" % m]) for m, n in enumerate(g["tab/names"])]
+    books = {"Samples/DeltaBeta/TablesDeltaBeta.xls": [_table_sheet(tabs)]}
+    Ex = 15.0 + np.arange(60)
+    fx = np.maximum(76.0 / Ex - 1.0, 0.0) * np.exp(-((20.0 / Ex) ** 3)) * 3e5
+    grid = [["E", "N"]] + [[float(a), float(b)] for a, b in zip(Ex, fx)]
+    books["spectrum.xls"] = [grid]
+    SRC.xlrd = SAM.xlrd = DET.xlrd = _fake_xlrd(books)
+    src = object.__new__(SRC.Source)
+    src.mySpectrum = []
+    src.spectrumFromXls = True
+    src.source_dict = {"myType": "Polychromatic", "myEnergySampling": 10.0, "energyUnit": "keV",
+                       "pathXlsSpectrum": "spectrum.xls", "energyColumnKey": "E", "fluenceColumnKey": "N",
+                       "filterMaterial": None, "mySize": 30.0}
+    src.setMySpectrum()
+    spectrum = list(src.mySpectrum)
+    d = {"xls/E": Ex, "xls/fluence": fx, "xls/sampling": np.array(10.0), "scint/thickness_um": np.array(120.0)}
+    for sim in ("RT", "Fresnel"):
+        exp, membrane_geom = build_experiment((24, 28), 2, spectrum, [40.0], 10.0, 1.0, 30.0, False, True, 70)
+        smp = exp.mySampleofInterest
+        smp.myMaterials, smp.delta, smp.beta = ["SynthNylon"], [], []
+        smp.getDeltaBeta(spectrum)                                       # table walk, Sample.py:112-148
+        det = exp.myDetector
+        det.det_param["myScintillatorMaterial"] = "SynthGadox"
+        det.det_param["myScintillatorThickness"] = 120.0
+        det.getBeta(spectrum)                                            # Detector.py:131-158
+        det.getSpectralEfficiency()
+        t = "chain/%s" % sim
+        record_inputs(d, t, exp)
+        d[t + "/scint_beta"] = np.array(det.beta)
+        for point in (0, 1):
+            exp.myMembrane.myGeometry = membrane_geom(point)
+            d["%s/p%d/membrane" % (t, point)] = exp.myMembrane.myGeometry
+            exp.exp_dict["meanEnergy"] = 0
+            if sim == "RT":
+                S, R, Pg, W, Dx, Dy, DF = exp.computeSampleAndReferenceImages_RT(point)
+            else:
+                S, R, Pg, W = exp.computeSampleAndReferenceImages_Fresnel(point)
+            for nm, a in (("Sample", S), ("Reference", R), ("Propag", Pg), ("White", W)):
+                d["%s/p%d/%s" % (t, point, nm)] = np.asarray(a, dtype=np.float64)
+            d["%s/p%d/meanEnergy" % (t, point)] = np.array(exp.exp_dict["meanEnergy"])
+    save("frontend_chain.npz", d)
+
+
 if __name__ == "__main__":
     gold_scalars()
     gold_transmission()
@@ -469,4 +647,6 @@ if __name__ == "__main__":
     gold_experiment()
     gold_membrane()
     gold_darkfield()
+    gold_frontend()
+    gold_frontend_chain()
     os.chdir(_cwd)

@@ -167,3 +167,40 @@ def test_darkfield_chain():
             assert tuple(Dx.shape) == g[t + "Dx"].shape
             assert relmax(Dx.cpu().numpy(), g[t + "Dx"]) < 1e-6
             assert relmax(DF.cpu().numpy(), g[t + "DF"]) < 1e-6
+
+
+@pytest.mark.parametrize("sim", ["RT", "Fresnel"])
+def test_polychromatic_frontend_chain(sim):
+    """the energy loop as a reduced axis -- 5 energies from the re-binned tabulated spectrum, table-walk
+    delta/beta, scintillator efficiency, air, plate, two detector bins -- against the reference's own run."""
+    from paresis_amd import materials
+    from paresis_amd.Source import Source
+    g = load("frontend_chain.npz")
+    f = load("frontend.npz")
+    cfg = experiment_cfg(g, "chain/" + sim, orc.Obj)
+    exp = build_experiment(cfg, sim, sample_materials=("SynthNylon",))
+    # the same front-end on the package side: spectrum from the injected sheet rows, delta/beta from registered tables
+    src = Source()
+    src.spectrumFromXls = True
+    src.source_dict.update({"myType": "Polychromatic", "myEnergySampling": float(g["xls/sampling"]), "energyUnit": "keV",
+                            "xlsRows": list(zip(g["xls/E"], g["xls/fluence"])), "mySize": cfg["source_size_um"]})
+    src.setMySpectrum()
+    assert src.mySpectrum == cfg["spectrum"]
+    exp.mySource.mySpectrum = src.mySpectrum
+    for m, n in enumerate(f["tab/names"]):
+        materials.register_table(str(n), f["tab/%d/E_eV" % m], f["tab/%d/delta" % m], f["tab/%d/beta" % m])
+    smp = exp.mySampleofInterest
+    smp.delta, smp.beta = [], []
+    smp.getDeltaBeta(src.mySpectrum)
+    exp.myDetector.det_param["myScintillatorMaterial"] = "SynthGadox"
+    exp.myDetector.getBeta(src.mySpectrum)
+    exp.myDetector.getSpectralEfficiency()
+    assert np.array_equal(np.array(exp.myDetector.beta), g["chain/%s/scint_beta" % sim])
+    for point in (0, 1):
+        exp.myMembrane.myGeometry = g["chain/%s/p%d/membrane" % (sim, point)]
+        exp.exp_dict["meanEnergy"] = 0
+        out = exp.computeSampleAndReferenceImages(point)
+        t = "chain/%s/p%d/" % (sim, point)
+        for nm, a in zip(("Sample", "Reference", "Propag", "White"), out[:4]):
+            err = relmax(a.cpu().numpy(), g[t + nm])
+            assert err < TOL, (sim, point, nm, err)

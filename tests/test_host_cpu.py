@@ -144,3 +144,45 @@ def test_position_partition():
     assert synth.position_seed(5) == 1005
     a = synth.sphere_membrane(64, 48, 3e-6, 2)
     assert np.array_equal(a, synth.sphere_membrane(64, 48, 3e-6, 2)) and a.dtype == np.float32
+
+
+def test_polychromatic_frontend_host_logic():
+    """The package's own front-end (materials.table_walk, Sample.getDeltaBeta, Detector.getBeta/getSpectralEfficiency,
+    Source.setMySpectrum on injected raw data) reproduces the reference's output bit for bit."""
+    from paresis_amd import materials
+    from paresis_amd.Detector import Detector
+    from paresis_amd.Sample import AnalyticalSample
+    from paresis_amd.Source import Source
+    g = load("frontend.npz")
+    spec = [tuple(r) for r in g["spectrum"]]
+    names = [str(n) for n in g["tab/names"]]
+    for m, n in enumerate(names):
+        materials.register_table(n, g["tab/%d/E_eV" % m], g["tab/%d/delta" % m], g["tab/%d/beta" % m])
+    s = object.__new__(AnalyticalSample)
+    s.myMaterials, s.delta, s.beta = names, [], []
+    s.getDeltaBeta(spec)
+    assert np.array_equal(np.array(s.delta), g["sample/delta"]) and np.array_equal(np.array(s.beta), g["sample/beta"])
+    d = object.__new__(Detector)
+    d.det_param = {"myScintillatorMaterial": names[1], "myScintillatorThickness": 150.0}
+    d.getBeta(spec)
+    d.getSpectralEfficiency()
+    assert np.array_equal(np.array(d.beta), g["det/beta"])
+    assert relmax(np.array(d.mySpectralEfficiency), g["det/efficiency"]) < 1e-15
+    with pytest.raises(IndexError):                       # beyond the last table row: the reference's cell() raises too
+        materials.table_walk(names[0], [(500.0, 1.0)])
+    with pytest.raises(ValueError):
+        materials.register_table("bad", [2.0, 1.0], [0, 0], [0, 0])
+
+    src = Source()
+    src.source_dict.update({"myType": "Polychromatic", "myEnergySampling": 0.5,
+                            "spectrum": list(zip(g["spek/E"], g["spek/fluence"]))})
+    src.setMySpectrum()
+    assert np.array_equal(np.array(src.mySpectrum), g["spek/out"])
+    for c in range(int(g["xls/n"])):
+        src = Source()
+        src.spectrumFromXls = True
+        src.source_dict.update({"myType": "Polychromatic", "myEnergySampling": float(g["xls/%d/sampling" % c]),
+                                "energyUnit": "eV" if g["xls/%d/unit_is_eV" % c] else "keV",
+                                "xlsRows": list(zip(g["xls/%d/E" % c], g["xls/%d/fluence" % c]))})
+        src.setMySpectrum()
+        assert np.array_equal(np.array(src.mySpectrum), g["xls/%d/out" % c]), c

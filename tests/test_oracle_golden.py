@@ -177,3 +177,37 @@ def test_darkfield_chain():
         if point == 0:
             assert relmax(Dx, g[t + "Dx"]) < TOL
             assert relmax(cfg["_darkFieldPropag"], g[t + "DF"]) < TOL
+
+
+def test_polychromatic_frontend():
+    """delta/beta table walk (Sample.py:112-148, Detector.py:139-170), tube spectrum thresholding
+    (Source.py:108-123) and tabulated-spectrum re-binning (Source.py:132-233) against the reference's own output."""
+    g = load("frontend.npz")
+    spec = [tuple(r) for r in g["spectrum"]]
+    for m in range(2):
+        d, b = orc.table_walk(spec, g["tab/%d/E_eV" % m], g["tab/%d/delta" % m], g["tab/%d/beta" % m])
+        assert np.array_equal(np.array(d), g["sample/delta"][m]) and np.array_equal(np.array(b), g["sample/beta"][m])
+    _, b = orc.table_walk(spec, g["tab/1/E_eV"], g["tab/1/delta"], g["tab/1/beta"])
+    assert np.array_equal(np.array(b), g["det/beta"])
+    assert relmax(np.array(orc.spectral_efficiency(b, 150.0)), g["det/efficiency"]) < 1e-15
+    assert np.array_equal(np.array(orc.tube_spectrum(g["spek/E"], g["spek/fluence"])), g["spek/out"])
+    for c in range(int(g["xls/n"])):
+        out = orc.xls_spectrum(g["xls/%d/E" % c], g["xls/%d/fluence" % c], 0.001 if g["xls/%d/unit_is_eV" % c] else 1.0,
+                               float(g["xls/%d/sampling" % c]))
+        assert np.array_equal(np.array(out), g["xls/%d/out" % c]), c
+
+
+@pytest.mark.parametrize("sim", ["RT", "Fresnel"])
+def test_polychromatic_frontend_chain(sim):
+    """Re-binned tabulated spectrum + table-walk delta/beta + scintillator efficiency + air + plate + 2 bins through both
+    chains, against the reference's own run (tests/golden/frontend_chain.npz)."""
+    g = load("frontend_chain.npz")
+    spec = orc.xls_spectrum(g["xls/E"], g["xls/fluence"], 1.0, float(g["xls/sampling"]))
+    cfg = experiment_cfg(g, "chain/" + sim, orc.Obj)
+    assert np.array_equal(np.array(spec), np.array(cfg["spectrum"]))
+    for point in (0, 1):
+        cfg["membrane"] = orc.Obj(g["chain/%s/p%d/membrane" % (sim, point)], cfg["membrane"].delta, cfg["membrane"].beta)
+        out = orc.compute_rt(cfg, point) if sim == "RT" else orc.compute_fresnel(cfg, point)
+        t = "chain/%s/p%d/" % (sim, point)
+        for nm, a in zip(("Sample", "Reference", "Propag", "White"), out[:4]):
+            assert relmax(a, g[t + nm]) < TOL, (sim, point, nm)
