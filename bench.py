@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--engine", default="auto", choices=["auto", "rocfft", "lds"])
     ap.add_argument("--halo", type=int, default=8, choices=[4, 8], help="refraction gather halo (speed knob)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="issue the refractions after the Fresnel call on one stream (default: on a second stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -86,7 +88,19 @@ def main():
     refr = [torch.empty((N, N), dtype=torch.float32, device=dev) for _ in DISTANCES]
     amp = float(np.sqrt(I0))
 
-    def step():
+    # The two models of a step are independent, so the refractions go to a second HIP stream: their workgroups fill the
+    # CUs that the persistent Fresnel kernels leave idle at the end of each launch (+3.8 % at 4096^2).
+    side = None if a.no_overlap else torch.cuda.Stream()
+
+    def step(overlap=True):
+        if side is not None and overlap:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for i in range(len(DISTANCES)):
+                    ops.refract((N, N), rt_mats, dsc[i], (N, N), I0=I0, out=refr[i])
+            plan.propagate(aa, gp, du, amp=amp, mats=wave_mats, want_wave=[False] * len(DISTANCES), inten_out=fres)
+            torch.cuda.current_stream().wait_stream(side)
+            return
         plan.propagate(aa, gp, du, amp=amp, mats=wave_mats, want_wave=[False] * len(DISTANCES), inten_out=fres)
         for i in range(len(DISTANCES)):
             ops.refract((N, N), rt_mats, dsc[i], (N, N), I0=I0, out=refr[i])
@@ -123,7 +137,7 @@ def main():
         import ctypes
         lib.psx_profile_enable(1)
         for _ in range(a.steps):
-            step()
+            step(overlap=False)         # one stream: every kernel has the GPU to itself while its events are recorded
         barrier()
         buf = ctypes.create_string_buffer(1 << 16)
         _lib.check(lib.psx_profile_summary(buf, len(buf)), "psx_profile_summary")
@@ -158,6 +172,7 @@ def main():
                                   "membrane thickness maps (transmission evaluated inside the step); 52 keV, "
                                   "dSM/dMO/dOD=140/1.6/3.6 m" % (N, N),
                       "units_per_step": units, "fresnel_engine": {1: "rocfft", 2: "lds"}[plan.engine],
+                      "streams": 1 if side is None else 2,
                       "parallelism": "positions sharded, 1 per GPU" if world > 1 else "single GPU"}}
     if gather_ms is not None:
         out["gather_ms"] = round(gather_ms, 3)
@@ -176,7 +191,8 @@ def main():
         per = {nm: tot / cnt for nm, (cnt, tot) in kern.items()}
         step_share = {nm: tot / a.steps for nm, (cnt, tot) in kern.items()}
         out["kernel_ms_per_step"] = {nm: round(v, 4) for nm, v in sorted(step_share.items(), key=lambda kv: -kv[1])}
-        out["kernel_timing"] = "HIP event pairs recorded by the library around each launch, on a second pass of the same K steps"
+        out["kernel_timing"] = ("HIP event pairs recorded by the library around each launch, on a second pass of the same K "
+                            "steps issued on ONE stream")
         dom = None
         for nm, v in sorted(step_share.items(), key=lambda kv: -kv[1]):
             if nm in alg:
