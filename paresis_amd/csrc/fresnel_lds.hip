@@ -316,7 +316,11 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         const float2 *Hd = a.H;
 #pragma unroll
         for (int r = 0; r < NSLAB; ++r) {
-            const int sw = (tid & 63) + 64 * r;     // slab of this lane inside the wave's own 96 (round 2: 32 lanes)
+            // slab of this lane inside the wave's own 96 (round 2: 32 lanes).  Within each half-wave the first 16 lanes
+            // take the even slabs and the last 16 the odd ones: the 16 lanes of a ds_write_b64 group then carry 16
+            // different pad offsets (one pad slot per TWO slabs) and hit 16 different bank pairs instead of 8.
+            const int ln = tid & 63, lr = ln & 31;
+            const int sw = (ln & 32) + (lr < 16 ? 2 * lr : 2 * (lr - 16) + 1) + 64 * r;
             if (sw >= WSLABS) break;
             const int s = (tid >> 6) * WSLABS + sw, line = s / (M / SLAB), p0 = (s % (M / SLAB)) * SLAB;
             v2f *base = reinterpret_cast<v2f *>(lds) + line * MP + phys(p0);   // p0 % 16 == 0: no pad slot inside a slab
