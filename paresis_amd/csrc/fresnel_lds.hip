@@ -23,6 +23,7 @@
 // Each CU runs ONE persistent 16-wave workgroup: 12 engine waves own the butterflies (packed-fp32 arithmetic,
 // fft_pk.hpp), 4 loader waves fetch the next line group from HBM during the transform and spread it into LDS while the
 // engine finishes the last butterfly and its stores.
+#include <cstdint>
 #include <cstdlib>
 #include <vector>
 
@@ -455,21 +456,57 @@ __global__ __launch_bounds__(256) void k_source_out(const float2 *__restrict__ s
 // maps are read along y (their fast axis), the wave is written along x.
 template <int NM>
 __global__ __launch_bounds__(256) void k_source_transposed(const float2 *__restrict__ src, float amp, Mats m,
-                                                           float2 *__restrict__ out, int Nx, int Ny) {
+                                                           float2 *__restrict__ out, int Nx, int Ny, int vec_ok) {
     __shared__ float2 tile[64][65];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int ntx = (Ny + 63) / 64;                       // tiles along y
     const int y0 = (blockIdx.x % ntx) * 64, x0 = (blockIdx.x / ntx) * 64;
-    float2 v[16];
+    // read phase: a thread takes 4 consecutive y of one image row per pass (one 16-byte load per thickness map), a wave
+    // 4 rows x 64 y; 4 passes cover the 64 rows of the tile.  Full tiles of maps whose rows are 16-byte aligned only.
+    const bool vec = vec_ok && x0 + 64 <= Nx && y0 + 64 <= Ny;   // vec_ok: no input wave, Ny % 4 == 0, 16-byte aligned maps
+    if (vec) {
+        const int yq = (threadIdx.x & 15) * 4, xr = threadIdx.x >> 4;
+        float4 t[4][NM > 0 ? NM : 1];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int x = x0 + ty + 4 * r, y = y0 + tx;
-        const bool ok = x < Nx && y < Ny;
-        v[r] = source_wave<NM>(src, amp, m, ok ? (int64_t)x * Ny + y : (int64_t)0);   // clamped: loads stay unconditional
+        for (int r = 0; r < 4; ++r) {
+            const int64_t p = (int64_t)(x0 + xr + 16 * r) * Ny + y0 + yq;
+#pragma unroll
+            for (int i = 0; i < NM; ++i) t[r][i] = *reinterpret_cast<const float4 *>(m.T[i] + p);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float2 w = make_float2(amp, 0.f);
+                if (NM > 0) {
+                    double ph = 0.0, la = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NM; ++i) {
+                        const float tv = e == 0 ? t[r][i].x : (e == 1 ? t[r][i].y : (e == 2 ? t[r][i].z : t[r][i].w));
+                        ph = fma(m.cphase[i], (double)tv, ph);
+                        la = fma(m.catt[i], (double)tv, la);
+                    }
+                    float c, sn;
+                    cis_f64(ph, c, sn);
+                    const float av = amp * expf((float)la);
+                    w = make_float2(av * c, av * sn);
+                }
+                tile[xr + 16 * r][yq + e] = w;
+            }
+        }
+    } else {
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+        float2 v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int x = x0 + ty + 4 * r, y = y0 + tx;
+            const bool ok = x < Nx && y < Ny;
+            v[r] = source_wave<NM>(src, amp, m, ok ? (int64_t)x * Ny + y : (int64_t)0);   // clamped: loads stay unconditional
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[ty + 4 * r][tx] = v[r];
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tile[ty + 4 * r][tx] = v[r];
     __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int y = y0 + ty + 4 * r, x = x0 + tx;
@@ -753,8 +790,10 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
     }
     {
         const int ntiles = (int)(cdiv(p->Nx, 64) * cdiv(p->Ny, 64));
+        int vec_ok = a.wave_in == nullptr && p->Ny % 4 == 0;
+        for (int i = 0; i < a.m.n && i < PSX_MAX_MAT; ++i) vec_ok = vec_ok && ((uintptr_t)a.m.T[i] % 16 == 0);
         PSX_DISPATCH_NMAT(a.m.n, PSX_TIMED("k_source_transposed", st, k_source_transposed<NM><<<ntiles, 256, 0, st>>>(
-                                                                           a.wave_in, a.amp, a.m, e->pre, p->Nx, p->Ny)));
+                                                                           a.wave_in, a.amp, a.m, e->pre, p->Nx, p->Ny, vec_ok)));
         if (int rc = launch_check("k_source_transposed")) return rc;
     }
 
