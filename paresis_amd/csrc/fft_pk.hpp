@@ -8,8 +8,8 @@
 // the VOP3P modifiers op_sel / op_sel_hi / neg_lo / neg_hi:
 //     a + (-/+ i) b        one v_pk_add_f32      (swap b's halves, negate one of them)
 //     a * b (complex)      v_pk_mul_f32 + v_pk_fma_f32
-// Compile-time twiddles sit in SGPR pairs (one constant-bus operand per instruction).  Natural order in and out, like
-// fft_regs.hpp; INV selects the conjugate transform (unnormalised).
+// Compile-time twiddles sit in SGPR pairs (one constant-bus operand per instruction).  Natural order in and out; INV
+// selects the conjugate transform (unnormalised).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -28,7 +28,6 @@
 #include <vector>
 
 #include "fft_pk.hpp"
-#include "fft_regs.hpp"
 #include "fresnel_plan.hpp"
 
 using namespace psx;
@@ -409,7 +408,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             const v2f gp = (v2f){a.gph.x, a.gph.y};
             if (l0 + lineA < a.nlines) {
                 // S1 is a multiple of IB: in the blocked layout too the 24 outputs of a thread are one pointer + q * stride
-                static_assert(S1 % IB == 0, "blocked output stride");
+                static_assert(S1 % IB == 0 && IB == 8, "blocked output stride; the block index below is i >> 3");
                 const int64_t ob = a.out_blocked ? ((int64_t)(ifirst >> 3) * a.nlines + (l0 + lineA)) * IB + (ifirst & (IB - 1))
                                                  : (int64_t)(l0 + lineA) * a.out_ld + ifirst;
                 const int64_t oq = a.out_blocked ? (int64_t)(S1 / IB) * a.nlines * IB : (int64_t)S1;
