@@ -119,6 +119,16 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     const int cstart = xcd * cq + (xcd < cr ? xcd : cr), clen = cq + (xcd < cr ? 1 : 0);
     const int nj = slot < clen ? (clen - slot + nslot - 1) / nslot : 0;   // groups cstart + slot + j*nslot, j < nj
 
+    // Stage B's twiddles w_S1^{n q} (n < R3, q < 24: 3 KiB) live in LDS behind the line buffers, rows padded to 25 so that
+    // the 16 rows start on 16 different bank pairs: a ds_read_b64 costs 2 LDS cycles where the 16-byte global loads of
+    // the same table (L1 hits) took the CU's 64 B/clk vector-memory return path that the loaders and the other tables need.
+    constexpr int TWB_LD = RAD + 1;
+    v2f *twl = reinterpret_cast<v2f *>(lds) + LINES * MP;
+    for (int idx = tid; idx < R3 * RAD; idx += T) {
+        const float2 w = a.twB[idx];
+        twl[(idx / RAD) * TWB_LD + idx % RAD] = (v2f){w.x, w.y};
+    }
+
     // LDS index of butterfly element j: with S1 a multiple of 32 (and R3 | 32) the pad term of phys() is affine in j, so
     // every element is one base register + a compile-time offset (ds_read/ds_write immediate offsets)
     constexpr bool AFF = (S1 % 32 == 0);
@@ -270,7 +280,6 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         PSX_STAMP(2);
 
         // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}
-        float4 xfb[6];
         {
             v2f v[RAD];
 #pragma unroll
@@ -280,7 +289,6 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             tw_load(a.twA, nA, xb, I6{});
             tw_apply(xfa, v, I0{}, std::false_type{});
-            tw_load(a.twB, nB, xfb, I0{});               // forward B's first half: in flight across barrier (1)
             tw_apply(xb, v, I6{}, std::false_type{});
 #pragma unroll
             for (int q = 0; q < RAD; ++q) baseA[idxA(nA, q)] = v[q];
@@ -293,12 +301,13 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             v2f v[RAD];
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = lds_read(baseA + idxB(p0B, q));
-            float4 xb[6];
             DftPk<RAD, false>::run(v);
             __builtin_amdgcn_sched_barrier(0);
-            tw_load(a.twB, nB, xb, I6{});
-            tw_apply(xfb, v, I0{}, std::false_type{});
-            tw_apply(xb, v, I6{}, std::false_type{});
+            v2f w[RAD];
+#pragma unroll
+            for (int q = 1; q < RAD; ++q) w[q] = lds_read(twl + nB * TWB_LD + q);
+#pragma unroll
+            for (int q = 1; q < RAD; ++q) v[q] = pk_cmul(v[q], w[q]);
 #pragma unroll
             for (int q = 0; q < RAD; ++q) baseA[idxB(p0B, q)] = v[q];
         }
@@ -365,16 +374,17 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         // loads become flat_load, which also count against the LDS counter.)
         size_t opaque0 = 0;
         asm volatile("" : "+s"(opaque0));
-        const float2 *twA_i = a.twA + opaque0, *twB_i = a.twB + opaque0;
+        const float2 *twA_i = a.twA + opaque0;
         // ---- 6. inverse stage B: conjugate twiddle on the inputs, then the inverse radix-24 butterfly
         float4 xia[12];
         {
-            v2f v[RAD];
-            float4 x[12];
-            tw_load(twB_i, nB, x, I0{});
+            v2f v[RAD], w[RAD];
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = lds_read(baseA + idxB(p0B, q));
-            tw_apply(x, v, I0{}, std::true_type{});
+#pragma unroll
+            for (int q = 1; q < RAD; ++q) w[q] = lds_read(twl + nB * TWB_LD + q);
+#pragma unroll
+            for (int q = 1; q < RAD; ++q) v[q] = pk_cmulc(v[q], w[q]);
             __builtin_amdgcn_sched_barrier(0);
             DftPk<RAD, true>::run(v);
             __builtin_amdgcn_sched_barrier(0);
@@ -730,7 +740,7 @@ static int kernel_spectrum(psx_fresnel_plan *p, const AxisTables &t, double a, d
 template <int R3, bool CONTIG>
 static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
     constexpr int M = 576 * R3, LINES = TOT / M;
-    constexpr size_t lds_bytes = sizeof(float2) * (size_t)LINES * (M + M / 32);
+    constexpr size_t lds_bytes = sizeof(float2) * ((size_t)LINES * (M + M / 32) + R3 * (RAD + 1));   // lines + stage-B twiddles
     static bool attr_set = false;
     if (!attr_set) {
         PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize,
