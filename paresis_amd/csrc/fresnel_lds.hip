@@ -122,11 +122,22 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     // Stage B's twiddles w_S1^{n q} (n < R3, q < 24: 3 KiB) live in LDS behind the line buffers, rows padded to 25 so that
     // the 16 rows start on 16 different bank pairs: a ds_read_b64 costs 2 LDS cycles where the 16-byte global loads of
     // the same table (L1 hits) took the CU's 64 B/clk vector-memory return path that the loaders and the other tables need.
+    // Stage A's twiddles w_M^{n q}, n < S1 = 24 R3, would be 72 KiB; with n = R3 n1 + n0 they factor into
+    // w_576^{n1 q} * w_M^{n0 q}: a [24][24] and an [R3][24] table (rows R3*n1 and n0 of the global table), 7.8 KiB, at the
+    // price of one more complex multiply per point and stage (+46 packed instructions per butterfly).  With all three
+    // tables in LDS the engine's only global loads are the kernel spectrum's.
     constexpr int TWB_LD = RAD + 1;
-    v2f *twl = reinterpret_cast<v2f *>(lds) + LINES * MP;
+    v2f *twl = reinterpret_cast<v2f *>(lds) + LINES * MP;          // [R3][25]  stage B
+    v2f *tw1 = twl + R3 * TWB_LD;                                  // [24][25]  stage A, n1 part
+    v2f *tw0 = tw1 + RAD * TWB_LD;                                 // [R3][25]  stage A, n0 part
     for (int idx = tid; idx < R3 * RAD; idx += T) {
-        const float2 w = a.twB[idx];
+        const float2 w = a.twB[idx], w0 = a.twA[idx];
         twl[(idx / RAD) * TWB_LD + idx % RAD] = (v2f){w.x, w.y};
+        tw0[(idx / RAD) * TWB_LD + idx % RAD] = (v2f){w0.x, w0.y};
+    }
+    for (int idx = tid; idx < RAD * RAD; idx += T) {
+        const float2 w = a.twA[(size_t)(idx / RAD) * R3 * RAD + idx % RAD];     // row n = R3 * n1
+        tw1[(idx / RAD) * TWB_LD + idx % RAD] = (v2f){w.x, w.y};
     }
 
     // LDS index of butterfly element j: with S1 a multiple of 32 (and R3 | 32) the pad term of phys() is affine in j, so
@@ -241,37 +252,30 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     }
 
     // =================================== engine waves =========================================================================
-    // The 24 twiddles of butterfly n are 12 x 16-byte loads from one base (layout [n][24]).  The engine has 128 VGPRs: an
-    // inverse stage (twiddle BEFORE the butterfly) issues all 12 together with its LDS reads, one latency; a forward
-    // stage (twiddle AFTER the butterfly) issues the first half before the butterfly, the second half after it.
-    auto tw_load = [&](const float2 *tw, int n, auto &x, auto first_tag) __attribute__((always_inline)) {
-        constexpr int Q0 = decltype(first_tag)::value;
-        const float4 *t4 = reinterpret_cast<const float4 *>(tw + (size_t)n * RAD);
-#pragma unroll
-        for (int q = 0; q < (int)(sizeof(x) / sizeof(float4)); ++q) x[q] = t4[Q0 + q];
-    };
-    auto tw_apply = [&](const auto &x, v2f(&v)[RAD], auto first_tag, auto conj_tag) __attribute__((always_inline)) {
-        constexpr int Q0 = decltype(first_tag)::value;
-        constexpr bool CONJ = decltype(conj_tag)::value;
-#pragma unroll
-        for (int q = 0; q < (int)(sizeof(x) / sizeof(float4)); ++q) {
-            const int k = 2 * (Q0 + q);
-            const v2f w0 = (v2f){x[q].x, x[q].y}, w1 = (v2f){x[q].z, x[q].w};
-            if (k > 0) v[k] = CONJ ? pk_cmulc(v[k], w0) : pk_cmul(v[k], w0);
-            v[k + 1] = CONJ ? pk_cmulc(v[k + 1], w1) : pk_cmul(v[k + 1], w1);
-        }
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I6 = std::integral_constant<int, 6>;
-
     // stage A and B thread mapping (one butterfly per thread per stage)
     const int lineA = tid / S1, nA = tid % S1;
     const int remB = tid % S1, q1B = remB / R3, nB = remB % R3, p0B = q1B * S1 + nB;
     v2f *baseA = reinterpret_cast<v2f *>(lds) + lineA * MP;
-    // Table loads are issued one barrier EARLY wherever registers are idle (while a stage's results drain to LDS): they
-    // are in flight during the barrier wait instead of after it.  xfa: first half of forward A's twiddles.
-    float4 xfa[6];
-    tw_load(a.twA, nA, xfa, I0{});
+    const v2f *rowA1 = tw1 + (nA / R3) * TWB_LD, *rowA0 = tw0 + (nA % R3) * TWB_LD, *rowB = twl + nB * TWB_LD;
+    // v[q] *= (or conj-*=) row1[q] * row0[q] for q in [Q0, Q1): half of the 23 twiddles at a time (128-VGPR budget)
+    auto twiddle_A = [&](v2f(&v)[RAD], auto q0_tag, auto q1_tag, auto conj_tag) __attribute__((always_inline)) {
+        constexpr int Q0 = decltype(q0_tag)::value, Q1 = decltype(q1_tag)::value;
+        constexpr bool CONJ = decltype(conj_tag)::value;
+        v2f w1[Q1 - Q0], w0[Q1 - Q0];
+#pragma unroll
+        for (int q = Q0; q < Q1; ++q) {
+            w1[q - Q0] = lds_read(rowA1 + q);
+            w0[q - Q0] = lds_read(rowA0 + q);
+        }
+#pragma unroll
+        for (int q = Q0; q < Q1; ++q) {
+            const v2f w = pk_cmul(w1[q - Q0], w0[q - Q0]);
+            v[q] = CONJ ? pk_cmulc(v[q], w) : pk_cmul(v[q], w);
+        }
+    };
+    using Q1 = std::integral_constant<int, 1>;
+    using Q12 = std::integral_constant<int, 12>;
+    using Q24 = std::integral_constant<int, 24>;
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 0] = wall_clock64();
     lds_barrier();                                       // (0) first group is in LDS
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 1] = wall_clock64();
@@ -284,12 +288,10 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             v2f v[RAD];
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = baseA[idxA(nA, q)];
-            float4 xb[6];
             DftPk<RAD, false>::run(v);
             __builtin_amdgcn_sched_barrier(0);
-            tw_load(a.twA, nA, xb, I6{});
-            tw_apply(xfa, v, I0{}, std::false_type{});
-            tw_apply(xb, v, I6{}, std::false_type{});
+            twiddle_A(v, Q1{}, Q12{}, std::false_type{});
+            twiddle_A(v, Q12{}, Q24{}, std::false_type{});
 #pragma unroll
             for (int q = 0; q < RAD; ++q) baseA[idxA(nA, q)] = v[q];
         }
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             v2f w[RAD];
 #pragma unroll
-            for (int q = 1; q < RAD; ++q) w[q] = lds_read(twl + nB * TWB_LD + q);
+            for (int q = 1; q < RAD; ++q) w[q] = lds_read(rowB + q);
 #pragma unroll
             for (int q = 1; q < RAD; ++q) v[q] = pk_cmul(v[q], w[q]);
 #pragma unroll
@@ -368,27 +370,17 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         wave_sync();
         PSX_STAMP(8);
 
-        // The inverse stages use the same twiddles as the forward ones; launder the pointers so that the compiler
-        // reloads them (L2-resident) instead of keeping them alive across the whole kernel.
-        // (An opaque zero OFFSET, not an opaque pointer: a pointer that went through the asm is a generic one, and its
-        // loads become flat_load, which also count against the LDS counter.)
-        size_t opaque0 = 0;
-        asm volatile("" : "+s"(opaque0));
-        const float2 *twA_i = a.twA + opaque0;
         // ---- 6. inverse stage B: conjugate twiddle on the inputs, then the inverse radix-24 butterfly
-        float4 xia[12];
         {
             v2f v[RAD], w[RAD];
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = lds_read(baseA + idxB(p0B, q));
 #pragma unroll
-            for (int q = 1; q < RAD; ++q) w[q] = lds_read(twl + nB * TWB_LD + q);
+            for (int q = 1; q < RAD; ++q) w[q] = lds_read(rowB + q);
 #pragma unroll
             for (int q = 1; q < RAD; ++q) v[q] = pk_cmulc(v[q], w[q]);
             __builtin_amdgcn_sched_barrier(0);
             DftPk<RAD, true>::run(v);
-            __builtin_amdgcn_sched_barrier(0);
-            tw_load(twA_i, nA, xia, I0{});               // inverse A's twiddles: in flight across barriers (2) and (3)
 #pragma unroll
             for (int q = 0; q < RAD; ++q) baseA[idxB(p0B, q)] = v[q];
         }
@@ -404,7 +396,8 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             for (int q = 0; q < RAD; ++q) v[q] = baseA[idxA(nA, q)];
             lds_barrier();                           // (3)
             PSX_STAMP(11);
-            tw_apply(xia, v, I0{}, std::true_type{});
+            twiddle_A(v, Q1{}, Q12{}, std::true_type{});
+            twiddle_A(v, Q12{}, Q24{}, std::true_type{});
             __builtin_amdgcn_sched_barrier(0);
             DftPk<RAD, true>::run(v);
             // output sample i = nA + q*S1 - jout (jout = LDS position of output sample 0).  The first index is made opaque
@@ -437,7 +430,6 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 }
             }
         }
-        tw_load(a.twA, nA, xfa, I0{});               // next group's forward A, first half: in flight across barrier (4)
         PSX_STAMP(12);
         lds_barrier();                               // (4)
         PSX_STAMP(13);
@@ -740,7 +732,7 @@ static int kernel_spectrum(psx_fresnel_plan *p, const AxisTables &t, double a, d
 template <int R3, bool CONTIG>
 static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
     constexpr int M = 576 * R3, LINES = TOT / M;
-    constexpr size_t lds_bytes = sizeof(float2) * ((size_t)LINES * (M + M / 32) + R3 * (RAD + 1));   // lines + stage-B twiddles
+    constexpr size_t lds_bytes = sizeof(float2) * ((size_t)LINES * (M + M / 32) + (2 * R3 + RAD) * (RAD + 1));   // lines + the three twiddle tables
     static bool attr_set = false;
     if (!attr_set) {
         PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize,
