@@ -203,6 +203,11 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, N),
                                "ms_per_launch": round(per[dom], 4), "algorithmic_bytes_per_launch": alg[dom]}
+            # the same figure for every kernel that has an algorithmic price (the step has three of similar weight)
+            out["roofline"]["by_kernel"] = {
+                nm: {"ms_per_launch": round(per[nm], 4), "achieved": round(alg[nm] / (per[nm] * 1e-3) / 1e9, 1),
+                     "frac": round(alg[nm] / (per[nm] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(nm, N)}
+                for nm in sorted(per) if nm in alg}
             # whole-step view with the same accounting: 4 x (64 + 12 + 4*nmat) bytes per padded pixel
             step_bytes = units * (64 + 12 + 4 * nmat) * P * P
             out["roofline"]["step_achieved"] = round(step_bytes / (dt / a.steps) / 1e9, 1)
