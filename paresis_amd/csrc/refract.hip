@@ -248,7 +248,9 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
             // float -> fixed point with one native conversion: the unit is 2^-30 of (the power of two above) the
             // largest staged intensity, so |v|*2^s <= 2^30 fits int32; the 64-bit sum has 2^33 of headroom
             auto dep = [&](bool ok, int t, float v) __attribute__((always_inline)) {
-                const long long q = (long long)(int)rintf(ok ? v : 0.f);
+                int qi;                                  // floor(v + 0.5) in ONE instruction (rintf + cvt are two)
+                asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(qi) : "v"(ok ? v : 0.f));
+                const long long q = (long long)qi;
                 atomicAdd((unsigned long long *)&sacc[ok ? t : trash], (unsigned long long)q);
             };
             dep(i0 && j0, ti * TW + tj, Is_ * ((1.f - wx) * (1.f - wy)));
