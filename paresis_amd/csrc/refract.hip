@@ -34,7 +34,11 @@ struct Geo {
     static constexpr int TH = TH_, TW = TW_, H = H_, NT = NT_;
     static constexpr int SR = TH + 2 * H + 2, SC = TW + 2 * H + 2;   // staged phase (one more ring for the stencil)
     static constexpr int GR = TH + 2 * H, GC = TW + 2 * H;           // source pixels gathered by one tile
-    static constexpr size_t LDS = sizeof(double) * SR * SC + sizeof(float) * GR * GC + sizeof(long long) * (TH * TW + 64) + 16;
+    // accumulator: the tile plus a one-pixel guard ring (a ray whose base pixel lies in [-1, TH-1] x [-1, TW-1] deposits
+    // its four shares at base + {0, 1, AW, AW+1} with no per-share test; the ring is never written out), then a trash
+    // area for rays that miss altogether
+    static constexpr int AW = TW + 2, ACC = (TH + 2) * AW, TRASH = 2 * 64 + AW + 2;
+    static constexpr size_t LDS = sizeof(double) * SR * SC + sizeof(float) * GR * GC + sizeof(long long) * (ACC + TRASH) + 16;
 };
 using GeoSmall = Geo<56, 56, 4, 512>;    // 76 KiB of LDS: two workgroups per CU; 1.31 source evaluations per pixel
 using GeoWide = Geo<48, 48, 8, 512>;     // 70 KiB: two workgroups per CU (one stages while the other deposits); 1.78 evaluations
@@ -104,8 +108,9 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
     constexpr int TH = G::TH, TW = G::TW, H = G::H, SR = G::SR, SC = G::SC, GR = G::GR, GC = G::GC, NTHREADS = G::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *sphi = (double *)smem;                                        // [SR][SC]
-    long long *sacc = (long long *)(smem + sizeof(double) * SR * SC);     // [TH][TW] fixed point
-    float *sI = (float *)(sacc + TH * TW + 64);                           // [GR][GC] (after 64 per-lane trash slots)
+    constexpr int AW = G::AW, ACC = G::ACC;
+    long long *sacc = (long long *)(smem + sizeof(double) * SR * SC);     // [TH+2][AW] fixed point + trash
+    float *sI = (float *)(sacc + ACC + G::TRASH);                         // [GR][GC]
     unsigned *sfar = (unsigned *)(sI + GR * GC);                          // far rays of this tile so far
     unsigned *smax = sfar + 1;                                            // largest |source intensity| (float bits)
 
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
         }
     }
     PSX_RSTAMP(1);
-    for (int idx = tid; idx < TH * TW; idx += NTHREADS) sacc[idx] = 0ll;
+    for (int idx = tid; idx < ACC; idx += NTHREADS) sacc[idx] = 0ll;
     for (int o = 32; o > 0; o >>= 1) imax = max(imax, (unsigned)__shfl_xor((int)imax, o));
     if ((tid & 63) == 0) atomicMax(smax, imax);
     __syncthreads();
@@ -240,23 +245,22 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
         }
         {
             const float wx = dx - fx, wy = dy - fy;                  // exact in float32
-            const int ti = gr - H + (int)fx, tj = gc - H + (int)fy;  // base target, tile-relative
+            // base target in ring coordinates (+1): the four shares land inside the accumulator iff 0 <= ti <= TH, 0 <= tj <= TW
+            const int ti = gr - H + (int)fx + 1, tj = gc - H + (int)fy + 1;
             const float Is_ = near ? I * fscale_f : 0.f;             // 2^s scaling is exact
-            const bool i0 = near && ti >= 0 && ti < TH, i1 = near && ti + 1 >= 0 && ti + 1 < TH;
-            const bool j0 = tj >= 0 && tj < TW, j1 = tj + 1 >= 0 && tj + 1 < TW;
-            const int trash = TH * TW + lane;
+            const bool hit = near && (unsigned)ti <= (unsigned)TH && (unsigned)tj <= (unsigned)TW;
+            long long *acc = sacc + (hit ? ti * AW + tj : ACC + 2 * lane);   // a miss adds its shares to the trash area
             // float -> fixed point with one native conversion: the unit is 2^-30 of (the power of two above) the
             // largest staged intensity, so |v|*2^s <= 2^30 fits int32; the 64-bit sum has 2^33 of headroom
-            auto dep = [&](bool ok, int t, float v) __attribute__((always_inline)) {
+            auto dep = [&](int off, float v) __attribute__((always_inline)) {
                 int qi;                                  // floor(v + 0.5) in ONE instruction (rintf + cvt are two)
-                asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(qi) : "v"(ok ? v : 0.f));
-                const long long q = (long long)qi;
-                atomicAdd((unsigned long long *)&sacc[ok ? t : trash], (unsigned long long)q);
+                asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(qi) : "v"(v));
+                atomicAdd((unsigned long long *)(acc + off), (unsigned long long)(long long)qi);
             };
-            dep(i0 && j0, ti * TW + tj, Is_ * ((1.f - wx) * (1.f - wy)));
-            dep(i1 && j0, (ti + 1) * TW + tj, Is_ * (wx * (1.f - wy)));
-            dep(i0 && j1, ti * TW + tj + 1, Is_ * ((1.f - wx) * wy));
-            dep(i1 && j1, (ti + 1) * TW + tj + 1, Is_ * (wx * wy));
+            dep(0, Is_ * ((1.f - wx) * (1.f - wy)));
+            dep(AW, Is_ * (wx * (1.f - wy)));
+            dep(1, Is_ * ((1.f - wx) * wy));
+            dep(AW + 1, Is_ * (wx * wy));
         }
         // wave-aggregated append of far rays to this tile's own list: one LDS atomic per wave, no global atomics
         // (a single global counter saturates at ~90 returning atomics per microsecond on this chip)
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
         const int i = r0 + tr, j = c0 + tc;
         if (i < a.Nx && j < a.Ny) {
             const int64_t p = (int64_t)i * a.Ny + j;
-            float v = finite_in ? a.out_scale * (float)((double)sacc[idx] * finv) : __uint_as_float(0x7fc00000u);
+            float v = finite_in ? a.out_scale * (float)((double)sacc[(tr + 1) * AW + tc + 1] * finv) : __uint_as_float(0x7fc00000u);
             if (a.accumulate) v += a.I_out[p];
             any_bad |= !(fabsf(v) <= 3.0e38f);
             a.I_out[p] = v;
