@@ -130,36 +130,42 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
         *smax = 0u;
     }
     __syncthreads();
+    // Tiles whose staged window (tile + halo + stencil ring) lies inside the image -- all but the outermost ring of
+    // tiles -- take loops compiled without the clamps, the out-of-image tests and np.gradient's edge formulas: the
+    // kernel is bound by instruction issue (vector AND scalar), and those tests are a quarter of its instructions.
+    const bool window_inside = r0 - H - 1 >= 0 && r0 + TH + H + 1 <= a.Nx && c0 - H - 1 >= 0 && c0 + TW + H + 1 <= a.Ny;
     constexpr int U = 4;   // staged pixels per thread whose loads are issued together
-    for (int it0 = 0; it0 < SITERS; it0 += U) {
-        float t[U][NM > 0 ? NM : 1], Iin[U];
-        double phin[U];
-        bool ok[U];
+    auto stage = [&](auto inside_tag) __attribute__((always_inline)) {
+        constexpr bool IN = decltype(inside_tag)::value;
+        for (int it0 = 0; it0 < SITERS; it0 += U) {
+            float t[U][NM > 0 ? NM : 1], Iin[U];
+            double phin[U];
+            bool ok[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = (it0 + u) * NTHREADS + tid;
-            const int sr = idx / SC, sc = idx - sr * SC;
-            const int i = r0 - H - 1 + sr, j = c0 - H - 1 + sc;
-            ok[u] = idx < SR * SC && i >= 0 && i < a.Nx && j >= 0 && j < a.Ny;
-            const int64_t p = (int64_t)min(max(i, 0), a.Nx - 1) * a.Ny + min(max(j, 0), a.Ny - 1);
+            for (int u = 0; u < U; ++u) {
+                const int idx = min((it0 + u) * NTHREADS + tid, SR * SC - 1);   // the last pass re-stages the last pixel
+                const int sr = idx / SC, sc = idx - sr * SC;
+                const int i = r0 - H - 1 + sr, j = c0 - H - 1 + sc;
+                ok[u] = IN || (i >= 0 && i < a.Nx && j >= 0 && j < a.Ny);
+                const int64_t p = IN ? (int64_t)i * a.Ny + j
+                                     : (int64_t)min(max(i, 0), a.Nx - 1) * a.Ny + min(max(j, 0), a.Ny - 1);
 #pragma unroll
-            for (int m = 0; m < NM; ++m) t[u][m] = a.m.T[m][p];
-            Iin[u] = HAS_I ? a.I_in[p] : 1.f;
-            phin[u] = HAS_PHI ? a.phi_in[p] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = (it0 + u) * NTHREADS + tid;
-            const int sr = idx / SC, sc = idx - sr * SC;
-            double ph = phin[u], la = 0.0;
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                ph = fma(a.m.cphase[m], (double)t[u][m], ph);
-                la = fma(a.m.catt[m], (double)t[u][m], la);
+                for (int m = 0; m < NM; ++m) t[u][m] = a.m.T[m][p];
+                Iin[u] = HAS_I ? a.I_in[p] : 1.f;
+                phin[u] = HAS_PHI ? a.phi_in[p] : 0.0;
             }
-            float I = a.I0 * Iin[u];
-            if (NM > 0) I *= expf((float)la);
-            if (idx < SR * SC) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = min((it0 + u) * NTHREADS + tid, SR * SC - 1);
+                const int sr = idx / SC, sc = idx - sr * SC;
+                double ph = phin[u], la = 0.0;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    ph = fma(a.m.cphase[m], (double)t[u][m], ph);
+                    la = fma(a.m.catt[m], (double)t[u][m], la);
+                }
+                float I = a.I0 * Iin[u];
+                if (NM > 0) I *= expf((float)la);
                 sphi[idx] = ok[u] ? ph : 0.0;
                 if (sr >= 1 && sr <= GR && sc >= 1 && sc <= GC) {
                     sI[(sr - 1) * GC + (sc - 1)] = ok[u] ? I : 0.f;
@@ -167,7 +173,11 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
                 }
             }
         }
-    }
+    };
+    if (window_inside)
+        stage(std::true_type{});
+    else
+        stage(std::false_type{});
     PSX_RSTAMP(1);
     for (int idx = tid; idx < ACC; idx += NTHREADS) sacc[idx] = 0ll;
     for (int o = 32; o > 0; o >>= 1) imax = max(imax, (unsigned)__shfl_xor((int)imax, o));
@@ -189,17 +199,19 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
     bool any_bad = false;
     constexpr int ITERS = (GR * GC + NTHREADS - 1) / NTHREADS;   // uniform trip count: the loop holds wave ballots
     const int lane = tid & 63;
+    auto gather = [&](auto inside_tag) __attribute__((always_inline)) {
+    constexpr bool IN = decltype(inside_tag)::value && (GR * GC) % NTHREADS == 0;   // every slot is a pixel inside the image
     for (int it = 0; it < ITERS; ++it) {
-        const int idx = min(it * NTHREADS + tid, GR * GC - 1);
-        const bool live = it * NTHREADS + tid < GR * GC;
+        const int idx = IN ? it * NTHREADS + tid : min(it * NTHREADS + tid, GR * GC - 1);
+        const bool live = IN || it * NTHREADS + tid < GR * GC;
         const int gr = idx / GC, gc = idx - gr * GC;
         const int i = r0 - H + gr, j = c0 - H + gc;
-        const bool inside = live && i >= 0 && i < a.Nx && j >= 0 && j < a.Ny;
+        const bool inside = IN || (live && i >= 0 && i < a.Nx && j >= 0 && j < a.Ny);
         const bool core = gr >= H && gr < H + TH && gc >= H && gc < H + TW;
         float I = live ? sI[idx] : 0.f;                              // 0 outside the image
         const int sidx = (gr + 1) * SC + (gc + 1);                   // this pixel in the staged phase tile
         double gx, gy;
-        if (i > 0 && i < a.Nx - 1 && j > 0 && j < a.Ny - 1) {        // interior: central differences (RF2:54)
+        if (IN || (i > 0 && i < a.Nx - 1 && j > 0 && j < a.Ny - 1)) {   // interior: central differences (RF2:54)
             gx = 0.5 * (sphi[sidx + SC] - sphi[sidx - SC]);
             gy = 0.5 * (sphi[sidx + 1] - sphi[sidx - 1]);
         } else if (inside) {                                         // image border: np.gradient(edge_order=2)
@@ -278,6 +290,11 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
             }
         }
     }
+    };
+    if (window_inside)
+        gather(std::true_type{});
+    else
+        gather(std::false_type{});
     PSX_RSTAMP(3);
     __syncthreads();
     PSX_RSTAMP(4);
