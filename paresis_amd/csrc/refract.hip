@@ -197,6 +197,7 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
     // the image carry I = 0, deposits that miss the tile (or rays that are not "near") add 0 to a per-lane trash slot,
     // so the four LDS atomics are unconditional.
     bool any_bad = false;
+    const double hscale = 0.5 * a.dscale;
     constexpr int ITERS = (GR * GC + NTHREADS - 1) / NTHREADS;   // uniform trip count: the loop holds wave ballots
     const int lane = tid & 63;
     auto gather = [&](auto inside_tag) __attribute__((always_inline)) {
@@ -211,9 +212,10 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
         float I = live ? sI[idx] : 0.f;                              // 0 outside the image
         const int sidx = (gr + 1) * SC + (gc + 1);                   // this pixel in the staged phase tile
         double gx, gy;
+        // gx, gy hold gradient * dscale.  (d * 0.5) * dscale == d * (0.5 * dscale) bit for bit: halving is exact.
         if (IN || (i > 0 && i < a.Nx - 1 && j > 0 && j < a.Ny - 1)) {   // interior: central differences (RF2:54)
-            gx = 0.5 * (sphi[sidx + SC] - sphi[sidx - SC]);
-            gy = 0.5 * (sphi[sidx + 1] - sphi[sidx - 1]);
+            gx = (sphi[sidx + SC] - sphi[sidx - SC]) * hscale;
+            gy = (sphi[sidx + 1] - sphi[sidx - 1]) * hscale;
         } else if (inside) {                                         // image border: np.gradient(edge_order=2)
             if (i == 0)
                 gx = -1.5 * sphi[sidx] + 2.0 * sphi[sidx + SC] - 0.5 * sphi[sidx + 2 * SC];
@@ -227,12 +229,14 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
                 gy = 0.5 * sphi[sidx - 2] - 2.0 * sphi[sidx - 1] + 1.5 * sphi[sidx];
             else
                 gy = 0.5 * (sphi[sidx + 1] - sphi[sidx - 1]);
+            gx *= a.dscale;
+            gy *= a.dscale;
         } else {
             gx = 0.0;
             gy = 0.0;
         }
         // the displacement is a small number: everything after the float64 differencing runs in float32
-        float dx = (float)(gx * a.dscale), dy = (float)(gy * a.dscale);
+        float dx = (float)gx, dy = (float)gy;
         dx = fabsf(dx) < 1e-12f ? 0.f : dx;                          // RF2:59-60
         dy = fabsf(dy) < 1e-12f ? 0.f : dy;
         const bool clx = fabsf(dx) > a.clamp_xf, cly = fabsf(dy) > a.clamp_yf;   // RF2:61-64
@@ -241,7 +245,8 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
         dx = clx ? 0.f : dx;
         dy = cly ? 0.f : dy;
         const float fx = floorf(dx), fy = floorf(dy);
-        const bool near = fx >= -H && fx <= H - 1 && fy >= -H && fy <= H - 1;
+        const int ifx = (int)fx, ify = (int)fy;                      // |d| <= clamp: far inside int range (saturates beyond)
+        const bool near = (unsigned)(ifx + H) < 2u * H && (unsigned)(ify + H) < 2u * H;
         const bool far = core && inside && !near && I != 0.f;
         const float Dxs = dx, Dys = dy, Is = I;
         if (a.Dx_out || a.I_mut) {                                   // wave-uniform: only the class API asks for these
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
         {
             const float wx = dx - fx, wy = dy - fy;                  // exact in float32
             // base target in ring coordinates (+1): the four shares land inside the accumulator iff 0 <= ti <= TH, 0 <= tj <= TW
-            const int ti = gr - H + (int)fx + 1, tj = gc - H + (int)fy + 1;
+            const int ti = gr - H + ifx + 1, tj = gc - H + ify + 1;
             const float Is_ = near ? I * fscale_f : 0.f;             // 2^s scaling is exact
             const bool hit = near && (unsigned)ti <= (unsigned)TH && (unsigned)tj <= (unsigned)TW;
             long long *acc = sacc + (hit ? ti * AW + tj : ACC + 2 * lane);   // a miss adds its shares to the trash area
@@ -273,6 +278,8 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
             dep(AW, Is_ * (wx * (1.f - wy)));
             dep(1, Is_ * ((1.f - wx) * wy));
             dep(AW + 1, Is_ * (wx * wy));
+            // (kept as the reference's products I * (wx-part * wy-part), RF2:241-262: regrouping them as (I * wy-part) * wx-part
+            // would save two multiplies but round differently)
         }
         // wave-aggregated append of far rays to this tile's own list: one LDS atomic per wave, no global atomics
         // (a single global counter saturates at ~90 returning atomics per microsecond on this chip)
