@@ -158,14 +158,17 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
             for (int u = 0; u < U; ++u) {
                 const int idx = min((it0 + u) * NTHREADS + tid, SR * SC - 1);
                 const int sr = idx / SC, sc = idx - sr * SC;
-                double ph = phin[u], la = 0.0;
+                // the phase needs float64 (it is differenced); the attenuation exponent, at most a few units, does not:
+                // exp(sum catt T) = exp2(sum (catt log2 e) T) in float32 is three instructions and good to 1e-7
+                double ph = phin[u];
+                float la2 = 0.f;
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
                     ph = fma(a.m.cphase[m], (double)t[u][m], ph);
-                    la = fma(a.m.catt[m], (double)t[u][m], la);
+                    la2 = fmaf((float)(a.m.catt[m] * 1.4426950408889634), t[u][m], la2);
                 }
                 float I = a.I0 * Iin[u];
-                if (NM > 0) I *= expf((float)la);
+                if (NM > 0) I *= exp2f(la2);
                 sphi[idx] = ok[u] ? ph : 0.0;
                 if (sr >= 1 && sr <= GR && sc >= 1 && sc <= GC) {
                     sI[(sr - 1) * GC + (sc - 1)] = ok[u] ? I : 0.f;
