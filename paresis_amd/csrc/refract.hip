@@ -40,8 +40,10 @@ struct Geo {
     static constexpr int AW = TW + 2, ACC = (TH + 2) * AW, TRASH = 2 * 64 + AW + 2;
     static constexpr size_t LDS = sizeof(double) * SR * SC + sizeof(float) * GR * GC + sizeof(long long) * (ACC + TRASH) + 16;
 };
-using GeoSmall = Geo<56, 56, 4, 512>;    // 76 KiB of LDS: two workgroups per CU; 1.31 source evaluations per pixel
-using GeoWide = Geo<48, 48, 8, 512>;     // 70 KiB: two workgroups per CU (one stages while the other deposits); 1.78 evaluations
+using GeoSmall = Geo<56, 56, 4, 1024>;   // 80 KiB of LDS: two workgroups per CU; 1.31 source evaluations per pixel
+// 16 waves per workgroup, 32 per CU: the staging loads of one tile are hidden by more waves that are depositing (512
+// threads: 134 us per 4096^2 launch, 1024: 123 us)
+using GeoWide = Geo<48, 48, 8, 1024>;    // 73 KiB: two workgroups per CU (one stages while the other deposits); 1.78 evaluations
 constexpr int FAR_THREADS = 128;
 
 // a far ray, already evaluated by the tile that owns its source pixel
@@ -134,7 +136,9 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
     // tiles -- take loops compiled without the clamps, the out-of-image tests and np.gradient's edge formulas: the
     // kernel is bound by instruction issue (vector AND scalar), and those tests are a quarter of its instructions.
     const bool window_inside = r0 - H - 1 >= 0 && r0 + TH + H + 1 <= a.Nx && c0 - H - 1 >= 0 && c0 + TW + H + 1 <= a.Ny;
-    constexpr int U = 4;   // staged pixels per thread whose loads are issued together
+    // staged pixels per thread whose loads are issued together: ALL of them (9 x nmat loads in flight, registers are
+    // plentiful at 4 waves per SIMD) -- one memory latency per tile instead of one per batch of four
+    constexpr int U = SITERS;
     auto stage = [&](auto inside_tag) __attribute__((always_inline)) {
         constexpr bool IN = decltype(inside_tag)::value;
         for (int it0 = 0; it0 < SITERS; it0 += U) {
