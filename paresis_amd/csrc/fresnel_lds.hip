@@ -32,6 +32,8 @@
 
 using namespace psx;
 
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
 namespace {
 
 // One 16-wave workgroup per CU owns the whole LDS.  Waves 0..11 (TC threads) are the butterfly engine -- 3 per SIMD are
@@ -409,9 +411,52 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             float *io = a.inten_out;
             const float sc = a.scale;
             const v2f gp = (v2f){a.gph.x, a.gph.y};
-            if (l0 + lineA < a.nlines) {
-                // S1 is a multiple of IB: in the blocked layout too the 24 outputs of a thread are one pointer + q * stride
-                static_assert(S1 % IB == 0 && IB == 8, "blocked output stride; the block index below is i >> 3");
+            static_assert(S1 % IB == 0 && IB == 8, "blocked output stride; the block index below is i >> 3");
+            if constexpr (S1 % 64 == 0) {
+                // A wave's 64 butterflies belong to ONE line, so its outputs go through a buffer descriptor whose range is
+                // exactly the window they may touch: the hardware drops the stores of the unwanted outputs (i < 0 wraps to
+                // a huge offset, i >= N lies past the window).  No compare, no exec-mask bookkeeping per output -- the
+                // scalar unit is shared by the whole CU (0.9 instructions per cycle, tools/salu_bench.hip) and the masked
+                // form of this loop issued 500 scalar instructions per wave.
+                const int l = l0 + __builtin_amdgcn_readfirstlane(lineA);
+                const bool lok = l < a.nlines;
+                // element index of output i inside the window: plain rows: i (window = row l); blocked: ((i>>3)*nlines+l)*8 + i%8
+                const int e0 = a.out_blocked ? ((ifirst >> 3) * a.nlines + l) * IB + (ifirst & (IB - 1)) : ifirst;
+                const int estep = a.out_blocked ? (S1 / IB) * a.nlines * IB : S1;
+                const int64_t wbase = a.out_blocked ? 0 : (int64_t)l * a.out_ld;
+                const int welems = lok ? (a.out_blocked ? ((N + IB - 1) / IB) * IB * a.nlines : N) : 0;
+                if (wo) {
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wo + wbase, 0, welems * 8, 0x00020000);
+                    int off = e0 * 8;
+#pragma unroll
+                    for (int q = 0; q < RAD; ++q) {
+                        const v2f r = pk_cmul_s(v[q], gp);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, r), rs, off, 0, 0);
+                        off += estep * 8;
+                    }
+                }
+                if (io) {
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(io + wbase, 0, welems * 4, 0x00020000);
+                    int off = e0 * 4;
+                    if (a.accumulate) {
+#pragma unroll
+                        for (int q = 0; q < RAD; ++q) {
+                            const float I = sc * (v[q].x * v[q].x + v[q].y * v[q].y);
+                            const float old = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, old + I), rs, off, 0, 0);
+                            off += estep * 4;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < RAD; ++q) {
+                            const float I = sc * (v[q].x * v[q].x + v[q].y * v[q].y);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, I), rs, off, 0, 0);
+                            off += estep * 4;
+                        }
+                    }
+                }
+            } else if (l0 + lineA < a.nlines) {
+                // short lines (R3 <= 4): a wave straddles lines, per-lane pointers and masks
                 const int64_t ob = a.out_blocked ? ((int64_t)(ifirst >> 3) * a.nlines + (l0 + lineA)) * IB + (ifirst & (IB - 1))
                                                  : (int64_t)(l0 + lineA) * a.out_ld + ifirst;
                 const int64_t oq = a.out_blocked ? (int64_t)(S1 / IB) * a.nlines * IB : (int64_t)S1;
