@@ -195,9 +195,10 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         auto spread = [&](int g) __attribute__((always_inline)) {       // periodic / mirrored images -> LDS
             const int l0 = g * LINES;
             const bool line_ok = l0 + line < a.nlines;
-            for (int idx = lt; idx < LINES * (M - a.L); idx += TL) {    // zeros in [L, M)
-                const int ln = idx / (M - a.L), jz = a.L + idx % (M - a.L);
-                lds[ln * MP + phys(jz)] = make_float2(0.f, 0.f);
+            for (int jz = a.L + lt; jz < M; jz += TL) {                  // zeros in [L, M) of every line (no division:
+                const int pz = phys(jz);                                 // this burst is issue-bound on ONE wave per SIMD)
+#pragma unroll
+                for (int ln = 0; ln < LINES; ++ln) lds[ln * MP + pz] = make_float2(0.f, 0.f);
             }
 #pragma unroll
             for (int k = 0; k < NLD; ++k) {
