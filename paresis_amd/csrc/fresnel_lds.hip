@@ -259,6 +259,11 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     const int lineA = tid / S1, nA = tid % S1;
     const int remB = tid % S1, q1B = remB / R3, nB = remB % R3, p0B = q1B * S1 + nB;
     v2f *baseA = reinterpret_cast<v2f *>(lds) + lineA * MP;
+    // middle stage: slab of this lane inside the wave's own 96 (round 2: 32 lanes).  Within each half-wave the first 16
+    // lanes take the even slabs and the last 16 the odd ones: the 16 lanes of a ds_write_b64 group then carry 16
+    // different pad offsets (one pad slot per TWO slabs) and hit 16 different bank pairs instead of 8.
+    const int slabw = ((tid & 63) & 32) + ((tid & 31) < 16 ? 2 * (tid & 31) : 2 * ((tid & 31) - 16) + 1);
+    const int slab0 = (tid >> 6) * WSLABS + slabw;
     const v2f *rowA1 = tw1 + (nA / R3) * TWB_LD, *rowA0 = tw0 + (nA % R3) * TWB_LD, *rowB = twl + nB * TWB_LD;
     // v[q] *= (or conj-*=) row1[q] * row0[q] for q in [Q0, Q1): half of the 23 twiddles at a time (128-VGPR budget)
     auto twiddle_A = [&](v2f(&v)[RAD], auto q0_tag, auto q1_tag, auto conj_tag) __attribute__((always_inline)) {
@@ -298,6 +303,14 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 #pragma unroll
             for (int q = 0; q < RAD; ++q) baseA[idxA(nA, q)] = v[q];
         }
+        // The kernel spectrum (the engine's only global loads) travels one step ahead of its use: the first slab's 128
+        // bytes are requested here, before barrier (1); the second slab's right after the first one's multiply.
+        float4 hh[SLAB / 2];
+        {
+            const float4 *h4 = reinterpret_cast<const float4 *>(a.H + (slab0 % (M / SLAB)) * SLAB);
+#pragma unroll
+            for (int q = 0; q < SLAB / 2; ++q) hh[q] = h4[q];
+        }
         PSX_STAMP(3);
         lds_barrier();                               // (1)
         PSX_STAMP(4);
@@ -308,11 +321,15 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             for (int q = 0; q < RAD; ++q) v[q] = lds_read(baseA + idxB(p0B, q));
             DftPk<RAD, false>::run(v);
             __builtin_amdgcn_sched_barrier(0);
-            v2f w[RAD];
+            // twiddles in two halves: the kernel spectrum of the first slab (hh0, 32 registers) is in flight here
 #pragma unroll
-            for (int q = 1; q < RAD; ++q) w[q] = lds_read(rowB + q);
+            for (int h = 0; h < 2; ++h) {
+                v2f w[RAD / 2];
 #pragma unroll
-            for (int q = 1; q < RAD; ++q) v[q] = pk_cmul(v[q], w[q]);
+                for (int q = (h == 0 ? 1 : 0); q < RAD / 2; ++q) w[q] = lds_read(rowB + h * (RAD / 2) + q);
+#pragma unroll
+                for (int q = (h == 0 ? 1 : 0); q < RAD / 2; ++q) v[h * (RAD / 2) + q] = pk_cmul(v[h * (RAD / 2) + q], w[q]);
+            }
 #pragma unroll
             for (int q = 0; q < RAD; ++q) baseA[idxB(p0B, q)] = v[q];
         }
@@ -330,18 +347,9 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         const float2 *Hd = a.H;
 #pragma unroll
         for (int r = 0; r < NSLAB; ++r) {
-            // slab of this lane inside the wave's own 96 (round 2: 32 lanes).  Within each half-wave the first 16 lanes
-            // take the even slabs and the last 16 the odd ones: the 16 lanes of a ds_write_b64 group then carry 16
-            // different pad offsets (one pad slot per TWO slabs) and hit 16 different bank pairs instead of 8.
-            const int ln = tid & 63, lr = ln & 31;
-            const int sw = (ln & 32) + (lr < 16 ? 2 * lr : 2 * (lr - 16) + 1) + 64 * r;
-            if (sw >= WSLABS) break;
-            const int s = (tid >> 6) * WSLABS + sw, line = s / (M / SLAB), p0 = (s % (M / SLAB)) * SLAB;
+            if (slabw + 64 * r >= WSLABS) break;
+            const int s = slab0 + 64 * r, line = s / (M / SLAB), p0 = (s % (M / SLAB)) * SLAB;
             v2f *base = reinterpret_cast<v2f *>(lds) + line * MP + phys(p0);   // p0 % 16 == 0: no pad slot inside a slab
-            float4 hh[SLAB / 2];                            // kernel spectrum of this slab: issued before the LDS reads
-            const float4 *h4 = reinterpret_cast<const float4 *>(Hd + p0);
-#pragma unroll
-            for (int q = 0; q < SLAB / 2; ++q) hh[q] = h4[q];
             v2f f[SLAB];
 #pragma unroll
             for (int q = 0; q < SLAB; ++q) f[q] = lds_read(base + q);
@@ -358,6 +366,13 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             for (int q = 0; q < SLAB / 2; ++q) {
                 f[2 * q] = pk_cmul(f[2 * q], (v2f){hh[q].x, hh[q].y});
                 f[2 * q + 1] = pk_cmul(f[2 * q + 1], (v2f){hh[q].z, hh[q].w});
+            }
+            if (r + 1 < NSLAB && slabw + 64 * (r + 1) < WSLABS) {      // next slab's spectrum, under this one's inverse DFT
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 *h4 = reinterpret_cast<const float4 *>(Hd + ((slab0 + 64 * (r + 1)) % (M / SLAB)) * SLAB);
+#pragma unroll
+                for (int q = 0; q < SLAB / 2; ++q) hh[q] = h4[q];
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int c = 0; c < SLAB / R3; ++c) {
