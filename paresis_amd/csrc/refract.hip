@@ -181,10 +181,57 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
             }
         }
     };
-    if (window_inside)
-        stage(std::true_type{});
-    else
+    // Interior tiles, sources first: the GR x GC block of pixels that deposit is (GR*GC / NTHREADS) whole passes with
+    // shift/mask indexing and no membership test; the one-pixel stencil ring around it only needs the phase.
+    constexpr bool SPLIT = (GC & (GC - 1)) == 0 && (GR * GC) % NTHREADS == 0 && 2 * (SR + SC) <= NTHREADS;
+    auto stage_interior = [&]() __attribute__((always_inline)) {
+        constexpr int NP = GR * GC / NTHREADS;
+        float t[NP + 1][NM > 0 ? NM : 1], Iin[NP + 1];
+        double phin[NP + 1];
+        // ring pixel of this thread (threads < 2*SC + 2*GR): top row, bottom row, left column, right column
+        const int rt = tid;
+        const bool ring = rt < 2 * SC + 2 * GR;
+        const int rsr = rt < SC ? 0 : (rt < 2 * SC ? SR - 1 : 1 + ((rt - 2 * SC) >> 1));
+        const int rsc = rt < SC ? rt : (rt < 2 * SC ? rt - SC : (((rt - 2 * SC) & 1) ? SC - 1 : 0));
+#pragma unroll
+        for (int u = 0; u <= NP; ++u) {
+            const int idx = u * NTHREADS + tid;
+            const int sr = u < NP ? 1 + idx / GC : (ring ? rsr : 0), sc = u < NP ? 1 + (idx & (GC - 1)) : (ring ? rsc : 0);
+            const int64_t p = (int64_t)(r0 - H - 1 + sr) * a.Ny + (c0 - H - 1 + sc);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) t[u][m] = a.m.T[m][p];
+            Iin[u] = (HAS_I && u < NP) ? a.I_in[p] : 1.f;
+            phin[u] = HAS_PHI ? a.phi_in[p] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u <= NP; ++u) {
+            const int idx = u * NTHREADS + tid;
+            double ph = phin[u];
+            float la2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                ph = fma(a.m.cphase[m], (double)t[u][m], ph);
+                if (u < NP) la2 = fmaf((float)(a.m.catt[m] * 1.4426950408889634), t[u][m], la2);
+            }
+            if (u < NP) {
+                float I = a.I0 * Iin[u];
+                if (NM > 0) I *= exp2f(la2);
+                sphi[(1 + idx / GC) * SC + 1 + (idx & (GC - 1))] = ph;
+                sI[idx] = I;
+                imax = max(imax, __float_as_uint(fabsf(I)));
+            } else if (ring) {
+                sphi[rsr * SC + rsc] = ph;
+            }
+        }
+    };
+    if (window_inside) {
+        if constexpr (SPLIT)
+            stage_interior();
+        else
+            stage(std::true_type{});
+    } else {
         stage(std::false_type{});
+    }
     PSX_RSTAMP(1);
     for (int idx = tid; idx < ACC; idx += NTHREADS) sacc[idx] = 0ll;
     for (int o = 32; o > 0; o >>= 1) imax = max(imax, (unsigned)__shfl_xor((int)imax, o));
