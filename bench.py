@@ -37,8 +37,10 @@ def parse():
     ap.add_argument("--engine", default="auto", choices=["auto", "rocfft", "lds"])
     ap.add_argument("--halo", type=int, default=8, choices=[4, 8], help="refraction gather halo (speed knob)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="issue the refractions after the Fresnel call on one stream (default: on a second stream)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="issue the step's refractions on a second stream (no gain since the Fresnel call became two long "
+                         "persistent launches; kept for experiments)")
+    ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)   # former default switch, accepted and ignored
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -88,9 +90,9 @@ def main():
     refr = [torch.empty((N, N), dtype=torch.float32, device=dev) for _ in DISTANCES]
     amp = float(np.sqrt(I0))
 
-    # The two models of a step are independent, so the refractions go to a second HIP stream: their workgroups fill the
-    # CUs that the persistent Fresnel kernels leave idle at the end of each launch (+3.8 % at 4096^2).
-    side = None if a.no_overlap else torch.cuda.Stream()
+    # The two models of a step are independent and could share the GPU from two HIP streams.  That paid (+3.8 %) while a
+    # Fresnel call was 9 launches with idle tails; with the distances merged into two persistent launches it does not.
+    side = torch.cuda.Stream() if a.overlap else None
 
     def step(overlap=True):
         if side is not None and overlap:

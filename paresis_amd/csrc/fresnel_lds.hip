@@ -54,18 +54,19 @@ constexpr int IB = 8;
 __host__ __device__ constexpr int phys(int p) { return p + (p >> 5); }   // one pad slot per 32: conflict-free slabs
 
 struct LineArgs {
-    const float2 *src;      // input wave
+    int n_dist;             // distances merged into this launch: work item w = d * ngroups + g  (d-th table / buffers, group g)
+    const float2 *src[PSX_MAX_DIST];        // input wave of each distance
     int N, nlines, margin, P, L;
     int64_t in_si, in_sl;   // sample i of line l is element i*in_si + l*in_sl of src ...
     int in_blocked;         // ... or, blocked: element ((l / IB)*N + i)*IB + l % IB  (the intermediate, see IB)
     int64_t out_ld;         // output sample i of line l goes to l*out_ld + i ...
     int out_blocked;        // ... or, blocked: element ((i / IB)*nlines + l)*IB + i % IB
     const float2 *twA, *twB;   // [n][24] stage twiddles
-    const float2 *H;        // kernel spectrum FFT_M(h) of this distance, digit-reversed, 1/M folded in
-    float2 *wave_out;       // complex result (pass 1: the transposed intermediate) or null
-    float *inten_out;       // scale * |result|^2 or null
-    float scale;
-    float2 gph;             // global phase factor exp(i k z / M) of the complex result
+    const float2 *H[PSX_MAX_DIST];          // kernel spectrum FFT_M(h) of each distance, digit-reversed, 1/M folded in
+    float2 *wave_out[PSX_MAX_DIST];         // complex result (pass 1: the blocked intermediate) or null
+    float *inten_out[PSX_MAX_DIST];         // scale * |result|^2 or null
+    float scale[PSX_MAX_DIST];
+    float2 gph[PSX_MAX_DIST];               // global phase factor exp(i k z / M) of the complex result
     int accumulate;
     unsigned long long *stamps;   // optional diagnostics: 32 phase timestamps per workgroup (psx_debug_stamps)
 };
@@ -116,10 +117,11 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     // ---- line groups of this workgroup: XCD x = blockIdx % 8 owns a contiguous chunk of groups (its 32 CUs then read
     // neighbouring columns at the same time: the 128-byte lines of the strided source are shared in that XCD's L2)
     const int ngroups = (a.nlines + LINES - 1) / LINES;
+    const int nwork = ngroups * a.n_dist;      // all distances of a call in ONE launch: one prologue, one tail
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
-    const int cq = ngroups >> 3, cr = ngroups & 7;
+    const int cq = nwork >> 3, cr = nwork & 7;
     const int cstart = xcd * cq + (xcd < cr ? xcd : cr), clen = cq + (xcd < cr ? 1 : 0);
-    const int nj = slot < clen ? (clen - slot + nslot - 1) / nslot : 0;   // groups cstart + slot + j*nslot, j < nj
+    const int nj = slot < clen ? (clen - slot + nslot - 1) / nslot : 0;   // work items cstart + slot + j*nslot, j < nj
 
     // Stage B's twiddles w_S1^{n q} (n < R3, q < 24: 3 KiB) live in LDS behind the line buffers, rows padded to 25 so that
     // the 16 rows start on 16 different bank pairs: a ds_read_b64 costs 2 LDS cycles where the 16-byte global loads of
@@ -176,7 +178,9 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         const int64_t pstep = (int64_t)STEP * (a.in_blocked ? (int64_t)IB : a.in_si);
 
         float2 xs[NLD], xm = make_float2(0.f, 0.f);
-        auto fetch = [&](int g) __attribute__((always_inline)) {        // issue every load of group g, wait for none
+        auto fetch = [&](int w) __attribute__((always_inline)) {        // issue every load of work item w, wait for none
+            const int d = w / ngroups, g = w - d * ngroups;
+            const float2 *src = a.src[d];
             const int l0 = g * LINES;
             const bool line_ok = l0 + line < a.nlines;
             const int64_t pix0 = a.in_blocked
@@ -186,13 +190,14 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             for (int k = 0; k < NLD; ++k) {
                 // out-of-range samples re-read element 0 (always valid): unconditional loads issue back to back
                 const bool ok = line_ok && i0 + STEP * k < N;
-                xs[k] = a.src[ok ? pix0 + pstep * k : (int64_t)0];
+                xs[k] = src[ok ? pix0 + pstep * k : (int64_t)0];
             }
             const int64_t pixm = a.in_blocked ? ((int64_t)((l0 + lm) / IB) * N + im) * IB + (l0 + lm) % IB
                                               : (int64_t)im * a.in_si + (int64_t)(l0 + lm) * a.in_sl;
-            xm = a.src[(im >= 0 && l0 + lm < a.nlines) ? pixm : (int64_t)0];
+            xm = src[(im >= 0 && l0 + lm < a.nlines) ? pixm : (int64_t)0];
         };
-        auto spread = [&](int g) __attribute__((always_inline)) {       // periodic / mirrored images -> LDS
+        auto spread = [&](int w) __attribute__((always_inline)) {       // periodic / mirrored images -> LDS
+            const int d = w / ngroups, g = w - d * ngroups;
             const int l0 = g * LINES;
             const bool line_ok = l0 + line < a.nlines;
             for (int jz = a.L + lt; jz < M; jz += TL) {                  // zeros in [L, M) of every line (no division:
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 const int i2 = r < mg ? r + 1 : N - 1 - 2 * mg + r, j2 = r < mg ? N + 2 * mg - 1 - i2 : 2 * N - 3 - i2;
                 float2 x2 = make_float2(0.f, 0.f);
                 if (l0 + ln < a.nlines)
-                    x2 = a.src[a.in_blocked ? ((int64_t)((l0 + ln) / IB) * N + i2) * IB + (l0 + ln) % IB
+                    x2 = a.src[d][a.in_blocked ? ((int64_t)((l0 + ln) / IB) * N + i2) * IB + (l0 + ln) % IB
                                             : (int64_t)i2 * a.in_si + (int64_t)(l0 + ln) * a.in_sl];
                 lds[ln * MP + phys(j2)] = x2;
             }
@@ -288,7 +293,8 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     lds_barrier();                                       // (0) first group is in LDS
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 1] = wall_clock64();
     for (int j = 0; j < nj; ++j) {
-        const int l0 = (cstart + slot + j * nslot) * LINES;
+        const int w = cstart + slot + j * nslot, d = w / ngroups;
+        const int l0 = (w - d * ngroups) * LINES;
         PSX_STAMP(2);
 
         // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         // bytes are requested here, before barrier (1); the second slab's right after the first one's multiply.
         float4 hh[SLAB / 2];
         {
-            const float4 *h4 = reinterpret_cast<const float4 *>(a.H + (slab0 % (M / SLAB)) * SLAB);
+            const float4 *h4 = reinterpret_cast<const float4 *>(a.H[d] + (slab0 % (M / SLAB)) * SLAB);
 #pragma unroll
             for (int q = 0; q < SLAB / 2; ++q) hh[q] = h4[q];
         }
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 
         // ---- 4+5. middle stage, slab by slab: forward radix R3 on contiguous chunks, x FFT_M(h_d), inverse radix R3,
         // back to LDS.  Each thread rewrites exactly the slabs it read.
-        const float2 *Hd = a.H;
+        const float2 *Hd = a.H[d];
 #pragma unroll
         for (int r = 0; r < NSLAB; ++r) {
             if (slabw + 64 * r >= WSLABS) break;
@@ -423,10 +429,10 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             // would occupy 96 VGPRs there and spill).
             int ifirst = nA - (N + 2 * mg - 1);
             asm volatile("" : "+v"(ifirst));
-            v2f *wo = reinterpret_cast<v2f *>(a.wave_out);
-            float *io = a.inten_out;
-            const float sc = a.scale;
-            const v2f gp = (v2f){a.gph.x, a.gph.y};
+            v2f *wo = reinterpret_cast<v2f *>(a.wave_out[d]);
+            float *io = a.inten_out[d];
+            const float sc = a.scale[d];
+            const v2f gp = (v2f){a.gph[d].x, a.gph[d].y};
             static_assert(S1 % IB == 0 && IB == 8, "blocked output stride; the block index below is i >> 3");
             if constexpr (S1 % 64 == 0) {
                 // A wave's 64 butterflies belong to ONE line, so its outputs go through a buffer descriptor whose range is
@@ -808,9 +814,9 @@ static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
         PSX_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
         if (n_cu < 8) n_cu = 8;
     }
-    const int ngroups = (la.nlines + LINES - 1) / LINES;
+    const int nwork = ((la.nlines + LINES - 1) / LINES) * la.n_dist;
     int nslot = n_cu / 8;
-    if (nslot > (ngroups + 7) / 8) nslot = (ngroups + 7) / 8;
+    if (nslot > (nwork + 7) / 8) nslot = (nwork + 7) / 8;
     PSX_TIMED(name, st, k_fresnel_lines<R3, CONTIG><<<8 * nslot, T, lds_bytes, st>>>(la));
     return launch_check(name);
 }
@@ -860,40 +866,56 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
     }
 
     // ---- pass 1: lines along axis 0 of the image = rows of the transposed source (contiguous reads); line y writes row
-    // y of the intermediate [Ny][Nx].  One launch per distance: the in-place middle stage consumes the forward spectrum
-    // (keeping it in registers across distances needs 64 VGPRs the engine waves do not have).
+    // y of the blocked intermediate of each distance.  ONE launch covers all distances (work item = (distance, line
+    // group)): one prologue and one tail instead of n_dist.  The in-place middle stage consumes the forward spectrum, so the
+    // forward stages are repeated per distance (keeping it in registers needs 64 VGPRs the engine waves do not have).
     static const bool stamp_pass1 = getenv("PSX_STAMP_PASS1") != nullptr;   // diagnostics only
-    for (int i = 0; i < nnz; ++i) {
+    {
         LineArgs la;
-        la.src = e->pre;
         la.N = p->Nx; la.nlines = p->Ny; la.margin = p->margin; la.P = p->Px; la.L = p->Nx + p->Px - 1;
         la.in_si = 1; la.in_sl = p->Nx; la.in_blocked = 0; la.out_ld = 0; la.out_blocked = 1;
         la.twA = e->ax[0].twA; la.twB = e->ax[0].twB;
         la.accumulate = 0; la.stamps = stamp_pass1 ? g_stamps : nullptr;
-        if (int rc = kernel_spectrum(p, e->ax[0], a.a[nz[i]], a.du_x, st, &la.H)) return rc;
-        la.wave_out = e->inter + (size_t)i * e->inter_elems;
-        la.inten_out = nullptr;
-        la.scale = 1.f;
-        la.gph = make_float2(1.f, 0.f);
+        la.n_dist = nnz;
+        for (int i = 0; i < PSX_MAX_DIST; ++i) {
+            const int k = i < nnz ? i : 0;
+            la.src[i] = e->pre;
+            if (i < nnz) {
+                if (int rc = kernel_spectrum(p, e->ax[0], a.a[nz[i]], a.du_x, st, &la.H[i])) return rc;
+            } else {
+                la.H[i] = la.H[0];
+            }
+            la.wave_out[i] = e->inter + (size_t)k * e->inter_elems;
+            la.inten_out[i] = nullptr;
+            la.scale[i] = 1.f;
+            la.gph[i] = make_float2(1.f, 0.f);
+        }
         if (int rc = launch_lines_r3<true>(e->ax[0].R3, la, st, "k_fresnel_cols")) return rc;
     }
 
     // ---- pass 2: lines along axis 1 of the image = columns of the intermediate (strided reads: the second transpose);
-    // line x writes row x of the result
-    for (int i = 0; i < nnz; ++i) {
-        const int d = nz[i];
+    // line x writes row x of the result.  Again one launch for all distances.
+    {
         LineArgs lb;
-        lb.src = e->inter + (size_t)i * e->inter_elems;
         lb.N = p->Ny; lb.nlines = p->Nx; lb.margin = p->margin; lb.P = p->Py; lb.L = p->Ny + p->Py - 1;
         lb.in_si = 0; lb.in_sl = 0; lb.in_blocked = 1; lb.out_ld = p->Ny; lb.out_blocked = 0;
         lb.twA = e->ax[1].twA; lb.twB = e->ax[1].twB;
         lb.accumulate = a.accumulate; lb.stamps = stamp_pass1 ? nullptr : g_stamps;
-        if (int rc2 = kernel_spectrum(p, e->ax[1], a.a[d], a.du_y, st, &lb.H)) return rc2;
-        lb.wave_out = a.wave_out ? a.wave_out[d] : nullptr;
-        lb.inten_out = a.inten_out ? a.inten_out[d] : nullptr;
-        lb.scale = a.inten_scale ? a.inten_scale[d] : 1.f;
-        const double g = a.gphase ? a.gphase[d] : 0.0;
-        lb.gph = make_float2((float)std::cos(g), (float)std::sin(g));   // exact reduction of ~1e11 rad (EXP:250)
+        lb.n_dist = nnz;
+        for (int i = 0; i < PSX_MAX_DIST; ++i) {
+            const int k = i < nnz ? i : 0, d = nz[k];
+            lb.src[i] = e->inter + (size_t)k * e->inter_elems;
+            if (i < nnz) {
+                if (int rc2 = kernel_spectrum(p, e->ax[1], a.a[d], a.du_y, st, &lb.H[i])) return rc2;
+            } else {
+                lb.H[i] = lb.H[0];
+            }
+            lb.wave_out[i] = a.wave_out ? a.wave_out[d] : nullptr;
+            lb.inten_out[i] = a.inten_out ? a.inten_out[d] : nullptr;
+            lb.scale[i] = a.inten_scale ? a.inten_scale[d] : 1.f;
+            const double g = a.gphase ? a.gphase[d] : 0.0;
+            lb.gph[i] = make_float2((float)std::cos(g), (float)std::sin(g));   // exact reduction of ~1e11 rad (EXP:250)
+        }
         if (int rc2 = launch_lines_r3<false>(e->ax[1].R3, lb, st, "k_fresnel_rows")) return rc2;
     }
     return 0;
