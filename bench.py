@@ -182,14 +182,17 @@ def main():
     if rank == 0:
         P = N + 30
         nmat = 2
-        # algorithmic bytes per launch of each timed kernel (DESIGN.md "Roofline accounting")
-        alg = {
+        # algorithmic bytes of each timed kernel per UNIT (one distance) -- DESIGN.md "Roofline accounting"; BASELINE.md
+        # section 4 -- turned into bytes per launch with the launches the kernel really had (the LDS engine covers all
+        # distances of a step in one launch per pass)
+        alg_unit = {
             "k_refract_near": (12 + 4 * nmat) * P * P,
             "rocfft_forward": 32 * P * P,
             "rocfft_inverse": 32 * P * P,
             "k_fresnel_rows": 32 * P * P,
             "k_fresnel_cols": 32 * P * P,
         }
+        alg = {nm: b * units * a.steps // kern[nm][0] for nm, b in alg_unit.items() if nm in kern}
         per = {nm: tot / cnt for nm, (cnt, tot) in kern.items()}
         step_share = {nm: tot / a.steps for nm, (cnt, tot) in kern.items()}
         out["kernel_ms_per_step"] = {nm: round(v, 4) for nm, v in sorted(step_share.items(), key=lambda kv: -kv[1])}
