@@ -41,6 +41,8 @@ def parse():
                     help="issue the step's refractions on a second stream (no gain since the Fresnel call became two long "
                          "persistent launches; kept for experiments)")
     ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)   # former default switch, accepted and ignored
+    ap.add_argument("--refract-per-distance", action="store_true",
+                    help="one refraction call per distance instead of the distance batch (for comparison)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -104,8 +106,11 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             return
         plan.propagate(aa, gp, du, amp=amp, mats=wave_mats, want_wave=[False] * len(DISTANCES), inten_out=fres)
-        for i in range(len(DISTANCES)):
-            ops.refract((N, N), rt_mats, dsc[i], (N, N), I0=I0, out=refr[i])
+        if a.refract_per_distance:
+            for i in range(len(DISTANCES)):
+                ops.refract((N, N), rt_mats, dsc[i], (N, N), I0=I0, out=refr[i])
+        else:       # the call's distances in one launch per kernel, like the Fresnel call above
+            ops.refract_multi((N, N), rt_mats, dsc, (N, N), I0=I0, outs=refr)
 
     def barrier():
         torch.cuda.synchronize()

@@ -94,6 +94,19 @@ int psx_refract_f32(const float *I_in, float I0, const float *const *T, const do
                     float *Dy_out, float *I_mut, int Nx, int Ny, int margin, double dscale, double clamp_x,
                     double clamp_y, unsigned *status, void *workspace, void *stream);
 
+/* Propagation-distance batch (BASELINE.json north_star: "propagation-distance batches"; the reference would call
+ * Experiment.refraction, Experiment.py:255-277, once per distance on the same (I, phi)): ndist <= PSX_MAX_DIST
+ * refractions of ONE source (same I_in/I0/T/phi_in) with displacement scales dscale[d] into the distinct images
+ * I_out[d] (host arrays of ndist entries), in one launch per kernel -- the thickness maps are read and the
+ * transmission evaluated once per tile instead of once per distance.  Each image is bit-identical to the one
+ * psx_refract_f32 gives for that distance (up to the float-atomics order of far rays).  Dx_out/Dy_out/I_mut are
+ * only accepted with ndist == 1.  workspace: psx_refract_multi_workspace_bytes(Nx, Ny, ndist) bytes. */
+size_t psx_refract_multi_workspace_bytes(int Nx, int Ny, int ndist);
+int psx_refract_multi_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,
+                          int nmat, const double *phi_in, float *const *I_out, float out_scale, int accumulate,
+                          float *Dx_out, float *Dy_out, float *I_mut, int Nx, int Ny, int margin, const double *dscale,
+                          int ndist, double clamp_x, double clamp_y, unsigned *status, void *workspace, void *stream);
+
 /* The raw scatter loop on explicit displacement fields: fastloopNumba (refractionFileNumba2.py:198-263).
  * I, Dx, Dy, I2 are [Nx][Ny]; I2 is accumulated into (float atomics; order-dependent in the last bits). */
 int psx_fastloop_f32(const float *I, const float *Dx, const float *Dy, float *I2, int Nx, int Ny, void *stream);

@@ -57,17 +57,18 @@ struct RefractArgs {
     float I0;
     Mats m;
     const double *phi_in;
-    float *I_out;
+    float *I_out[PSX_MAX_DIST];   // one output image per distance of the call
+    double dscale[PSX_MAX_DIST];  // displacement scale z / k / (h M) / h of each distance
+    int ndist;
     float out_scale;
     int accumulate;
     float *Dx_out, *Dy_out;
     float *I_mut;
     int Nx, Ny, margin;
-    double dscale;
     float clamp_xf, clamp_yf;
     unsigned *status;
-    unsigned *far_count;     // workspace: [ntiles] far rays found by each tile
-    FarRay *far_list;        // then [ntiles][TH*TW] records (a tile can never overflow its slot)
+    unsigned *far_count;     // workspace: [ndist][ntiles] far rays found by each tile at each distance
+    FarRay *far_list;        // then [ndist][ntiles][TH*TW] records (a tile can never overflow its slot)
     int tiles_x, tiles_y, tile_cap;
     unsigned long long *stamps;   // diagnostics (psx_debug_stamps): 16 phase timestamps per workgroup
 };
@@ -106,7 +107,7 @@ __device__ __forceinline__ int xcd_tile(int b, int nt) {
 }
 
 template <class G, int NM, bool HAS_I, bool HAS_PHI>
-__global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
+__global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_refract_near(RefractArgs a) {
     constexpr int TH = G::TH, TW = G::TW, H = G::H, SR = G::SR, SC = G::SC, GR = G::GR, GC = G::GC, NTHREADS = G::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *sphi = (double *)smem;                                        // [SR][SC]
@@ -250,15 +251,26 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
     // Written with as few divergent branches as possible (each costs a save/restore of the exec mask): pixels outside
     // the image carry I = 0, deposits that miss the tile (or rays that are not "near") add 0 to a per-lane trash slot,
     // so the four LDS atomics are unconditional.
+    // All distances of the call share the staged tile (the phase gradient is linear in z): the thickness maps are read
+    // and the transmission evaluated ONCE per tile, then each distance runs its own deposit loop into the same
+    // accumulator and writes its own image.
     bool any_bad = false;
-    const double hscale = 0.5 * a.dscale;
     constexpr int ITERS = (GR * GC + NTHREADS - 1) / NTHREADS;   // uniform trip count: the loop holds wave ballots
-    const int lane = tid & 63;
+    for (int d = 0; d < a.ndist; ++d) {
+    // the per-thread index arithmetic is recomputed per distance rather than kept live across the loop (opaque copy of
+    // the thread index): hoisted, it costs 40 VGPRs and the second workgroup of the CU
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    const int lane = tl & 63;
+    const double dscale = a.dscale[d];
+    const double hscale = 0.5 * dscale;
+    float *const I_out = a.I_out[d];
+    FarRay *const far_list = a.far_list + ((size_t)d * nt + tile) * (TH * TW);
     auto gather = [&](auto inside_tag) __attribute__((always_inline)) {
     constexpr bool IN = decltype(inside_tag)::value && (GR * GC) % NTHREADS == 0;   // every slot is a pixel inside the image
     for (int it = 0; it < ITERS; ++it) {
-        const int idx = IN ? it * NTHREADS + tid : min(it * NTHREADS + tid, GR * GC - 1);
-        const bool live = IN || it * NTHREADS + tid < GR * GC;
+        const int idx = IN ? it * NTHREADS + tl : min(it * NTHREADS + tl, GR * GC - 1);
+        const bool live = IN || it * NTHREADS + tl < GR * GC;
         const int gr = idx / GC, gc = idx - gr * GC;
         const int i = r0 - H + gr, j = c0 - H + gc;
         const bool inside = IN || (live && i >= 0 && i < a.Nx && j >= 0 && j < a.Ny);
@@ -283,8 +295,8 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
                 gy = 0.5 * sphi[sidx - 2] - 2.0 * sphi[sidx - 1] + 1.5 * sphi[sidx];
             else
                 gy = 0.5 * (sphi[sidx + 1] - sphi[sidx - 1]);
-            gx *= a.dscale;
-            gy *= a.dscale;
+            gx *= dscale;
+            gy *= dscale;
         } else {
             gx = 0.0;
             gy = 0.0;
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
                 const unsigned rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
                 FarRay fr;
                 fr.dx = Dxs; fr.dy = Dys; fr.I = Is; fr.src = i * a.Ny + j;
-                a.far_list[(size_t)tile * (TH * TW) + base + rank] = fr;
+                far_list[base + rank] = fr;
             }
         }
     }
@@ -360,28 +372,38 @@ __global__ __launch_bounds__(G::NT) void k_refract_near(RefractArgs a) {
     __syncthreads();
     PSX_RSTAMP(4);
 
-    // ---- write the tile once (coalesced rows of TW floats)
-    for (int idx = tid; idx < TH * TW; idx += NTHREADS) {
+    // ---- write the tile once (coalesced rows of TW floats) and clear it for the next distance (the guard ring
+    // is never read, so it may keep what it collected)
+    const bool more = d + 1 < a.ndist;
+    for (int idx = tl; idx < TH * TW; idx += NTHREADS) {
         const int tr = idx / TW, tc = idx - tr * TW;
         const int i = r0 + tr, j = c0 + tc;
+        const long long q = sacc[(tr + 1) * AW + tc + 1];
+        if (more) sacc[(tr + 1) * AW + tc + 1] = 0ll;
         if (i < a.Nx && j < a.Ny) {
             const int64_t p = (int64_t)i * a.Ny + j;
-            float v = finite_in ? a.out_scale * (float)((double)sacc[(tr + 1) * AW + tc + 1] * finv) : __uint_as_float(0x7fc00000u);
-            if (a.accumulate) v += a.I_out[p];
+            float v = finite_in ? a.out_scale * (float)((double)q * finv) : __uint_as_float(0x7fc00000u);
+            if (a.accumulate) v += I_out[p];
             any_bad |= !(fabsf(v) <= 3.0e38f);
-            a.I_out[p] = v;
+            I_out[p] = v;
         }
     }
-    if (a.status && __any(any_bad) && (tid & 63) == 0) atomicOr(a.status, PSX_STATUS_NONFINITE);
     PSX_RSTAMP(5);
-    if (tid == 0) a.far_count[tile] = *sfar;     // the barrier above ordered every append before this read
+    if (tl == 0) {
+        a.far_count[(size_t)d * nt + tile] = *sfar;     // the barrier above ordered every append before this read
+        *sfar = 0u;
+    }
+    if (more) __syncthreads();
+    }   // distances
+    if (a.status && __any(any_bad) && (tid & 63) == 0) atomicOr(a.status, PSX_STATUS_NONFINITE);
 }
 
 // Replay of the far rays with the reference's literal border rules (RF2:235-262) in padded coordinates.
 __global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a) {
-    const unsigned n = a.far_count[blockIdx.x];
+    const unsigned n = a.far_count[blockIdx.x];          // blockIdx.x = distance * ntiles + tile
     if (n == 0) return;
     const FarRay *list = a.far_list + (size_t)blockIdx.x * a.tile_cap;
+    float *const I_out = a.I_out[blockIdx.x / (unsigned)(a.tiles_x * a.tiles_y)];
     const int Px = a.Nx + 2 * a.margin, Py = a.Ny + 2 * a.margin;
     for (unsigned e = threadIdx.x; e < n; e += blockDim.x) {
         const FarRay fr = list[e];
@@ -397,7 +419,7 @@ __global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a) {
             if (ui >= 0 && ui < a.Nx && uj >= 0 && uj < a.Ny && v != 0.f) {
                 const float add = a.out_scale * v;
                 if (a.status && !(fabsf(add) <= 3.0e38f)) atomicOr(a.status, PSX_STATUS_NONFINITE);
-                atomicAdd(&a.I_out[(int64_t)ui * a.Ny + uj], add);
+                atomicAdd(&I_out[(int64_t)ui * a.Ny + uj], add);
             }
         };
         deposit(bi, bj, I * wbi * wbj);
@@ -438,8 +460,8 @@ __global__ __launch_bounds__(256) void k_fastloop(const float *__restrict__ I, c
 int g_refract_geometry = 1;   // 0: GeoSmall (H=4), 1: GeoWide (H=8)
 
 template <class G>
-size_t workspace_for(int Nx, int Ny) {
-    const size_t nt = (size_t)cdiv(Nx, G::TH) * (size_t)cdiv(Ny, G::TW);
+size_t workspace_for(int Nx, int Ny, int ndist) {
+    const size_t nt = (size_t)cdiv(Nx, G::TH) * (size_t)cdiv(Ny, G::TW) * (size_t)ndist;
     return 16 * ((sizeof(unsigned) * nt + 15) / 16) + sizeof(FarRay) * nt * G::TH * G::TW;
 }
 
@@ -449,7 +471,7 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
     a.tiles_y = (int)cdiv(a.Ny, G::TW);
     a.tile_cap = G::TH * G::TW;
     a.far_count = (unsigned *)workspace;
-    a.far_list = (FarRay *)((char *)workspace + 16 * ((sizeof(unsigned) * (size_t)a.tiles_x * a.tiles_y + 15) / 16));
+    a.far_list = (FarRay *)((char *)workspace + 16 * ((sizeof(unsigned) * (size_t)a.tiles_x * a.tiles_y * a.ndist + 15) / 16));
     int rc_launch = 0;
     auto launch = [&](auto nm, auto hi, auto hp) -> int {
         constexpr int NM = decltype(nm)::value;
@@ -463,7 +485,7 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
         PSX_TIMED("k_refract_near", st,
                   k_refract_near<G, NM, HI, HP><<<a.tiles_x * a.tiles_y, G::NT, G::LDS, st>>>(a));
         if (int rc = launch_check("k_refract_near")) return rc;
-        PSX_TIMED("k_refract_far", st, k_refract_far<<<a.tiles_x * a.tiles_y, FAR_THREADS, 0, st>>>(a));
+        PSX_TIMED("k_refract_far", st, k_refract_far<<<a.tiles_x * a.tiles_y * a.ndist, FAR_THREADS, 0, st>>>(a));
         return 0;
     };
     PSX_DISPATCH_NMAT(nmat, {
@@ -481,11 +503,13 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
 
 extern "C" {
 
-size_t psx_refract_workspace_bytes(int Nx, int Ny) {
-    if (Nx <= 0 || Ny <= 0) return 16;
-    const size_t a = workspace_for<GeoSmall>(Nx, Ny), b = workspace_for<GeoWide>(Nx, Ny);
+size_t psx_refract_multi_workspace_bytes(int Nx, int Ny, int ndist) {
+    if (Nx <= 0 || Ny <= 0 || ndist <= 0) return 16;
+    const size_t a = workspace_for<GeoSmall>(Nx, Ny, ndist), b = workspace_for<GeoWide>(Nx, Ny, ndist);
     return a > b ? a : b;
 }
+
+size_t psx_refract_workspace_bytes(int Nx, int Ny) { return psx_refract_multi_workspace_bytes(Nx, Ny, 1); }
 
 int psx_refract_set_halo(int halo) {
     PSX_REQUIRE(halo == 4 || halo == 8, "psx_refract_set_halo: halo must be 4 or 8, got %d", halo);
@@ -493,22 +517,34 @@ int psx_refract_set_halo(int halo) {
     return 0;
 }
 
-int psx_refract_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,
-                    int nmat, const double *phi_in, float *I_out, float out_scale, int accumulate, float *Dx_out,
-                    float *Dy_out, float *I_mut, int Nx, int Ny, int margin, double dscale, double clamp_x,
-                    double clamp_y, unsigned *status, void *workspace, void *stream) {
-    PSX_REQUIRE(I_out != nullptr && workspace != nullptr, "psx_refract_f32: null output or workspace");
-    PSX_REQUIRE(Nx >= 3 && Ny >= 3, "psx_refract_f32: grid %dx%d too small for the edge_order=2 gradient", Nx, Ny);
-    PSX_REQUIRE((int64_t)Nx * Ny < (1ll << 31), "psx_refract_f32: grid %dx%d exceeds int32 pixel indices", Nx, Ny);
-    PSX_REQUIRE(margin >= 8 && margin <= 4096, "psx_refract_f32: margin %d must be >= 8 (the widest gather halo)", margin);
-    PSX_REQUIRE((Dx_out == nullptr) == (Dy_out == nullptr), "psx_refract_f32: Dx_out and Dy_out go together");
-    PSX_REQUIRE(nmat > 0 || phi_in != nullptr, "psx_refract_f32: no phase source (nmat=0 and phi_in=NULL)");
+int psx_refract_multi_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,
+                          int nmat, const double *phi_in, float *const *I_out, float out_scale, int accumulate,
+                          float *Dx_out, float *Dy_out, float *I_mut, int Nx, int Ny, int margin, const double *dscale,
+                          int ndist, double clamp_x, double clamp_y, unsigned *status, void *workspace, void *stream) {
+    PSX_REQUIRE(I_out != nullptr && dscale != nullptr && workspace != nullptr, "psx_refract_multi_f32: null outputs, distances or workspace");
+    PSX_REQUIRE(ndist >= 1 && ndist <= PSX_MAX_DIST, "psx_refract_multi_f32: %d distances, 1..%d supported per call", ndist, PSX_MAX_DIST);
+    PSX_REQUIRE(Nx >= 3 && Ny >= 3, "psx_refract_multi_f32: grid %dx%d too small for the edge_order=2 gradient", Nx, Ny);
+    PSX_REQUIRE((int64_t)Nx * Ny < (1ll << 31), "psx_refract_multi_f32: grid %dx%d exceeds int32 pixel indices", Nx, Ny);
+    PSX_REQUIRE(margin >= 8 && margin <= 4096, "psx_refract_multi_f32: margin %d must be >= 8 (the widest gather halo)", margin);
+    PSX_REQUIRE((Dx_out == nullptr) == (Dy_out == nullptr), "psx_refract_multi_f32: Dx_out and Dy_out go together");
+    PSX_REQUIRE(ndist == 1 || (Dx_out == nullptr && I_mut == nullptr),
+                "psx_refract_multi_f32: displacement maps / input mutation belong to ONE distance (got %d)", ndist);
+    PSX_REQUIRE(nmat > 0 || phi_in != nullptr, "psx_refract_multi_f32: no phase source (nmat=0 and phi_in=NULL)");
     RefractArgs a;
     if (int rc = pack_mats(a.m, T, cphase, catt, nmat)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    a.I_in = I_in; a.I0 = I0; a.phi_in = phi_in; a.I_out = I_out; a.out_scale = out_scale; a.accumulate = accumulate;
+    for (int d = 0; d < PSX_MAX_DIST; ++d) {
+        const int e = d < ndist ? d : 0;
+        PSX_REQUIRE(I_out[e] != nullptr, "psx_refract_multi_f32: null output image %d", e);
+        for (int f = 0; f < e; ++f)
+            PSX_REQUIRE(I_out[f] != I_out[e], "psx_refract_multi_f32: distances %d and %d share an output image", f, e);
+        a.I_out[d] = I_out[e];
+        a.dscale[d] = dscale[e];
+    }
+    a.ndist = ndist;
+    a.I_in = I_in; a.I0 = I0; a.phi_in = phi_in; a.out_scale = out_scale; a.accumulate = accumulate;
     a.Dx_out = Dx_out; a.Dy_out = Dy_out; a.I_mut = I_mut; a.Nx = Nx; a.Ny = Ny; a.margin = margin;
-    a.dscale = dscale; a.clamp_xf = (float)clamp_x; a.clamp_yf = (float)clamp_y; a.status = status; a.stamps = g_stamps;
+    a.clamp_xf = (float)clamp_x; a.clamp_yf = (float)clamp_y; a.status = status; a.stamps = g_stamps;
     if (Dx_out) {
         const size_t padded = sizeof(float) * (size_t)(Nx + 2 * margin) * (size_t)(Ny + 2 * margin);
         PSX_HIP(hipMemsetAsync(Dx_out, 0, padded, st));     // zero margins (RF2:65-66)
@@ -516,6 +552,15 @@ int psx_refract_f32(const float *I_in, float I0, const float *const *T, const do
     }
     return g_refract_geometry ? launch_refract<GeoWide>(a, I_in, phi_in, nmat, workspace, st)
                               : launch_refract<GeoSmall>(a, I_in, phi_in, nmat, workspace, st);
+}
+
+int psx_refract_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,
+                    int nmat, const double *phi_in, float *I_out, float out_scale, int accumulate, float *Dx_out,
+                    float *Dy_out, float *I_mut, int Nx, int Ny, int margin, double dscale, double clamp_x,
+                    double clamp_y, unsigned *status, void *workspace, void *stream) {
+    PSX_REQUIRE(I_out != nullptr, "psx_refract_f32: null output");
+    return psx_refract_multi_f32(I_in, I0, T, cphase, catt, nmat, phi_in, &I_out, out_scale, accumulate, Dx_out, Dy_out,
+                                 I_mut, Nx, Ny, margin, &dscale, 1, clamp_x, clamp_y, status, workspace, stream);
 }
 
 int psx_fastloop_f32(const float *I, const float *Dx, const float *Dy, float *I2, int Nx, int Ny, void *stream) {

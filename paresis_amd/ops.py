@@ -217,6 +217,38 @@ def refract(shape, mats, dscale, clamp, margin=15, I_in=None, I0=1.0, phi_in=Non
     return out, Dx, Dy
 
 
+def refract_multi(shape, mats, dscales, clamp, margin=15, I_in=None, I0=1.0, phi_in=None, outs=None, out_scale=1.0,
+                  add=False):
+    """A propagation-distance batch of K9-K13: len(dscales) refractions of the SAME source (I_in/I0, mats, phi_in) in
+    one launch per kernel (psx_refract_multi_f32); the thickness maps are read once per tile for all distances.
+    Returns the list of images, each identical to refract(..., dscale=dscales[d])[0]."""
+    mats = _mats(mats)
+    Nx, Ny = int(shape[0]), int(shape[1])
+    nd = len(dscales)
+    dev = (I_in if I_in is not None else (phi_in if phi_in is not None else mats.map(0))).device
+    if I_in is not None:
+        _need(I_in, torch.float32, "I_in", (Nx, Ny))
+    if phi_in is not None:
+        _need(phi_in, torch.float64, "phi_in", (Nx, Ny))
+    if outs is None:
+        if add:
+            raise PsxError("add=True needs existing output images")
+        outs = [torch.empty((Nx, Ny), dtype=torch.float32, device=dev) for _ in range(nd)]
+    if len(outs) != nd:
+        raise PsxError("refract_multi: %d output images for %d distances" % (len(outs), nd))
+    for o in outs:
+        _need(o, torch.float32, "I_out", (Nx, Ny))
+    ws = _workspace(dev, lib().psx_refract_multi_workspace_bytes(Nx, Ny, nd))
+    T, cp, ca, n = mats.cargs((Nx, Ny))
+    optr = (c_void_p * nd)(*[o.data_ptr() for o in outs])
+    dsc = (c_double * nd)(*[float(x) for x in dscales])
+    check(lib().psx_refract_multi_f32(_ptr(I_in), c_float(I0), T, cp, ca, n, _ptr(phi_in), optr, c_float(out_scale),
+                                      1 if add else 0, None, None, None, Nx, Ny, int(margin), dsc, nd,
+                                      c_double(clamp[0]), c_double(clamp[1]), _ptr(status_word(dev)), _ptr(ws),
+                                      _stream()), "psx_refract_multi_f32")
+    return outs
+
+
 def darkfield_blur(I2DF, DF, I2, R):
     """Variable-width Gaussian re-splat of fastRefractionDF (refractionFileNumba2.py:168-186): returns
     I2 + sum_s I2DF[s] * gaussian_shape(DF[s]/2) centred on s.  DF in pixels at the target pixels; R = max half-size."""

@@ -225,6 +225,54 @@ def test_refraction_far_rays_and_border_rules(ops):
 
 
 @pytest.mark.parametrize("halo", [4, 8])
+def test_refraction_distance_batch(ops, halo):
+    """psx_refract_multi_f32: the distances of a call share one staged tile; every image equals the oracle's and the
+    one-distance call's (bitwise where no ray is far, i.e. where no global float atomics are involved)."""
+    from paresis_amd._lib import lib
+    g = load("refraction.npz")
+    zs = (0.3, 1.6, 3.6, 7.2, 40.0)          # the last one sends most rays through the far replay
+    try:
+        assert lib().psx_refract_set_halo(halo) == 0
+        for k in range(int(g["n"])):
+            _, E, M, pix = g["%d/params" % k]
+            T = g["%d/T" % k]
+            Nx, Ny = T.shape
+            kk = orc.k_sample(E)
+            geom = np.stack([T, np.full_like(T, 6e-3)])
+            I_ref, phi_ref, _ = orc.set_wave_rt(np.full((Nx, Ny), 7500.0), geom, [6.2e-7, 9.87e-8], [4.0e-9, 4.5e-11], E, 0)
+            m = ops.MaterialStack(dev(geom, torch.float32), cphase=[-kk * 6.2e-7, -kk * 9.87e-8],
+                                  catt=[-2 * kk * 4.0e-9, -2 * kk * 4.5e-11])
+            h = pix * 1e-6
+            dsc = [z / orc.k_refraction(E) / (h * M) / h for z in zs]
+            outs = ops.refract_multi((Nx, Ny), m, dsc, (Nx, Ny), I0=7500.0)
+            for z, d, o in zip(zs, dsc, outs):
+                ref, Dxr, Dyr = orc.fast_refraction(I_ref.copy(), phi_ref, z, E, M, pix)
+                assert relmax(o.cpu().numpy(), ref) < TOL, (k, z)
+                single, _, _ = ops.refract((Nx, Ny), m, d, (Nx, Ny), I0=7500.0)
+                if max(np.abs(Dxr).max(), np.abs(Dyr).max()) < halo - 1:
+                    assert torch.equal(o, single), (k, z)
+                else:
+                    assert relmax(o.cpu().numpy(), single.cpu().numpy()) < 1e-6, (k, z)
+            # explicit (I, phi) source, accumulate + scale into existing images
+            I32 = dev(I_ref, torch.float32)
+            accs = [torch.full((Nx, Ny), 3.0 + i, dtype=torch.float32, device="cuda") for i in range(2)]
+            ops.refract_multi((Nx, Ny), None, dsc[1:3], (Nx, Ny), I_in=I32, phi_in=dev(phi_ref, torch.float64), outs=accs,
+                              out_scale=0.5, add=True)
+            for i, z in enumerate(zs[1:3]):
+                ref, _, _ = orc.fast_refraction(I32.cpu().numpy().astype(np.float64), phi_ref, z, E, M, pix)
+                assert relmax(accs[i].cpu().numpy(), 3.0 + i + 0.5 * ref) < TOL, (k, z)
+        # argument checks: more distances than a call takes, two distances sharing an image
+        from paresis_amd._lib import PsxError
+        with pytest.raises(PsxError):
+            ops.refract_multi((Nx, Ny), m, [1.0] * 9, (Nx, Ny))
+        o = torch.empty((Nx, Ny), dtype=torch.float32, device="cuda")
+        with pytest.raises(PsxError):
+            ops.refract_multi((Nx, Ny), m, [1.0, 2.0], (Nx, Ny), outs=[o, o])
+    finally:
+        lib().psx_refract_set_halo(8)
+
+
+@pytest.mark.parametrize("halo", [4, 8])
 def test_refraction_both_tile_geometries(ops, halo):
     """The gather halo (4 or 8 pixels) is a pure speed knob: every golden case passes with either."""
     from paresis_amd._lib import lib
