@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--engine", default="auto", choices=["auto", "rocfft", "lds"])
-    ap.add_argument("--halo", type=int, default=8, choices=[4, 8], help="refraction gather halo (speed knob)")
+    ap.add_argument("--halo", type=int, default=4, choices=[4, 6, 8], help="refraction gather halo (speed knob)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     ap.add_argument("--overlap", action="store_true",
                     help="issue the step's refractions on a second stream (no gain since the Fresnel call became two long "

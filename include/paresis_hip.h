@@ -86,8 +86,9 @@ int psx_accumulate_f32(float *acc, const float *img, float scale, const float *c
  * workspace         device scratch of psx_refract_workspace_bytes(Nx,Ny) bytes (far-ray list), caller-owned.
  */
 size_t psx_refract_workspace_bytes(int Nx, int Ny);
-/* Gather halo of the tile kernel, 4 or 8 pixels (default 8): rays displaced further than the halo take the slower
- * far-ray replay.  A pure speed knob: results are identical up to float atomics order of the far rays. */
+/* Gather halo of the tile kernel: 4, 6 or 8 pixels (default 4).  A tile gathers every ray of its window (tile + halo)
+ * that lands in it, however long; what remains for the slower far-ray replay are the shares whose source lies outside
+ * the window of the target's tile.  A pure speed knob: results are identical up to the float-atomics order of those. */
 int psx_refract_set_halo(int halo);
 int psx_refract_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,
                     int nmat, const double *phi_in, float *I_out, float out_scale, int accumulate, float *Dx_out,

@@ -20,6 +20,7 @@
 //
 // HBM traffic per pixel: 4*nmat (thickness maps) + 4 (intensity, if given) read, 4 written  (BASELINE.md section 4
 // prices the scatter at 12+4*nmat because the reference zero-initialises and read-modify-writes its output).
+#include <algorithm>
 #include <type_traits>
 
 #include "common.hpp"
@@ -43,6 +44,7 @@ struct Geo {
 using GeoSmall = Geo<56, 56, 4, 1024>;   // 80 KiB of LDS: two workgroups per CU; 1.31 source evaluations per pixel
 // 16 waves per workgroup, 32 per CU: the staging loads of one tile are hidden by more waves that are depositing (512
 // threads: 134 us per 4096^2 launch, 1024: 123 us)
+using GeoMid = Geo<52, 52, 6, 1024>;     // 76 KiB; 1.51 evaluations
 using GeoWide = Geo<48, 48, 8, 1024>;    // 73 KiB: two workgroups per CU (one stages while the other deposits); 1.78 evaluations
 constexpr int FAR_THREADS = 128;
 
@@ -70,6 +72,7 @@ struct RefractArgs {
     unsigned *far_count;     // workspace: [ndist][ntiles] far rays found by each tile at each distance
     FarRay *far_list;        // then [ndist][ntiles][TH*TW] records (a tile can never overflow its slot)
     int tiles_x, tiles_y, tile_cap;
+    int tile_h, tile_w, halo;     // geometry of the gather that ran before the replay
     unsigned long long *stamps;   // diagnostics (psx_debug_stamps): 16 phase timestamps per workgroup
 };
 
@@ -312,8 +315,12 @@ __global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         dy = cly ? 0.f : dy;
         const float fx = floorf(dx), fy = floorf(dy);
         const int ifx = (int)fx, ify = (int)fy;                      // |d| <= clamp: far inside int range (saturates beyond)
+        // rays with floor(D) in [-H, H-1] on both axes are gathered whole by the tiles of their targets; a longer one
+        // goes on this tile's list unless all four of its shares land in this tile's own core (the replay sorts out, share
+        // by share, what the gathers already covered)
         const bool near = (unsigned)(ifx + H) < 2u * H && (unsigned)(ify + H) < 2u * H;
-        const bool far = core && inside && !near && I != 0.f;
+        const bool own = (unsigned)(gr - H + ifx) < (unsigned)(TH - 1) && (unsigned)(gc - H + ify) < (unsigned)(TW - 1);
+        const bool far = core && inside && !near && !own && I != 0.f;
         const float Dxs = dx, Dys = dy, Is = I;
         if (a.Dx_out || a.I_mut) {                                   // wave-uniform: only the class API asks for these
             if (core && inside) {
@@ -330,8 +337,11 @@ __global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             const float wx = dx - fx, wy = dy - fy;                  // exact in float32
             // base target in ring coordinates (+1): the four shares land inside the accumulator iff 0 <= ti <= TH, 0 <= tj <= TW
             const int ti = gr - H + ifx + 1, tj = gc - H + ify + 1;
-            const float Is_ = near ? I * fscale_f : 0.f;             // 2^s scaling is exact
-            const bool hit = near && (unsigned)ti <= (unsigned)TH && (unsigned)tj <= (unsigned)TW;
+            // ANY ray of the window whose base pixel falls in the accumulator is deposited, however long it is: the
+            // share of a ray at target pixel t is gathered exactly when the source lies in the window of t's tile, and
+            // k_refract_far applies the same test to decide what is left for it
+            const float Is_ = I * fscale_f;                          // 2^s scaling is exact
+            const bool hit = (unsigned)ti <= (unsigned)TH && (unsigned)tj <= (unsigned)TW;
             long long *acc = sacc + (hit ? ti * AW + tj : ACC + 2 * lane);   // a miss adds its shares to the trash area
             // float -> fixed point with one native conversion: the unit is 2^-30 of (the power of two above) the
             // largest staged intensity, so |v|*2^s <= 2^30 fits int32; the 64-bit sum has 2^33 of headroom
@@ -417,6 +427,9 @@ __global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a) {
         auto deposit = [&](int pi, int pj, float v) {
             const int ui = pi - a.margin, uj = pj - a.margin;           // crop (RF2:78)
             if (ui >= 0 && ui < a.Nx && uj >= 0 && uj < a.Ny && v != 0.f) {
+                // already deposited by the gather of the target's tile iff the source lies in that tile's window
+                const int r0 = (ui / a.tile_h) * a.tile_h, c0 = (uj / a.tile_w) * a.tile_w;
+                if (i >= r0 - a.halo && i < r0 + a.tile_h + a.halo && j >= c0 - a.halo && j < c0 + a.tile_w + a.halo) return;
                 const float add = a.out_scale * v;
                 if (a.status && !(fabsf(add) <= 3.0e38f)) atomicOr(a.status, PSX_STATUS_NONFINITE);
                 atomicAdd(&I_out[(int64_t)ui * a.Ny + uj], add);
@@ -457,7 +470,7 @@ __global__ __launch_bounds__(256) void k_fastloop(const float *__restrict__ I, c
 
 // Which geometry a call uses.  The wide halo costs ~20 % more source evaluations but keeps rays displaced by up to
 // 8 pixels inside the LDS gather; the far replay (scattered global float atomics, ~0.1 TB/s) is what it avoids.
-int g_refract_geometry = 1;   // 0: GeoSmall (H=4), 1: GeoWide (H=8)
+int g_refract_geometry = 0;   // 0: GeoSmall (H=4), 1: GeoWide (H=8), 2: GeoMid (H=6)
 
 template <class G>
 size_t workspace_for(int Nx, int Ny, int ndist) {
@@ -470,6 +483,7 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
     a.tiles_x = (int)cdiv(a.Nx, G::TH);
     a.tiles_y = (int)cdiv(a.Ny, G::TW);
     a.tile_cap = G::TH * G::TW;
+    a.tile_h = G::TH; a.tile_w = G::TW; a.halo = G::H;
     a.far_count = (unsigned *)workspace;
     a.far_list = (FarRay *)((char *)workspace + 16 * ((sizeof(unsigned) * (size_t)a.tiles_x * a.tiles_y * a.ndist + 15) / 16));
     int rc_launch = 0;
@@ -505,15 +519,16 @@ extern "C" {
 
 size_t psx_refract_multi_workspace_bytes(int Nx, int Ny, int ndist) {
     if (Nx <= 0 || Ny <= 0 || ndist <= 0) return 16;
-    const size_t a = workspace_for<GeoSmall>(Nx, Ny, ndist), b = workspace_for<GeoWide>(Nx, Ny, ndist);
-    return a > b ? a : b;
+    const size_t a = workspace_for<GeoSmall>(Nx, Ny, ndist), b = workspace_for<GeoWide>(Nx, Ny, ndist),
+                 c = workspace_for<GeoMid>(Nx, Ny, ndist);
+    return std::max(a, std::max(b, c));
 }
 
 size_t psx_refract_workspace_bytes(int Nx, int Ny) { return psx_refract_multi_workspace_bytes(Nx, Ny, 1); }
 
 int psx_refract_set_halo(int halo) {
-    PSX_REQUIRE(halo == 4 || halo == 8, "psx_refract_set_halo: halo must be 4 or 8, got %d", halo);
-    g_refract_geometry = halo == 8 ? 1 : 0;
+    PSX_REQUIRE(halo == 4 || halo == 6 || halo == 8, "psx_refract_set_halo: halo must be 4, 6 or 8, got %d", halo);
+    g_refract_geometry = halo == 8 ? 1 : (halo == 6 ? 2 : 0);
     return 0;
 }
 
@@ -550,8 +565,9 @@ int psx_refract_multi_f32(const float *I_in, float I0, const float *const *T, co
         PSX_HIP(hipMemsetAsync(Dx_out, 0, padded, st));     // zero margins (RF2:65-66)
         PSX_HIP(hipMemsetAsync(Dy_out, 0, padded, st));
     }
-    return g_refract_geometry ? launch_refract<GeoWide>(a, I_in, phi_in, nmat, workspace, st)
-                              : launch_refract<GeoSmall>(a, I_in, phi_in, nmat, workspace, st);
+    return g_refract_geometry == 1   ? launch_refract<GeoWide>(a, I_in, phi_in, nmat, workspace, st)
+           : g_refract_geometry == 2 ? launch_refract<GeoMid>(a, I_in, phi_in, nmat, workspace, st)
+                                     : launch_refract<GeoSmall>(a, I_in, phi_in, nmat, workspace, st);
 }
 
 int psx_refract_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,

@@ -224,7 +224,7 @@ def test_refraction_far_rays_and_border_rules(ops):
     assert relmax(out.cpu().numpy(), ref) < TOL
 
 
-@pytest.mark.parametrize("halo", [4, 8])
+@pytest.mark.parametrize("halo", [4, 6, 8])
 def test_refraction_distance_batch(ops, halo):
     """psx_refract_multi_f32: the distances of a call share one staged tile; every image equals the oracle's and the
     one-distance call's (bitwise where no ray is far, i.e. where no global float atomics are involved)."""
@@ -269,10 +269,10 @@ def test_refraction_distance_batch(ops, halo):
         with pytest.raises(PsxError):
             ops.refract_multi((Nx, Ny), m, [1.0, 2.0], (Nx, Ny), outs=[o, o])
     finally:
-        lib().psx_refract_set_halo(8)
+        lib().psx_refract_set_halo(4)
 
 
-@pytest.mark.parametrize("halo", [4, 8])
+@pytest.mark.parametrize("halo", [4, 6, 8])
 def test_refraction_both_tile_geometries(ops, halo):
     """The gather halo (4 or 8 pixels) is a pure speed knob: every golden case passes with either."""
     from paresis_amd._lib import lib
@@ -295,7 +295,7 @@ def test_refraction_both_tile_geometries(ops, halo):
         a2, _, _ = ops.refract(I.shape, None, z / orc.k_refraction(E) / (h * M) / h, I.shape, I_in=I, phi_in=phi)
         assert torch.equal(a1, a2)
     finally:
-        lib().psx_refract_set_halo(8)
+        lib().psx_refract_set_halo(4)
     assert lib().psx_refract_set_halo(5) != 0
 
 

@@ -115,13 +115,13 @@ def test_refraction_flux_and_halos_4096():
     dsc = 5.2 / k_refraction(52.0) / (h * g["M"]) / h
     outs = []
     try:
-        for halo in (4, 8):
+        for halo in (4, 6, 8):
             lib().psx_refract_set_halo(halo)
             out, _, _ = ops.refract((N, N), rt, dsc, (N, N), I0=7500.0)
             outs.append(out)
     finally:
-        lib().psx_refract_set_halo(8)
-    assert float((outs[0] - outs[1]).abs().max() / outs[0].max()) < 2e-6
+        lib().psx_refract_set_halo(4)
+    assert max(float((outs[0] - o).abs().max() / outs[0].max()) for o in outs[1:]) < 2e-6
     I_in, _ = ops.transmit_rt(None, 7500.0, rt, want_phi=False)
     m = 64   # rays near the frame may leave; compare the bulk
     lost = abs(float(outs[1][m:-m, m:-m].sum(dtype=torch.float64) / I_in[m:-m, m:-m].sum(dtype=torch.float64)) - 1)
