@@ -5,8 +5,9 @@
 
 One STEP = one pass of the hot path over one membrane position of the 4096x4096 workload (BASELINE.json configs[2],
 SURVEY.md section 8d): the membrane exit wave (2-material transmission fused into the load) is Fresnel-propagated to the
-4 distances z = {1.6, 3.6, 5.2, 7.2} m (one shared forward transform) and the ray-tracing refraction (2-material
-transmission fused) is run at the same 4 distances: 4 units of "Fresnel propagation + refraction" on N^2 pixels.
+4 distances z = {1.6, 3.6, 5.2, 7.2} m (one call: transmission evaluated once) and the ray-tracing refraction (2-material
+transmission fused) is run at the same 4 distances (one call: each tile's window staged once): 4 units of "Fresnel
+propagation + refraction" on N^2 pixels.
 value = units * N^2 * n_gpus / time  [Mpixel/s], inputs resident in HBM before the timed region.
 
 N GPUs: one process per GPU (torchrun), each rank runs its own membrane position (seed 1000+rank): weak scaling, no
