@@ -46,7 +46,7 @@ using GeoSmall = Geo<56, 56, 4, 1024>;   // 80 KiB of LDS: two workgroups per CU
 // threads: 134 us per 4096^2 launch, 1024: 123 us)
 using GeoMid = Geo<52, 52, 6, 1024>;     // 76 KiB; 1.51 evaluations
 using GeoWide = Geo<48, 48, 8, 1024>;    // 73 KiB: two workgroups per CU (one stages while the other deposits); 1.78 evaluations
-constexpr int FAR_THREADS = 128;
+constexpr int FAR_THREADS = 256;
 
 // a far ray, already evaluated by the tile that owns its source pixel
 struct FarRay {
@@ -72,7 +72,6 @@ struct RefractArgs {
     unsigned *far_count;     // workspace: [ndist][ntiles] far rays found by each tile at each distance
     FarRay *far_list;        // then [ndist][ntiles][TH*TW] records (a tile can never overflow its slot)
     int tiles_x, tiles_y, tile_cap;
-    int tile_h, tile_w, halo;     // geometry of the gather that ran before the replay
     unsigned long long *stamps;   // diagnostics (psx_debug_stamps): 16 phase timestamps per workgroup
 };
 
@@ -264,6 +263,7 @@ __global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     // the thread index): hoisted, it costs 40 VGPRs and the second workgroup of the CU
     int tl = tid;
     asm volatile("" : "+v"(tl));
+    tl &= NTHREADS - 1;                 // tells the compiler the range again (unsigned shifts for the index split)
     const int lane = tl & 63;
     const double dscale = a.dscale[d];
     const double hscale = 0.5 * dscale;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     for (int it = 0; it < ITERS; ++it) {
         const int idx = IN ? it * NTHREADS + tl : min(it * NTHREADS + tl, GR * GC - 1);
         const bool live = IN || it * NTHREADS + tl < GR * GC;
-        const int gr = idx / GC, gc = idx - gr * GC;
+        const int gr = (int)((unsigned)idx / (unsigned)GC), gc = (int)((unsigned)idx % (unsigned)GC);
         const int i = r0 - H + gr, j = c0 - H + gc;
         const bool inside = IN || (live && i >= 0 && i < a.Nx && j >= 0 && j < a.Ny);
         const bool core = gr >= H && gr < H + TH && gc >= H && gc < H + TW;
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         }
         // the displacement is a small number: everything after the float64 differencing runs in float32
         float dx = (float)gx, dy = (float)gy;
-        dx = fabsf(dx) < 1e-12f ? 0.f : dx;                          // RF2:59-60
-        dy = fabsf(dy) < 1e-12f ? 0.f : dy;
+        // RF2:59-60 zeroes |D| < 1e-12.  For the deposit that is a no-op in float32 -- such a ray puts weight 1.0f on its
+        // own pixel and less than 2^-30 of a unit elsewhere either way -- so only the displacement maps apply it.
         const bool clx = fabsf(dx) > a.clamp_xf, cly = fabsf(dy) > a.clamp_yf;   // RF2:61-64
         const bool clamped = clx || cly;
         I = clamped ? 0.f : I;
@@ -327,8 +327,8 @@ __global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 if (a.Dx_out) {
                     const int64_t Py = a.Ny + 2 * a.margin;
                     const int64_t q = (int64_t)(i + a.margin) * Py + (j + a.margin);
-                    a.Dx_out[q] = dx;
-                    a.Dy_out[q] = dy;
+                    a.Dx_out[q] = fabsf(dx) < 1e-12f ? 0.f : dx;
+                    a.Dy_out[q] = fabsf(dy) < 1e-12f ? 0.f : dy;
                 }
                 if (clamped && a.I_mut) a.I_mut[(int64_t)i * a.Ny + j] = 0.f;
             }
@@ -342,7 +342,10 @@ __global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             // k_refract_far applies the same test to decide what is left for it
             const float Is_ = I * fscale_f;                          // 2^s scaling is exact
             const bool hit = (unsigned)ti <= (unsigned)TH && (unsigned)tj <= (unsigned)TW;
-            long long *acc = sacc + (hit ? ti * AW + tj : ACC + 2 * lane);   // a miss adds its shares to the trash area
+            // a miss adds its shares to the trash area; 24-bit multiply + select, not a divergent branch
+            int aidx = (int)__umul24((unsigned)ti, (unsigned)AW) + tj;
+            asm volatile("" : "+v"(aidx));               // computed for every lane, then selected
+            long long *acc = sacc + (hit ? aidx : ACC + 2 * lane);
             // float -> fixed point with one native conversion: the unit is 2^-30 of (the power of two above) the
             // largest staged intensity, so |v|*2^s <= 2^30 fits int32; the 64-bit sum has 2^33 of headroom
             auto dep = [&](int off, float v) __attribute__((always_inline)) {
@@ -409,13 +412,20 @@ __global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 }
 
 // Replay of the far rays with the reference's literal border rules (RF2:235-262) in padded coordinates.
+// One WAVE per list (list = distance * ntiles + tile): a list holds a few dozen records and the kernel is a chain of
+// dependent latencies (count -> records -> atomics), so it wants as many lists in flight per CU as there are wave slots.
+template <class G>
 __global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a) {
-    const unsigned n = a.far_count[blockIdx.x];          // blockIdx.x = distance * ntiles + tile
+    constexpr int TH = G::TH, TW = G::TW, H = G::H;
+    const unsigned nlists = (unsigned)(a.tiles_x * a.tiles_y) * (unsigned)a.ndist;
+    const unsigned lst = blockIdx.x * (FAR_THREADS / 64) + (threadIdx.x >> 6);
+    if (lst >= nlists) return;
+    const unsigned n = a.far_count[lst];
     if (n == 0) return;
-    const FarRay *list = a.far_list + (size_t)blockIdx.x * a.tile_cap;
-    float *const I_out = a.I_out[blockIdx.x / (unsigned)(a.tiles_x * a.tiles_y)];
+    const FarRay *list = a.far_list + (size_t)lst * (TH * TW);
+    float *const I_out = a.I_out[lst / (unsigned)(a.tiles_x * a.tiles_y)];
     const int Px = a.Nx + 2 * a.margin, Py = a.Ny + 2 * a.margin;
-    for (unsigned e = threadIdx.x; e < n; e += blockDim.x) {
+    for (unsigned e = threadIdx.x & 63; e < n; e += 64) {
         const FarRay fr = list[e];
         const int i = fr.src / a.Ny, j = fr.src - i * a.Ny;
         const float I = fr.I;
@@ -428,8 +438,8 @@ __global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a) {
             const int ui = pi - a.margin, uj = pj - a.margin;           // crop (RF2:78)
             if (ui >= 0 && ui < a.Nx && uj >= 0 && uj < a.Ny && v != 0.f) {
                 // already deposited by the gather of the target's tile iff the source lies in that tile's window
-                const int r0 = (ui / a.tile_h) * a.tile_h, c0 = (uj / a.tile_w) * a.tile_w;
-                if (i >= r0 - a.halo && i < r0 + a.tile_h + a.halo && j >= c0 - a.halo && j < c0 + a.tile_w + a.halo) return;
+                const int r0 = (ui / TH) * TH, c0 = (uj / TW) * TW;
+                if (i >= r0 - H && i < r0 + TH + H && j >= c0 - H && j < c0 + TW + H) return;
                 const float add = a.out_scale * v;
                 if (a.status && !(fabsf(add) <= 3.0e38f)) atomicOr(a.status, PSX_STATUS_NONFINITE);
                 atomicAdd(&I_out[(int64_t)ui * a.Ny + uj], add);
@@ -483,7 +493,6 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
     a.tiles_x = (int)cdiv(a.Nx, G::TH);
     a.tiles_y = (int)cdiv(a.Ny, G::TW);
     a.tile_cap = G::TH * G::TW;
-    a.tile_h = G::TH; a.tile_w = G::TW; a.halo = G::H;
     a.far_count = (unsigned *)workspace;
     a.far_list = (FarRay *)((char *)workspace + 16 * ((sizeof(unsigned) * (size_t)a.tiles_x * a.tiles_y * a.ndist + 15) / 16));
     int rc_launch = 0;
@@ -499,7 +508,9 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
         PSX_TIMED("k_refract_near", st,
                   k_refract_near<G, NM, HI, HP><<<a.tiles_x * a.tiles_y, G::NT, G::LDS, st>>>(a));
         if (int rc = launch_check("k_refract_near")) return rc;
-        PSX_TIMED("k_refract_far", st, k_refract_far<<<a.tiles_x * a.tiles_y * a.ndist, FAR_THREADS, 0, st>>>(a));
+        const int nlists = a.tiles_x * a.tiles_y * a.ndist;
+        PSX_TIMED("k_refract_far", st,
+                  k_refract_far<G><<<(nlists + FAR_THREADS / 64 - 1) / (FAR_THREADS / 64), FAR_THREADS, 0, st>>>(a));
         return 0;
     };
     PSX_DISPATCH_NMAT(nmat, {
