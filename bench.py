@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)   # former default switch, accepted and ignored
     ap.add_argument("--refract-per-distance", action="store_true",
                     help="one refraction call per distance instead of the distance batch (for comparison)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI, the real thing) or gloo (rehearsal of "
+                         "the multi-rank control flow with several ranks on ONE GPU; collectives then go through host copies)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -64,7 +67,7 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (a.gpus, a.gpus))
     torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
     if world > 1:
-        td.init_process_group(backend="nccl", rank=rank, world_size=world)
+        td.init_process_group(backend=a.backend, rank=rank, world_size=world)
     dev = torch.device("cuda", torch.cuda.current_device())
     lib = _lib.lib()
     assert lib.psx_device_ok() == 1, lib.psx_last_error()
@@ -154,7 +157,7 @@ def main():
             kern[nm] = (int(cnt), float(tot))
         lib.psx_profile_enable(0)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -163,8 +166,9 @@ def main():
     if world > 1:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        bucket = [torch.empty_like(fres[1]) for _ in range(world)] if rank == 0 else None
-        td.gather(fres[1], bucket, dst=0)
+        img = fres[1] if a.backend == "nccl" else fres[1].cpu()
+        bucket = [torch.empty_like(img) for _ in range(world)] if rank == 0 else None
+        td.gather(img, bucket, dst=0)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t1) * 1e3
 

@@ -95,6 +95,20 @@ class AnalyticalSample(Sample):
             if fn == "CreateSampleSphere":
                 self.myGeometry, self.geom_parameters = geometry.sphere(dimX, dimY, studyPixelSize, self.myRadius)
                 return
+            if fn == "CreateYourSampleGeometry":                                # SAM:196-203
+                self.myGeometry, self.geom_parameters = geometry.your_sample_geometry(dimX, dimY)
+                return
+            if fn == "CreateSampleSpheresInCylinder":                           # SAM:204-206
+                self.myGeometry, self.geom_parameters = geometry.spheres_in_cylinder(dimX, dimY, studyPixelSize)
+                return
+            if fn == "CreateSampleSpheresInParallelepiped":                     # SAM:207-209
+                self.myGeometry, self.geom_parameters = geometry.spheres_in_parallelepiped(dimX, dimY, studyPixelSize)
+                return
+            if fn == "loadSampleGeometryFromImages":                            # SAM:222-225
+                geom, self.geom_parameters = geometry.load_sample_geometry_from_images(self.myGeometryFolder, dimX, dimY,
+                                                                                       studyPixelSize)
+                self.myGeometry = np.array(geom)
+                return
         if self.myType == "membrane":
             if fn == "getMembraneFromFile":                                   # SAM:230-233
                 from .Samples.getMembraneFromFile import getMembraneFromFile

@@ -638,7 +638,37 @@ def gold_frontend_chain():
     save("frontend_chain.npz", d)
 
 
+def gold_geometry():
+    """Analytic sample generators of Samples/createSampGeom.py (the deterministic ones that need no imutils):
+    CreateSampleSphere (:15-53, radius from xmlFiles/Samples.xml), CreateSampleSpheresInCylinder (:108-171) and
+    CreateYourSampleGeometry (:289-318)."""
+    from Samples import createSampGeom as CSG
+    d = {}
+    geom, par = CSG.CreateSampleSphere("PMMA_sphere", 96, 130, 25.0)       # radius 1000 um = 40 px
+    d["sphere/args"] = np.array([96, 130, 25.0])
+    d["sphere/geom"] = geom
+    d["sphere/radius_um"] = np.array(par["Sphere_radius"][0])
+    geom, par = CSG.CreateSampleSpheresInCylinder("spheres_in_cylinder", 210, 120, 20.0)
+    d["sic/args"] = np.array([210, 120, 20.0])
+    d["sic/geom"] = geom
+    d["sic/params"] = np.array([par["Spheres_radius"][0], par["Cylinder_radius"][0], par["Position_Sphere_1"][0],
+                                par["Position_Sphere_2"][0]])
+    geom, par = CSG.CreateSampleSpheresInCylinder("spheres_in_cylinder", 561, 333, 7.7)    # odd sizes, fractional radius
+    d["sic2/args"] = np.array([561, 333, 7.7])
+    d["sic2/geom"] = geom.astype(np.float32)
+    geom, par = CSG.CreateYourSampleGeometry("x", 33, 47, 1.0)
+    d["your/args"] = np.array([33, 47, 1.0])
+    d["your/geom"] = geom
+    d["your/thickness"] = np.array(par["geometry thickness"][0])
+    save("geometry.npz", d)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                    # regenerate only the named groups:  make_golden.py geometry membrane
+        for g in sys.argv[1:]:
+            globals()["gold_" + g]()
+        os.chdir(_cwd)
+        sys.exit(0)
     gold_scalars()
     gold_transmission()
     gold_fresnel()
@@ -649,4 +679,5 @@ if __name__ == "__main__":
     gold_darkfield()
     gold_frontend()
     gold_frontend_chain()
+    gold_geometry()
     os.chdir(_cwd)

@@ -186,3 +186,56 @@ def test_polychromatic_frontend_host_logic():
                                 "xlsRows": list(zip(g["xls/%d/E" % c], g["xls/%d/fluence" % c]))})
         src.setMySpectrum()
         assert np.array_equal(np.array(src.mySpectrum), g["xls/%d/out" % c]), c
+
+
+def test_sample_generators_match_the_reference(tmp_path):
+    """Samples/createSampGeom.py restated (paresis_amd/geometry.py) against arrays the reference produced
+    (tests/golden/geometry.npz, written by tests/golden/make_golden.py geometry), plus the dispatch of
+    AnalyticalSample.getMyGeometry (Sample.py:163-245) for the generators the XML files name."""
+    from paresis_amd import geometry
+    from paresis_amd.Sample import AnalyticalSample
+    from paresis_amd.InputOutput.pagailleIO import save_image
+    g = load("geometry.npz")
+    dx, dy, pix = g["sphere/args"]
+    geom, par = geometry.sphere(int(dx), int(dy), float(pix), float(g["sphere/radius_um"]))
+    assert relmax(geom, g["sphere/geom"]) < 1e-7                       # float32 maps against the float64 reference
+    assert par["Sphere_radius"] == (1000.0, "um")
+    for tag, tol in (("sic", 1e-15), ("sic2", 1e-7)):                  # sic2 was stored as float32
+        dx, dy, pix = g[tag + "/args"]
+        geom, par = geometry.spheres_in_cylinder(int(dx), int(dy), float(pix))
+        assert geom.shape == g[tag + "/geom"].shape and relmax(geom, g[tag + "/geom"]) <= tol, tag
+    assert np.allclose([par[k][0] for k in ("Spheres_radius", "Cylinder_radius")], [500.0, 1000.0])
+    dx, dy, pix = g["sic/args"]
+    _, par = geometry.spheres_in_cylinder(int(dx), int(dy), float(pix))
+    assert np.array_equal([par["Spheres_radius"][0], par["Cylinder_radius"][0], par["Position_Sphere_1"][0],
+                           par["Position_Sphere_2"][0]], g["sic/params"])
+    with pytest.raises(Exception, match="too big"):
+        geometry.spheres_in_cylinder(40, 40, 20.0)
+    geom, par = geometry.your_sample_geometry(33, 47)
+    assert np.array_equal(geom, g["your/geom"]) and par["geometry thickness"][0] == float(g["your/thickness"])
+    # the tilted slab has no golden (the reference rotates with imutils/cv2, absent here): shape and mass only
+    geom, par = geometry.spheres_in_parallelepiped(300, 300, 20.0)
+    assert geom.shape == (3, 300, 300) and par["Parallelepipede_size"] == (1000.0, "um")
+    vol = geom.sum() * (20e-6) ** 2          # m^3: section ~ 3.2 R^2 (R = 1 mm) times the 6 mm field of view / cos 15
+    assert 1.5e-8 < vol < 3.5e-8
+    sph = (geom[0].sum() + geom[1].sum()) * (20e-6) ** 2
+    assert abs(sph / (2 * 4 / 3 * np.pi * 0.5e-3 ** 3) - 1) < 0.02          # the two spheres keep their volume under rotation
+    # image-folder loader + dispatch through getMyGeometry
+    maps = np.random.default_rng(0).uniform(0, 1e-4, (2, 20, 30)).astype(np.float32)
+    save_image(maps[1], str(tmp_path / "b_second.tif"))
+    save_image(maps[0], str(tmp_path / "a_first.edf"))
+    s = AnalyticalSample.__new__(AnalyticalSample)
+    s.myType, s._dev_geometry, s._dev_src = "sample_of_interest", None, None
+    s.myGeometryFunction, s.myGeometryFolder = "loadSampleGeometryFromImages", str(tmp_path)
+    s.getMyGeometry((20, 30), 1.0, 1)
+    assert s.myGeometry.shape == (2, 20, 30) and np.array_equal(s.myGeometry[0], maps[0]) and np.array_equal(s.myGeometry[1], maps[1])
+    s.myGeometryFolder = str(tmp_path / "missing")
+    with pytest.raises(Exception, match="does not exist"):
+        s.getMyGeometry((20, 30), 1.0, 1)
+    for fn, nmat in (("CreateSampleSpheresInCylinder", 3), ("CreateYourSampleGeometry", 1), ("CreateSampleSpheresInParallelepiped", 3)):
+        s.myGeometryFunction = fn
+        s.getMyGeometry((210, 120), 20.0, 1)
+        assert np.shape(s.myGeometry) == (nmat, 210, 120), fn
+    s.myGeometryFunction = "nope"
+    with pytest.raises(ValueError, match="Could not define sample geometry"):
+        s.getMyGeometry((20, 30), 1.0, 1)
