@@ -56,6 +56,8 @@ __host__ __device__ constexpr int phys(int p) { return p + (p >> 5); }   // one 
 
 struct LineArgs {
     int n_dist;             // distances merged into this launch: work item w = d * ngroups + g  (d-th table / buffers, group g)
+    int dist_inner;         // 1: every distance reads the SAME source (pass 1): a workgroup takes the n_dist work items of a
+                            // line group in consecutive rounds and its loaders fetch the group once, spreading it n_dist times
     const float2 *src[PSX_MAX_DIST];        // input wave of each distance
     int N, nlines, margin, P, L;
     int64_t in_si, in_sl;   // sample i of line l is element i*in_si + l*in_sl of src ...
@@ -118,11 +120,24 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     // ---- line groups of this workgroup: XCD x = blockIdx % 8 owns a contiguous chunk of groups (its 32 CUs then read
     // neighbouring columns at the same time: the 128-byte lines of the strided source are shared in that XCD's L2)
     const int ngroups = (a.nlines + LINES - 1) / LINES;
-    const int nwork = ngroups * a.n_dist;      // all distances of a call in ONE launch: one prologue, one tail
+    const int nwork = a.dist_inner ? ngroups : ngroups * a.n_dist;   // all distances of a call in ONE launch: one prologue, one tail
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     const int cq = nwork >> 3, cr = nwork & 7;
     const int cstart = xcd * cq + (xcd < cr ? xcd : cr), clen = cq + (xcd < cr ? 1 : 0);
-    const int nj = slot < clen ? (clen - slot + nslot - 1) / nslot : 0;   // work items cstart + slot + j*nslot, j < nj
+    const int nunits = slot < clen ? (clen - slot + nslot - 1) / nslot : 0;   // units cstart + slot + u*nslot, u < nunits
+    const int nj = a.dist_inner ? nunits * a.n_dist : nunits;                  // rounds of this workgroup
+    // round j -> (distance, line group)
+    auto item = [&](int j, int &d, int &g) __attribute__((always_inline)) {
+        if (a.dist_inner) {
+            const int u = j / a.n_dist;
+            d = j - u * a.n_dist;
+            g = cstart + slot + u * nslot;
+        } else {
+            const int w = cstart + slot + j * nslot;
+            d = w / ngroups;
+            g = w - d * ngroups;
+        }
+    };
 
     // Stage B's twiddles w_S1^{n q} (n < R3, q < 24: 3 KiB) live in LDS behind the line buffers, rows padded to 25 so that
     // the 16 rows start on 16 different bank pairs: a ds_read_b64 costs 2 LDS cycles where the 16-byte global loads of
@@ -179,8 +194,10 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         const int64_t pstep = (int64_t)STEP * (a.in_blocked ? (int64_t)IB : a.in_si);
 
         float2 xs[NLD], xm = make_float2(0.f, 0.f);
-        auto fetch = [&](int w) __attribute__((always_inline)) {        // issue every load of work item w, wait for none
-            const int d = w / ngroups, g = w - d * ngroups;
+        auto fetch = [&](int j) __attribute__((always_inline)) {        // issue every load of round j, wait for none
+            int d, g;
+            item(j, d, g);
+            if (a.dist_inner && d != 0) return;                          // same line group as the round before: registers keep it
             const float2 *src = a.src[d];
             const int l0 = g * LINES;
             const bool line_ok = l0 + line < a.nlines;
@@ -197,8 +214,9 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                                               : (int64_t)im * a.in_si + (int64_t)(l0 + lm) * a.in_sl;
             xm = src[(im >= 0 && l0 + lm < a.nlines) ? pixm : (int64_t)0];
         };
-        auto spread = [&](int w) __attribute__((always_inline)) {       // periodic / mirrored images -> LDS
-            const int d = w / ngroups, g = w - d * ngroups;
+        auto spread = [&](int j) __attribute__((always_inline)) {       // periodic / mirrored images -> LDS
+            int d, g;
+            item(j, d, g);
             const int l0 = g * LINES;
             const bool line_ok = l0 + line < a.nlines;
             for (int jz = a.L + lt; jz < M; jz += TL) {                  // zeros in [L, M) of every line (no division:
@@ -232,8 +250,8 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         };
 
         if (nj > 0) {
-            fetch(cstart + slot);
-            spread(cstart + slot);
+            fetch(0);
+            spread(0);
         }
         lds_barrier();                                   // (0) first group is in LDS
         for (int j = 0; j < nj; ++j) {
@@ -242,7 +260,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             // Issued after barrier (1), not before: issuing strided loads stalls for ~5 us (the texture path hands out one
             // 128-byte line per lane pair) and forward stage A lasts only 3 us -- the engine would wait for the loaders.
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 16] = wall_clock64();
-            if (more) fetch(cstart + slot + (j + 1) * nslot);
+            if (more) fetch(j + 1);
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 17] = wall_clock64();
             lds_barrier();                               // (2) engine: wave-private stages done
             lds_barrier();                               // (3) engine: inverse stage A holds all of LDS in registers
@@ -251,7 +269,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             // otherwise get every fourth issue slot).  The fetch keeps normal priority: hurrying the strided loads only
             // queues the engine's twiddle loads behind them.
             __builtin_amdgcn_s_setprio(3);
-            if (more) spread(cstart + slot + (j + 1) * nslot);
+            if (more) spread(j + 1);
             __builtin_amdgcn_s_setprio(0);
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 19] = wall_clock64();
             lds_barrier();                               // (4) next group is in LDS
@@ -294,8 +312,9 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     lds_barrier();                                       // (0) first group is in LDS
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 1] = wall_clock64();
     for (int j = 0; j < nj; ++j) {
-        const int w = cstart + slot + j * nslot, d = w / ngroups;
-        const int l0 = (w - d * ngroups) * LINES;
+        int d, g;
+        item(j, d, g);
+        const int l0 = g * LINES;
         PSX_STAMP(2);
 
         // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}
@@ -815,7 +834,7 @@ static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
         PSX_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
         if (n_cu < 8) n_cu = 8;
     }
-    const int nwork = ((la.nlines + LINES - 1) / LINES) * la.n_dist;
+    const int nwork = ((la.nlines + LINES - 1) / LINES) * (la.dist_inner ? 1 : la.n_dist);
     int nslot = n_cu / 8;
     if (nslot > (nwork + 7) / 8) nslot = (nwork + 7) / 8;
     PSX_TIMED(name, st, k_fresnel_lines<R3, CONTIG><<<8 * nslot, T, lds_bytes, st>>>(la));
@@ -878,6 +897,8 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         la.twA = e->ax[0].twA; la.twB = e->ax[0].twB;
         la.accumulate = 0; la.stamps = stamp_pass1 ? g_stamps : nullptr;
         la.n_dist = nnz;
+        static const bool no_inner = getenv("PSX_NO_DIST_INNER") != nullptr;   // diagnostics: A/B of the work order
+        la.dist_inner = no_inner ? 0 : 1;   // one source for all distances
         for (int i = 0; i < PSX_MAX_DIST; ++i) {
             const int k = i < nnz ? i : 0;
             la.src[i] = e->pre;
@@ -903,6 +924,7 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         lb.twA = e->ax[1].twA; lb.twB = e->ax[1].twB;
         lb.accumulate = a.accumulate; lb.stamps = stamp_pass1 ? nullptr : g_stamps;
         lb.n_dist = nnz;
+        lb.dist_inner = 0;
         for (int i = 0; i < PSX_MAX_DIST; ++i) {
             const int k = i < nnz ? i : 0, d = nz[k];
             lb.src[i] = e->inter + (size_t)k * e->inter_elems;
