@@ -2,11 +2,16 @@
 //
 // Replaces Detector.detection (Detector.py:79-119), resize (:185-198) and create_gaussian_shape (:201-220).
 // reflect-pad(15*ov) -> Gaussian source blur (zero-extended 'same' convolution) -> ov x ov block SUM -> Gaussian PSF
-// -> crop(15) is a chain of linear, separable operators, so per axis it collapses to ONE banded matrix
-// C [n x N] (n detector pixels, N study pixels).  The plan composes C_x and C_y on the host in float64 by pushing unit
-// vectors back through the chain (so reflect padding, zero extension at the padded border, banker's rounding of the
-// kernel support and the bin-SUM are reproduced exactly), and the image is formed as  out = C_x * img * C_y^T  in two
-// passes: along the contiguous axis first (shrinks the data by ov), then along axis 0.
+// -> crop(15) is a chain of linear, separable operators, so per axis it is a banded matrix.  The operators are composed
+// on the host in float64 by pushing unit vectors back through the chain (so reflect padding, zero extension at the padded
+// border, banker's rounding of the kernel support and the bin-SUM are reproduced exactly) and applied in two STAGES:
+//   front  F [npad x N]: pad + source blur + bin  -- band width ov + 2 r_src, applied at study resolution, where the bytes are;
+//   back   B [n x npad]: PSF + crop               -- band width 2 r_psf + 1, applied at detector resolution (ov^2 fewer pixels).
+// (One composite [n x N] matrix per axis, as first built, has width (2 r_psf + 1) ov + 2 r_src: 36 taps for the 16384^2 ->
+// 4096^2 case instead of 4 + 9, and every tap was a strided, uncoalesced load: 6.3 ms where the image streams in 0.3.)
+// out = B_x F_x img F_y^T B_y^T in four passes: F_y along the contiguous axis first (the only pass that touches the
+// full-resolution image), F_x, then the two small PSF passes.  Without a PSF the front operator carries the crop and the
+// back passes are skipped.
 #include <algorithm>
 #include <vector>
 
@@ -14,14 +19,23 @@
 
 using namespace psx;
 
+// one banded operator: output o = sum_{k<W} w[o][k] * in[start[o] + k]
+struct BandOp {
+    int n_out = 0, n_in = 0, W = 0;
+    int span = 0;          // longest input span of 256 consecutive outputs (LDS staging of the contiguous pass)
+    int *start = nullptr;  // [n_out] device
+    int2 *blk = nullptr;   // [ceil(n_out/256)] device: input range [x, y) the outputs of a 256-block read (start[] is not
+                           // monotonic where the reflect pad folds the axis back)
+    float *w = nullptr;    // [n_out][W] device (row-major: the axis-0 pass reads a row with scalar loads)
+    float *wT = nullptr;   // [W][n_out] device (transposed: the contiguous pass reads it coalesced)
+};
+
 struct psx_detector_plan {
     int Nx, Ny, ov, nx, ny, margin;
-    int Wx, Wy;          // band widths
-    int *sx = nullptr;   // [nx] first study row of output row r
-    int *sy = nullptr;   // [ny]
-    float *wx = nullptr; // [nx][Wx]
-    float *wy = nullptr; // [ny][Wy]
-    float *tmp = nullptr;  // [Nx][ny]
+    BandOp fx, fy, bx, by;   // front / back operator of each axis; back.n_out == 0 when there is no PSF
+    float *t1 = nullptr;     // [Nx][fy.n_out]
+    float *t2 = nullptr;     // [fx.n_out][fy.n_out]   (only with a PSF)
+    float *t3 = nullptr;     // [fx.n_out][ny]         (only with a PSF)
     size_t bytes = 0;
 };
 
@@ -46,8 +60,12 @@ std::vector<double> gauss1d(double sigma, int &radius) {
 }
 
 // Composite operator of one axis: row r of C as a window [lo, hi] over the N study pixels, then a common band width.
+// stage: STAGE_ALL = the whole chain [n x N]; STAGE_FRONT = pad + blur + bin [npad x N] (rows = binned, uncropped
+// indices); STAGE_BACK = PSF + crop [n x npad].
+enum { STAGE_ALL = 0, STAGE_FRONT = 1, STAGE_BACK = 2 };
+
 void compose_axis(int N, int ov, int n, int margin, double sigma_src, double sigma_psf, std::vector<int> &start,
-                  std::vector<float> &weights, int &W) {
+                  std::vector<float> &weights, int &W, int stage = STAGE_ALL) {
     const int Npad = N + 2 * margin * ov;   // DET:93
     const int npad = n + 2 * margin;        // DET:103
     const int s = Npad / npad;              // DET:192 (the axis-0 factor is used on both axes; equal for ov grids)
@@ -55,14 +73,29 @@ void compose_axis(int N, int ov, int n, int margin, double sigma_src, double sig
     std::vector<double> g1, g2;
     if (sigma_src != 0.0) g1 = gauss1d(sigma_src, r1);
     if (sigma_psf != 0.0) g2 = gauss1d(sigma_psf, r2);
-    std::vector<std::vector<double>> rows(n);
-    std::vector<int> lo(n, 0);
+    if (stage == STAGE_BACK) {              // rows of PSF + crop over the binned, uncropped axis
+        W = 2 * r2 + 1;
+        start.assign(n, 0);
+        weights.assign((size_t)n * W, 0.f);
+        for (int r = 0; r < n; ++r) {
+            const int p = r + margin;
+            const int qa = std::max(0, p - r2), qb = std::min(npad - 1, p + r2);
+            const int st = std::max(0, std::min(qa, npad - W));
+            start[r] = st;
+            for (int q = qa; q <= qb; ++q) weights[(size_t)r * W + (q - st)] = (float)(g2.empty() ? 1.0 : g2[r2 + (p - q)]);
+        }
+        return;
+    }
+    const int nrows = stage == STAGE_FRONT ? npad : n;
+    std::vector<std::vector<double>> rows(nrows);
+    std::vector<int> lo(nrows, 0);
     std::vector<double> wb(npad, 0.0), wp(Npad, 0.0), wq(Npad, 0.0), acc(N, 0.0);
-    for (int r = 0; r < n; ++r) {
+    for (int r = 0; r < nrows; ++r) {
         // crop^T: unit at binned index r+margin (DET:118); PSF^T (DET:106-108, zero-extended 'same')
-        const int p = r + margin;
-        const int qa = std::max(0, p - r2), qb = std::min(npad - 1, p + r2);
-        for (int q = qa; q <= qb; ++q) wb[q] = g2.empty() ? 1.0 : g2[r2 + (p - q)];
+        const int p = stage == STAGE_FRONT ? r : r + margin;
+        const int rr2 = stage == STAGE_FRONT ? 0 : r2;
+        const int qa = std::max(0, p - rr2), qb = std::min(npad - 1, p + rr2);
+        for (int q = qa; q <= qb; ++q) wb[q] = (g2.empty() || stage == STAGE_FRONT) ? 1.0 : g2[r2 + (p - q)];
         // bin^T: binned q gathers padded study pixels [q*s, q*s+s) (DET:194-196; numpy slices clip at the array end)
         const int ka = qa * s, kb = std::min(qb * s + s, Npad) - 1;
         for (int q = qa; q <= qb; ++q)
@@ -101,45 +134,163 @@ void compose_axis(int N, int ov, int n, int margin, double sigma_src, double sig
         for (int l = la; l <= lb; ++l) wq[l] = 0.0;
     }
     W = 1;
-    for (int r = 0; r < n; ++r) W = std::max(W, (int)rows[r].size());
-    start.assign(n, 0);
-    weights.assign((size_t)n * W, 0.f);
-    for (int r = 0; r < n; ++r) {
+    for (int r = 0; r < nrows; ++r) W = std::max(W, (int)rows[r].size());
+    start.assign(nrows, 0);
+    weights.assign((size_t)nrows * W, 0.f);
+    for (int r = 0; r < nrows; ++r) {
         const int st = std::max(0, std::min(lo[r], N - W));
         start[r] = st;
         for (size_t w = 0; w < rows[r].size(); ++w) weights[(size_t)r * W + (lo[r] - st) + w] = (float)rows[r][w];
     }
 }
 
-// pass 1: tmp[i][c] = sum_w wy[c][w] * img[i][sy[c]+w]      (contiguous axis; ny outputs per row)
-__global__ __launch_bounds__(256) void k_detect_cols(const float *__restrict__ img, float *__restrict__ tmp,
-                                                     const int *__restrict__ sy, const float *__restrict__ wy, int Nx,
-                                                     int Ny, int ny, int Wy) {
-    const int64_t n = (int64_t)Nx * ny;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
-        const int i = (int)(q / ny), c = (int)(q - (int64_t)i * ny);
-        const float *row = img + (int64_t)i * Ny + sy[c];
-        const float *w = wy + (int64_t)c * Wy;
-        const int lim = min(Wy, Ny - sy[c]);
-        float acc = 0.f;
-        for (int k = 0; k < lim; ++k) acc = fmaf(w[k], row[k], acc);
-        tmp[q] = acc;
+// Banded operator along the CONTIGUOUS axis: out[i][c] = sum_k wT[k][c] * in[i][start[c] + k].
+// A workgroup owns 256 consecutive outputs c and a strip of rows.  The weights of output c sit in registers (WMAX of
+// them, the band is narrower than that); the input span the 256 outputs need -- start[c0] .. start[c0+255] + W, about
+// 256 ov + W floats -- is staged row by row (RG rows per round) in LDS with coalesced loads, so HBM sees every input once.
+template <int WMAX, int RG>
+__global__ __launch_bounds__(256) void k_band_cols(const float *__restrict__ in, float *__restrict__ out,
+                                                   const int *__restrict__ start, const int2 *__restrict__ blk,
+                                                   const float *__restrict__ wT, int R, int Cin, int Cout, int W,
+                                                   int span_ld, int rows_per_block) {
+    extern __shared__ float sdet[];                       // [RG][span_ld]
+    const int c0 = blockIdx.x * 256, c = c0 + threadIdx.x;
+    const bool live = c < Cout;
+    const int cl = live ? c : Cout - 1;
+    const int s0 = blk[blockIdx.x].x, s1 = blk[blockIdx.x].y;             // input range of this block's outputs
+    const int span = s1 - s0, valid = min(s1, Cin) - s0;                  // a band wider than the axis reads zeros beyond it
+    const int off = start[cl] - s0;
+    float w[WMAX];
+#pragma unroll
+    for (int k = 0; k < WMAX; ++k) w[k] = k < W ? wT[(int64_t)k * Cout + cl] : 0.f;
+    const int r_begin = blockIdx.y * rows_per_block, r_end = min(R, r_begin + rows_per_block);
+    for (int i0 = r_begin; i0 < r_end; i0 += RG) {
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < RG; ++rr) {
+            const int i = min(i0 + rr, R - 1);
+            const float *row = in + (int64_t)i * Cin + s0;
+            for (int t = threadIdx.x; t < span; t += 256) sdet[rr * span_ld + t] = t < valid ? row[t] : 0.f;
+        }
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int rr = 0; rr < RG; ++rr) {
+                if (i0 + rr < r_end) {
+                    const float *x = sdet + rr * span_ld + off;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < WMAX; ++k)
+                        if (k < W) acc = fmaf(w[k], x[k], acc);     // off + k < span for every k < W by construction
+                    out[(int64_t)(i0 + rr) * Cout + c] = acc;
+                }
+            }
+        }
     }
 }
 
-// pass 2: out[r][c] = sum_w wx[r][w] * tmp[sx[r]+w][c]
-__global__ __launch_bounds__(256) void k_detect_rows(const float *__restrict__ tmp, float *__restrict__ out,
-                                                     const int *__restrict__ sx, const float *__restrict__ wx, int Nx,
-                                                     int nx, int ny, int Wx) {
-    const int64_t n = (int64_t)nx * ny;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
-        const int r = (int)(q / ny), c = (int)(q - (int64_t)r * ny);
-        const float *col = tmp + (int64_t)sx[r] * ny + c;
-        const float *w = wx + (int64_t)r * Wx;
-        const int lim = min(Wx, Nx - sx[r]);
-        float acc = 0.f;
-        for (int k = 0; k < lim; ++k) acc = fmaf(w[k], col[(int64_t)k * ny], acc);
-        out[q] = acc;
+// The same with 16-byte staging loads, for rows that are 16-byte aligned (Cin % 4 == 0, aligned base) and spans of at most
+// 64 * MIT float4 per row: wave v of the workgroup stages rows v, v+4 of the round; all of a thread's loads (2 rows x MIT
+// float4) are issued before the first LDS write, so ~10 KB per wave are in flight.
+template <int WMAX, int MIT>
+__global__ __launch_bounds__(256) void k_band_cols_v4(const float *__restrict__ in, float *__restrict__ out,
+                                                      const int *__restrict__ start, const int2 *__restrict__ blk,
+                                                      const float *__restrict__ wT, int R, int Cin, int Cout, int W,
+                                                      int span_ld, int rows_per_block) {
+    constexpr int RG = 8;
+    extern __shared__ __attribute__((aligned(16))) float sdet[];     // [RG][span_ld], span_ld % 4 == 0
+    const int c0 = blockIdx.x * 256, c = c0 + threadIdx.x;
+    const bool live = c < Cout;
+    const int cl = live ? c : Cout - 1;
+    const int s0 = blk[blockIdx.x].x & ~3, s1 = blk[blockIdx.x].y;
+    const int n4 = (s1 - s0 + 3) >> 2;                                 // float4 per row (<= 64 * MIT, checked by the host)
+    const int off = start[cl] - s0;
+    float w[WMAX];
+#pragma unroll
+    for (int k = 0; k < WMAX; ++k) w[k] = k < W ? wT[(int64_t)k * Cout + cl] : 0.f;
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int r_begin = blockIdx.y * rows_per_block, r_end = min(R, r_begin + rows_per_block);
+    for (int i0 = r_begin; i0 < r_end; i0 += RG) {
+        float4 v[2][MIT];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = min(i0 + wv + 4 * h, R - 1);
+            const float4 *row = reinterpret_cast<const float4 *>(in + (int64_t)i * Cin + s0);
+#pragma unroll
+            for (int m = 0; m < MIT; ++m) {
+                const int t4 = ln + 64 * m;
+                // a float4 of an aligned row lies wholly inside or wholly outside it; beyond the row: zeros (a band wider than the axis)
+                v[h][m] = (t4 < n4 && s0 + 4 * t4 < Cin) ? row[t4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        __syncthreads();                                               // the previous round's reads are done
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int m = 0; m < MIT; ++m) {
+                const int t4 = ln + 64 * m;
+                if (t4 < n4) *reinterpret_cast<float4 *>(sdet + (wv + 4 * h) * span_ld + 4 * t4) = v[h][m];
+            }
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int rr = 0; rr < RG; ++rr) {
+                if (i0 + rr < r_end) {
+                    const float *x = sdet + rr * span_ld + off;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < WMAX; ++k)
+                        if (k < W) acc = fmaf(w[k], x[k], acc);
+                    out[(int64_t)(i0 + rr) * Cout + c] = acc;
+                }
+            }
+        }
+    }
+}
+
+// Banded operator along axis 0: out[r][c] = sum_k w[r][k] * in[start[r] + k][c].  Lanes run along c (coalesced), a
+// workgroup takes 256 columns and a strip of output rows; the weights of a row are wave-uniform (scalar loads).
+// RB output rows are formed together: their RB x W loads are independent and issued back to back (the narrow front
+// operator would otherwise have W = ov loads in flight per thread).  WMAX = 0: any band width, one row at a time.
+template <int WMAX, int RB>
+__global__ __launch_bounds__(256) void k_band_rows(const float *__restrict__ in, float *__restrict__ out,
+                                                   const int *__restrict__ start, const float *__restrict__ w, int Rin,
+                                                   int Rout, int C, int W, int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r_begin = blockIdx.y * rows_per_block, r_end = min(Rout, r_begin + rows_per_block);
+    if constexpr (WMAX == 0) {
+        for (int r = r_begin; r < r_end; ++r) {
+            const int st = start[r];
+            const float *wr = w + (int64_t)r * W;
+            const float *col = in + (int64_t)st * C + c;
+            const int lim = min(W, Rin - st);
+            float acc = 0.f;
+            for (int k = 0; k < lim; ++k) acc = fmaf(wr[k], col[(int64_t)k * C], acc);
+            out[(int64_t)r * C + c] = acc;
+        }
+    } else {
+        for (int r0 = r_begin; r0 < r_end; r0 += RB) {
+            float x[RB][WMAX];
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const int st = start[min(r0 + b, Rout - 1)];
+#pragma unroll
+                for (int k = 0; k < WMAX; ++k)
+                    if (k < W) x[b][k] = in[(int64_t)min(st + k, Rin - 1) * C + c];     // clamped: the weight there is not used
+            }
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const int r = min(r0 + b, Rout - 1);
+                const float *wr = w + (int64_t)r * W;
+                const int lim = min(W, Rin - start[r]);
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < WMAX; ++k)
+                    if (k < lim) acc = fmaf(wr[k], x[b][k], acc);
+                if (r0 + b < r_end) out[(int64_t)r * C + c] = acc;
+            }
+        }
     }
 }
 
@@ -246,26 +397,52 @@ int psx_detector_plan_create(int Nx, int Ny, int ov, int nx, int ny, int margin,
                 "psx_detector_plan_create: different resampling factors on the two axes");
     psx_detector_plan *p = new psx_detector_plan();
     p->Nx = Nx; p->Ny = Ny; p->ov = ov; p->nx = nx; p->ny = ny; p->margin = margin;
-    std::vector<int> sx, sy;
-    std::vector<float> wx, wy;
-    compose_axis(Nx, ov, nx, margin, sigma_src, sigma_psf, sx, wx, p->Wx);
-    compose_axis(Ny, ov, ny, margin, sigma_src, sigma_psf, sy, wy, p->Wy);
+    int rc = 0;
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
         PSX_HIP(hipMalloc(dst, bytes));
         PSX_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
         p->bytes += bytes;
         return 0;
     };
-    int rc = 0;
-    if (!rc) rc = up((void **)&p->sx, sx.data(), sizeof(int) * sx.size());
-    if (!rc) rc = up((void **)&p->sy, sy.data(), sizeof(int) * sy.size());
-    if (!rc) rc = up((void **)&p->wx, wx.data(), sizeof(float) * wx.size());
-    if (!rc) rc = up((void **)&p->wy, wy.data(), sizeof(float) * wy.size());
-    if (!rc) {
-        hipError_t e = hipMalloc((void **)&p->tmp, sizeof(float) * (size_t)Nx * (size_t)ny);
-        if (e != hipSuccess) rc = fail((int)e, "psx_detector_plan_create: hipMalloc(tmp) failed: %s", hipGetErrorString(e));
-        p->bytes += sizeof(float) * (size_t)Nx * (size_t)ny;
-    }
+    auto build = [&](BandOp &op, int N, int n, int stage) -> int {
+        std::vector<int> st;
+        std::vector<float> w;
+        compose_axis(N, ov, n, margin, sigma_src, sigma_psf, st, w, op.W, stage);
+        op.n_out = (int)st.size();
+        op.n_in = stage == STAGE_BACK ? n + 2 * margin : N;
+        std::vector<float> wT((size_t)op.W * op.n_out);
+        for (int o = 0; o < op.n_out; ++o)
+            for (int k = 0; k < op.W; ++k) wT[(size_t)k * op.n_out + o] = w[(size_t)o * op.W + k];
+        op.span = 0;
+        std::vector<int2> blk;
+        for (int o0 = 0; o0 < op.n_out; o0 += 256) {
+            int lo = st[o0], hi = st[o0];
+            for (int o = o0; o < std::min(o0 + 256, op.n_out); ++o) {
+                lo = std::min(lo, st[o]);
+                hi = std::max(hi, st[o]);
+            }
+            blk.push_back(make_int2(lo, hi + op.W));
+            op.span = std::max(op.span, hi + op.W - lo);
+        }
+        if (int e = up((void **)&op.blk, blk.data(), sizeof(int2) * blk.size())) return e;
+        if (int e = up((void **)&op.start, st.data(), sizeof(int) * st.size())) return e;
+        if (int e = up((void **)&op.w, w.data(), sizeof(float) * w.size())) return e;
+        return up((void **)&op.wT, wT.data(), sizeof(float) * wT.size());
+    };
+    const bool psf = sigma_psf != 0.0;
+    if (!rc) rc = build(p->fx, Nx, nx, psf ? STAGE_FRONT : STAGE_ALL);
+    if (!rc) rc = build(p->fy, Ny, ny, psf ? STAGE_FRONT : STAGE_ALL);
+    if (!rc && psf) rc = build(p->bx, Nx, nx, STAGE_BACK);
+    if (!rc && psf) rc = build(p->by, Ny, ny, STAGE_BACK);
+    auto scratch = [&](float **dst, size_t elems) -> int {
+        hipError_t e = hipMalloc((void **)dst, sizeof(float) * elems);
+        if (e != hipSuccess) return fail((int)e, "psx_detector_plan_create: hipMalloc(scratch) failed: %s", hipGetErrorString(e));
+        p->bytes += sizeof(float) * elems;
+        return 0;
+    };
+    if (!rc) rc = scratch(&p->t1, (size_t)Nx * (size_t)p->fy.n_out);
+    if (!rc && psf) rc = scratch(&p->t2, (size_t)p->fx.n_out * (size_t)p->fy.n_out);
+    if (!rc && psf) rc = scratch(&p->t3, (size_t)p->fx.n_out * (size_t)ny);
     if (rc) {
         psx_detector_plan_destroy(p);
         return rc;
@@ -292,24 +469,97 @@ int psx_detector_operator_host(int N, int ov, int n, int margin, double sigma_sr
 
 int psx_detector_plan_destroy(psx_detector_plan *p) {
     if (!p) return 0;
-    (void)hipFree(p->sx);
-    (void)hipFree(p->sy);
-    (void)hipFree(p->wx);
-    (void)hipFree(p->wy);
-    (void)hipFree(p->tmp);
+    for (BandOp *op : {&p->fx, &p->fy, &p->bx, &p->by}) {
+        (void)hipFree(op->start);
+        (void)hipFree(op->blk);
+        (void)hipFree(op->w);
+        (void)hipFree(op->wT);
+    }
+    (void)hipFree(p->t1);
+    (void)hipFree(p->t2);
+    (void)hipFree(p->t3);
     delete p;
     return 0;
 }
 
+namespace {
+
+// strips of rows per workgroup: enough workgroups to fill 256 CUs several times over, strips long enough to amortise
+// the weight loads
+int strip_rows(int rows, int col_blocks) {
+    int strips = std::max(1, 4096 / std::max(1, col_blocks));
+    int per = (rows + strips - 1) / strips;
+    return std::max(per, 8);
+}
+
+int band_cols(const BandOp &op, const float *in, float *out, int R, hipStream_t st) {
+    // 16-byte staging when the rows allow it (the full-resolution pass always does for even grids)
+    constexpr int MIT = 5;
+    if (op.n_in % 4 == 0 && (uintptr_t)in % 16 == 0 && op.span + 3 + 3 <= 4 * 64 * MIT && op.W <= 64) {
+        constexpr int RG8 = 8;
+        const int cb = (op.n_out + 255) / 256;
+        const int per = (strip_rows(R, cb) + RG8 - 1) / RG8 * RG8;
+        const dim3 grid(cb, (R + per - 1) / per);
+        const int span_ld = (op.span + 3 + 3 + 4) / 4 * 4;      // + alignment slack of the block's first input, whole float4s
+        const size_t lds = sizeof(float) * RG8 * (size_t)span_ld;
+#define PSX_BAND_COLS_V4(WMAX)                                                                                          \
+    PSX_TIMED("k_band_cols", st, k_band_cols_v4<WMAX, MIT><<<grid, 256, lds, st>>>(in, out, op.start, op.blk, op.wT, R, \
+                                                                                     op.n_in, op.n_out, op.W, span_ld, per))
+        if (op.W <= 8) PSX_BAND_COLS_V4(8);
+        else if (op.W <= 16) PSX_BAND_COLS_V4(16);
+        else if (op.W <= 32) PSX_BAND_COLS_V4(32);
+        else PSX_BAND_COLS_V4(64);
+#undef PSX_BAND_COLS_V4
+        return launch_check("k_band_cols");
+    }
+    constexpr int RG = 4;
+    const int cb = (op.n_out + 255) / 256;
+    const int per = (strip_rows(R, cb) + RG - 1) / RG * RG;
+    const dim3 grid(cb, (R + per - 1) / per);
+    const int span_ld = op.span + 1;
+    const size_t lds = sizeof(float) * RG * (size_t)span_ld;
+    PSX_REQUIRE(lds <= 64 * 1024, "detector: oversampling %d needs %zu bytes of LDS per row strip", op.span / 256, lds);
+#define PSX_BAND_COLS(WMAX)                                                                                            \
+    PSX_TIMED("k_band_cols", st, k_band_cols<WMAX, RG><<<grid, 256, lds, st>>>(in, out, op.start, op.blk, op.wT, R, op.n_in, \
+                                                                                 op.n_out, op.W, span_ld, per))
+    if (op.W <= 8) PSX_BAND_COLS(8);
+    else if (op.W <= 16) PSX_BAND_COLS(16);
+    else if (op.W <= 32) PSX_BAND_COLS(32);
+    else if (op.W <= 64) PSX_BAND_COLS(64);
+    else if (op.W <= 128) PSX_BAND_COLS(128);
+    else return fail(PSX_E_UNSUPPORTED, "detector: band of %d taps (source blur of more than 60 study pixels?)", op.W);
+#undef PSX_BAND_COLS
+    return launch_check("k_band_cols");
+}
+
+int band_rows(const BandOp &op, const float *in, float *out, int C, hipStream_t st) {
+    const int cb = (C + 255) / 256;
+    const int per = strip_rows(op.n_out, cb);
+    const dim3 grid(cb, (op.n_out + per - 1) / per);
+#define PSX_BAND_ROWS(WMAX, RB)                                                                                          \
+    PSX_TIMED("k_band_rows", st, k_band_rows<WMAX, RB><<<grid, 256, 0, st>>>(in, out, op.start, op.w, op.n_in, op.n_out, \
+                                                                             C, op.W, per))
+    if (op.W <= 4) PSX_BAND_ROWS(4, 8);
+    else if (op.W <= 8) PSX_BAND_ROWS(8, 4);
+    else if (op.W <= 16) PSX_BAND_ROWS(16, 2);
+    else PSX_BAND_ROWS(0, 1);
+#undef PSX_BAND_ROWS
+    return launch_check("k_band_rows");
+}
+
+}  // namespace
+
 int psx_detect_f32(psx_detector_plan *p, const float *img, float *out, void *stream) {
     PSX_REQUIRE(p && img && out, "psx_detect_f32: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    PSX_TIMED("k_detect_cols", st, k_detect_cols<<<ew_grid((int64_t)p->Nx * p->ny, 256), 256, 0, st>>>(img, p->tmp, p->sy, p->wy, p->Nx, p->Ny, p->ny,
-                                                                        p->Wy));
-    if (int rc = launch_check("k_detect_cols")) return rc;
-    PSX_TIMED("k_detect_rows", st, k_detect_rows<<<ew_grid((int64_t)p->nx * p->ny, 256), 256, 0, st>>>(p->tmp, out, p->sx, p->wx, p->Nx, p->nx, p->ny,
-                                                                        p->Wx));
-    return launch_check("k_detect_rows");
+    const bool psf = p->bx.n_out != 0;
+    // front operator: contiguous axis first (the only pass over the full-resolution image), then axis 0
+    if (int rc = band_cols(p->fy, img, p->t1, p->Nx, st)) return rc;
+    if (int rc = band_rows(p->fx, p->t1, psf ? p->t2 : out, p->fy.n_out, st)) return rc;
+    if (!psf) return 0;
+    // back operator (PSF + crop) at detector resolution
+    if (int rc = band_cols(p->by, p->t2, p->t3, p->fx.n_out, st)) return rc;
+    return band_rows(p->bx, p->t3, out, p->ny, st);
 }
 
 int psx_resize_f32(const float *img, int Nx, int Ny, float *out, int sx, int sy, void *stream) {
