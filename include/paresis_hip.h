@@ -115,7 +115,8 @@ int psx_fastloop_f32(const float *I, const float *Dx, const float *Dy, float *I2
 /* ---- K3-K8: Experiment.wavePropagation (Experiment.py:219-252) ------------------------------------------------
  * A plan fixes the study grid [Nx][Ny] and the reflect margin (15, EXP:236) and owns the padded work buffers.
  * engine: 0 = auto, 1 = rocFFT on the padded grid (pad -> FFT2 -> chirp -> IFFT2 -> crop, any size),
- *         2 = LDS-resident FFT convolution (row pass + column pass, the padded spectrum never touches HBM). */
+ *         2 = LDS-resident FFT convolution (row pass + column pass, the padded spectrum never touches HBM; lines longer
+ *             than one LDS transform, N > 4593, as a partitioned convolution).  Auto picks 2 for every supported grid. */
 #define PSX_ENGINE_AUTO 0
 #define PSX_ENGINE_ROCFFT 1
 #define PSX_ENGINE_LDS 2

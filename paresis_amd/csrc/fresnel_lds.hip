@@ -71,6 +71,12 @@ struct LineArgs {
     float scale[PSX_MAX_DIST];
     float2 gph[PSX_MAX_DIST];               // global phase factor exp(i k z / M) of the complex result
     int accumulate;
+    // Partitioned convolution (PART instantiations; lines too long for one M-point transform in LDS): the N outputs of a
+    // line are cut into NB blocks of B, the P-tap kernel into S segments of Lh (B + Lh - 1 <= M); a work unit is
+    // (distance, line group, block) and takes S consecutive rounds, one per segment, whose results add up in `part`
+    // (complex, same layout as the complex output; it IS the complex output when that is wanted).  H[d] then holds S spectra.
+    int B, Lh, S, NB;
+    float2 *part[PSX_MAX_DIST];
     unsigned long long *stamps;   // optional diagnostics: 32 phase timestamps per workgroup (psx_debug_stamps)
 };
 
@@ -105,7 +111,7 @@ __device__ __forceinline__ void lds_barrier() {
 
 // CONTIG: the samples of a line are adjacent in memory (in_si == 1) -- the lanes of a loader wave then walk along the line;
 // otherwise they walk across the LINES lines of the group (adjacent columns of a row-major image).
-template <int R3, bool CONTIG>
+template <int R3, bool CONTIG, bool PART = false>
 __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     constexpr int M = 576 * R3, LINES = TOT / M, S1 = M / RAD, MP = M + M / 32;
     constexpr int SLAB = 16, NSLABS = TOT / SLAB;       // 16 contiguous points per slab in the middle stage
@@ -120,15 +126,24 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     // ---- line groups of this workgroup: XCD x = blockIdx % 8 owns a contiguous chunk of groups (its 32 CUs then read
     // neighbouring columns at the same time: the 128-byte lines of the strided source are shared in that XCD's L2)
     const int ngroups = (a.nlines + LINES - 1) / LINES;
-    const int nwork = a.dist_inner ? ngroups : ngroups * a.n_dist;   // all distances of a call in ONE launch: one prologue, one tail
+    const int nwork = PART ? ngroups * a.n_dist * a.NB : (a.dist_inner ? ngroups : ngroups * a.n_dist);   // all distances of a call in ONE launch
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     const int cq = nwork >> 3, cr = nwork & 7;
     const int cstart = xcd * cq + (xcd < cr ? xcd : cr), clen = cq + (xcd < cr ? 1 : 0);
     const int nunits = slot < clen ? (clen - slot + nslot - 1) / nslot : 0;   // units cstart + slot + u*nslot, u < nunits
-    const int nj = a.dist_inner ? nunits * a.n_dist : nunits;                  // rounds of this workgroup
-    // round j -> (distance, line group)
+    const int nj = PART ? nunits * a.S : (a.dist_inner ? nunits * a.n_dist : nunits);   // rounds of this workgroup
+    // round j -> (distance, line group) [, output block, kernel segment]
+    int pb = 0, ps = 0;       // PART: block and segment of the round last decoded
     auto item = [&](int j, int &d, int &g) __attribute__((always_inline)) {
-        if (a.dist_inner) {
+        if (PART) {
+            const int u = j / a.S;
+            ps = j - u * a.S;
+            const int w = cstart + slot + u * nslot;         // unit: ((d * NB) + b) * ngroups + g
+            const int db = w / ngroups;
+            g = w - db * ngroups;
+            d = db / a.NB;
+            pb = db - d * a.NB;
+        } else if (a.dist_inner) {
             const int u = j / a.n_dist;
             d = j - u * a.n_dist;
             g = cstart + slot + u * nslot;
@@ -171,6 +186,80 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     };
 
     if (tid >= TC) {
+        if constexpr (PART) {
+            // =========================== loader waves, partitioned convolution ============================================
+            // LDS position t of a line holds e[a0 + t], e = the periodic / mirrored extension of the line the linear
+            // convolution runs over (e[te] = x_per[te - (P-1) + margin]), a0 = b*B + P - (s+1)*Lh; zeros outside the window of
+            // B + Lh - 1 positions.  A window is twice a regular line's share of registers, so it moves in two halves: the
+            // first is fetched during the transform (as in the regular engine), the second between barriers (3) and (4), after
+            // the first has been written out of the same registers.
+            const int lt = tid - TC;
+            constexpr int STEP = TL / LINES, NH = M / STEP / 2, PSTEP = STEP + STEP / 32;
+            static_assert(STEP % 32 == 0 && (M / STEP) % 2 == 0, "affine LDS addressing of the loader halves");
+            const int line = CONTIG ? lt / STEP : lt % LINES, i0 = CONTIG ? lt % STEP : lt / LINES;
+            float2 *base = lds + line * MP + phys(i0);
+            const int P = a.P, Lw = a.B + a.Lh - 1, Etot = N + P - 1;
+            float2 xs[NH];
+            unsigned vm0 = 0u, vm1 = 0u;                    // which of the NH positions hold a sample (the rest are zeros)
+            static_assert(NH <= 64, "validity mask");
+            auto fetch_half = [&](int j, int h) __attribute__((always_inline)) {
+                int d, g;
+                item(j, d, g);
+                const int l = g * LINES + line;
+                const int lc = min(l, a.nlines - 1);          // addresses stay inside the image for the idle lines of the last group
+                // PART sources are the blocked intermediate or contiguous lines (in_si == 1): 32-bit element offsets from the line's base
+                const float2 *srcl = a.src[d] + (a.in_blocked ? ((int64_t)(lc / IB) * N) * IB + lc % IB : (int64_t)lc * a.in_sl);
+                const int istep = a.in_blocked ? IB : 1;
+                const int a0 = pb * a.B + P - (ps + 1) * a.Lh;
+                const unsigned tlim = l < a.nlines ? (unsigned)Lw : 0u;
+                vm0 = 0u;
+                vm1 = 0u;
+#pragma unroll
+                for (int k = 0; k < NH; ++k) {
+                    const int t = i0 + STEP * (k + NH * h);
+                    const int te = a0 + t;
+                    const bool ok = (unsigned)t < tlim && (unsigned)te < (unsigned)Etot;
+                    int jp = te - (P - 1) + mg;                  // index into the padded line, one period either side
+                    jp += (jp >> 31) & P;
+                    int i = abs(jp - mg);                        // np.pad 'reflect' (EXP:237): -r on the left ...
+                    i = i >= N ? 2 * N - 2 - i : i;              // ... 2N-2-r on the right
+                    i = ok ? i : 0;                              // unconditional loads issue back to back
+                    xs[k] = srcl[(unsigned)(i * istep)];
+                    if (k < 32) vm0 |= (ok ? 1u : 0u) << (k & 31);
+                    else vm1 |= (ok ? 1u : 0u) << (k & 31);
+                }
+            };
+            auto spread_half = [&](int h) __attribute__((always_inline)) {
+#pragma unroll
+                for (int k = 0; k < NH; ++k) {
+                    const bool ok = ((k < 32 ? vm0 : vm1) >> (k & 31)) & 1u;
+                    base[(k + NH * h) * PSTEP] = ok ? xs[k] : make_float2(0.f, 0.f);
+                }
+            };
+            if (nj > 0) {
+                fetch_half(0, 0);
+                spread_half(0);
+                fetch_half(0, 1);
+                spread_half(1);
+            }
+            lds_barrier();                                   // (0)
+            for (int j = 0; j < nj; ++j) {
+                const bool more = j + 1 < nj;
+                lds_barrier();                               // (1)
+                if (more) fetch_half(j + 1, 0);
+                lds_barrier();                               // (2)
+                lds_barrier();                               // (3)
+                __builtin_amdgcn_s_setprio(3);
+                if (more) {
+                    spread_half(0);
+                    fetch_half(j + 1, 1);
+                    spread_half(1);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                lds_barrier();                               // (4)
+            }
+            return;
+        }
         // =============================== loader waves =====================================================================
         // Thread lt owns the samples i0 + STEP*k (k < NLD) of ONE line.  STEP is a multiple of 32 (R3 >= 4), so the padded
         // LDS index of sample k is the index of sample 0 plus a compile-time offset.
@@ -333,7 +422,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         // bytes are requested here, before barrier (1); the second slab's right after the first one's multiply.
         float4 hh[SLAB / 2];
         {
-            const float4 *h4 = reinterpret_cast<const float4 *>(a.H[d] + (slab0 % (M / SLAB)) * SLAB);
+            const float4 *h4 = reinterpret_cast<const float4 *>(a.H[d] + (PART ? ps * M : 0) + (slab0 % (M / SLAB)) * SLAB);
 #pragma unroll
             for (int q = 0; q < SLAB / 2; ++q) hh[q] = h4[q];
         }
@@ -370,7 +459,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 
         // ---- 4+5. middle stage, slab by slab: forward radix R3 on contiguous chunks, x FFT_M(h_d), inverse radix R3,
         // back to LDS.  Each thread rewrites exactly the slabs it read.
-        const float2 *Hd = a.H[d];
+        const float2 *Hd = a.H[d] + (PART ? ps * M : 0);
 #pragma unroll
         for (int r = 0; r < NSLAB; ++r) {
             if (slabw + 64 * r >= WSLABS) break;
@@ -447,7 +536,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             // output sample i = nA + q*S1 - jout (jout = LDS position of output sample 0).  The first index is made opaque
             // so that the 48 per-q addresses are formed here from ONE pointer, not hoisted out of the group loop (they
             // would occupy 96 VGPRs there and spill).
-            int ifirst = nA - (N + 2 * mg - 1);
+            int ifirst = nA - (PART ? a.Lh - 1 : N + 2 * mg - 1);      // PART: index inside the output block
             asm volatile("" : "+v"(ifirst));
             v2f *wo = reinterpret_cast<v2f *>(a.wave_out[d]);
             float *io = a.inten_out[d];
@@ -465,9 +554,45 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 // element index of output i inside the window: plain rows: i (window = row l); blocked: ((i>>3)*nlines+l)*8 + i%8
                 const int e0 = a.out_blocked ? ((ifirst >> 3) * a.nlines + l) * IB + (ifirst & (IB - 1)) : ifirst;
                 const int estep = a.out_blocked ? (S1 / IB) * a.nlines * IB : S1;
-                const int64_t wbase = a.out_blocked ? 0 : (int64_t)l * a.out_ld;
-                const int welems = lok ? (a.out_blocked ? ((N + IB - 1) / IB) * IB * a.nlines : N) : 0;
-                if (wo) {
+                // PART: the window is the output block only -- samples [b*B, b*B + Bv) of the line; in the blocked layout
+                // they are the contiguous range of B/8 sample-blocks (B is a multiple of 8)
+                const int nout = PART ? min(a.B, N - pb * a.B) : N;
+                const int64_t wbase = a.out_blocked ? (PART ? (int64_t)(pb * a.B / IB) * a.nlines * IB : 0)
+                                                    : (int64_t)l * a.out_ld + (PART ? pb * a.B : 0);
+                const int welems = lok ? (a.out_blocked ? ((nout + IB - 1) / IB) * IB * a.nlines : nout) : 0;
+                bool emit = true;                // PART: only the last kernel segment produces the outputs proper
+                if constexpr (PART) {
+                    // segments 0..S-2 leave their sum in `part`, the last one adds it to its own result.  Every round of a
+                    // unit maps output element -> (wave, lane, q) identically, so a lane re-reads what it wrote itself.
+                    const bool first = ps == 0, last = ps == a.S - 1;
+                    emit = last;
+                    if (a.S > 1) {
+                        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+                            reinterpret_cast<v2f *>(a.part[d]) + wbase, 0, welems * 8, 0x00020000);
+                        int off = e0 * 8;
+                        if (!first) {
+                            // eight loads at a time, fenced: hoisted above the butterfly (they do not depend on it) the 24
+                            // loads would not fit the 128-VGPR budget next to its temporaries
+#pragma unroll
+                            for (int q0 = 0; q0 < RAD; q0 += 8) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                v2u o[8];
+#pragma unroll
+                                for (int q = 0; q < 8; ++q)
+                                    o[q] = __builtin_amdgcn_raw_buffer_load_b64(rp, off + (q0 + q) * estep * 8, 0, 0);   // 0 outside the window
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) v[q0 + q] += __builtin_bit_cast(v2f, o[q]);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (!last) {
+#pragma unroll
+                            for (int q = 0; q < RAD; ++q)
+                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v[q]), rp, off + q * estep * 8, 0, 0);
+                        }
+                    }
+                }
+                if (wo && emit) {
                     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wo + wbase, 0, welems * 8, 0x00020000);
                     int off = e0 * 8;
 #pragma unroll
@@ -477,7 +602,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                         off += estep * 8;
                     }
                 }
-                if (io) {
+                if (io && emit) {
                     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(io + wbase, 0, welems * 4, 0x00020000);
                     int off = e0 * 4;
                     if (a.accumulate) {
@@ -638,13 +763,14 @@ __global__ void k_kern_h(const double2 *H, const double2 *twP, double2 *h, int P
     h[d] = make_double2(re / P, im / P);
 }
 
-__global__ void k_kern_Hhat(const double2 *h, const double2 *twM, double2 *Hh, int P, int M) {   // FFT_M(h zero-padded)
+// FFT_M of the taps h[off .. off+len) zero-padded (the whole kernel, or one segment of the partitioned convolution)
+__global__ void k_kern_Hhat(const double2 *h, const double2 *twM, double2 *Hh, int off, int len, int M) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= M) return;
     double re = 0.0, im = 0.0;
     int r = 0;
-    for (int d = 0; d < P; ++d) {
-        const double2 x = h[d], w = twM[r];       // conj(w): exp(-2 pi i k d / M)
+    for (int d = 0; d < len; ++d) {
+        const double2 x = h[off + d], w = twM[r];       // conj(w): exp(-2 pi i k d / M)
         re += x.x * w.x + x.y * w.y;
         im += x.y * w.x - x.x * w.y;
         r += k;
@@ -689,19 +815,40 @@ int pick_r3(int N, int margin) {
     return 0;
 }
 
+// Lines longer than that: partition outputs (blocks of B, a multiple of 8) and kernel taps (segments of Lh) so that one
+// block x segment product is an M-point convolution, B + Lh - 1 <= M; fewest products, then fewest segments.
+constexpr int PART_M = 576 * 16;
+void part_geometry(int N, int margin, int &B, int &Lh, int &S, int &NB) {
+    const int P = N + 2 * margin;
+    long best = -1;
+    for (int s = 1; s <= 64; ++s) {
+        const int lh = (P + s - 1) / s;
+        const int bmax = (PART_M - lh + 1) / 8 * 8;
+        if (bmax < 8) continue;
+        const int nb = (N + bmax - 1) / bmax;
+        const long cost = (long)s * nb;
+        if (best < 0 || cost < best) {
+            best = cost;
+            S = s; Lh = lh; NB = nb;
+            B = ((N + nb - 1) / nb + 7) / 8 * 8;
+        }
+    }
+}
+
 }  // namespace
 
 namespace psx {
 
 struct AxisTables {
     int N = 0, R3 = 0, M = 0;
+    int part = 0, B = 0, Lh = 0, S = 1, NB = 1;     // partitioned convolution (lines that do not fit one transform)
     float2 *twA = nullptr, *twB = nullptr;
 };
 
 struct KernEntry {
     double a, du;
-    int N, M;
-    float2 *H;
+    int N, M, S;
+    float2 *H;          // S spectra of M points
     unsigned long long stamp;
 };
 
@@ -710,6 +857,7 @@ struct LdsEngine {
     float2 *inter = nullptr;     // [max_dist][Nx/IB][Ny][IB] intermediates (pass-1 line y, sample x)
     size_t inter_elems = 0;
     float2 *pre = nullptr;       // [Nx][Ny] pre-transmitted wave when nmat exceeds the fused variants
+    float2 *part = nullptr;      // [max_dist][Nx][Ny] partial sums of pass 2 of the partitioned convolution when only |.|^2 is wanted
     double2 *wH = nullptr, *wh = nullptr, *wHh = nullptr, *twP = nullptr, *twM = nullptr;
     int twP_n = 0, twM_n = 0;
     std::vector<KernEntry> cache;
@@ -717,12 +865,19 @@ struct LdsEngine {
 };
 
 bool lds_engine_supported(int Nx, int Ny, int margin) {
-    return margin >= 0 && margin <= Nx - 1 && margin <= Ny - 1 && pick_r3(Nx, margin) && pick_r3(Ny, margin);
+    // any line length: one transform per line up to N = 4593, the partitioned convolution beyond; the blocked intermediate
+    // of a partitioned pass 1 is addressed with 32-bit byte offsets inside one output block
+    return margin >= 0 && margin <= Nx - 1 && margin <= Ny - 1 && margin <= 2048 && (int64_t)Nx * Ny < (1ll << 31);
 }
 
 static int make_axis(AxisTables &t, int N, int margin, size_t &bytes) {
     t.N = N;
     t.R3 = pick_r3(N, margin);
+    if (!t.R3) {
+        t.R3 = 16;
+        t.part = 1;
+        part_geometry(N, margin, t.B, t.Lh, t.S, t.NB);
+    }
     t.M = 576 * t.R3;
     const int S1 = t.M / RAD;
     PSX_HIP(hipMalloc((void **)&t.twA, sizeof(float2) * RAD * S1));
@@ -763,6 +918,7 @@ void lds_engine_destroy(psx_fresnel_plan *p) {
     for (auto &k : e->cache) (void)hipFree(k.H);
     (void)hipFree(e->inter);
     (void)hipFree(e->pre);
+    (void)hipFree(e->part);
     (void)hipFree(e->wH);
     (void)hipFree(e->wh);
     (void)hipFree(e->wHh);
@@ -783,20 +939,20 @@ static int kernel_spectrum(psx_fresnel_plan *p, const AxisTables &t, double a, d
             *out = k.H;
             return 0;
         }
-    KernEntry k{a, du, t.N, t.M, nullptr, ++e->clock};
+    KernEntry k{a, du, t.N, t.M, t.S, nullptr, ++e->clock};
     if (e->cache.size() >= 64) {   // evict the least recently used table
         size_t lru = 0;
         for (size_t i = 1; i < e->cache.size(); ++i)
             if (e->cache[i].stamp < e->cache[lru].stamp) lru = i;
         k.H = e->cache[lru].H;
-        if (e->cache[lru].M != t.M) {
+        if (e->cache[lru].M != t.M || e->cache[lru].S != t.S) {
             PSX_HIP(hipStreamSynchronize(st));
             (void)hipFree(k.H);
             k.H = nullptr;
         }
         e->cache.erase(e->cache.begin() + lru);
     }
-    if (!k.H) PSX_HIP(hipMalloc((void **)&k.H, sizeof(float2) * t.M));
+    if (!k.H) PSX_HIP(hipMalloc((void **)&k.H, sizeof(float2) * t.M * t.S));
     const int P = t.N + 2 * p->margin;
     if (e->twP_n != P) {
         PSX_TIMED("k_cis_table", st, k_cis_table<<<(int)cdiv(P, 256), 256, 0, st>>>(e->twP, P));
@@ -808,21 +964,24 @@ static int kernel_spectrum(psx_fresnel_plan *p, const AxisTables &t, double a, d
     }
     PSX_TIMED("k_kern_H", st, k_kern_H<<<(int)cdiv(P, 256), 256, 0, st>>>(e->wH, P, a, du));
     PSX_TIMED("k_kern_h", st, k_kern_h<<<(int)cdiv(P, 64), 64, 0, st>>>(e->wH, e->twP, e->wh, P));
-    PSX_TIMED("k_kern_Hhat", st, k_kern_Hhat<<<(int)cdiv(t.M, 64), 64, 0, st>>>(e->wh, e->twM, e->wHh, P, t.M));
-    PSX_TIMED("k_kern_perm", st, k_kern_perm<<<(int)cdiv(t.M, 256), 256, 0, st>>>(e->wHh, k.H, t.M, t.R3));
+    for (int sg = 0; sg < t.S; ++sg) {      // one spectrum per kernel segment (S = 1: the whole kernel)
+        const int off = t.part ? sg * t.Lh : 0, len = t.part ? std::min(t.Lh, P - off) : P;
+        PSX_TIMED("k_kern_Hhat", st, k_kern_Hhat<<<(int)cdiv(t.M, 64), 64, 0, st>>>(e->wh, e->twM, e->wHh, off, len, t.M));
+        PSX_TIMED("k_kern_perm", st, k_kern_perm<<<(int)cdiv(t.M, 256), 256, 0, st>>>(e->wHh, k.H + (size_t)sg * t.M, t.M, t.R3));
+    }
     if (int rc = launch_check("kernel spectrum")) return rc;
     e->cache.push_back(k);
     *out = k.H;
     return 0;
 }
 
-template <int R3, bool CONTIG>
+template <int R3, bool CONTIG, bool PART = false>
 static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
     constexpr int M = 576 * R3, LINES = TOT / M;
     constexpr size_t lds_bytes = sizeof(float2) * ((size_t)LINES * (M + M / 32) + (2 * R3 + RAD) * (RAD + 1));   // lines + the three twiddle tables
     static bool attr_set = false;
     if (!attr_set) {
-        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG, PART>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_bytes));
         attr_set = true;
     }
@@ -834,15 +993,16 @@ static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
         PSX_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
         if (n_cu < 8) n_cu = 8;
     }
-    const int nwork = ((la.nlines + LINES - 1) / LINES) * (la.dist_inner ? 1 : la.n_dist);
+    const int nwork = ((la.nlines + LINES - 1) / LINES) * (PART ? la.n_dist * la.NB : (la.dist_inner ? 1 : la.n_dist));
     int nslot = n_cu / 8;
     if (nslot > (nwork + 7) / 8) nslot = (nwork + 7) / 8;
-    PSX_TIMED(name, st, k_fresnel_lines<R3, CONTIG><<<8 * nslot, T, lds_bytes, st>>>(la));
+    PSX_TIMED(name, st, k_fresnel_lines<R3, CONTIG, PART><<<8 * nslot, T, lds_bytes, st>>>(la));
     return launch_check(name);
 }
 
 template <bool CONTIG>
-static int launch_lines_r3(int R3, const LineArgs &la, hipStream_t st, const char *name) {
+static int launch_lines_r3(int R3, const LineArgs &la, hipStream_t st, const char *name, bool part = false) {
+    if (part) return launch_lines<16, CONTIG, true>(la, st, name);
     switch (R3) {
         case 2: return launch_lines<2, CONTIG>(la, st, name);
         case 4: return launch_lines<4, CONTIG>(la, st, name);
@@ -898,7 +1058,8 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         la.accumulate = 0; la.stamps = stamp_pass1 ? g_stamps : nullptr;
         la.n_dist = nnz;
         static const bool no_inner = getenv("PSX_NO_DIST_INNER") != nullptr;   // diagnostics: A/B of the work order
-        la.dist_inner = no_inner ? 0 : 1;   // one source for all distances
+        la.dist_inner = (no_inner || e->ax[0].part) ? 0 : 1;   // one source for all distances
+        la.B = e->ax[0].B; la.Lh = e->ax[0].Lh; la.S = e->ax[0].S; la.NB = e->ax[0].NB;
         for (int i = 0; i < PSX_MAX_DIST; ++i) {
             const int k = i < nnz ? i : 0;
             la.src[i] = e->pre;
@@ -908,11 +1069,12 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
                 la.H[i] = la.H[0];
             }
             la.wave_out[i] = e->inter + (size_t)k * e->inter_elems;
+            la.part[i] = la.wave_out[i];            // partial sums of a partitioned pass build up in the intermediate itself
             la.inten_out[i] = nullptr;
             la.scale[i] = 1.f;
             la.gph[i] = make_float2(1.f, 0.f);
         }
-        if (int rc = launch_lines_r3<true>(e->ax[0].R3, la, st, "k_fresnel_cols")) return rc;
+        if (int rc = launch_lines_r3<true>(e->ax[0].R3, la, st, "k_fresnel_cols", e->ax[0].part)) return rc;
     }
 
     // ---- pass 2: lines along axis 1 of the image = columns of the intermediate (strided reads: the second transpose);
@@ -925,6 +1087,15 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         lb.accumulate = a.accumulate; lb.stamps = stamp_pass1 ? nullptr : g_stamps;
         lb.n_dist = nnz;
         lb.dist_inner = 0;
+        lb.B = e->ax[1].B; lb.Lh = e->ax[1].Lh; lb.S = e->ax[1].S; lb.NB = e->ax[1].NB;
+        if (e->ax[1].part && e->ax[1].S > 1 && !e->part) {     // complex partial sums when only |.|^2 leaves the pass
+            bool need = false;
+            for (int i = 0; i < nnz; ++i) need = need || !(a.wave_out && a.wave_out[nz[i]]);
+            if (need) {
+                PSX_HIP(hipMalloc((void **)&e->part, sizeof(float2) * npix * p->max_dist));
+                p->bytes += sizeof(float2) * npix * p->max_dist;
+            }
+        }
         for (int i = 0; i < PSX_MAX_DIST; ++i) {
             const int k = i < nnz ? i : 0, d = nz[k];
             lb.src[i] = e->inter + (size_t)k * e->inter_elems;
@@ -934,12 +1105,13 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
                 lb.H[i] = lb.H[0];
             }
             lb.wave_out[i] = a.wave_out ? a.wave_out[d] : nullptr;
+            lb.part[i] = lb.wave_out[i] ? lb.wave_out[i] : (e->part ? e->part + (size_t)k * npix : nullptr);
             lb.inten_out[i] = a.inten_out ? a.inten_out[d] : nullptr;
             lb.scale[i] = a.inten_scale ? a.inten_scale[d] : 1.f;
             const double g = a.gphase ? a.gphase[d] : 0.0;
             lb.gph[i] = make_float2((float)std::cos(g), (float)std::sin(g));   // exact reduction of ~1e11 rad (EXP:250)
         }
-        if (int rc2 = launch_lines_r3<false>(e->ax[1].R3, lb, st, "k_fresnel_rows")) return rc2;
+        if (int rc2 = launch_lines_r3<false>(e->ax[1].R3, lb, st, "k_fresnel_rows", e->ax[1].part)) return rc2;
     }
     return 0;
 }
