@@ -177,6 +177,17 @@ int psx_darkfield_blur_f32(const float *I2DF, const float *DF, const float *I2, 
 int psx_membrane_f32(const double *xf, const double *yf, const double *rad, int64_t n, int dimX, int dimY, int margin,
                      int margin2, double scale, int accumulate, float *out, void *stream);
 
+/* The same with the sphere list resident on the GPU.  The reference re-places ONE scaled, stitched list for every
+ * membrane position and layer with a new integer offset (getMembraneFromFile.py:139-142); a plan takes the list once
+ * (HOST arrays x, y, r in pixels of the list frame, i.e. par/pixSize before the offset), bins it by 32-pixel cell, and
+ * psx_membrane_layer_f32 renders one layer at offset (offx, offy) -- xfloat = x - offx, yfloat = y - offy -- without
+ * touching the host: asynchronous on the stream like the rest of the ABI. */
+typedef struct psx_membrane_plan psx_membrane_plan;
+int psx_membrane_plan_create(const double *x, const double *y, const double *r, int64_t n, psx_membrane_plan **plan);
+int psx_membrane_plan_destroy(psx_membrane_plan *plan);
+int psx_membrane_layer_f32(psx_membrane_plan *plan, int offx, int offy, int dimX, int dimY, int margin, int margin2,
+                           double scale, int accumulate, float *out, void *stream);
+
 /* ---- per-kernel timing (bench.py's roofline leg) ----------------------------------------------------------------------
  * psx_profile_enable(1) clears the log and makes every kernel launch of the library record a HIP event pair on the
  * stream it is launched on; psx_profile_summary() waits for the recorded events and writes one line per kernel,

@@ -27,16 +27,28 @@ SPHERE_FILE = "Samples/Membranes/CuSn.txt"
 _DP = ctypes.POINTER(c_double)
 
 
+_lists = {}
+
+
 def load_sphere_list(path=SPHERE_FILE):
-    """[[y, x, r], ...] in file units: the JSON file of the reference when it exists, else the synthetic stand-in."""
-    if path and os.path.exists(path):
-        with open(path) as f:
-            return np.asarray(json.load(f), dtype=np.float64)
-    return synth.sphere_list()
+    """[[y, x, r], ...] in file units: the JSON file of the reference when it exists, else the synthetic stand-in.
+    Read (or synthesised) once per process: main.py asks for it at every membrane position."""
+    key = (os.path.abspath(path), os.path.getmtime(path)) if path and os.path.exists(path) else None
+    lst = _lists.get(key)
+    if lst is None:
+        if key is not None:
+            with open(path) as f:
+                lst = np.asarray(json.load(f), dtype=np.float64)
+        else:
+            lst = synth.sphere_list()
+        lst.setflags(write=False)
+        _lists[key] = lst
+    return lst
 
 
-def sphere_layers(sphere_list, dimX, dimY, pixSize, meanSphereRadius, nbOfLayers, rand_state):
-    """getMembraneFromFile.py:79-142 (host part): returns (margin, margin2, [(xfloat, yfloat, radFloat)] per layer)."""
+def stitched_list(sphere_list, dimX, dimY, pixSize, meanSphereRadius):
+    """getMembraneFromFile.py:79-137 (host part, the same for every position): scale the list to the requested mean
+    radius, centre it, stitch copies until it covers the grid.  Returns (margin, margin2, par [n,3] in um, sizeX, sizeY)."""
     margin = int(np.ceil(10 * meanSphereRadius / pixSize))
     margin2 = int(np.floor(margin / 2))
     corrFactor = meanSphereRadius / 12.8
@@ -59,28 +71,83 @@ def sphere_layers(sphere_list, dimX, dimY, pixSize, meanSphereRadius, nbOfLayers
         extra[:, 0] += sizeY
         par = np.concatenate((par, extra), axis=0)
         sizeY += sy0
-    layers = []
+    return margin, margin2, par, sizeX, sizeY
+
+
+def layer_offsets(rand_state, nbOfLayers, margin2, sizeX, sizeY, pixSize, dimX, dimY):
+    """getMembraneFromFile.py:139-140: one integer offset pair per layer, drawn x then y."""
+    offs = []
     for _ in range(int(nbOfLayers)):
         Offsetx = rand_state.randint(margin2, sizeX / pixSize - dimX - margin2)
         Offsety = rand_state.randint(margin2, sizeY / pixSize - dimY - margin2)
-        layers.append((par[:, 1] / pixSize - Offsetx, par[:, 0] / pixSize - Offsety, par[:, 2] / pixSize))
+        offs.append((int(Offsetx), int(Offsety)))
+    return offs
+
+
+def sphere_layers(sphere_list, dimX, dimY, pixSize, meanSphereRadius, nbOfLayers, rand_state):
+    """getMembraneFromFile.py:79-142 (host part): returns (margin, margin2, [(xfloat, yfloat, radFloat)] per layer)."""
+    margin, margin2, par, sizeX, sizeY = stitched_list(sphere_list, dimX, dimY, pixSize, meanSphereRadius)
+    layers = [(par[:, 1] / pixSize - ox, par[:, 0] / pixSize - oy, par[:, 2] / pixSize)
+              for ox, oy in layer_offsets(rand_state, nbOfLayers, margin2, sizeX, sizeY, pixSize, dimX, dimY)]
     return margin, margin2, layers
 
 
+class _MembranePlan:
+    """The stitched list of one (sphere list, grid, pixel size, mean radius) resident on one GPU (psx_membrane_plan)."""
+
+    def __init__(self, lst, dimX, dimY, pixSize, meanSphereRadius):
+        self.margin, self.margin2, par, self.sizeX, self.sizeY = stitched_list(lst, dimX, dimY, pixSize, meanSphereRadius)
+        x, y, r = (np.ascontiguousarray(v, dtype=np.float64) for v in (par[:, 1] / pixSize, par[:, 0] / pixSize, par[:, 2] / pixSize))
+        self.h = c_void_p(None)
+        check(lib().psx_membrane_plan_create(x.ctypes.data_as(_DP), y.ctypes.data_as(_DP), r.ctypes.data_as(_DP), len(r),
+                                             ctypes.byref(self.h)), "psx_membrane_plan_create")
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().psx_membrane_plan_destroy(self.h)
+        except Exception:
+            pass
+
+
+_plans = {}
+
+
+def _plan_for(lst, dimX, dimY, pixSize, meanSphereRadius, dev):
+    import zlib
+    arr = np.asarray(lst)
+    # a read-only array (what load_sphere_list hands out) is identified by its address; anything else by its content
+    ident = (id(lst),) if isinstance(lst, np.ndarray) and not lst.flags.writeable else (
+        zlib.crc32(np.ascontiguousarray(arr, dtype=np.float64).tobytes()),)
+    key = (dev.index, arr.shape, ident, dimX, dimY, float(pixSize), float(meanSphereRadius))
+    plan = _plans.get(key)
+    if plan is None:
+        if len(_plans) >= 8:
+            _plans.pop(next(iter(_plans)))
+        plan = _plans[key] = _MembranePlan(arr, dimX, dimY, pixSize, meanSphereRadius)
+        plan.source = lst          # keeps the array alive, so its id stays unique
+    return plan
+
+
 def getMembraneSegmentedFromFile(sample, dimX, dimY, pixSize, pointNum, supportThickness, seed=None, sphere_list=None):
-    """getMembraneFromFile.py:60-171.  Returns ([membrane_m, support_m] float32 tensors in HBM, parameters_dic)."""
+    """getMembraneFromFile.py:60-171.  Returns ([membrane_m, support_m] float32 tensors in HBM, parameters_dic).
+
+    main.py:64-65 calls this for every membrane position: the scaled, stitched list is the same each time, only the layer
+    offsets change, so the list is uploaded and binned once (psx_membrane_plan) and a position costs the draws of its
+    offsets plus one kernel per layer."""
     dimX, dimY = int(dimX), int(dimY)
     lst = load_sphere_list() if sphere_list is None else sphere_list
     rs = np.random.RandomState(synth.position_seed(pointNum) if seed is None else int(seed))
-    margin, margin2, layers = sphere_layers(lst, dimX, dimY, pixSize, sample.myMeanSphereRadius, sample.myNbOfLayers, rs)
     dev = device()
-    membrane = torch.zeros((dimX, dimY), dtype=torch.float32, device=dev)
+    plan = _plan_for(lst, dimX, dimY, pixSize, sample.myMeanSphereRadius, dev)
+    offs = layer_offsets(rs, sample.myNbOfLayers, plan.margin2, plan.sizeX, plan.sizeY, pixSize, dimX, dimY)
+    membrane = torch.empty((dimX, dimY), dtype=torch.float32, device=dev)
     st = c_void_p(torch.cuda.current_stream().cuda_stream)
-    for li, (xf, yf, rad) in enumerate(layers):
-        xf, yf, rad = (np.ascontiguousarray(v, dtype=np.float64) for v in (xf, yf, rad))
-        check(lib().psx_membrane_f32(xf.ctypes.data_as(_DP), yf.ctypes.data_as(_DP), rad.ctypes.data_as(_DP), len(rad),
-                                     dimX, dimY, margin, margin2, c_double(pixSize * 1e-6), 1 if li else 0,
-                                     c_void_p(membrane.data_ptr()), st), "psx_membrane_f32")
+    for li, (ox, oy) in enumerate(offs):
+        check(lib().psx_membrane_layer_f32(plan.h, ox, oy, dimX, dimY, plan.margin, plan.margin2, c_double(pixSize * 1e-6),
+                                           1 if li else 0, c_void_p(membrane.data_ptr()), st), "psx_membrane_layer_f32")
+    if not offs:
+        membrane.zero_()
     support = torch.full((dimX, dimY), float(supportThickness) * 1e-6, dtype=torch.float32, device=dev)
     parameters_dic = {'Average sphere radius': (sample.myMeanSphereRadius, 'um'),
                       'Number of layers': (sample.myNbOfLayers, ''),

@@ -64,9 +64,158 @@ __global__ __launch_bounds__(256) void k_membrane(const Sphere *__restrict__ sph
     }
 }
 
+// ---- plan variant: the sphere list lives on the GPU, binned ONCE by 32-pixel cell of its own frame -------------------
+// getMembraneSegmentedFromFile re-places the same (scaled, stitched) list for every membrane position and layer with a
+// new integer offset (getMembraneFromFile.py:139-142).  Binning by tile on the host per call -- what psx_membrane_f32
+// does -- then costs 6 ms per layer at 4096^2 against 0.1 ms for the kernel.  Here a tile finds its spheres itself: its
+// pixels, shifted by the offset, overlap a few cells of the list frame, whose lists are contiguous per cell row.
+struct CellSphere {
+    double x, y, r;     // pixels of the list frame (par / pixSize)
+};
+
+__global__ __launch_bounds__(256) void k_membrane_cells(const CellSphere *__restrict__ spheres,
+                                                        const int *__restrict__ cell_off, int ncx, int ncy, double x0,
+                                                        double y0, int rmax_int, int offx, int offy,
+                                                        float *__restrict__ out, int dimX, int dimY, int margin,
+                                                        int margin2, int tiles_y, double scale, int accumulate) {
+    __shared__ Sphere sh[64];
+    const int tile = blockIdx.x, t0 = (tile / tiles_y) * MT, c0 = (tile % tiles_y) * MT;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 columns x 8 rows; each thread owns 4 rows
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int py = c0 + tx + margin;
+    // cells whose spheres can reach this tile: |centre - pixel| <= radInt + 1/2 on each axis
+    const double xlo = (double)(offx + t0 + margin - rmax_int - 1) - x0, xhi = (double)(offx + t0 + margin + MT + rmax_int + 1) - x0;
+    const double ylo = (double)(offy + c0 + margin - rmax_int - 1) - y0, yhi = (double)(offy + c0 + margin + MT + rmax_int + 1) - y0;
+    const int cx0 = max(0, (int)floor(xlo / MT)), cx1 = min(ncx - 1, (int)floor(xhi / MT));
+    const int cy0 = max(0, (int)floor(ylo / MT)), cy1 = min(ncy - 1, (int)floor(yhi / MT));
+    for (int cx = cx0; cx <= cx1 && cy0 <= cy1; ++cx) {
+        const int beg = cell_off[cx * ncy + cy0], end = cell_off[cx * ncy + cy1 + 1];
+        for (int base = beg; base < end; base += 64) {
+            const int cnt = min(64, end - base);
+            __syncthreads();
+            if (threadIdx.x < cnt) {
+                const CellSphere cs = spheres[base + threadIdx.x];
+                Sphere sp;
+                sp.xf = cs.x - (double)offx;                                   // getMembraneFromFile.py:141-142
+                sp.yf = cs.y - (double)offy;
+                sp.r = cs.r;
+                sp.xi = (int)rint(sp.xf);                                      // np.round: half to even
+                sp.yi = (int)rint(sp.yf);
+                const bool ok = cs.r > 0.0 && margin2 < sp.xi && sp.xi < dimX + margin + margin2 && margin2 < sp.yi &&
+                                sp.yi < dimY + margin + margin2;               // :152
+                sp.radInt = ok ? (int)floor(cs.r) + 1 : 0;                     // 0: touches no pixel
+                sp.pad = 0;
+                sh[threadIdx.x] = sp;
+            }
+            __syncthreads();
+            for (int s = 0; s < cnt; ++s) {
+                const Sphere sp = sh[s];
+                const int jj = py - sp.yi;
+                if (jj < -sp.radInt || jj >= sp.radInt) continue;
+                const double dy = (double)py - sp.yf;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int px = t0 + ty + 8 * k + margin;
+                    const int ii = px - sp.xi;
+                    if (ii >= -sp.radInt && ii < sp.radInt) {
+                        const double dx = (double)px - sp.xf;
+                        const double dist = sqrt(dx * dx + dy * dy);                 // getMembraneFromFile.py:157
+                        if (dist < sp.r) acc[k] += 2.0 * sqrt(sp.r * sp.r - dist * dist);   // :159
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = t0 + ty + 8 * k, j = c0 + tx;
+        if (i < dimX && j < dimY) {
+            const float v = (float)(acc[k] * scale);
+            const int64_t p = (int64_t)i * dimY + j;
+            out[p] = accumulate ? out[p] + v : v;
+        }
+    }
+}
+
 }  // namespace
 
+struct psx_membrane_plan {
+    CellSphere *spheres = nullptr;   // sorted by cell (row-major cells), list order inside a cell
+    int *cell_off = nullptr;         // [ncx*ncy + 1]
+    int ncx = 0, ncy = 0, rmax_int = 1;
+    double x0 = 0.0, y0 = 0.0;
+    int64_t n = 0;
+};
+
 extern "C" {
+
+int psx_membrane_plan_create(const double *x, const double *y, const double *r, int64_t n, psx_membrane_plan **plan) {
+    PSX_REQUIRE(plan != nullptr, "psx_membrane_plan_create: null plan pointer");
+    *plan = nullptr;
+    PSX_REQUIRE(n >= 0 && (n == 0 || (x && y && r)), "psx_membrane_plan_create: null sphere arrays");
+    psx_membrane_plan *p = new psx_membrane_plan();
+    double xmin = 0, xmax = 0, ymin = 0, ymax = 0, rmax = 0;
+    bool any = false;
+    for (int64_t s = 0; s < n; ++s) {
+        if (!(r[s] > 0.0) || !std::isfinite(x[s]) || !std::isfinite(y[s]) || !std::isfinite(r[s])) continue;
+        if (!any) { xmin = xmax = x[s]; ymin = ymax = y[s]; any = true; }
+        xmin = std::min(xmin, x[s]); xmax = std::max(xmax, x[s]);
+        ymin = std::min(ymin, y[s]); ymax = std::max(ymax, y[s]);
+        rmax = std::max(rmax, r[s]);
+    }
+    p->x0 = std::floor(xmin); p->y0 = std::floor(ymin);
+    const double ex = xmax - p->x0, ey = ymax - p->y0;
+    if (!(ex / MT < 30000.0 && ey / MT < 30000.0 && (ex / MT + 1) * (ey / MT + 1) < 2.0e8 && rmax < 1.0e6)) {
+        delete p;
+        return fail(PSX_E_ARG, "psx_membrane_plan_create: sphere list spans %.3g x %.3g pixels (radius up to %.3g)", ex, ey, rmax);
+    }
+    p->ncx = (int)(ex / MT) + 1; p->ncy = (int)(ey / MT) + 1;
+    p->rmax_int = (int)std::floor(rmax) + 1;
+    const size_t nc = (size_t)p->ncx * p->ncy;
+    std::vector<int> off(nc + 1, 0);
+    std::vector<int> cell(n > 0 ? n : 1, -1);
+    for (int64_t s = 0; s < n; ++s) {
+        if (!(r[s] > 0.0) || !std::isfinite(x[s]) || !std::isfinite(y[s]) || !std::isfinite(r[s])) continue;
+        const int cx = (int)((x[s] - p->x0) / MT), cy = (int)((y[s] - p->y0) / MT);
+        cell[s] = cx * p->ncy + cy;
+        off[cell[s] + 1]++;
+    }
+    for (size_t c = 0; c < nc; ++c) off[c + 1] += off[c];
+    std::vector<CellSphere> sorted(off[nc] ? off[nc] : 1);
+    std::vector<int> cursor(off.begin(), off.end() - 1);
+    for (int64_t s = 0; s < n; ++s)
+        if (cell[s] >= 0) sorted[cursor[cell[s]]++] = CellSphere{x[s], y[s], r[s]};
+    p->n = off[nc];
+    hipError_t e = hipMalloc((void **)&p->spheres, sizeof(CellSphere) * sorted.size());
+    if (e == hipSuccess) e = hipMalloc((void **)&p->cell_off, sizeof(int) * off.size());
+    if (e == hipSuccess) e = hipMemcpy(p->spheres, sorted.data(), sizeof(CellSphere) * sorted.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->cell_off, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        psx_membrane_plan_destroy(p);
+        return fail((int)e, "psx_membrane_plan_create: %s", hipGetErrorString(e));
+    }
+    *plan = p;
+    return 0;
+}
+
+int psx_membrane_plan_destroy(psx_membrane_plan *p) {
+    if (!p) return 0;
+    (void)hipFree(p->spheres);
+    (void)hipFree(p->cell_off);
+    delete p;
+    return 0;
+}
+
+int psx_membrane_layer_f32(psx_membrane_plan *p, int offx, int offy, int dimX, int dimY, int margin, int margin2,
+                           double scale, int accumulate, float *out, void *stream) {
+    PSX_REQUIRE(p != nullptr && out != nullptr && dimX > 0 && dimY > 0 && margin >= 0, "psx_membrane_layer_f32: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles_x = (int)cdiv(dimX, MT), tiles_y = (int)cdiv(dimY, MT);
+    PSX_TIMED("k_membrane", st, k_membrane_cells<<<tiles_x * tiles_y, 256, 0, st>>>(p->spheres, p->cell_off, p->ncx, p->ncy, p->x0, p->y0,
+                                                                                    p->rmax_int, offx, offy, out, dimX, dimY, margin,
+                                                                                    margin2, tiles_y, scale, accumulate));
+    return launch_check("k_membrane");
+}
 
 // xf, yf, rad: HOST arrays (pixels of the margin-extended grid).  out: DEVICE [dimX][dimY] float32.
 int psx_membrane_f32(const double *xf, const double *yf, const double *rad, int64_t n, int dimX, int dimY, int margin,

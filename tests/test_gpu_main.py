@@ -80,3 +80,37 @@ def test_membrane_synthesis_golden_and_seeding():
     # against the oracle at a larger size
     ref = orc.membrane_segmented(synth.sphere_list(), 400, 400, 1.45, 15.0, 2, 6000.0, synth.position_seed(3))
     assert relmax(a.cpu().numpy(), ref[0]) < 2e-7
+
+
+def test_membrane_entry_points_agree():
+    """psx_membrane_f32 (host sphere arrays, tile binning on the host) and the plan path (list resident on the GPU, cells
+    found by the kernel) render the same layers, ragged grids and far-off offsets included."""
+    import ctypes
+    from ctypes import c_double, c_void_p
+    from paresis_amd import synth
+    from paresis_amd._lib import check, lib
+    from paresis_amd.Samples import getMembraneFromFile as GM
+    lst = synth.sphere_list()
+    DP = ctypes.POINTER(c_double)
+    for dimX, dimY, pix, meanR in ((333, 517, 1.45, 15.0), (96, 40, 2.9, 50.0), (1000, 1000, 0.8, 15.0)):
+        margin, margin2, par, sizeX, sizeY = GM.stitched_list(lst, dimX, dimY, pix, meanR)
+        x, y, r = (np.ascontiguousarray(v) for v in (par[:, 1] / pix, par[:, 0] / pix, par[:, 2] / pix))
+        plan = c_void_p(None)
+        check(lib().psx_membrane_plan_create(x.ctypes.data_as(DP), y.ctypes.data_as(DP), r.ctypes.data_as(DP), len(r),
+                                             ctypes.byref(plan)), "plan")
+        try:
+            st = c_void_p(torch.cuda.current_stream().cuda_stream)
+            for ox, oy in ((margin2, margin2), (int(sizeX / pix) - dimX - margin2 - 1, 7), (-500, 100000)):
+                a = torch.full((dimX, dimY), 1.0, dtype=torch.float32, device="cuda")
+                b = torch.full((dimX, dimY), 1.0, dtype=torch.float32, device="cuda")
+                xf, yf = np.ascontiguousarray(x - ox), np.ascontiguousarray(y - oy)
+                check(lib().psx_membrane_f32(xf.ctypes.data_as(DP), yf.ctypes.data_as(DP), r.ctypes.data_as(DP), len(r), dimX,
+                                             dimY, margin, margin2, c_double(pix * 1e-6), 1, c_void_p(a.data_ptr()), st), "host")
+                check(lib().psx_membrane_layer_f32(plan, ox, oy, dimX, dimY, margin, margin2, c_double(pix * 1e-6), 1,
+                                                   c_void_p(b.data_ptr()), st), "plan")
+                torch.cuda.synchronize()
+                assert float((a - b).abs().max()) <= 1e-12 + 2e-7 * float(a.abs().max()), (dimX, dimY, ox, oy)
+                if (ox, oy) == (margin2, margin2):
+                    assert float(a.max()) > 1.0            # something was rendered
+        finally:
+            lib().psx_membrane_plan_destroy(plan)
