@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Diagnostic: wall and kernel time of fastRefractionDF at 4096^2 (dark field of ~2.5 px inside a cylinder)."""
+import os, sys, time, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from paresis_amd import _lib, synth
+from paresis_amd import refractionFileNumba2 as RF2
+lib = _lib.lib()
+N = 4096
+geo = synth.bench_geometry(N)
+pix, M = geo["pix_um"], geo["M"]
+k = 2 * np.pi * 52e3 * 1.6e-19 / (6.626e-34 * 2.998e8)
+phi = torch.from_numpy(-k * 6.2e-7 * geo["membrane"][0].astype(np.float64)).cuda()
+I = torch.full((N, N), 7500.0, dtype=torch.float32, device="cuda")
+df = torch.from_numpy(np.where(geo["sample"][0] > 0, 2.0e-6, 0.0)).cuda()
+f = lambda: RF2.fastRefractionDF(I.clone(), phi, 3.6, 52.0, M, pix, df)
+f(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3): f()
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / 3 * 1e3
+lib.psx_profile_enable(1); f(); torch.cuda.synchronize()
+buf = ctypes.create_string_buffer(1 << 16); lib.psx_profile_summary(buf, len(buf)); lib.psx_profile_enable(0)
+print("fastRefractionDF %dx%d: %.1f ms wall; library kernels: %s" % (N, N, wall, buf.value.decode().replace("\n", "; ")))
