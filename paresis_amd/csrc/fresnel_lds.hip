@@ -675,22 +675,46 @@ __global__ __launch_bounds__(256) void k_source_transposed(const float2 *__restr
     const int y0 = (blockIdx.x % ntx) * 64, x0 = (blockIdx.x / ntx) * 64;
     // read phase: a thread takes 4 consecutive y of one image row per pass (one 16-byte load per thickness map), a wave
     // 4 rows x 64 y; 4 passes cover the 64 rows of the tile.  Full tiles of maps whose rows are 16-byte aligned only.
-    const bool vec = vec_ok && x0 + 64 <= Nx && y0 + 64 <= Ny;   // vec_ok: no input wave, Ny % 4 == 0, 16-byte aligned maps
+    const bool vec = vec_ok && x0 + 64 <= Nx && y0 + 64 <= Ny;   // vec_ok: Ny % 4 == 0, 16-byte aligned maps (and input wave)
     if (vec) {
         const int yq = (threadIdx.x & 15) * 4, xr = threadIdx.x >> 4;
-        float4 t[4][NM > 0 ? NM : 1];
+        float4 t[4][NM > 0 ? NM : 1], wv[4][2];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t p = (int64_t)(x0 + xr + 16 * r) * Ny + y0 + yq;
 #pragma unroll
             for (int i = 0; i < NM; ++i) t[r][i] = *reinterpret_cast<const float4 *>(m.T[i] + p);
+            if (src) {                                   // 4 complex samples of the input wave: two 16-byte loads
+                wv[r][0] = *reinterpret_cast<const float4 *>(src + p);
+                wv[r][1] = *reinterpret_cast<const float4 *>(src + p + 2);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float2 w = make_float2(amp, 0.f);
-                if (NM > 0) {
+                if (src) {                               // same operation order as source_wave<NM>
+                    const float2 wi = e == 0 ? make_float2(wv[r][0].x, wv[r][0].y)
+                                             : (e == 1 ? make_float2(wv[r][0].z, wv[r][0].w)
+                                                       : (e == 2 ? make_float2(wv[r][1].x, wv[r][1].y) : make_float2(wv[r][1].z, wv[r][1].w)));
+                    float a = amp;
+                    float2 ww = wi;
+                    if (NM > 0) {
+                        double ph = 0.0, la = 0.0;
+#pragma unroll
+                        for (int i = 0; i < NM; ++i) {
+                            const float tv = e == 0 ? t[r][i].x : (e == 1 ? t[r][i].y : (e == 2 ? t[r][i].z : t[r][i].w));
+                            ph = fma(m.cphase[i], (double)tv, ph);
+                            la = fma(m.catt[i], (double)tv, la);
+                        }
+                        float c, sn;
+                        cis_f64(ph, c, sn);
+                        a *= expf((float)la);
+                        ww = make_float2(wi.x * c - wi.y * sn, wi.x * sn + wi.y * c);
+                    }
+                    w = make_float2(a * ww.x, a * ww.y);
+                } else if (NM > 0) {
                     double ph = 0.0, la = 0.0;
 #pragma unroll
                     for (int i = 0; i < NM; ++i) {
@@ -1038,7 +1062,7 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
     }
     {
         const int ntiles = (int)(cdiv(p->Nx, 64) * cdiv(p->Ny, 64));
-        int vec_ok = a.wave_in == nullptr && p->Ny % 4 == 0;
+        int vec_ok = p->Ny % 4 == 0 && (uintptr_t)a.wave_in % 16 == 0;
         for (int i = 0; i < a.m.n && i < PSX_MAX_MAT; ++i) vec_ok = vec_ok && ((uintptr_t)a.m.T[i] % 16 == 0);
         PSX_DISPATCH_NMAT(a.m.n, PSX_TIMED("k_source_transposed", st, k_source_transposed<NM><<<ntiles, 256, 0, st>>>(
                                                                            a.wave_in, a.amp, a.m, e->pre, p->Nx, p->Ny, vec_ok)));
