@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Diagnostic: the membrane-position loop of main.py:63-110 on ONE GPU at the bench size -- per position: membrane
+synthesis (seeded offsets, sphere splat on the GPU) + the image-formation chain + detection; images stay in HBM.
+BASELINE.json config 4 is 64 such positions over 8 GPUs (8 per GPU, no data-path collective)."""
+import os, sys, time, types
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import paresis_oracle as orc     # Obj container only (diagnostic tool)
+from tests._build import build_experiment
+from paresis_amd import synth
+from paresis_amd.Samples.getMembraneFromFile import getMembraneSegmentedFromFile
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+NPOS = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+geo = synth.bench_geometry(N, pointNum=0)
+d = synth.DELTA_BETA_52KEV
+obj = lambda g, mats: orc.Obj(g, [[d[m][0]] for m in mats], [[d[m][1]] for m in mats])
+cfg = dict(dSM=140.0, dMO=1.6, dOD=3.6, meanShotCount=30000.0, ov=2, pix_um=geo["pix_um"], M=geo["M"], inVacuum=True,
+           N=(N, N), spectrum=[(52.0, 1.0)], source_size_um=10.0, energy_sampling=1.0, det_dims=(N // 2, N // 2),
+           det_pix_um=6.0, psf=1.2, bins=[], membrane=obj(geo["membrane"], geo["membrane_materials"]),
+           sample=obj(geo["sample"], ["Nylon"]), air=None, plate=None, scintillator=None)
+smp = types.SimpleNamespace(myMeanSphereRadius=15.0, myNbOfLayers=2)
+mpix = geo["pix_um"] * 140.0 / 141.6
+for sim in ("Fresnel", "RT"):
+    exp = build_experiment(cfg, sim, noise=True)
+    def position(p):
+        geom, _ = getMembraneSegmentedFromFile(smp, N, N, mpix, p, 6000.0)
+        exp.myMembrane.myGeometry = torch.stack(geom)
+        return exp.computeSampleAndReferenceImages(p)
+    position(0); position(1); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    keep = [position(p)[:2] for p in range(1, NPOS + 1)]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("%s: %d positions of %dx%d (detector %dx%d) in %.1f ms = %.2f ms per position (%.0f Mpixel/s of study grid)"
+          % (sim, NPOS, N, N, N // 2, N // 2, dt * 1e3, dt / NPOS * 1e3, NPOS * N * N / dt / 1e6))
