@@ -5,14 +5,14 @@ bench's hot step (detections, accumulations, host code)."""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from oracle import paresis_oracle as orc     # Obj container only (diagnostic tool)
+import types
 from tests._build import build_experiment
 from paresis_amd import _lib, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 lib = _lib.lib()
 geo = synth.bench_geometry(N, pointNum=0)
 d = synth.DELTA_BETA_52KEV
-obj = lambda g, mats: orc.Obj(g, [[d[m][0]] for m in mats], [[d[m][1]] for m in mats])
+obj = lambda g, mats: types.SimpleNamespace(geometry=g, delta=[[d[m][0]] for m in mats], beta=[[d[m][1]] for m in mats])
 cfg = dict(dSM=140.0, dMO=1.6, dOD=3.6, meanShotCount=30000.0, ov=2, pix_um=geo["pix_um"], M=geo["M"], inVacuum=True,
            N=(N, N), spectrum=[(52.0, 1.0)], source_size_um=10.0, energy_sampling=1.0, det_dims=(N // 2, N // 2),
            det_pix_um=6.0, psf=1.2, bins=[], membrane=obj(geo["membrane"], geo["membrane_materials"]),
