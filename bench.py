@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--engine", default="auto", choices=["auto", "rocfft", "lds"])
     ap.add_argument("--halo", type=int, default=4, choices=[4, 6, 8], help="refraction gather halo (speed knob)")
