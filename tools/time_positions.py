@@ -9,8 +9,9 @@ import types
 from tests._build import build_experiment
 from paresis_amd import synth
 from paresis_amd.Samples.getMembraneFromFile import getMembraneSegmentedFromFile
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-NPOS = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+_args = [a for a in sys.argv[1:] if not a.startswith('--')]
+N = int(_args[0]) if len(_args) > 0 else 4096
+NPOS = int(_args[1]) if len(_args) > 1 else 16
 geo = synth.bench_geometry(N, pointNum=0)
 d = synth.DELTA_BETA_52KEV
 obj = lambda g, mats: types.SimpleNamespace(geometry=g, delta=[[d[m][0]] for m in mats], beta=[[d[m][1]] for m in mats])
@@ -27,9 +28,22 @@ for sim in ("Fresnel", "RT"):
         exp.myMembrane.myGeometry = torch.stack(geom)
         return exp.computeSampleAndReferenceImages(p)
     position(0); position(1); torch.cuda.synchronize()
+    if "--no-reserve" not in sys.argv:
+        exp.reserve_outputs(NPOS)             # what main.py does: no hipMalloc inside the loop for the kept stacks
     t0 = time.perf_counter()
     keep = [position(p)[:2] for p in range(1, NPOS + 1)]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("%s: %d positions of %dx%d (detector %dx%d) in %.1f ms = %.2f ms per position (%.0f Mpixel/s of study grid)"
           % (sim, NPOS, N, N, N // 2, N // 2, dt * 1e3, dt / NPOS * 1e3, NPOS * N * N / dt / 1e6))
+    import ctypes
+    from paresis_amd import _lib
+    lib = _lib.lib()
+    lib.psx_profile_enable(1)
+    for p in range(1, 5): position(p)
+    torch.cuda.synchronize()
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.psx_profile_summary(buf, len(buf)); lib.psx_profile_enable(0)
+    ks = {l.split()[0]: (int(l.split()[1]) / 4, float(l.split()[2]) / 4) for l in buf.value.decode().splitlines()}
+    print("   library kernels per position %.2f ms: %s" % (sum(v[1] for v in ks.values()),
+          ", ".join("%s x%.0f %.3f" % (k, c, t) for k, (c, t) in sorted(ks.items(), key=lambda kv: -kv[1][1]))))
