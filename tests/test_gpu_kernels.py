@@ -326,6 +326,33 @@ def test_detector_golden(ops):
         plan.close()
 
 
+@pytest.mark.parametrize("case", [(1100, 1204, 2, 1.3, 1.2), (1101, 1203, 3, 0.0, 0.8), (1600, 2052, 4, 2.6, 0.0),
+                                  (700, 520, 1, 0.9, 1.7), (2400, 600, 2, 9.0, 3.1)])
+def test_detector_multi_block_grids(ops, case):
+    """The two-stage banded detector kernels on grids of several 256-output blocks, aligned (16-byte staging) and
+    unaligned rows, with and without each blur: against the dense composite operator of the host builder (the one the
+    CPU suite holds to the oracle), applied in float64."""
+    Nx, Ny, ov, sig_src, sig_psf = case
+    nx, ny = Nx // ov, Ny // ov
+    rng = np.random.default_rng(Nx + Ny)
+    img = rng.uniform(0.5, 2.0, (Nx, Ny)).astype(np.float32)
+
+    def dense(N, n):
+        start, w = ops.detector_operator_host(N, ov, n, sig_src, sig_psf)
+        C = np.zeros((n, N))
+        for r in range(n):
+            k = min(w.shape[1], N - start[r])
+            C[r, start[r]:start[r] + k] = w[r, :k]
+        return C
+
+    ref = dense(Nx, nx) @ img.astype(np.float64) @ dense(Ny, ny).T
+    plan = ops.DetectorPlan(Nx, Ny, ov, nx, ny, sig_src, sig_psf)
+    out = plan.detect(dev(img, torch.float32))
+    plan.close()
+    assert out.shape == (nx, ny)
+    assert relmax(out.cpu().numpy(), ref) < 2e-6, case
+
+
 def test_resize_golden(ops):
     g = load("scalars.npz")
     for k in range(int(g["resize/n"])):
