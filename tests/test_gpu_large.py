@@ -170,6 +170,27 @@ def test_refraction_flux_and_halos_4096():
     assert lost < 1e-3
 
 
+def test_refraction_distance_batch_4096():
+    """The bench's refraction call (4 distances, one launch per kernel) against four one-distance calls at full size, and
+    flux conservation of every image of the batch."""
+    from paresis_amd import ops
+    from paresis_amd.getk import k_refraction
+    N = 4096
+    g, T = _membrane(N, 5)
+    _, rt = _stacks(ops, T)
+    h = g["pix_um"] * 1e-6
+    dsc = [z / k_refraction(52.0) / (h * g["M"]) / h for z in (1.6, 3.6, 5.2, 7.2)]
+    outs = ops.refract_multi((N, N), rt, dsc, (N, N), I0=7500.0)
+    I_in, _ = ops.transmit_rt(None, 7500.0, rt, want_phi=False)
+    m = 64
+    tot = float(I_in[m:-m, m:-m].sum(dtype=torch.float64))
+    for d, o in zip(dsc, outs):
+        single, _, _ = ops.refract((N, N), rt, d, (N, N), I0=7500.0)
+        assert float((o - single).abs().max() / single.max()) < 1e-6
+        assert abs(float(o[m:-m, m:-m].sum(dtype=torch.float64)) / tot - 1) < 1e-3
+    ops.check_status(outs[0].device)
+
+
 def test_16384_partitioned_engine_and_detector():
     """Config 5: 16384^2 study grid (detector 4096^2 x oversampling 4, PSF 1.2 px, 10 um source) resident in HBM."""
     from paresis_amd import ops
