@@ -203,20 +203,6 @@ class Experiment:
         raise Exception("simulation Type not defined: ", self.exp_dict['simulation_type'])
 
     # ------------------------------------------------------------------------------------------- helpers
-    def reserve_outputs(self, n_positions):
-        """Make room in torch's caching allocator for the images of `n_positions` positions that the caller will keep
-        (main.py keeps every position's stacks until the final gather).  Without it each kept stack costs a hipMalloc --
-        a device-synchronising call of about a millisecond -- in the middle of the position loop: 4.6 ms per position
-        instead of 2.3 at 4096^2.  One allocation of the total, released at once, leaves a cached block the per-position
-        allocations are split from."""
-        dp = self.myDetector.det_param
-        nbins = len(dp["myBinsThersholds"]) + 1          # position 0 appends the closing threshold (EXP:296-301): upper bound
-        n0, n1 = int(dp['myDimensions'][0]), int(dp['myDimensions'][1])
-        per_stack = ((nbins * n0 * n1 * 4 + (2 << 20) - 1) // (2 << 20)) * (2 << 20)        # the allocator rounds large blocks to 2 MiB
-        total = per_stack * (2 * int(n_positions) + 4)
-        if total > 0:
-            torch.empty(total, dtype=torch.uint8, device=device())        # freed on return: stays cached
-
     def _begin(self, pointNum):
         """Bin thresholds (EXP:296-305) and output stacks."""
         dp, spec = self.myDetector.det_param, self.mySource.mySpectrum

@@ -327,6 +327,36 @@ struct Philox {
     }
 };
 
+// log of the Poisson probability  -L + k log L - log k!  for PTRS's acceptance test.  The three terms are of order
+// L log L and cancel to order 1, so a direct evaluation needs float64 (log, lgamma: ~500 instructions that every wave
+// ends up executing, since 14 % of the candidates take this test).  With x = (k - L)/L and Stirling's series for log k!
+//     log pmf = -L g(x) - log(2 pi k)/2 - 1/(12 k) + 1/(360 k^3),      g(x) = (1 + x) log(1 + x) - x = x^2/2 - x^3/6 + ...
+// every term is small and float32 is enough (|error| < 1e-4 for k, L >= 64: an acceptance decision can only change when the
+// two sides are that close); small k or L keep the float64 form.
+__device__ __forceinline__ float log_pmf(float k, float L) {
+    if (k >= 64.f && L >= 64.f) {
+        const float x = (k - L) / L;                           // k - L is exact (Sterbenz) or far in the tail
+        float g;
+        if (fabsf(x) < 0.125f) {                               // sum_{n>=2} (-1)^n x^n / (n (n-1)), 9 terms: < 1e-9 relative
+            g = 1.f / 90.f;
+            g = fmaf(g, -x, 1.f / 72.f);
+            g = fmaf(g, -x, 1.f / 56.f);
+            g = fmaf(g, -x, 1.f / 42.f);
+            g = fmaf(g, -x, 1.f / 30.f);
+            g = fmaf(g, -x, 1.f / 20.f);
+            g = fmaf(g, -x, 1.f / 12.f);
+            g = fmaf(g, -x, 1.f / 6.f);
+            g = fmaf(g, -x, 0.5f);
+            g *= x * x;
+        } else {
+            g = (1.f + x) * log1pf(x) - x;
+        }
+        const float ik = 1.f / k;
+        return -L * g - 0.5f * logf(6.2831853f * k) - ik * (1.f / 12.f) + ik * ik * ik * (1.f / 360.f);
+    }
+    return (float)(-(double)L + (double)k * log((double)L) - lgamma((double)k + 1.0));
+}
+
 // Poisson draw: product-of-uniforms for lam < 10, Hormann's PTRS transformed rejection otherwise (both exact).
 __global__ __launch_bounds__(256) void k_poisson(const float *__restrict__ lam, float *__restrict__ out, int64_t n,
                                                  uint64_t seed) {
@@ -366,8 +396,8 @@ __global__ __launch_bounds__(256) void k_poisson(const float *__restrict__ lam, 
                     const float k = floorf((2.f * a / us + b) * U + L + 0.43f);
                     if (us >= 0.07f && V <= vr) { res = k; acc = true; break; }
                     if (k < 0.f || (us < 0.013f && V > us)) continue;
-                    if (log((double)V) + log((double)invalpha) - log((double)a / ((double)us * us) + b) <=
-                        -(double)L + (double)k * log((double)L) - lgamma((double)k + 1.0)) {
+                    const float lhs = logf(V) + logf(invalpha) - logf(a / (us * us) + b);
+                    if (lhs <= log_pmf(k, L)) {
                         res = k;
                         acc = true;
                     }

@@ -28,9 +28,7 @@ def run(exp_dict, save=True, saving_format=".tif"):
     experiment = Experiment(exp_dict)
     print("\nImages calculation")
     results = {}
-    mine = dist.my_positions(exp_dict['nbExpPoints'], rank, world)
-    experiment.reserve_outputs(len(mine))          # the stacks of every position stay in HBM until the gather
-    for pointNum in mine:
+    for pointNum in dist.my_positions(exp_dict['nbExpPoints'], rank, world):
         experiment.myMembrane.myGeometry = []
         experiment.myMembrane.getMyGeometry(experiment.exp_dict['studyDimensions'], experiment.myMembrane.membranePixelSize,
                                             experiment.exp_dict['overSampling'], pointNum, exp_dict['nbExpPoints'])   # main.py:64-65

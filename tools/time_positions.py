@@ -28,12 +28,19 @@ for sim in ("Fresnel", "RT"):
         exp.myMembrane.myGeometry = torch.stack(geom)
         return exp.computeSampleAndReferenceImages(p)
     position(0); position(1); torch.cuda.synchronize()
-    if "--no-reserve" not in sys.argv:
-        exp.reserve_outputs(NPOS)             # what main.py does: no hipMalloc inside the loop for the kept stacks
     t0 = time.perf_counter()
-    keep = [position(p)[:2] for p in range(1, NPOS + 1)]
+    keep, each = [], []
+    for p in range(1, NPOS + 1):
+        t1 = time.perf_counter()
+        na = torch.cuda.memory_stats()["num_device_alloc"]
+        keep.append(position(p)[:2])
+        each.append((time.perf_counter() - t1) * 1e3)
+        if torch.cuda.memory_stats()["num_device_alloc"] != na:
+            each[-1] = -each[-1]              # printed negative: the caching allocator went to hipMalloc during this position
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    print("   per position (host, ms; negative: the caching allocator called hipMalloc):", " ".join("%.1f" % t for t in each))
+    print("   median %.2f ms per position" % float(np.median(np.abs(each))))
     print("%s: %d positions of %dx%d (detector %dx%d) in %.1f ms = %.2f ms per position (%.0f Mpixel/s of study grid)"
           % (sim, NPOS, N, N, N // 2, N // 2, dt * 1e3, dt / NPOS * 1e3, NPOS * N * N / dt / 1e6))
     import ctypes
