@@ -889,9 +889,17 @@ struct LdsEngine {
 };
 
 bool lds_engine_supported(int Nx, int Ny, int margin) {
-    // any line length: one transform per line up to N = 4593, the partitioned convolution beyond; the blocked intermediate
-    // of a partitioned pass 1 is addressed with 32-bit byte offsets inside one output block
-    return margin >= 0 && margin <= Nx - 1 && margin <= Ny - 1 && margin <= 2048 && (int64_t)Nx * Ny < (1ll << 31);
+    // any line length: one transform per line up to N = 4593, the partitioned convolution beyond.  The output windows are
+    // buffer descriptors with 32-bit byte ranges: the whole blocked intermediate for a one-transform pass 1, one output
+    // block of it (B/8 sample-blocks x Ny lines) for a partitioned one; a row of the result in pass 2.
+    if (!(margin >= 0 && margin <= Nx - 1 && margin <= Ny - 1 && margin <= 2048 && (int64_t)Nx * Ny < (1ll << 31))) return false;
+    int64_t span = (int64_t)cdiv(Nx, IB) * IB;                       // samples of a pass-1 line inside one window
+    if (!pick_r3(Nx, margin)) {
+        int B, Lh, S, NB;
+        part_geometry(Nx, margin, B, Lh, S, NB);
+        span = B;
+    }
+    return span * (int64_t)Ny * (int64_t)sizeof(float2) < (1ll << 31);
 }
 
 static int make_axis(AxisTables &t, int N, int margin, size_t &bytes) {
