@@ -223,6 +223,11 @@ def main():
                 nm: {"ms_per_launch": round(per[nm], 4), "achieved": round(alg[nm] / (per[nm] * 1e-3) / 1e9, 1),
                      "frac": round(alg[nm] / (per[nm] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(nm, N)}
                 for nm in sorted(per) if nm in alg}
+            # the bytes the kernels REALLY move (PMC counters of the committed profile) over the live launch time: what HBM
+            # sees, next to the algorithmic figure above -- these kernels are bound by instruction issue, not by HBM
+            for nm, e in out["roofline"]["by_kernel"].items():
+                if e["traffic"]:
+                    e["hbm_gbs_measured"] = round(e["traffic"] / (per[nm] * 1e-3) / 1e9, 1)
             # whole-step view with the same accounting: 4 x (64 + 12 + 4*nmat) bytes per padded pixel
             step_bytes = units * (64 + 12 + 4 * nmat) * P * P
             out["roofline"]["step_achieved"] = round(step_bytes / (dt / a.steps) / 1e9, 1)
