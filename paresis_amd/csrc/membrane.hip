@@ -47,8 +47,11 @@ __global__ __launch_bounds__(256) void k_membrane(const Sphere *__restrict__ sph
                 const int ii = px - sp.xi;
                 if (ii >= -sp.radInt && ii < sp.radInt) {
                     const double dx = (double)px - sp.xf;
-                    const double dist = sqrt(dx * dx + dy * dy);                 // getMembraneFromFile.py:157
-                    if (dist < sp.r) acc[k] += 2.0 * sqrt(sp.r * sp.r - dist * dist);   // :159
+                    // getMembraneFromFile.py:157-159 takes dist = sqrt(dx^2 + dy^2), tests dist < r and adds 2 sqrt(r^2 - dist^2);
+                    // comparing the squares saves one of the two float64 square roots and moves the chord by one rounding
+                    // of dist^2 (below 1e-9 of the membrane thickness, also at a sphere's rim)
+                    const double d2 = dx * dx + dy * dy, r2 = sp.r * sp.r;
+                    if (d2 < r2) acc[k] += 2.0 * sqrt(r2 - d2);
                 }
             }
         }
@@ -119,8 +122,11 @@ __global__ __launch_bounds__(256) void k_membrane_cells(const CellSphere *__rest
                     const int ii = px - sp.xi;
                     if (ii >= -sp.radInt && ii < sp.radInt) {
                         const double dx = (double)px - sp.xf;
-                        const double dist = sqrt(dx * dx + dy * dy);                 // getMembraneFromFile.py:157
-                        if (dist < sp.r) acc[k] += 2.0 * sqrt(sp.r * sp.r - dist * dist);   // :159
+                        // getMembraneFromFile.py:157-159 takes dist = sqrt(dx^2 + dy^2), tests dist < r and adds 2 sqrt(r^2 - dist^2);
+                        // comparing the squares saves one of the two float64 square roots and moves the chord by one rounding
+                        // of dist^2 (below 1e-9 of the membrane thickness, also at a sphere's rim)
+                        const double d2 = dx * dx + dy * dy, r2 = sp.r * sp.r;
+                        if (d2 < r2) acc[k] += 2.0 * sqrt(r2 - d2);
                     }
                 }
             }
