@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void k_membrane_cells(const CellSphere *__rest
                                                         float *__restrict__ out, int dimX, int dimY, int margin,
                                                         int margin2, int tiles_y, double scale, int accumulate) {
     __shared__ Sphere sh[64];
+    __shared__ int shcnt;
     const int tile = blockIdx.x, t0 = (tile / tiles_y) * MT, c0 = (tile % tiles_y) * MT;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 columns x 8 rows; each thread owns 4 rows
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -94,23 +95,31 @@ __global__ __launch_bounds__(256) void k_membrane_cells(const CellSphere *__rest
     for (int cx = cx0; cx <= cx1 && cy0 <= cy1; ++cx) {
         const int beg = cell_off[cx * ncy + cy0], end = cell_off[cx * ncy + cy1 + 1];
         for (int base = beg; base < end; base += 64) {
-            const int cnt = min(64, end - base);
+            const int nraw = min(64, end - base);
             __syncthreads();
-            if (threadIdx.x < cnt) {
-                const CellSphere cs = spheres[base + threadIdx.x];
-                Sphere sp;
-                sp.xf = cs.x - (double)offx;                                   // getMembraneFromFile.py:141-142
-                sp.yf = cs.y - (double)offy;
-                sp.r = cs.r;
-                sp.xi = (int)rint(sp.xf);                                      // np.round: half to even
-                sp.yi = (int)rint(sp.yf);
-                const bool ok = cs.r > 0.0 && margin2 < sp.xi && sp.xi < dimX + margin + margin2 && margin2 < sp.yi &&
-                                sp.yi < dimY + margin + margin2;               // :152
-                sp.radInt = ok ? (int)floor(cs.r) + 1 : 0;                     // 0: touches no pixel
-                sp.pad = 0;
-                sh[threadIdx.x] = sp;
+            if (threadIdx.x < 64) {                  // the first wave stages and compacts: only spheres whose window meets the tile
+                Sphere sp = {};
+                bool hit = false;
+                if (threadIdx.x < nraw) {
+                    const CellSphere cs = spheres[base + threadIdx.x];
+                    sp.xf = cs.x - (double)offx;                                   // getMembraneFromFile.py:141-142
+                    sp.yf = cs.y - (double)offy;
+                    sp.r = cs.r;
+                    sp.xi = (int)rint(sp.xf);                                      // np.round: half to even
+                    sp.yi = (int)rint(sp.yf);
+                    const bool ok = cs.r > 0.0 && margin2 < sp.xi && sp.xi < dimX + margin + margin2 && margin2 < sp.yi &&
+                                    sp.yi < dimY + margin + margin2;               // :152
+                    sp.radInt = (int)floor(cs.r) + 1;
+                    // window [xi - radInt, xi + radInt) against the tile's pixels [t0 + margin, t0 + margin + MT)
+                    hit = ok && sp.xi + sp.radInt > t0 + margin && sp.xi - sp.radInt < t0 + margin + MT &&
+                          sp.yi + sp.radInt > c0 + margin && sp.yi - sp.radInt < c0 + margin + MT;
+                }
+                const unsigned long long m = __ballot(hit);
+                if (hit) sh[__popcll(m & ((1ull << threadIdx.x) - 1ull))] = sp;
+                if (threadIdx.x == 0) shcnt = __popcll(m);
             }
             __syncthreads();
+            const int cnt = shcnt;
             for (int s = 0; s < cnt; ++s) {
                 const Sphere sp = sh[s];
                 const int jj = py - sp.yi;
