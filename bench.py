@@ -251,7 +251,7 @@ def pmc_traffic(kernel, N):
     except (OSError, ValueError, KeyError):
         return None
     # pass 2 (k_fresnel_rows) is the <16, false> instance of the line kernel (strided reads), pass 1 the <16, true> one
-    key = {"k_fresnel_rows": "k_fresnel_lines<16, false>", "k_fresnel_cols": "k_fresnel_lines<16, true>",
+    key = {"k_fresnel_rows": "k_fresnel_lines<16, false", "k_fresnel_cols": "k_fresnel_lines<16, true",
            "k_refract_near": "k_refract_near<"}.get(kernel)
     if not key:
         return None
