@@ -239,3 +239,13 @@ def test_sample_generators_match_the_reference(tmp_path):
     s.myGeometryFunction = "nope"
     with pytest.raises(ValueError, match="Could not define sample geometry"):
         s.getMyGeometry((20, 30), 1.0, 1)
+
+
+def test_bench_finds_its_pmc_traffic():
+    """bench.py reports roofline.traffic from the committed rocprof PMC summary: the kernel-name prefixes it looks up must
+    match what the profile holds (a template parameter added to a kernel once silently turned the figure into null)."""
+    import bench
+    for k in ("k_fresnel_rows", "k_fresnel_cols", "k_refract_near"):
+        t = bench.pmc_traffic(k, 4096)
+        assert isinstance(t, int) and 1e8 < t < 1e10, (k, t)
+    assert bench.pmc_traffic("k_fresnel_rows", 2048) is None        # the profile is for the 4096^2 workload only
