@@ -202,7 +202,19 @@ def test_16384_partitioned_engine_and_detector():
     plan.propagate([2e-12], [0.1], (3e5, 3e5), wave_in=u, want_wave=[False], inten_out=[inten])
     assert float((inten - 2.25).abs().max()) < 1e-4
     del u
+    # a random wave through both engines at the full size (5 output blocks x 3 kernel segments per line on either axis)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    w = torch.complex(1.0 + 0.2 * torch.randn(N, N, device="cuda", generator=gen),
+                      0.2 * torch.randn(N, N, device="cuda", generator=gen)).to(torch.complex64)
+    lds = plan.propagate([2e-12], [0.1], (3e5, 3e5), wave_in=w)[0]
     plan.close()
+    ref_plan = ops.FresnelPlan(N, N, max_dist=1, engine=1)
+    ref = ref_plan.propagate([2e-12], [0.1], (3e5, 3e5), wave_in=w)[0]
+    ref_plan.close()
+    err = float((lds - ref).abs().max() / ref.abs().max())
+    del w, lds, ref
+    torch.cuda.empty_cache()
+    assert err < 3e-6, err
     det = ops.DetectorPlan(N, N, ov, n, n, 10 * 3.6 / 141.6 / 6 * ov / 2.355, 1.2)
     img = det.detect(inten)
     assert img.shape == (n, n)
