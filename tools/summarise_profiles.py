@@ -35,7 +35,7 @@ for k in sorted(set(fetch) | set(write) | set(sq)):
     e.update(sq.get(k, {}))
     summary[k] = e
 json.dump({"note": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ counters each in its own run) of "
-                   "`python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-timing` on one MI355X; averages per "
+                   "`python3 bench.py --no-cpu-baseline` (the default run: 5 warm-up + 50 timed steps + the 50-step per-kernel event pass) on one MI355X; averages per "
                    "launch.  hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE reads half of a wide "
                    "coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section), WRITE_SIZE is exact.",
            "kernels": summary}, open("profiles/%s_pmc_summary.json" % tag, "w"), indent=1)
