@@ -71,6 +71,12 @@ int psx_transmit_rt_f32(const float *I_in, float I0, const float *const *T, cons
 int psx_accumulate_f32(float *acc, const float *img, float scale, const float *const *T, const double *catt, int nmat,
                        int accumulate, int64_t n, void *stream);
 
+/* The same, also reducing what it adds (Experiment.py:360-361 / 485-486: np.mean of the per-energy reference image feeds
+ * the intensity-weighted mean energy): with v[p] = scale*img[p]*exp(sum catt*T[p]),  sums[0] += sum_p v[p] and
+ * sums[1] += weight * sum_p v[p]  (device float64[2], caller-zeroed; weight = the energy).  acc may be NULL (sums only). */
+int psx_accumulate_sum_f32(float *acc, const float *img, float scale, const float *const *T, const double *catt, int nmat,
+                           int accumulate, int64_t n, double *sums, double weight, void *stream);
+
 /* ---- K9-K13: fastRefraction (refractionFileNumba2.py:25-86; variant v1: refractionFileNumba.py:11-68) ----------
  * Source intensity  I_src = I0 * I_in * exp(sum catt*T)          (I_in may be NULL = ones; fused K2)
  * Phase             phi   = phi_in + sum cphase*T                 (phi_in float64, may be NULL)
@@ -159,6 +165,11 @@ int psx_resize_f32(const float *img, int Nx, int Ny, float *out, int sx, int sy,
 /* out[p] = Poisson(lam[p]) drawn from a counter-based generator keyed by (seed, p)  (Detector.py:113-115;
  * the reference seeds from the wall clock, so only the distribution is reproducible) */
 int psx_poisson_f32(const float *lam, float *out, int64_t n, uint64_t seed, void *stream);
+/* The same IN PLACE on nimg <= PSX_MAX_POISSON images of n pixels in ONE launch, image i under key seeds[i] (imgs, seeds:
+ * host arrays) -- the three or four detector images of an energy bin (Experiment.py:388-394).  Image i comes out exactly as
+ * psx_poisson_f32(imgs[i], imgs[i], n, seeds[i]) would leave it. */
+#define PSX_MAX_POISSON 8
+int psx_poisson_multi_f32(float *const *imgs, const uint64_t *seeds, int nimg, int64_t n, void *stream);
 
 /* ---- dark-field refraction, second half: the per-pixel variable-width Gaussian re-splat of
  * fastRefractionDF (refractionFileNumba2.py:168-186).  I2DF: refracted dark-field intensity, DF: dark-field width in

@@ -62,18 +62,38 @@ class Detector:
             self._plans[key] = plan
         return plan
 
-    def detection(self, incidentWave, effectiveSourceSize, exp_param):
+    def detection(self, incidentWave, effectiveSourceSize, exp_param, key=None, out=None):
         """Detector.py:79-119: blur with the projected source, resample to detector pixels, PSF, shot noise.
 
         incidentWave: intensity on the study grid; effectiveSourceSize: projected source FWHM in study pixels;
-        exp_param: needs 'overSampling'; optional 'noise' (default True) and 'seed' (default 0)."""
-        img = to_dev(incidentWave, torch.float32)
+        exp_param: needs 'overSampling'; optional 'noise' (default True) and 'seed' (default 0).
+        key (not in the reference): (pointNum, ibin, kind) of the image -- the shot noise is then a function of WHAT is
+        drawn (paresis_amd.ops.poisson_key) and does not depend on call order or on the number of GPUs; without it the
+        draws of this detector are numbered in call order (the reference seeds from the wall clock, DET:113).
+        out: optional float32 [n, n] tensor in HBM that receives the image."""
+        return self.detect_many([incidentWave], effectiveSourceSize, exp_param, [out], [key])[0]
+
+    def detect_many(self, images, effectiveSourceSize, exp_param, outs=None, keys=None):
+        """detection() of several images of one energy bin (EXP:388-394): the detector operator once per image, then the
+        shot noise of all of them in ONE launch."""
         sigma_src = effectiveSourceSize / 2.355 if effectiveSourceSize != 0 else 0.0     # DET:96-97
-        out = self._plan(img.shape, exp_param["overSampling"], sigma_src, img.device).detect(img)
+        outs = [None] * len(images) if outs is None else list(outs)
+        keys = [None] * len(images) if keys is None else list(keys)
+        res = []
+        for im, o in zip(images, outs):
+            img = to_dev(im, torch.float32)
+            res.append(self._plan(img.shape, exp_param["overSampling"], sigma_src, img.device).detect(img, out=o))
         if exp_param.get("noise", True):
-            self._draws += 1
-            out = ops.poisson(out, seed=(int(exp_param.get("seed", 0)) << 20) + self._draws)
-        return out
+            seed = int(exp_param.get("seed", 0))
+            seeds = []
+            for k in keys:
+                if k is None:
+                    self._draws += 1
+                    seeds.append((seed << 20) + self._draws)
+                else:
+                    seeds.append(ops.poisson_key(seed, *k))
+            ops.poisson_multi(res, seeds)
+        return res
 
     def getBeta(self, sourceSpectrum):
         """Detector.py:131-160 reads the scintillator's beta from an .xls table; here from a registered table (same walk and

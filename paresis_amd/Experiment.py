@@ -51,6 +51,9 @@ class Experiment:
         ed['distMembraneToObject_unit'] = "m"
         ed['distObjectToDetector_unit'] = "m"
         self._init_state()
+        if exp_dict.get('allowSyntheticMaterials'):
+            from . import materials
+            materials.allow_synthetic(True)
 
         self.defineCorrectValues(exp_dict)
         self.myDetector.defineCorrectValuesDetector()
@@ -99,6 +102,11 @@ class Experiment:
         self.imageReferenceBeforeDetection = []
         self.imagePropagBeforeDetection = []
         self._fresnel_plan = None
+        self._bins_ready = False      # thresholds validated and closed with the last spectrum energy (EXP:296-301)
+        self._accs = None             # study-grid accumulators [4][Nx][Ny], allocated once
+        self._tmp = None
+        self._pending_means = []
+        self.darkFieldPropag = None
 
     @classmethod
     def from_objects(cls, exp_dict, source, detector, membrane, sample, air=None, plate=None):
@@ -204,20 +212,38 @@ class Experiment:
 
     # ------------------------------------------------------------------------------------------- helpers
     def _begin(self, pointNum):
-        """Bin thresholds (EXP:296-305) and output stacks."""
-        dp, spec = self.myDetector.det_param, self.mySource.mySpectrum
-        if pointNum == 0:
-            thr = dp["myBinsThersholds"]
+        """Bin thresholds (EXP:296-305), output stacks, accumulators.
+
+        The reference validates the thresholds and appends the last spectrum energy when it computes position 0, which a
+        serial run always does first.  Here a rank of a sharded run may never see position 0 (dist.my_positions), so it is
+        done once per Experiment, whichever position comes first."""
+        dp = self.myDetector.det_param
+        nbins = self._close_bins()
+        dev = device()
+        n0, n1 = int(dp['myDimensions'][0]), int(dp['myDimensions'][1])
+        # one allocation for the four stacks; every slot of Sample/Reference is written by its bin's detection, Propag only at
+        # position 0 and White is zero elsewhere (the reference detects an all-zero white there: Poisson(0) = 0)
+        out = torch.empty((4, nbins, n0, n1), dtype=torch.float32, device=dev)
+        if pointNum != 0:
+            out[2:].zero_()
+        N = tuple(int(v) for v in self.exp_dict['studyDimensions'])
+        # the four study-grid accumulators live as long as the experiment; the first energy of a bin STORES into them, so they
+        # are never cleared (the reference re-allocates zeros after every bin, EXP:396-399)
+        if self._accs is None or tuple(self._accs.shape[1:]) != N or self._accs.device != dev:
+            self._accs = torch.empty((4,) + N, dtype=torch.float32, device=dev)
+            self._tmp = torch.empty((2,) + N, dtype=torch.float32, device=dev)
+        sums = torch.zeros(2, dtype=torch.float64, device=dev)      # [sum I_ref, sum E * I_ref] over the energies (EXP:360-361)
+        return [out[0], out[1], out[2], out[3]], [self._accs[0], self._accs[1], self._accs[2], self._accs[3]], N, dev, sums
+
+    def _close_bins(self):
+        """EXP:296-301, once per Experiment: thresholds inside the spectrum, last spectrum energy appended.  Returns nbins."""
+        thr, spec = self.myDetector.det_param["myBinsThersholds"], self.mySource.mySpectrum
+        if not self._bins_ready:
             if any(e < spec[0][0] for e in thr) or any(e > spec[-1][0] for e in thr):
                 raise Exception(f'At least one of your detector bin threshold is outside your source spectrum. \nYour source spectrum ranges from {spec[0][0]} to {spec[-1][0]}')
             thr.append(spec[-1][0])
-        nbins = len(dp["myBinsThersholds"])
-        dev = device()
-        n0, n1 = int(dp['myDimensions'][0]), int(dp['myDimensions'][1])
-        stacks = [torch.zeros((nbins, n0, n1), dtype=torch.float32, device=dev) for _ in range(4)]
-        N = tuple(int(v) for v in self.exp_dict['studyDimensions'])
-        accs = [torch.zeros(N, dtype=torch.float32, device=dev) for _ in range(4)]
-        return stacks, accs, N, dev
+            self._bins_ready = True
+        return len(thr)
 
     def _incident(self, flux, energy, ie):
         """Scalar incident intensity per study pixel after the source window (EXP:308,320) and the scintillator
@@ -240,49 +266,69 @@ class Experiment:
         return self.mySource.source_dict["mySize"] * ed['distObjectToDetector'] / (ed['distSourceToMembrane'] + ed['distMembraneToObject']) / self.myDetector.det_param['myPixelSize'] * ed['overSampling']   # EXP:380
 
     def _detect_bin(self, ibin, pointNum, stacks, accs):
-        """EXP:378-401 / 501-521: detection of the accumulated images of one energy bin, then reset."""
-        S, R, Pg, W = stacks
+        """EXP:378-401 / 501-521: detection of the accumulated images of one energy bin.  The detector operator writes
+        straight into the output stacks and the shot noise of the bin's images is ONE launch, each image under the key of
+        what it is (seed, position, bin, kind) -- not of when it was drawn."""
         ess = self._effective_source()
-        det = lambda im: self.myDetector.detection(im, ess, self.exp_dict)
-        S[ibin] = det(accs[0])
-        R[ibin] = det(accs[1])
-        if pointNum == 0:
-            Pg[ibin] = det(accs[2])
-        W[ibin] = det(accs[3])
-        for a in accs:
-            a.zero_()
+        kinds = (0, 1, 2, 3) if pointNum == 0 else (0, 1)       # Propag / White exist at position 0 only
+        self.myDetector.detect_many([accs[k] for k in kinds], ess, self.exp_dict, [stacks[k][ibin] for k in kinds],
+                                    [(pointNum, ibin, k) for k in kinds])
 
     # -------------------------------------------------------------------------------------- Fresnel chain
-    def _add_intensity(self, acc, img, plate_att):
-        """acc += img * plate attenuation (EXP:351-358); returns nothing, img is left untouched."""
-        ops.accumulate(acc, img, 1.0, plate_att, add=True)
+    def _add_intensity(self, acc, img, plate_att, add=True):
+        """acc (+)= img * plate attenuation (EXP:351-358); img is left untouched."""
+        ops.accumulate(acc, img, 1.0, plate_att, add=add)
 
-    def _white(self, white, I_scalar, air_rt, plate_att):
+    def _white(self, white, I_scalar, air_rt, plate_att, first):
         """EXP:372-375 / 494-497: the flat-field image of one energy (uniform unless air/plate maps are not)."""
         att = ops.MaterialStack.concat(air_rt, plate_att)
         if att.n == 0:
-            white += I_scalar
+            if first:
+                white.fill_(I_scalar)
+            else:
+                white += I_scalar
         else:
-            white += ops.transmit_rt(None, I_scalar, att, want_phi=False)[0]
+            w = ops.transmit_rt(None, I_scalar, att, want_phi=False)[0]
+            if first:
+                white.copy_(w)
+            else:
+                white += w
 
-    def _finish_mean_energy(self, e_sum, i_sum):
-        """EXP:360-361,403: intensity-weighted mean energy of the reference image (one synchronising read)."""
+    def _finish_mean_energy(self, sums, npix):
+        """EXP:360-361,403: intensity-weighted mean energy of the reference image.  One synchronising read of two float64
+        sums per position -- or none, with exp_dict['deferMeanEnergy'] (main.run, bench.py): the sums stay in HBM and
+        resolve_mean_energy() folds them in when the value is wanted, so the host keeps running ahead of the GPU."""
         ed = self.exp_dict
-        ed['meanEnergy'] = (ed.get('meanEnergy', 0) + float(e_sum.item())) / float(i_sum.item())
+        if ed.get('deferMeanEnergy'):
+            self._pending_means.append((sums, npix))
+            return
+        self._fold_mean(sums.tolist(), npix)
+
+    def _fold_mean(self, s, npix):
+        ed = self.exp_dict
+        ed['meanEnergy'] = (ed.get('meanEnergy', 0) + s[1] / npix) / (s[0] / npix)
+
+    def resolve_mean_energy(self):
+        """Fold the deferred per-position sums into exp_dict['meanEnergy'] in call order (one device-to-host copy)."""
+        if self._pending_means:
+            vals = torch.stack([t for t, _ in self._pending_means]).tolist()
+            for s, (_, npix) in zip(vals, self._pending_means):
+                self._fold_mean(s, npix)
+            self._pending_means = []
+        return self.exp_dict.get('meanEnergy', 0)
 
     def computeSampleAndReferenceImages_Fresnel(self, pointNum):
         """Experiment.py:279-405.  Returns (SampleImage, ReferenceImage, PropagImage, detectedWhite), each
         [nbins, n, n] float32 in HBM."""
         ed = self.exp_dict
-        stacks, accs, N, dev = self._begin(pointNum)
+        stacks, accs, N, dev, sums = self._begin(pointNum)
         accS, accR, accP, white = accs
         plan = self._plan()
         plate, air = self.myPlate, (None if ed['inVacuum'] else self.myAirVolume)
-        tmp = torch.empty(N, dtype=torch.float32, device=dev)
-        i_sum = torch.zeros((), dtype=torch.float64, device=dev)
-        e_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        tmp = self._tmp[0]
         dSM, dMO, dOD, M = ed['distSourceToMembrane'], ed['distMembraneToObject'], ed['distObjectToDetector'], ed['magnification']
         ibin = 0
+        first = True                     # first energy of the current bin: its images are stored, the later ones added
         for ie, (currentEnergy, flux) in enumerate(self.mySource.mySpectrum):
             I0 = self._incident(flux, currentEnergy, ie)
             amp = float(np.sqrt(I0))                                                      # EXP:334
@@ -298,30 +344,28 @@ class Experiment:
             wbs = plan.propagate([a1, a2], [g1, g2], du, amp=amp, mats=mem, want_wave=[True, False],
                                  inten_out=[None, tmp])[0]
             self.waveSampleBeforeSample = wbs
-            if plate_att is not None:
-                ops.accumulate(tmp, tmp, 1.0, plate_att, add=False)                       # EXP:355-356
-            ops.accumulate(accR, tmp, 1.0, None, add=True)                                # EXP:358
-            m = tmp.mean(dtype=torch.float64)                                             # EXP:360-361
-            i_sum += m
-            e_sum += currentEnergy * m
+            # EXP:355-361: plate attenuation, sum over energies and the image sum for the mean energy in one pass
+            ops.accumulate_sum(accR, tmp, sums, currentEnergy, mats=plate_att, add=not first)
             # EXP:344 + EXP:348: through the sample, on to the detector
             if plate_att is None:
-                plan.propagate([a3], [g3], du, wave_in=wbs, mats=smp, want_wave=[False], inten_out=[accS], add=True)
+                plan.propagate([a3], [g3], du, wave_in=wbs, mats=smp, want_wave=[False], inten_out=[accS], add=not first)
             else:
                 plan.propagate([a3], [g3], du, wave_in=wbs, mats=smp, want_wave=[False], inten_out=[tmp])
-                self._add_intensity(accS, tmp, plate_att)
+                self._add_intensity(accS, tmp, plate_att, add=not first)
             if pointNum == 0:                                                             # EXP:363-375
                 smp0 = ops.MaterialStack.concat(air_w, smp)
                 if plate_att is None:
-                    plan.propagate([a3], [g3], du, amp=amp, mats=smp0, want_wave=[False], inten_out=[accP], add=True)
+                    plan.propagate([a3], [g3], du, amp=amp, mats=smp0, want_wave=[False], inten_out=[accP], add=not first)
                 else:
                     plan.propagate([a3], [g3], du, amp=amp, mats=smp0, want_wave=[False], inten_out=[tmp])
-                    self._add_intensity(accP, tmp, plate_att)
-                self._white(white, I0, air_rt, plate_att)
+                    self._add_intensity(accP, tmp, plate_att, add=not first)
+                self._white(white, I0, air_rt, plate_att, first)
+            first = False
             if currentEnergy > self.myDetector.det_param["myBinsThersholds"][ibin] - self.mySource.source_dict["myEnergySampling"] / 2:
                 self._detect_bin(ibin, pointNum, stacks, accs)                            # EXP:378-401
                 ibin += 1
-        self._finish_mean_energy(e_sum, i_sum)
+                first = True
+        self._finish_mean_energy(sums, N[0] * N[1])
         return tuple(stacks)
 
     # ------------------------------------------------------------------------------------------- RT chain
@@ -335,17 +379,19 @@ class Experiment:
         """Experiment.py:407-526.  Returns (SampleImage, ReferenceImage, PropagImage, detectedWhite, Dxreal, Dyreal,
         darkFieldPropag); Dxreal/Dyreal are the PADDED [N+30, N+30] maps of the last energy (point 0 only)."""
         ed = self.exp_dict
-        stacks, accs, N, dev = self._begin(pointNum)
+        stacks, accs, N, dev, sums = self._begin(pointNum)
         accS, accR, accP, white = accs
         plate, air = self.myPlate, (None if ed['inVacuum'] else self.myAirVolume)
-        Ibs = torch.empty(N, dtype=torch.float32, device=dev)
-        tmp = torch.empty(N, dtype=torch.float32, device=dev)
-        self.darkFieldPropag = torch.zeros(N, dtype=torch.float32, device=dev)            # scalar dark field only
-        i_sum = torch.zeros((), dtype=torch.float64, device=dev)
-        e_sum = torch.zeros((), dtype=torch.float64, device=dev)
+        Ibs, tmp = self._tmp[1], self._tmp[0]
+        scattering = self.mySampleofInterest.has_dark_field()
+        if scattering and pointNum == 0:
+            self.darkFieldPropag = torch.zeros(N, dtype=torch.float32, device=dev)
+        elif not isinstance(self.darkFieldPropag, torch.Tensor) or tuple(self.darkFieldPropag.shape) != N:
+            self.darkFieldPropag = torch.zeros(N, dtype=torch.float32, device=dev)        # scalar dark field: stays zero
         dMO, dOD = ed['distMembraneToObject'], ed['distObjectToDetector']
         clamp = (N[0], N[1])                                                              # RF2:61-64
         ibin = 0
+        first = True
         for ie, (currentEnergy, flux) in enumerate(self.mySource.mySpectrum):
             I0 = self._incident(flux, currentEnergy, ie)
             air_rt = air.stack_rt(currentEnergy, phase=False) if air is not None else None
@@ -358,43 +404,42 @@ class Experiment:
             mem_phase = mem.with_coeffs(catt=[0.0] * mem.n)
             # EXP:474 reference image: refracted again with the membrane phase only
             ops.refract(N, mem_phase, self._dscale(dOD, currentEnergy), clamp, I_in=Ibs, out=tmp)
-            if plate_att is not None:
-                ops.accumulate(tmp, tmp, 1.0, plate_att, add=False)                       # EXP:480
-            ops.accumulate(accR, tmp, 1.0, None, add=True)                                # EXP:483
-            m = tmp.mean(dtype=torch.float64)                                             # EXP:485-486
-            i_sum += m
-            e_sum += currentEnergy * m
+            # EXP:480-486: plate attenuation, sum over energies and the image sum for the mean energy in one pass
+            ops.accumulate_sum(accR, tmp, sums, currentEnergy, mats=plate_att, add=not first)
             # EXP:469 + 473 sample image: sample attenuation and membrane+sample phase fused into the refraction
             both = ops.MaterialStack.concat(mem_phase, smp)
-            scattering = self.mySampleofInterest.has_dark_field()
             if scattering:                                       # Lung / cylinder_beeds: fastRefractionDF (EXP:272-275)
                 DF = self.mySampleofInterest.dark_field(currentEnergy)
                 Ias, phis = ops.transmit_rt(Ibs, 1.0, both)
                 img, _, _ = self.refraction(Ias, phis, dOD, currentEnergy, ed['magnification'], DF)
-                self._add_intensity(accS, img, plate_att)
+                self._add_intensity(accS, img, plate_att, add=not first)
             elif plate_att is None:
-                ops.refract(N, both, self._dscale(dOD, currentEnergy), clamp, I_in=Ibs, out=accS, add=True)
+                ops.refract(N, both, self._dscale(dOD, currentEnergy), clamp, I_in=Ibs, out=accS, add=not first)
             else:
                 ops.refract(N, both, self._dscale(dOD, currentEnergy), clamp, I_in=Ibs, out=tmp)
-                self._add_intensity(accS, tmp, plate_att)
+                self._add_intensity(accS, tmp, plate_att, add=not first)
             if pointNum == 0:                                                             # EXP:488-498
                 if scattering:
                     Ip, phip = ops.transmit_rt(None, I0, ops.MaterialStack.concat(air_rt, smp))
                     self.darkFieldPropag += (DF * flux).to(torch.float32)                 # EXP:491
                     img, self.Dxreal, self.Dyreal = self.refraction(Ip, phip, dOD, currentEnergy, ed['magnification'], DF)
-                    self._add_intensity(accP, img, plate_att)
+                    self._add_intensity(accP, img, plate_att, add=not first)
                 else:
                     _, self.Dxreal, self.Dyreal = ops.refract(N, ops.MaterialStack.concat(air_rt, smp),
                                                               self._dscale(dOD, currentEnergy), clamp, I0=I0, out=tmp,
                                                               want_D=True)
-                    self._add_intensity(accP, tmp, plate_att)
-                self._white(white, I0, air_rt, plate_att)
+                    self._add_intensity(accP, tmp, plate_att, add=not first)
+                self._white(white, I0, air_rt, plate_att, first)
+            first = False
             if currentEnergy > self.myDetector.det_param["myBinsThersholds"][ibin] - self.mySource.source_dict["myEnergySampling"] / 2:
                 self._detect_bin(ibin, pointNum, stacks, accs)                            # EXP:501-521
                 ibin += 1
-        ops.check_status(dev, "computeSampleAndReferenceImages_RT")                       # RF2:81-82, checked once
-        self._finish_mean_energy(e_sum, i_sum)
-        print("Mean detected energy in reference image", ed['meanEnergy'])
+                first = True
+        if not ed.get('deferStatus'):
+            ops.check_status(dev, "computeSampleAndReferenceImages_RT")                   # RF2:81-82, checked once
+        self._finish_mean_energy(sums, N[0] * N[1])
+        if not ed.get('deferMeanEnergy'):
+            print("Mean detected energy in reference image", ed['meanEnergy'])
         return stacks[0], stacks[1], stacks[2], stacks[3], self.Dxreal, self.Dyreal, self.darkFieldPropag
 
     # ------------------------------------------------------------------------------------------- reporting
@@ -423,12 +468,14 @@ class Experiment:
             f.write("\nSample name: %s" % self.mySampleofInterest.myName)
             f.write("\nSample type: %s" % self.mySampleType)
             f.write("\n    materials: %s" % self.mySampleofInterest.myMaterials)
+            f.write("\n    delta/beta source: %s" % getattr(self.mySampleofInterest, "materialProvenance", {}))
             for cle, valeur in (self.mySampleofInterest.geom_parameters or {}).items():
                 f.write(f'\n    {cle}: {valeur[0]} {valeur[1]}')
             f.write("\n\nMembrane informations:")
             f.write("\nMembrane name: %s" % self.myMembrane.myName)
             f.write("\nMembrane type: %s" % self.myMembrane.myType)
             f.write("\n    materials: %s" % self.myMembrane.myMaterials)
+            f.write("\n    delta/beta source: %s" % getattr(self.myMembrane, "materialProvenance", {}))
             f.write("\n    Membrane geometry function: %s" % self.myMembrane.myGeometryFunction)
             for cle, valeur in (self.myMembrane.geom_parameters or {}).items():
                 f.write(f'\n    {cle}: {valeur[0]} {valeur[1]}')
@@ -436,3 +483,4 @@ class Experiment:
                 f.write("\n\nDetectors protection Plate")
                 f.write("\nPlate thickness: %s" % getattr(self.myPlate, "myThickness", None))
                 f.write("\nPlate Material: %s" % self.myPlate.myMaterials)
+                f.write("\n    delta/beta source: %s" % getattr(self.myPlate, "materialProvenance", {}))

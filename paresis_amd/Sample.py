@@ -58,15 +58,18 @@ class Sample:
 
     def getDeltaBeta(self, sourceSpectrum):
         """Sample.py:83-152: per material, a list of (energy, value) for every energy of the spectrum."""
+        self.materialProvenance = {}
         for material in self.myMaterials:
             if materials.has_table(material):            # TablesDeltaBeta branch, Sample.py:112-148
                 delta, beta = materials.table_walk(material, sourceSpectrum)
                 self.delta.append(delta)
                 self.beta.append(beta)
+                self.materialProvenance[material] = materials.provenance(material)
                 continue
             db = [materials.delta_beta(material, e) for e, _ in sourceSpectrum]
             self.delta.append([(e, d) for (e, _), (d, _) in zip(sourceSpectrum, db)])
             self.beta.append([(e, b) for (e, _), (_, b) in zip(sourceSpectrum, db)])
+            self.materialProvenance[material] = materials.provenance(material)
         if len(self.delta) != len(self.myMaterials):
             raise ValueError("One or more materials have not been found in delta beta tables")
 

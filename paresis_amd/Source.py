@@ -62,8 +62,11 @@ class Source:
             self.mySpectrum.append((sd["Energy"], 1))       # SRC:90-93
             return
         if sd["myType"] == "Polychromatic":
-            if self.spectrumFromXls and "xlsRows" in sd:
+            if self.spectrumFromXls:
+                if "xlsRows" not in sd:
+                    sd["xlsRows"] = self._read_xls_rows(sd)        # Source.py:132-150 (needs xlrd)
                 self.mySpectrum.extend(self._from_table_rows(sd))
+                sd["spectrumModel"] = "tabulated (%s)" % sd.get("pathXlsSpectrum", "xlsRows injected")
                 return
             if "spectrum" in sd:
                 # NaN bins count as zero (Source.py:111-113)
@@ -71,13 +74,49 @@ class Source:
             elif Source.spectrum_provider is not None:
                 spec = list(Source.spectrum_provider(sd, flu_fluEn))
             else:
-                spec = self._kramers(sd)
-                sd["spectrumModel"] = "kramers-synthetic (spekpy/xlrd unavailable)"
+                spec = self._spekpy(sd, flu_fluEn)                  # Source.py:96-108, when spekpy is importable
+                if spec is None:
+                    import warnings
+                    warnings.warn("polychromatic source %r: spekpy is not available and no spectrum was injected "
+                                  "(source_dict['spectrum'] / Source.spectrum_provider); using a SYNTHETIC Kramers-law "
+                                  "spectrum." % self.myName, UserWarning, stacklevel=2)
+                    spec = self._kramers(sd)
+                    sd["spectrumModel"] = "kramers-synthetic (spekpy/xlrd unavailable)"
+                else:
+                    sd["spectrumModel"] = "spekpy"
             tot = sum(w for _, w in spec)
             # normalise and drop bins below 1e-4 of the flux like Source.py:118-123
             self.mySpectrum.extend((e, w / tot) for e, w in spec if w / tot > 0.0001)
             return
         raise ValueError("unknown source type %r" % sd["myType"])
+
+    @staticmethod
+    def _spekpy(sd, flu_fluEn):
+        """The reference's tube spectrum (Source.py:96-108) when spekpy is importable, else None."""
+        try:
+            import spekpy as sp
+        except ImportError:
+            return None
+        sd.setdefault("myTargetMaterial", 'W')
+        s = sp.Spek(kvp=sd["myVoltage"], th=12, targ=sd["myTargetMaterial"], dk=sd["myEnergySampling"])
+        if sd.get("filterMaterial") is not None:
+            s.filter(sd["filterMaterial"], sd["filterThickness"])
+        energies, weights = s.get_spectrum(flu=flu_fluEn)
+        return [(float(e), 0.0 if np.isnan(w) else float(w)) for e, w in zip(energies, weights)]
+
+    @staticmethod
+    def _read_xls_rows(sd):
+        """Rows (energy, fluence) of the sheet named by pathXlsSpectrum / energyColumnKey / fluenceColumnKey
+        (Source.py:132-150).  Needs xlrd like the reference; without it the rows must be injected as source_dict['xlsRows']."""
+        try:
+            import xlrd
+        except ImportError as exc:
+            raise ImportError("spectrumFromXls is set but xlrd is not available to read %r: inject the sheet rows as "
+                              "source_dict['xlsRows'] = [(energy, fluence), ...]" % sd.get("pathXlsSpectrum")) from exc
+        sh = xlrd.open_workbook(sd["pathXlsSpectrum"]).sheets()[0]
+        cols = {str(sh.cell(0, c).value): c for c in range(sh.ncols)}
+        ce, cf = cols[sd["energyColumnKey"]], cols[sd["fluenceColumnKey"]]
+        return [(float(sh.cell(r, ce).value), float(sh.cell(r, cf).value)) for r in range(1, sh.nrows)]
 
     @staticmethod
     def _from_table_rows(sd):

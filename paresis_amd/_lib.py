@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libparesis_hip.so")
 
 PSX_MAX_MAT = 8
 PSX_MAX_DIST = 8
+PSX_MAX_POISSON = 8
 ENGINE_AUTO, ENGINE_ROCFFT, ENGINE_LDS = 0, 1, 2
 STATUS_NONFINITE = 1
 ABI_VERSION = 1
@@ -34,6 +35,7 @@ PROTOTYPES = {
     "psx_transmit_wave_c64": (c_int, [_vp, c_float, _vpp, _dp, _dp, c_int, _vp, c_int64, _vp]),
     "psx_transmit_rt_f32": (c_int, [_vp, c_float, _vpp, _dp, _dp, c_int, _vp, _vp, _vp, c_int64, _vp]),
     "psx_accumulate_f32": (c_int, [_vp, _vp, c_float, _vpp, _dp, c_int, c_int, c_int64, _vp]),
+    "psx_accumulate_sum_f32": (c_int, [_vp, _vp, c_float, _vpp, _dp, c_int, c_int, c_int64, _vp, c_double, _vp]),
     "psx_refract_workspace_bytes": (c_size_t, [c_int, c_int]),
     "psx_refract_set_halo": (c_int, [c_int]),
     "psx_refract_f32": (c_int, [_vp, c_float, _vpp, _dp, _dp, c_int, _vp, _vp, c_float, c_int, _vp, _vp, _vp, c_int,
@@ -55,6 +57,7 @@ PROTOTYPES = {
                                            POINTER(c_int)]),
     "psx_resize_f32": (c_int, [_vp, c_int, c_int, _vp, c_int, c_int, _vp]),
     "psx_poisson_f32": (c_int, [_vp, _vp, c_int64, c_uint64, _vp]),
+    "psx_poisson_multi_f32": (c_int, [_vpp, POINTER(c_uint64), c_int, c_int64, _vp]),
     "psx_status_scan_f32": (c_int, [_vp, c_int64, _vp, _vp]),
     "psx_darkfield_workspace_bytes": (c_size_t, [c_int, c_int]),
     "psx_darkfield_blur_f32": (c_int, [_vp, _vp, _vp, _vp, c_int, c_int, c_int, _vp, _vp]),

@@ -315,8 +315,8 @@ struct Philox {
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
         c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
     }
-    __device__ void next(uint64_t ctr, uint32_t sub, uint64_t seed, float u[4]) {
-        c[0] = (uint32_t)ctr; c[1] = (uint32_t)(ctr >> 32); c[2] = sub; c[3] = 0x5058u;
+    __device__ void next(uint64_t ctr, uint32_t sub, uint64_t seed, float u[4], uint32_t tag) {
+        c[0] = (uint32_t)ctr; c[1] = (uint32_t)(ctr >> 32); c[2] = sub; c[3] = tag;
         k[0] = (uint32_t)seed; k[1] = (uint32_t)(seed >> 32);
         for (int r = 0; r < 10; ++r) {
             round_();
@@ -357,55 +357,111 @@ __device__ __forceinline__ float log_pmf(float k, float L) {
     return (float)(-(double)L + (double)k * log((double)L) - lgamma((double)k + 1.0));
 }
 
-// Poisson draw: product-of-uniforms for lam < 10, Hormann's PTRS transformed rejection otherwise (both exact).
-__global__ __launch_bounds__(256) void k_poisson(const float *__restrict__ lam, float *__restrict__ out, int64_t n,
-                                                 uint64_t seed) {
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        const float L = lam[p];
-        Philox g;
-        float u[4];
-        float res = 0.f;
-        if (!(L > 0.f)) {
-            res = 0.f;
-        } else if (L < 10.f) {
-            const float lim = expf(-L);
-            float prod = 1.f;
-            int k = 0;
-            uint32_t sub = 0;
-            bool done = false;
-            while (!done && sub < 64) {
-                g.next((uint64_t)p, sub++, seed, u);
-                for (int i = 0; i < 4 && !done; ++i) {
-                    prod *= u[i];
-                    if (prod <= lim) done = true; else ++k;
-                }
-            }
-            res = (float)k;
-        } else {
-            const float slam = sqrtf(L);
-            const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
-            const float invalpha = 1.1239f + 1.1328f / (b - 3.4f), vr = 0.9277f - 3.6224f / (b - 2.f);
-            uint32_t sub = 0;
-            res = floorf(L);
-            while (sub < 64) {
-                g.next((uint64_t)p, sub++, seed, u);
-                bool acc = false;
-                for (int h = 0; h < 2 && !acc; ++h) {
-                    const float U = u[2 * h] - 0.5f, V = u[2 * h + 1];
-                    const float us = 0.5f - fabsf(U);
-                    const float k = floorf((2.f * a / us + b) * U + L + 0.43f);
-                    if (us >= 0.07f && V <= vr) { res = k; acc = true; break; }
-                    if (k < 0.f || (us < 0.013f && V > us)) continue;
-                    const float lhs = logf(V) + logf(invalpha) - logf(a / (us * us) + b);
-                    if (lhs <= log_pmf(k, L)) {
-                        res = k;
-                        acc = true;
-                    }
-                }
-                if (acc) break;
+// Poisson draw: product-of-uniforms for lam < 10, Hormann's PTRS transformed rejection otherwise (both exact samplers).
+// The draw of pixel p is a pure function of (seed, p):
+//   * its FIRST PTRS candidate takes two words of the Philox block (counter p >> 1, tag 0x5058): one block serves the
+//     first candidates of two neighbouring pixels (86 % of the pixels accept it through the squeeze, no logarithm);
+//   * everything else -- later candidates, the product of uniforms of small means -- comes from the pixel's own stream
+//     (counter p, sub-counter 1, 2, ..., tag 0x5059).
+struct PoissonImgs {
+    float *img[PSX_MAX_POISSON];
+    uint64_t seed[PSX_MAX_POISSON];
+};
+
+// everything after the squeeze test of a candidate: the exact acceptance test, then further candidates
+__device__ __noinline__ float poisson_slow(float L, float U0, float V0, uint64_t p, uint64_t seed) {
+    Philox g;
+    float u[4];
+    if (L < 10.f) {
+        const float lim = expf(-L);
+        float prod = 1.f;
+        int k = 0;
+        for (uint32_t sub = 1; sub < 64; ++sub) {
+            g.next(p, sub, seed, u, 0x5059u);
+            for (int i = 0; i < 4; ++i) {
+                prod *= u[i];
+                if (prod <= lim) return (float)k;
+                ++k;
             }
         }
-        out[p] = res;
+        return (float)k;
+    }
+    const float slam = sqrtf(L);
+    const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
+    const float invalpha = 1.1239f + 1.1328f / (b - 3.4f), vr = 0.9277f - 3.6224f / (b - 2.f);
+    float U = U0, V = V0;
+    uint32_t sub = 1;
+    int have = 0;
+    for (int it = 0; it < 128; ++it) {
+        const float us = 0.5f - fabsf(U);
+        const float k = floorf((2.f * a / us + b) * U + L + 0.43f);
+        if (us >= 0.07f && V <= vr) return k;
+        if (!(k < 0.f || (us < 0.013f && V > us))) {
+            const float lhs = logf(V) + logf(invalpha) - logf(a / (us * us) + b);
+            if (lhs <= log_pmf(k, L)) return k;
+        }
+        if (have == 0) {
+            g.next(p, sub++, seed, u, 0x5059u);
+            have = 2;
+        }
+        U = u[4 - 2 * have] - 0.5f;
+        V = u[5 - 2 * have];
+        --have;
+    }
+    return floorf(L);
+}
+
+// One thread draws 4 consecutive pixels (16-byte load and store), in place; blockIdx.y = image of the batch (the three or
+// four detector images of one energy bin are drawn by ONE launch, each under its own key).
+__global__ __launch_bounds__(256) void k_poisson(PoissonImgs im, const float *__restrict__ lam_single, int64_t n) {
+    float *img = im.img[blockIdx.y];
+    const float *lam = lam_single ? lam_single : img;
+    const uint64_t seed = im.seed[blockIdx.y];
+    const int64_t nq = n >> 2;
+    const bool vec = ((uintptr_t)img % 16 == 0) && ((uintptr_t)lam % 16 == 0);
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < (vec ? nq : 0); q += (int64_t)gridDim.x * blockDim.x) {
+        const float4 L4 = reinterpret_cast<const float4 *>(lam)[q];
+        const float L[4] = {L4.x, L4.y, L4.z, L4.w};
+        Philox g;
+        float u[8];
+        g.next((uint64_t)(2 * q), 0, seed, u, 0x5058u);
+        g.next((uint64_t)(2 * q + 1), 0, seed, u + 4, 0x5058u);
+        float res[4];
+        unsigned pending = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float Li = L[i];
+            const float slam = sqrtf(Li);
+            const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
+            const float vr = 0.9277f - 3.6224f / (b - 2.f);
+            const float U = u[2 * i] - 0.5f, V = u[2 * i + 1];
+            const float us = 0.5f - fabsf(U);
+            const float k = floorf((2.f * a / us + b) * U + Li + 0.43f);
+            const bool fast = Li >= 10.f && us >= 0.07f && V <= vr;
+            res[i] = fast ? k : 0.f;
+            if (!fast && Li > 0.f) pending |= 1u << i;
+        }
+        while (pending) {
+            const int i = __builtin_ctz(pending);
+            pending &= pending - 1;
+            const float Li = i == 0 ? L[0] : (i == 1 ? L[1] : (i == 2 ? L[2] : L[3]));
+            const float r = poisson_slow(Li, u[2 * i] - 0.5f, u[2 * i + 1], (uint64_t)(4 * q + i), seed);
+            if (i == 0) res[0] = r; else if (i == 1) res[1] = r; else if (i == 2) res[2] = r; else res[3] = r;
+        }
+        reinterpret_cast<float4 *>(img)[q] = make_float4(res[0], res[1], res[2], res[3]);
+    }
+    // scalar path: the tail of an image whose size is not a multiple of 4, or a misaligned image as a whole
+    const int64_t t0 = vec ? nq * 4 : 0;
+    for (int64_t p = t0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const float Li = lam[p];
+        float r = 0.f;
+        if (Li > 0.f) {
+            Philox g;
+            float u[4];
+            g.next((uint64_t)(p >> 1), 0, seed, u, 0x5058u);
+            r = poisson_slow(Li, u[2 * (p & 1)] - 0.5f, u[2 * (p & 1) + 1], (uint64_t)p, seed);
+        }
+        img[p] = r;
     }
 }
 
@@ -602,7 +658,23 @@ int psx_resize_f32(const float *img, int Nx, int Ny, float *out, int sx, int sy,
 int psx_poisson_f32(const float *lam, float *out, int64_t n, uint64_t seed, void *stream) {
     PSX_REQUIRE(lam && out && n >= 0, "psx_poisson_f32: null pointer or negative n");
     if (n == 0) return 0;
-    PSX_TIMED("k_poisson", (hipStream_t)stream, k_poisson<<<ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(lam, out, n, seed));
+    PoissonImgs im = {};
+    im.img[0] = out;
+    im.seed[0] = seed;
+    PSX_TIMED("k_poisson", (hipStream_t)stream, k_poisson<<<dim3(ew_grid(n, 256, 4), 1), 256, 0, (hipStream_t)stream>>>(im, lam == out ? nullptr : lam, n));
+    return launch_check("k_poisson");
+}
+
+int psx_poisson_multi_f32(float *const *imgs, const uint64_t *seeds, int nimg, int64_t n, void *stream) {
+    PSX_REQUIRE(imgs && seeds && nimg >= 1 && nimg <= PSX_MAX_POISSON && n >= 0, "psx_poisson_multi_f32: bad image list");
+    PoissonImgs im = {};
+    for (int i = 0; i < nimg; ++i) {
+        PSX_REQUIRE(imgs[i] != nullptr, "psx_poisson_multi_f32: null image %d", i);
+        im.img[i] = imgs[i];
+        im.seed[i] = seeds[i];
+    }
+    if (n == 0) return 0;
+    PSX_TIMED("k_poisson", (hipStream_t)stream, k_poisson<<<dim3(ew_grid(n, 256, 4), nimg), 256, 0, (hipStream_t)stream>>>(im, nullptr, n));
     return launch_check("k_poisson");
 }
 

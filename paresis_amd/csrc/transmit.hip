@@ -54,6 +54,36 @@ __global__ __launch_bounds__(256) void k_accumulate(float *acc, const float *img
     }
 }
 
+// The same with the sum of what was added reduced on the way (EXP:360-361, 485-486: the reference takes np.mean of the
+// per-energy reference image for its intensity-weighted mean energy): sums[0] += S, sums[1] += weight * S, S = sum of v.
+// Wave shuffle reduction in float64, one pair of atomics per workgroup.
+template <int NM>
+__global__ __launch_bounds__(256) void k_accumulate_sum(float *acc, const float *img, float scale, Mats m, int accumulate,
+                                                        int64_t n, double *sums, double weight) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double s = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        float v = scale * img[p];
+        if (NM > 0) {
+            double ph, la;
+            mats_eval<NM>(m, p, ph, la);
+            v *= expf((float)la);
+        }
+        if (acc) acc[p] = accumulate ? acc[p] + v : v;
+        s += (double)v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = part[0] + part[1] + part[2] + part[3];
+        atomicAdd(&sums[0], t);
+        atomicAdd(&sums[1], weight * t);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_status_scan(const float *__restrict__ img, int64_t n, unsigned *status) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     bool bad = false;
@@ -95,6 +125,16 @@ int psx_accumulate_f32(float *acc, const float *img, float scale, const float *c
     if (n == 0) return 0;
     PSX_DISPATCH_NMAT(nmat, PSX_TIMED("k_accumulate", (hipStream_t)stream, k_accumulate<NM><<<ew_grid(n, 256), 256, 0, (hipStream_t)stream>>>(acc, img, scale, m, accumulate, n)));
     return launch_check("k_accumulate");
+}
+
+int psx_accumulate_sum_f32(float *acc, const float *img, float scale, const float *const *T, const double *catt, int nmat,
+                           int accumulate, int64_t n, double *sums, double weight, void *stream) {
+    PSX_REQUIRE(img && sums && n >= 0, "psx_accumulate_sum_f32: null pointer or negative n");
+    Mats m;
+    if (int rc = pack_mats(m, T, nullptr, catt, nmat)) return rc;
+    if (n == 0) return 0;
+    PSX_DISPATCH_NMAT(nmat, PSX_TIMED("k_accumulate_sum", (hipStream_t)stream, k_accumulate_sum<NM><<<ew_grid(n, 256, 4), 256, 0, (hipStream_t)stream>>>(acc, img, scale, m, accumulate, n, sums, weight)));
+    return launch_check("k_accumulate_sum");
 }
 
 int psx_status_scan_f32(const float *img, int64_t n, unsigned *status, void *stream) {

@@ -24,6 +24,20 @@ def init(backend=None):
     return rank, world
 
 
+def barrier():
+    if td.is_available() and td.is_initialized():
+        td.barrier()
+
+
+def broadcast_object(obj, rank, world, src=0):
+    """The same small Python object on every rank (rank `src`'s)."""
+    if world == 1:
+        return obj
+    box = [obj if rank == src else None]
+    td.broadcast_object_list(box, src=src, device=_dev())
+    return box[0]
+
+
 def finish():
     if td.is_available() and td.is_initialized():
         td.barrier()
@@ -38,11 +52,14 @@ def owner(position, world):
     return position % world
 
 
-def gather_positions(results, n_positions, rank, world, dst=0):
+def gather_positions(results, n_positions, rank, world, dst=0, to_host=True):
     """results: {position: tuple of tensors} computed on this rank.  Returns on `dst` a dict with every position
-    (tensors on the host), {} elsewhere.  One fixed-shape gather per round of positions: every rank contributes its
-    Sample/Reference stacks of round t (position t*world + rank), padded with zeros when it has none."""
-    host = lambda tup: tuple(t.detach().cpu() if isinstance(t, torch.Tensor) else t for t in tup)
+    (tensors on the host, or left in `dst`'s HBM with to_host=False), {} elsewhere.
+
+    ONE fixed-shape gather for the whole run: every rank contributes the Sample/Reference stacks of its positions
+    [rounds][2][nbins][n][n] (slot t = position t*world + rank, zeros when it has none) -- 7 point-to-point transfers into
+    rank `dst` over xGMI, no ring."""
+    host = lambda tup: tuple(t.detach().cpu() if isinstance(t, torch.Tensor) and to_host else t for t in tup)
     if world == 1:
         return {p: host(v) for p, v in results.items()}
     out = {}
@@ -57,23 +74,26 @@ def gather_positions(results, n_positions, rank, world, dst=0):
         shape_t[3] = 1
     td.all_reduce(shape_t, op=td.ReduceOp.MAX)          # ranks without work learn the stack shape
     shape = tuple(int(v) for v in shape_t[:3])
+    mine = torch.empty((rounds, 2) + shape, dtype=torch.float32, device=_dev())
     for t in range(rounds):
         p = t * world + rank
-        mine = torch.zeros((2,) + shape, dtype=torch.float32, device=_dev())
         if p in results:
-            mine[0] = results[p][0].to(mine.device, torch.float32)
-            mine[1] = results[p][1].to(mine.device, torch.float32)
-        bucket = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
-        td.gather(mine, bucket, dst=dst)
-        if rank == dst:
-            for r in range(world):
+            mine[t, 0].copy_(results[p][0])
+            mine[t, 1].copy_(results[p][1])
+        else:
+            mine[t].zero_()
+    bucket = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+    td.gather(mine, bucket, dst=dst)
+    if rank == dst:
+        if to_host:
+            bucket = [b.cpu() for b in bucket]
+        for r in range(world):
+            for t in range(rounds):
                 q = t * world + r
                 if q < n_positions:
-                    out[q] = (bucket[r][0].cpu(), bucket[r][1].cpu())
-    if rank == dst and 0 in results:                     # Propag / White / Dx,Dy exist for position 0 only
+                    out[q] = (bucket[r][t, 0], bucket[r][t, 1])
+    if rank == dst and 0 in results:                     # Propag / White / Dx,Dy exist for position 0 only (owner(0) == 0)
         out[0] = host(results[0])
-    elif owner(0, world) != dst:
-        pass
     return out if rank == dst else {}
 
 

@@ -16,16 +16,25 @@ import time
 import numpy as np
 
 
-def run(exp_dict, save=True, saving_format=".tif"):
+def run(exp_dict, save=True, saving_format=".tif", backend=None):
+    """main.py:58-115.  Returns on rank 0 {position: (Sample, Reference[, Propag, White, ...])} with host tensors."""
     from . import dist
     from .Experiment import Experiment
     from .InputOutput.pagailleIO import save_image
 
     time0 = time.time()
-    exp_dict['expID'] = datetime.datetime.now().strftime("%Y%m%d-%H%M%S")
-    rank, world = dist.init()
+    rank, world = dist.init(backend)
+    # one experiment ID for all ranks (the reference takes the wall clock, main.py:30; ranks would disagree by a second)
+    exp_dict['expID'] = dist.broadcast_object(datetime.datetime.now().strftime("%Y%m%d-%H%M%S"), rank, world)
+    exp_dict.setdefault('deferMeanEnergy', True)       # no host synchronisation per position (resolved before the dump)
     print("\n\nINITIALIZING EXPERIMENT PARAMETERS AND GEOMETRIES")
     experiment = Experiment(exp_dict)
+    sim = exp_dict['simulation_type']
+    root = exp_dict['filepath'] + ('Fresnel_' if sim == "Fresnel" else 'RayTracing_') + str(exp_dict['expID']) + '/'
+    if save:
+        if rank == 0:
+            os.makedirs(root + 'membraneThickness/', exist_ok=True)                       # main.py:84-85
+        dist.barrier()
     print("\nImages calculation")
     results = {}
     for pointNum in dist.my_positions(exp_dict['nbExpPoints'], rank, world):
@@ -35,10 +44,13 @@ def run(exp_dict, save=True, saving_format=".tif"):
         print("\nCalculations point", pointNum)
         out = experiment.computeSampleAndReferenceImages(pointNum)
         results[pointNum] = out
+        if save and exp_dict.get('saveMembrane', True):
+            # main.py:98: every rank writes the membrane maps of its own positions (one node, one file system: no gather)
+            save_image(experiment.myMembrane.myGeometry[0], root + 'membraneThickness/' + exp_dict['experimentName'] +
+                       '_sampling' + str(exp_dict['overSampling']) + '_' + str(pointNum) + saving_format)
     gathered = dist.gather_positions(results, exp_dict['nbExpPoints'], rank, world)
+    experiment.resolve_mean_energy()
     if rank == 0 and save:
-        sim = exp_dict['simulation_type']
-        root = exp_dict['filepath'] + ('Fresnel_' if sim == "Fresnel" else 'RayTracing_') + str(exp_dict['expID']) + '/'
         os.makedirs(root, exist_ok=True)
         thresholds = [experiment.mySource.mySpectrum[0][0]] + list(experiment.myDetector.det_param['myBinsThersholds'])
         nbin = gathered[0][0].shape[0]
@@ -48,6 +60,13 @@ def run(exp_dict, save=True, saving_format=".tif"):
             for sub in ("ref/", "sample/", "propag/"):
                 os.makedirs(p + sub, exist_ok=True)
             paths.append(p)
+        if sim == "RayT":
+            # main.py:100-101 writes Df after every position to the SAME file: what stays is the last position's, which is
+            # all zeros unless that position is 0 (darkFieldPropag only builds up there, EXP:491)
+            N = tuple(int(v) for v in experiment.exp_dict['studyDimensions'])
+            last = exp_dict['nbExpPoints'] - 1
+            df = gathered[0][6] if last == 0 and len(gathered[0]) > 6 else np.zeros(N, dtype=np.float32)
+            save_image(df, root + "DF" + saving_format)
         for pointNum in sorted(gathered):
             S, R = gathered[pointNum][0], gathered[pointNum][1]
             txt = '%2.2d' % pointNum

@@ -186,6 +186,20 @@ def accumulate(acc, img, scale=1.0, mats=None, add=True):
     return acc
 
 
+def accumulate_sum(acc, img, sums, weight, scale=1.0, mats=None, add=True):
+    """accumulate() that also reduces what it adds: sums[0] += sum(v), sums[1] += weight*sum(v), v = scale*img*att
+    (Experiment.py:360-361, 485-486).  sums: float64[2] in HBM.  acc may be None (reduction only)."""
+    mats = _mats(mats)
+    _need(img, torch.float32, "img")
+    if acc is not None:
+        _need(acc, torch.float32, "acc", img.shape)
+    _need(sums, torch.float64, "sums", (2,))
+    T, cp, ca, n = mats.cargs(tuple(img.shape))
+    check(lib().psx_accumulate_sum_f32(_ptr(acc), _ptr(img), c_float(scale), T, ca, n, 1 if add else 0, img.numel(),
+                                       _ptr(sums), c_double(weight), _stream()), "psx_accumulate_sum_f32")
+    return acc
+
+
 # ----------------------------------------------------------------------------------------------- refraction
 def refract(shape, mats, dscale, clamp, margin=15, I_in=None, I0=1.0, phi_in=None, out=None, out_scale=1.0, add=False,
             want_D=False, I_mut=None):
@@ -392,6 +406,35 @@ def poisson(lam, seed):
     check(lib().psx_poisson_f32(_ptr(lam), _ptr(out), lam.numel(), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _stream()),
           "psx_poisson_f32")
     return out
+
+
+def poisson_key(seed, pointNum=0, ibin=0, kind=0):
+    """64-bit generator key of one detector image: a hash of WHAT is drawn -- the user's seed, the membrane position, the
+    energy bin and the image kind (0 sample, 1 reference, 2 propagation, 3 white) -- so the noise of an image does not
+    depend on call order or on how the positions are sharded over GPUs (splitmix64 finaliser per field)."""
+    m = (1 << 64) - 1
+    h = 0x9E3779B97F4A7C15
+    for v in (int(seed), int(pointNum), int(ibin), int(kind)):
+        h = (h ^ (v & m)) & m
+        h = (h + 0x9E3779B97F4A7C15) & m
+        h = ((h ^ (h >> 30)) * 0xBF58476D1CE4E5B9) & m
+        h = ((h ^ (h >> 27)) * 0x94D049BB133111EB) & m
+        h = h ^ (h >> 31)
+    return h
+
+
+def poisson_multi(imgs, seeds):
+    """In-place shot noise on several equally sized images in ONE launch, image i under key seeds[i]."""
+    if not imgs:
+        return imgs
+    if len(imgs) > _lib.PSX_MAX_POISSON or len(seeds) != len(imgs):
+        raise PsxError("poisson_multi: 1..%d images with one key each" % _lib.PSX_MAX_POISSON)
+    for i, t in enumerate(imgs):
+        _need(t, torch.float32, "imgs[%d]" % i, imgs[0].shape)
+    ptr = (c_void_p * len(imgs))(*[t.data_ptr() for t in imgs])
+    sd = (ctypes.c_uint64 * len(imgs))(*[int(v) & (2 ** 64 - 1) for v in seeds])
+    check(lib().psx_poisson_multi_f32(ptr, sd, len(imgs), imgs[0].numel(), _stream()), "psx_poisson_multi_f32")
+    return imgs
 
 
 def status_scan(img):

@@ -8,6 +8,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+os.environ.setdefault("PARESIS_ALLOW_SYNTHETIC_MATERIALS", "1")   # the shipped XML materials resolve to the synthetic stand-ins here
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 

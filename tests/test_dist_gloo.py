@@ -60,3 +60,91 @@ def test_single_process_is_world_one(monkeypatch):
     assert dist.init() == (0, 1)
     out = dist.gather_positions({0: (torch.ones(1, 2, 2), torch.zeros(1, 2, 2))}, 1, 0, 1)
     assert list(out) == [0] and out[0][0].shape == (1, 2, 2)
+
+
+# ---- main.run across two ranks (CPU): the REAL entry point -- XML load, position sharding, the once-per-Experiment bin
+# thresholds, the single gather, the saves -- with the GPU compute replaced by the oracle (test infrastructure) and the
+# membrane synthesis by the seeded numpy stand-in.  Rank 1 never computes position 0: the case ADVICE r1 flagged.
+def _patch_cpu_compute():
+    import numpy as np
+    from oracle import paresis_oracle as orc
+    from paresis_amd import synth
+    from paresis_amd.Experiment import Experiment
+    from paresis_amd.Sample import AnalyticalSample
+    from tests._build import cfg_from_experiment
+
+    real_geometry = AnalyticalSample.getMyGeometry
+
+    def geometry(self, dims, pix, ov, pointNum=0, number_of_positions=0):
+        if self.myType == "membrane":
+            self.myGeometry = np.stack([synth.sphere_membrane(int(dims[0]), int(dims[1]), pix * 1e-6, pointNum),
+                                        synth.slab(int(dims[0]), int(dims[1]), 6e-3)])
+            return
+        return real_geometry(self, dims, pix, ov, pointNum, number_of_positions)
+
+    def compute(self, pointNum):
+        nbins = self._close_bins()                       # the product's own threshold logic
+        cfg = cfg_from_experiment(self, orc.Obj)
+        # the oracle follows the serial reference literally: it closes the thresholds when it is given position 0 and
+        # expects them closed already otherwise (EXP:296-301)
+        thr = list(self.myDetector.det_param["myBinsThersholds"])
+        cfg["bins"] = thr[:-1] if pointNum == 0 else thr
+        ref = orc.compute_rt(cfg, pointNum) if self.exp_dict["simulation_type"] == "RayT" else orc.compute_fresnel(cfg, pointNum)
+        out = tuple(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)) for a in ref[:4])
+        assert out[0].shape[0] == nbins
+        return out if pointNum == 0 else out[:2]
+
+    AnalyticalSample.getMyGeometry = geometry
+    Experiment.computeSampleAndReferenceImages = compute
+
+
+def _main_worker(rank, world, port, outdir, q):
+    if world > 1:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port))
+    else:
+        os.environ.pop("RANK", None)
+        os.environ["WORLD_SIZE"] = "1"
+    os.environ["PARESIS_ALLOW_SYNTHETIC_MATERIALS"] = "1"
+    _patch_cpu_compute()
+    from paresis_amd import main
+    ed = {"experimentName": "Fil_Nylon_ID17", "filepath": outdir + "/", "overSampling": 1, "nbExpPoints": 3,
+          "simulation_type": "RayT", "noise": False, "saveMembrane": True}
+    res = main.run(ed, save=True, saving_format=".edf", backend="gloo")
+    if rank == 0:
+        q.put({p: [t.numpy() for t in v[:2]] for p, v in res.items()})
+    else:
+        q.put(res == {})
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def test_main_run_world2_matches_world1(tmp_path):
+    import glob
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    runs = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = _free_port()
+        out = str(tmp_path / ("w%d" % world))
+        os.makedirs(out)
+        procs = [ctx.Process(target=_main_worker, args=(r, world, port, out, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=300) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        runs[world] = next(r for r in res if isinstance(r, dict))
+        assert all(r is True for r in res if not isinstance(r, dict))
+        # rank 0 wrote every position's images, the ranks together every membrane map (main.py:98-110)
+        assert len(glob.glob(out + "/RayTracing_*/sample/*.edf")) == 3
+        assert len(glob.glob(out + "/RayTracing_*/ref/*.edf")) == 3
+        assert len(glob.glob(out + "/RayTracing_*/membraneThickness/*.edf")) == 3
+        assert len(glob.glob(out + "/RayTracing_*/DF.edf")) == 1
+        assert len(glob.glob(out + "/RayTracing_*/propag/*.edf")) == 1
+    assert sorted(runs[1]) == sorted(runs[2]) == [0, 1, 2]
+    for p in range(3):
+        for a, b in zip(runs[1][p], runs[2][p]):
+            assert np.array_equal(a, b), p

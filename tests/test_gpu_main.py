@@ -54,6 +54,10 @@ def test_main_writes_images(tmp_path):
         assert img.shape == (200, 200) and np.all(img == np.floor(img)) and img.mean() > 1000    # Poisson counts
         assert glob.glob(ed["filepath"] + "*/ref/*" + fmt) and glob.glob(ed["filepath"] + "*/propag/*" + fmt)
         assert glob.glob(ed["filepath"] + "*.txt")                                                  # saveAllParameters
+        assert len(glob.glob(ed["filepath"] + "*/membraneThickness/*" + fmt)) == 2                  # main.py:98
+        assert bool(glob.glob(ed["filepath"] + "*/DF" + fmt)) == (sim == "RayT")                    # main.py:100-101
+        txt = open(glob.glob(ed["filepath"] + "*.txt")[0]).read()
+        assert "delta/beta source" in txt and "SYNTHETIC" in txt                                    # provenance in the dump
 
 
 def test_membrane_synthesis_golden_and_seeding():
@@ -114,3 +118,83 @@ def test_membrane_entry_points_agree():
                     assert float(a.max()) > 1.0            # something was rendered
         finally:
             lib().psx_membrane_plan_destroy(plan)
+
+
+def test_fresh_experiment_starts_at_any_position():
+    """a rank of a sharded run builds its own Experiment and may never compute position 0; the bin
+    thresholds must be closed whichever position comes first, and the images must not depend on what was computed before."""
+    from paresis_amd.Experiment import Experiment
+    outs = {}
+    for order in ((1,), (0, 1)):
+        ed = {"experimentName": "Fil_Nylon_ID17", "filepath": "/tmp/", "overSampling": 2, "nbExpPoints": 2,
+              "simulation_type": "Fresnel", "noise": True, "seed": 3}
+        exp = Experiment(ed)
+        for point in order:
+            exp.myMembrane.myGeometry = []
+            exp.myMembrane.getMyGeometry(ed["studyDimensions"], exp.myMembrane.membranePixelSize, 2, point, 2)
+            out = exp.computeSampleAndReferenceImages(point)
+        assert len(exp.myDetector.det_param["myBinsThersholds"]) == 1          # closed exactly once
+        outs[order] = [t.clone() for t in out[:2]]
+        assert out[0].shape[0] == 1 and float(out[0].mean()) > 100
+    # same position, same seed -> the same noisy image whether or not position 0 ran first (noise keyed by content)
+    for a, b in zip(outs[(1,)], outs[(0, 1)]):
+        assert torch.equal(a, b)
+
+
+def test_noise_keys_differ_between_positions_bins_and_kinds():
+    from paresis_amd import ops
+    keys = {ops.poisson_key(5, p, b, k) for p in range(8) for b in range(3) for k in range(4)}
+    assert len(keys) == 8 * 3 * 4
+    lam = torch.full((256, 256), 50.0, dtype=torch.float32, device="cuda")
+    a, b = lam.clone(), lam.clone()
+    ops.poisson_multi([a, b], [ops.poisson_key(5, 0, 0, 0), ops.poisson_key(5, 1, 0, 0)])
+    c = ops.poisson(lam, seed=ops.poisson_key(5, 0, 0, 0))
+    assert torch.equal(a, c) and not torch.equal(a, b)                          # multi == single; positions differ
+    corr = float(torch.corrcoef(torch.stack([a.flatten() - 50, b.flatten() - 50]))[0, 1])
+    assert abs(corr) < 0.02
+
+
+def _rank_main(rank, world, port, outdir, q):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      PARESIS_ALLOW_SYNTHETIC_MATERIALS="1")
+    import torch as th
+    from paresis_amd import main
+    ed = {"experimentName": "Fil_Nylon_ID17", "filepath": outdir + "/", "overSampling": 2, "nbExpPoints": 5,
+          "simulation_type": "Fresnel", "noise": True, "seed": 9}
+    res = main.run(ed, save=True, saving_format=".tif", backend="gloo")       # both ranks on the ONE GPU of the box
+    q.put({p: [t.numpy() for t in v[:2]] for p, v in res.items()} if rank == 0 else (res == {}))
+    th.distributed.destroy_process_group()
+
+
+def test_main_two_ranks_match_one(tmp_path):
+    """The XML entry point with 2 ranks (gloo control plane, both on this GPU) against the 1-process run: identical images,
+    shot noise included (noise keyed by position, not by call order)."""
+    import socket
+    import torch.multiprocessing as mp
+    from paresis_amd import main
+    ed = {"experimentName": "Fil_Nylon_ID17", "filepath": str(tmp_path) + "/one/", "overSampling": 2, "nbExpPoints": 5,
+          "simulation_type": "Fresnel", "noise": True, "seed": 9}
+    os.makedirs(ed["filepath"])
+    one = main.run(ed, save=False)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    out = str(tmp_path) + "/two"
+    os.makedirs(out)
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, out, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    two = next(r for r in res if isinstance(r, dict))
+    assert sorted(two) == sorted(one) == list(range(5))
+    for p in range(5):
+        for a, b in zip(one[p][:2], two[p]):
+            assert np.array_equal(a.numpy(), b), p
+    assert len(glob.glob(out + "/Fresnel_*/membraneThickness/*.tif")) == 5
