@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- Mpixels/s of the Fresnel + refraction step on synthetic grids (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 4096] [--engine auto|rocfft|lds] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 4096] [--positions 64] [--no-cpu-baseline] ...
 
 One STEP = one pass of the hot path over one membrane position of the 4096x4096 workload (BASELINE.json configs[2],
 SURVEY.md section 8d): the membrane exit wave (2-material transmission fused into the load) is Fresnel-propagated to the
@@ -10,12 +10,20 @@ transmission fused) is run at the same 4 distances (one call: each tile's window
 propagation + refraction" on N^2 pixels.
 value = units * N^2 * n_gpus / time  [Mpixel/s], inputs resident in HBM before the timed region.
 
-N GPUs: one process per GPU (torchrun), each rank runs its own membrane position (seed 1000+rank): weak scaling, no
-data-path collective; the final image gather over RCCL is done once after the timed region and reported as gather_ms.
+N GPUs: one process per GPU, each rank runs its own membrane position (seed 1000+rank): weak scaling, no data-path
+collective.  `python bench.py --gpus N` with no RANK in the environment starts its own N ranks (a child
+`python -m torch.distributed.run`, decided before anything touches the GPU); under torchrun it is one of the ranks.
+
+Config 4 of BASELINE.json (the 64-position membrane batch) is measured in the SAME run, after the timed steps, and reported
+in the `positions_batch` object of the JSON line: the whole position loop of main.py:63-110 -- membrane synthesis with
+seed(pointNum), the image-formation chain, detection, shot noise -- for 64 positions strided over the ranks, the RCCL
+gather of all 64 x 2 detector stacks onto rank 0 INSIDE its timed region; rank 0 then re-computes positions it did not
+own and checks the gathered images bit for bit.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,7 +34,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 DISTANCES = (1.6, 3.6, 5.2, 7.2)
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_GINST = 1228.8     # wave64 vector instructions per second, x1e9: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles (same guide)
+PARITY_TOL = 1e-5            # BASELINE.json north_star: max|out-ref|/max|ref|
 
 
 def parse():
@@ -47,24 +57,44 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI, the real thing) or gloo (rehearsal of "
                          "the multi-rank control flow with several ranks on ONE GPU; collectives then go through host copies)")
+    ap.add_argument("--positions", type=int, default=64,
+                    help="membrane positions of the config-4 batch measured after the timed steps (0 = skip)")
+    ap.add_argument("--positions-size", type=int, default=0, help="study grid of the batch (default: --size, at most 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
 
 
+def spawn_ranks(a):
+    """`--gpus N` outside torchrun: start N ranks as a child torch.distributed.run and leave with its exit code.  Runs before
+    torch.cuda / HIP is touched in this process (never exec or fork a process that has initialised the GPU)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" not in os.environ and a.gpus > 1:
+        spawn_ranks(a)
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; launch one rank per GPU (python bench.py --gpus N starts "
+                         "them itself)" % (a.gpus, world))
     import torch
     import torch.distributed as td
     from paresis_amd import _lib, ops, synth
     from paresis_amd.getk import getk, k_refraction, k_sample
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (a.gpus, a.gpus))
     torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
     if world > 1:
         td.init_process_group(backend=a.backend, rank=rank, world_size=world)
@@ -156,21 +186,15 @@ def main():
             nm, cnt, tot = line.split()
             kern[nm] = (int(cnt), float(tot))
         lib.psx_profile_enable(0)
+    cpu_dev = dev if a.backend == "nccl" else torch.device("cpu")
+    ranks_seen = 1
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+        tt = torch.tensor([dt], dtype=torch.float64, device=cpu_dev)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         dt = float(tt.item())
-
-    # final image gather (RCCL over xGMI), outside the timed region
-    gather_ms = None
-    if world > 1:
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        img = fres[1] if a.backend == "nccl" else fres[1].cpu()
-        bucket = [torch.empty_like(img) for _ in range(world)] if rank == 0 else None
-        td.gather(img, bucket, dst=0)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - t1) * 1e3
+        one = torch.ones(1, dtype=torch.int64, device=cpu_dev)
+        td.all_reduce(one)                                  # every rank really took part in the collective
+        ranks_seen = int(one.item())
 
     units = len(DISTANCES)
     ms_per_step = dt / a.steps * 1e3
@@ -185,9 +209,13 @@ def main():
                                   "dSM/dMO/dOD=140/1.6/3.6 m" % (N, N),
                       "units_per_step": units, "fresnel_engine": {1: "rocfft", 2: "lds"}[plan.engine],
                       "streams": 1 if side is None else 2,
-                      "parallelism": "positions sharded, 1 per GPU" if world > 1 else "single GPU"}}
-    if gather_ms is not None:
-        out["gather_ms"] = round(gather_ms, 3)
+                      "parallelism": "positions sharded, 1 per GPU" if world > 1 else "single GPU"},
+           "ranks_seen": ranks_seen}
+
+    # ---- BASELINE.json config 4: the membrane-position batch, its own timed region (all ranks take part)
+    if a.positions > 0:
+        pn = a.positions_size or min(N, 4096)
+        out["positions_batch"] = {sim: positions_batch(a, sim, pn, rank, world, dev) for sim in ("Fresnel", "RayT")}
 
     if rank == 0:
         P = N + 30
@@ -207,84 +235,240 @@ def main():
         step_share = {nm: tot / a.steps for nm, (cnt, tot) in kern.items()}
         out["kernel_ms_per_step"] = {nm: round(v, 4) for nm, v in sorted(step_share.items(), key=lambda kv: -kv[1])}
         out["kernel_timing"] = ("HIP event pairs recorded by the library around each launch, on a second pass of the same K "
-                            "steps issued on ONE stream")
+                                "steps issued on ONE stream")
         dom = None
         for nm, v in sorted(step_share.items(), key=lambda kv: -kv[1]):
             if nm in alg:
                 dom = nm
                 break
         if dom is not None:
+            prof = pmc_profile(N)
             ach = alg[dom] / (per[dom] * 1e-3) / 1e9
+            traffic = pmc_value(prof, dom, "hbm_bytes_per_launch")
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, N),
-                               "ms_per_launch": round(per[dom], 4), "algorithmic_bytes_per_launch": alg[dom]}
-            # the same figure for every kernel that has an algorithmic price (the step has three of similar weight)
-            out["roofline"]["by_kernel"] = {
-                nm: {"ms_per_launch": round(per[nm], 4), "achieved": round(alg[nm] / (per[nm] * 1e-3) / 1e9, 1),
-                     "frac": round(alg[nm] / (per[nm] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(nm, N)}
-                for nm in sorted(per) if nm in alg}
-            # the bytes the kernels REALLY move (PMC counters of the committed profile) over the live launch time: what HBM
-            # sees, next to the algorithmic figure above -- these kernels are bound by instruction issue, not by HBM
-            for nm, e in out["roofline"]["by_kernel"].items():
+                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "ms_per_launch": round(per[dom], 4), "algorithmic_bytes_per_launch": alg[dom],
+                               "pricing": "64 B per padded pixel and propagation (BASELINE.md section 4): 32*P^2 per distance "
+                                          "and line kernel; (12+4*nmat)*P^2 per refraction"}
+            if traffic:
+                # what HBM really sees: the PMC bytes of the committed profile over the LIVE launch time
+                out["roofline"]["hbm_frac_measured"] = round(traffic / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            # the same figures for every kernel that has an algorithmic price (the step has three of similar weight)
+            by = {}
+            for nm in sorted(per):
+                if nm not in alg:
+                    continue
+                e = {"ms_per_launch": round(per[nm], 4), "achieved": round(alg[nm] / (per[nm] * 1e-3) / 1e9, 1),
+                     "frac": round(alg[nm] / (per[nm] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "traffic": pmc_value(prof, nm, "hbm_bytes_per_launch")}
                 if e["traffic"]:
                     e["hbm_gbs_measured"] = round(e["traffic"] / (per[nm] * 1e-3) / 1e9, 1)
-            # whole-step view with the same accounting: 4 x (64 + 12 + 4*nmat) bytes per padded pixel
+                    e["hbm_frac_measured"] = round(e["hbm_gbs_measured"] / HBM_PEAK_GBS, 4)
+                valu = pmc_value(prof, nm, "SQ_INSTS_VALU")
+                if valu:
+                    e["valu_ginst_s"] = round(valu / (per[nm] * 1e-3) / 1e9, 1)
+                    e["valu_frac"] = round(e["valu_ginst_s"] / VALU_PEAK_GINST, 4)
+                by[nm] = e
+            out["roofline"]["by_kernel"] = by
+            # SURVEY.md section 8(d)'s price for a distance batch on ONE input wave: the forward half is shared,
+            # (32 + 32 d) P^2 for the whole Fresnel call (pre-pass + both line kernels), against 64 d P^2 above
+            fres_ms = sum(step_share.get(nm, 0.0) for nm in ("k_source_transposed", "k_fresnel_cols", "k_fresnel_rows",
+                                                             "k_pad_transmit", "rocfft_forward", "k_chirp_mul",
+                                                             "rocfft_inverse", "k_crop_out"))
+            shared_bytes = (32 + 32 * units) * P * P
+            if fres_ms > 0:
+                out["roofline"]["frac_shared"] = round(shared_bytes / (fres_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                out["roofline"]["frac_shared_note"] = ("whole Fresnel call (pre-pass + pass 1 + pass 2, %.4f ms) priced at "
+                                                       "(32+32*d)*P^2 = %d bytes (SURVEY.md 8d, shared forward transform)"
+                                                       % (fres_ms, shared_bytes))
+            # whole-step view, both prices
             step_bytes = units * (64 + 12 + 4 * nmat) * P * P
+            step_bytes_shared = shared_bytes + units * (12 + 4 * nmat) * P * P
             out["roofline"]["step_achieved"] = round(step_bytes / (dt / a.steps) / 1e9, 1)
             out["roofline"]["step_frac"] = round(step_bytes / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 4)
+            out["roofline"]["step_frac_shared"] = round(step_bytes_shared / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 4)
+            # second bound: these kernels are limited by vector instruction issue, not by HBM
+            valu = pmc_value(prof, dom, "SQ_INSTS_VALU")
+            if valu:
+                gi = valu / (per[dom] * 1e-3) / 1e9
+                busy = pmc_value(prof, dom, "SQ_BUSY_CYCLES")
+                out["roofline_valu"] = {"bound": "valu", "kernel": dom, "achieved": round(gi, 1), "peak": VALU_PEAK_GINST,
+                                        "unit": "G wave64-instructions/s", "frac": round(gi / VALU_PEAK_GINST, 4),
+                                        "SQ_INSTS_VALU_per_launch": valu, "SQ_BUSY_CYCLES_per_launch": busy,
+                                        "note": "SQ_INSTS_VALU of the committed PMC pass over the live launch time; peak = "
+                                                "1024 SIMD-32 x 2.4 GHz / 2 cycles per plain wave64 instruction -- most of the "
+                                                "engine's instructions are packed fp32 (v_pk_*), which hold the pipe twice as "
+                                                "long, so the pipe is busier than this fraction says",
+                                        "profile": prof.get("_file") if prof else None}
+        rc = 0
         if not a.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline(N, geo, delta, beta, E, M, pix, I0, fres, refr)
+            if not out["parity"]["ok"]:
+                rc = 3
+        pb = out.get("positions_batch", {})
+        for sim, e in pb.items():
+            if e.get("check", {}).get("ok") is False:
+                rc = 4
         print(json.dumps(out))
+        if rc:
+            sys.stderr.write("bench.py: parity check FAILED (exit %d)\n" % rc)
+    else:
+        rc = 0
     if world > 1:
+        code = torch.tensor([rc], dtype=torch.int64, device=cpu_dev)
+        td.broadcast(code, src=0)
+        rc = int(code.item())
         td.barrier()
         td.destroy_process_group()
+    sys.exit(rc)
 
 
-def pmc_traffic(kernel, N):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_summary.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    gfx950).  Only valid for the configuration it was collected on (N = 4096); None otherwise."""
-    if N != 4096:
+def positions_batch(a, sim, N, rank, world, dev):
+    """BASELINE.json config 4: `--positions` membrane positions strided over the ranks, the full loop of main.py:63-110 per
+    position (membrane synthesis with seed(pointNum), chain, detection, shot noise) and ONE RCCL gather of every position's
+    Sample/Reference stacks onto rank 0, all inside the timed region (barrier + synchronize on both sides, MAX over ranks)."""
+    import torch
+    import torch.distributed as td
+    from paresis_amd import dist, ops, synth
+
+    P = a.positions
+    exp, place = synth.bench_experiment(N, sim, noise=True, seed=7)
+    mine = dist.my_positions(P, rank, world)
+    cpu_dev = dev if (world == 1 or a.backend == "nccl") else torch.device("cpu")
+
+    def position(p):
+        place(p)
+        return exp.computeSampleAndReferenceImages(p)[:2]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for p in (P + 1 + rank, P + 1 + world + rank):       # untimed: plans, sphere list on the GPU, allocator pools
+        position(p)
+    if world > 1:                                        # and the gather path (communicator set-up)
+        w = torch.zeros(8, device=cpu_dev)
+        td.gather(w, [torch.empty_like(w) for _ in range(world)] if rank == 0 else None, dst=0)
+    barrier()
+    t0 = time.perf_counter()
+    results = {}
+    for p in mine:
+        results[p] = position(p)
+    torch.cuda.synchronize()
+    t_comp = time.perf_counter() - t0
+    gathered = dist.gather_positions(results, P, rank, world, to_host=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    exp.resolve_mean_energy()
+    ops.check_status(dev, "positions batch")
+    times = torch.tensor([dt, t_comp, dt - t_comp], dtype=torch.float64, device=cpu_dev)
+    per_rank = [times]
+    if world > 1:
+        per_rank = [torch.empty_like(times) for _ in range(world)]
+        td.all_gather(per_rank, times)
+    if rank != 0:
+        if world > 1:                                    # rank 0 recomputes a few positions meanwhile: wait for it
+            td.barrier()
         return None
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None
-    # pass 2 (k_fresnel_rows) is the <16, false> instance of the line kernel (strided reads), pass 1 the <16, true> one
-    key = {"k_fresnel_rows": "k_fresnel_lines<16, false", "k_fresnel_cols": "k_fresnel_lines<16, true",
-           "k_refract_near": "k_refract_near<"}.get(kernel)
-    if not key:
+    dt_max = max(float(t[0]) for t in per_rank)
+    n_det = int(exp.myDetector.det_param["myDimensions"][0])
+    res = {"positions": P, "n_gpus": world, "ranks_seen": len(per_rank), "study_grid": N, "detector": n_det,
+           "ms_total": round(dt_max * 1e3, 3), "ms_per_position": round(dt_max * 1e3 / P, 4),
+           "positions_per_s": round(P / dt_max, 1), "Mpixel_per_s": round(P * N * N / dt_max / 1e6, 1),
+           "per_rank_compute_ms": [round(float(t[1]) * 1e3, 3) for t in per_rank],
+           "gather_ms": round(max(float(t[2]) for t in per_rank) * 1e3, 3),
+           "gathered_bytes": int(sum(v[0].numel() + v[1].numel() for v in gathered.values()) * 4),
+           "timed_region": "synthesis + chain + detection + shot noise of every position + the gather onto rank 0 (images stay "
+                           "in rank 0's HBM)", "backend": a.backend if world > 1 else None}
+    # rank 0 re-computes positions it did not own (every position when it is alone) and compares with what arrived
+    others = [p for p in range(P) if p % world != 0] if world > 1 else list(range(P))
+    sample = sorted(set(others[:2] + others[-1:])) if others else []
+    worst, equal = 0.0, True
+    for p in sample:
+        S, R = position(p)
+        for mine_t, got in ((S, gathered[p][0]), (R, gathered[p][1])):
+            got = got.to(mine_t.device)
+            equal = equal and bool(torch.equal(mine_t, got))
+            worst = max(worst, float((mine_t - got).abs().max() / got.abs().max()))
+    torch.cuda.synchronize()
+    # Fresnel chain: no float atomics anywhere -> bit for bit; ray tracing: far rays are replayed with float atomics in
+    # arbitrary order, which the Poisson draw may turn into a different count at a few pixels
+    res["check"] = {"positions_recomputed_on_rank0": sample, "bit_equal": equal, "max_rel_diff": worst,
+                    "ok": bool(equal) if sim == "Fresnel" else bool(worst < 1e-3)}
+    if world > 1:
+        td.barrier()
+    return res
+
+
+def pmc_profile(N):
+    """The newest committed rocprofv3 PMC summary for study grid N (profiles/rNN_pmc_summary[_N].json: FETCH_SIZE, WRITE_SIZE
+    and the SQ counters each collected in its own run; hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950).  Only valid for the configuration it was collected on."""
+    import glob
+    suffix = "" if N == 4096 else "_%d" % N
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary%s.json" % suffix)))
+    for f in reversed(files):
+        try:
+            prof = json.load(open(f))["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        prof["_file"] = os.path.relpath(f, ROOT)
+        return prof
+    return None
+
+
+def pmc_value(prof, kernel, field):
+    if not prof:
         return None
     for name, e in prof.items():
-        if name.startswith(key):
-            return e.get("hbm_bytes_per_launch")
+        if not isinstance(e, dict):
+            continue
+        if kernel in ("k_fresnel_rows", "k_fresnel_cols"):
+            # pass 2 (k_fresnel_rows) is the <R3, false, .> instance of the line kernel (strided reads), pass 1 <R3, true, .>
+            if not name.startswith("k_fresnel_lines<"):
+                continue
+            contig = name.split(",")[1].strip()
+            if contig != ("true" if kernel == "k_fresnel_cols" else "false"):
+                continue
+            return e.get(field)
+        if name.startswith(kernel + "<") or name == kernel:
+            return e.get(field)
     return None
 
 
 def cpu_baseline(N, geo, delta, beta, E, M, pix, I0, fres, refr):
-    """The oracle (fp64 numpy/pocketfft + scalar C loop, ONE thread = what the reference's numpy.fft + Numba @jit use)
-    timed on this box's host cores for a bounded sample: ONE of the step's 4 units (z = 3.6 m) on the same inputs.
-    Also returns the fp32 error of the GPU images against it."""
+    """The build's CPU restatement (oracle/cpu_baseline.{cpp,py}: float64, the reference's algorithm and operation order,
+    golden-checked) timed on this box's host cores on ALL 4 units of the step, at 1 thread (the stand-in for the reference:
+    numpy.fft and a non-parallel Numba @jit are single-threaded) and at all cores (OpenMP + pocketfft workers).  Also the
+    fp32 error of all 8 GPU images against it; a failure makes bench.py exit non-zero."""
     import torch
-    from oracle import paresis_oracle as orc
+    from oracle import cpu_baseline as cb
     torch.set_num_threads(1)
-    g64 = geo["membrane"].astype(np.float64)
-    zi = 1
-    z = DISTANCES[zi]
-    t0 = time.perf_counter()
-    w = orc.set_wave(np.full((N, N), np.sqrt(I0) + 0j), g64, delta, beta, E)
-    Fi = np.abs(orc.wave_propagation(w, z, E, M, (N, N), pix)) ** 2
-    t1 = time.perf_counter()
-    I, phi, _ = orc.set_wave_rt(np.full((N, N), I0), g64, delta, beta, E, 0)
-    Ri, _, _ = orc.fast_refraction(I, phi, z, E, M, pix)
-    t2 = time.perf_counter()
-    ef = float(np.max(np.abs(fres[zi].cpu().numpy() - Fi)) / np.max(np.abs(Fi)))
-    er = float(np.max(np.abs(refr[zi].cpu().numpy() - Ri)) / np.max(np.abs(Ri)))
-    cb = {"value": round(N * N / (t2 - t0) / 1e6, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
-          "sample": "1 of the step's 4 units (z=3.6 m) on the same %dx%d inputs: transmission + Fresnel propagation "
-                    "(%.2f s) + transmission + refraction (%.2f s), fp64, 1 thread" % (N, N, t1 - t0, t2 - t1),
-          "host_cpus": os.cpu_count()}
-    return cb, {"metric": "max|gpu-oracle|/max|oracle|", "fresnel": ef, "refraction": er, "tolerance": 1e-5}
+    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    tf1, tr1, F, R = cb.time_units(geo["membrane"], delta, beta, I0, DISTANCES, E, M, pix, 1)
+    tfa, tra, _, _ = cb.time_units(geo["membrane"], delta, beta, I0, DISTANCES, E, M, pix, ncpu)
+    ef = [float(np.max(np.abs(fres[i].cpu().numpy() - F[i])) / np.max(np.abs(F[i]))) for i in range(len(DISTANCES))]
+    er = [float(np.max(np.abs(refr[i].cpu().numpy() - R[i])) / np.max(np.abs(R[i]))) for i in range(len(DISTANCES))]
+    units = len(DISTANCES)
+    cb1 = units * N * N / (tf1 + tr1) / 1e6
+    cba = units * N * N / (tfa + tra) / 1e6
+    out = {"value": round(cb1, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
+           "sample": "all %d units of one step on the same %dx%d inputs: %d x (transmission + Fresnel propagation) %.2f s + "
+                     "%d x (transmission + refraction) %.2f s, fp64, 1 thread" % (units, N, N, units, tf1, units, tr1),
+           "all_cores": {"value": round(cba, 3), "unit": "Mpixel/s", "cores": ncpu,
+                         "sample": "the same %d units with OpenMP + pocketfft workers on %d threads: Fresnel %.2f s, refraction "
+                                   "%.2f s" % (units, ncpu, tfa, tra)},
+           "host_cpus": os.cpu_count(), "cpu_model": cb.cpu_model(),
+           "implementation": "oracle/cpu_baseline.cpp (C++17 -O3 x86-64-v3, OpenMP) + pocketfft via scipy.fft for the 2-D FFTs"}
+    ok = max(ef + er) <= PARITY_TOL
+    return out, {"metric": "max|gpu-cpu_fp64|/max|cpu_fp64| per image, all %d distances" % units, "fresnel": ef,
+                 "refraction": er, "tolerance": PARITY_TOL, "ok": bool(ok)}
 
 
 if __name__ == "__main__":

@@ -122,8 +122,8 @@ class AnalyticalSample(Sample):
             if fn == "getMembraneSegmentedFromFile":                          # SAM:234-237, sphere splat on the GPU
                 from .Samples.getMembraneFromFile import getMembraneSegmentedFromFile
                 geom, self.geom_parameters = getMembraneSegmentedFromFile(self, dimX, dimY, studyPixelSize, pointNum,
-                                                                          self.myPMMAThickness)
-                self.myGeometry = torch.stack(geom)
+                                                                          self.myPMMAThickness, stacked=True)
+                self.myGeometry = geom[2]                      # [2, dimX, dimY]: membrane, support (a new tensor per position)
                 return
         if fn == "get_my_thickness":
             self.myGeometry = np.full((1, dimX, dimY), self.myThickness * 1e-6, dtype=np.float32)   # SAM:239-243

@@ -129,7 +129,8 @@ def _plan_for(lst, dimX, dimY, pixSize, meanSphereRadius, dev):
     return plan
 
 
-def getMembraneSegmentedFromFile(sample, dimX, dimY, pixSize, pointNum, supportThickness, seed=None, sphere_list=None):
+def getMembraneSegmentedFromFile(sample, dimX, dimY, pixSize, pointNum, supportThickness, seed=None, sphere_list=None,
+                                 stacked=False):
     """getMembraneFromFile.py:60-171.  Returns ([membrane_m, support_m] float32 tensors in HBM, parameters_dic).
 
     main.py:64-65 calls this for every membrane position: the scaled, stitched list is the same each time, only the layer
@@ -141,18 +142,24 @@ def getMembraneSegmentedFromFile(sample, dimX, dimY, pixSize, pointNum, supportT
     dev = device()
     plan = _plan_for(lst, dimX, dimY, pixSize, sample.myMeanSphereRadius, dev)
     offs = layer_offsets(rs, sample.myNbOfLayers, plan.margin2, plan.sizeX, plan.sizeY, pixSize, dimX, dimY)
-    membrane = torch.empty((dimX, dimY), dtype=torch.float32, device=dev)
+    # `stacked`: both maps are the two planes of ONE [2, dimX, dimY] tensor (what the kernels take as a material stack), so
+    # the caller needs no torch.stack copy; geom[0].base-style access: the stack is returned as the third list entry
+    stack = torch.empty((2, dimX, dimY), dtype=torch.float32, device=dev) if stacked else None
+    membrane = stack[0] if stacked else torch.empty((dimX, dimY), dtype=torch.float32, device=dev)
     st = c_void_p(torch.cuda.current_stream().cuda_stream)
     for li, (ox, oy) in enumerate(offs):
         check(lib().psx_membrane_layer_f32(plan.h, ox, oy, dimX, dimY, plan.margin, plan.margin2, c_double(pixSize * 1e-6),
                                            1 if li else 0, c_void_p(membrane.data_ptr()), st), "psx_membrane_layer_f32")
     if not offs:
         membrane.zero_()
-    support = torch.full((dimX, dimY), float(supportThickness) * 1e-6, dtype=torch.float32, device=dev)
+    if stacked:
+        support = stack[1].fill_(float(supportThickness) * 1e-6)
+    else:
+        support = torch.full((dimX, dimY), float(supportThickness) * 1e-6, dtype=torch.float32, device=dev)
     parameters_dic = {'Average sphere radius': (sample.myMeanSphereRadius, 'um'),
                       'Number of layers': (sample.myNbOfLayers, ''),
                       'Support total thickness': (supportThickness, 'um')}
-    return [membrane, support], parameters_dic
+    return ([membrane, support, stack] if stacked else [membrane, support]), parameters_dic
 
 
 def getMembraneFromFile(myMembraneFile, studyDimensions, numPoint, supportThickness):

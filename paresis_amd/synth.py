@@ -98,3 +98,61 @@ def sphere_list(seed=20211011, coverage=0.45, n_max=None):
     x = rng.uniform(-SPHERE_FILE_SIZE_X / 2, SPHERE_FILE_SIZE_X / 2, n)
     r = np.clip(rng.normal(SPHERE_FILE_MEAN_RADIUS, 3.0, n), 4.0, 24.0)
     return np.stack([y, x, r], axis=1)
+
+
+def bench_experiment(N, sim="Fresnel", noise=True, seed=0, ov=2, psf=1.2, source_size_um=10.0, spectrum=None):
+    """The synthetic experiment of SURVEY.md section 8d on an N x N study grid, built from objects (no XML): 52 keV
+    (or `spectrum` = [(E_keV, weight)]), dSM/dMO/dOD = 140/1.6/3.6 m, detector N/ov pixels of 6 um, PSF 1.2 px, 10 um source,
+    CuSn-sphere membrane on a 6 mm PMMA support, Nylon cylinder.  Returns (experiment, place) where place(pointNum) renders
+    that position's membrane on the GPU (seeded offsets, getMembraneSegmentedFromFile: what main.py:64-65 does per position).
+    bench.py's 64-position batch (BASELINE.json config 4) and tools/time_positions.py run on it."""
+    import types
+
+    import torch
+
+    from .Detector import Detector
+    from .Experiment import Experiment
+    from .Sample import AnalyticalSample
+    from .Samples.getMembraneFromFile import getMembraneSegmentedFromFile
+    from .Source import Source
+
+    geo = bench_geometry(N, pointNum=0, ov=ov)
+    spectrum = [(52.0, 1.0)] if spectrum is None else list(spectrum)
+    energies = [e for e, _ in spectrum]
+    src = Source()
+    src.myName = "synthetic"
+    src.mySpectrum = list(spectrum)
+    src.source_dict.update(mySize=source_size_um, myEnergySampling=1.0 if len(energies) < 2 else energies[1] - energies[0],
+                           myType="Monochromatic" if len(energies) == 1 else "Polychromatic")
+    det = Detector({})
+    det.myName = "synthetic"
+    det.det_param.update(myDimensions=np.array((N // ov, N // ov)), myPixelSize=6.0, myPSF=psf, myBinsThersholds=[])
+
+    def scaled(name, e):
+        d0, b0 = DELTA_BETA_52KEV[name]
+        return d0 * (52.0 / e) ** 2, b0 * (52.0 / e) ** 3
+
+    def sample(geom, name, mtype, mats):
+        s = AnalyticalSample()
+        s.myName, s.myType, s.myMaterials = name, mtype, list(mats)
+        s.myGeometry = geom
+        s.delta = [[(e, scaled(m, e)[0]) for e in energies] for m in mats]
+        s.beta = [[(e, scaled(m, e)[1]) for e in energies] for m in mats]
+        return s
+
+    exp_dict = {"experimentName": "synthetic", "overSampling": ov, "nbExpPoints": 64,
+                "simulation_type": "RayT" if sim in ("RT", "RayT") else "Fresnel", "studyPixelSize": geo["pix_um"],
+                "studyDimensions": [N, N], "inVacuum": True, "meanShotCount": 30000.0, "meanEnergy": 0,
+                "distSourceToMembrane": 140.0, "distMembraneToObject": 1.6, "distObjectToDetector": 3.6,
+                "magnification": geo["M"], "noise": noise, "seed": seed, "deferMeanEnergy": True, "deferStatus": True}
+    membrane = sample(geo["membrane"], "membrane", "membrane", geo["membrane_materials"])
+    exp = Experiment.from_objects(exp_dict, src, det, membrane,
+                                  sample(geo["sample"], "sample", "sample_of_interest", ["Nylon"]))
+    smp = types.SimpleNamespace(myMeanSphereRadius=15.0, myNbOfLayers=2)
+    mpix = geo["pix_um"] * 140.0 / 141.6
+
+    def place(pointNum):
+        geom, _ = getMembraneSegmentedFromFile(smp, N, N, mpix, pointNum, 6000.0, stacked=True)
+        exp.myMembrane.myGeometry = geom[2]
+
+    return exp, place

@@ -21,7 +21,10 @@ def _oracle_built():
     import subprocess
     so = os.path.join(ROOT, "oracle", "liboracle_loops.so")
     src = os.path.join(ROOT, "oracle", "oracle_loops.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    so2 = os.path.join(ROOT, "oracle", "libcpu_baseline.so")
+    src2 = os.path.join(ROOT, "oracle", "cpu_baseline.cpp")
+    if (not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src) or not os.path.exists(so2)
+            or os.path.getmtime(so2) < os.path.getmtime(src2)):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     yield
 

@@ -242,10 +242,15 @@ def test_sample_generators_match_the_reference(tmp_path):
 
 
 def test_bench_finds_its_pmc_traffic():
-    """bench.py reports roofline.traffic from the committed rocprof PMC summary: the kernel-name prefixes it looks up must
-    match what the profile holds (a template parameter added to a kernel once silently turned the figure into null)."""
+    """bench.py reports roofline.traffic / hbm_frac_measured / roofline_valu from the newest committed rocprof PMC summary:
+    the kernel names it looks up must match the names in that file (pass 1 = <R3, true, .>, pass 2 = <R3, false, .>)."""
     import bench
+    prof = bench.pmc_profile(4096)
+    assert prof is not None and prof["_file"].startswith("profiles/")
     for k in ("k_fresnel_rows", "k_fresnel_cols", "k_refract_near"):
-        t = bench.pmc_traffic(k, 4096)
-        assert isinstance(t, int) and 1e8 < t < 1e10, (k, t)
-    assert bench.pmc_traffic("k_fresnel_rows", 2048) is None        # the profile is for the 4096^2 workload only
+        t = bench.pmc_value(prof, k, "hbm_bytes_per_launch")
+        assert t is not None and 1e8 < t < 3e9, (k, t)
+        assert bench.pmc_value(prof, k, "SQ_INSTS_VALU") > 1e7
+    rows, cols = (bench.pmc_value(prof, k, "WRITE_SIZE_KB") for k in ("k_fresnel_rows", "k_fresnel_cols"))
+    assert cols > 1.5 * rows                                         # pass 1 writes complex, pass 2 |.|^2: not mixed up
+    assert bench.pmc_profile(2048) is None                           # a profile only serves the grid it was collected on

@@ -7,7 +7,7 @@
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
-CMD="python3 $ROOT/bench.py --no-cpu-baseline"      # the default bench run (50 timed steps + the per-kernel event pass), minus the CPU leg
+CMD="python3 $ROOT/bench.py --no-cpu-baseline --positions 0 ${BENCH_ARGS:-}"      # the default bench run (50 timed steps + the per-kernel event pass), minus the CPU leg
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/fin_stats $OUT/fin_fetch $OUT/fin_write $OUT/fin_sq
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fin_stats -o runc -- $CMD > $OUT/fin_stats.log 2>&1
