@@ -452,7 +452,13 @@ def cpu_baseline(N, geo, delta, beta, E, M, pix, I0, fres, refr):
     except (AttributeError, OSError):
         pass
     tf1, tr1, F, R = cb.time_units(geo["membrane"], delta, beta, I0, DISTANCES, E, M, pix, 1)
-    tfa, tra, _, _ = cb.time_units(geo["membrane"], delta, beta, I0, DISTANCES, E, M, pix, ncpu)
+    # all cores: hardware threads and half of them (one per physical core where SMT is on), the faster one is reported
+    best = None
+    for nt in sorted({ncpu, max(1, ncpu // 2)}, reverse=True):
+        tf, tr, _, _ = cb.time_units(geo["membrane"], delta, beta, I0, DISTANCES, E, M, pix, nt)
+        if best is None or tf + tr < best[0] + best[1]:
+            best = (tf, tr, nt)
+    tfa, tra, nta = best
     ef = [float(np.max(np.abs(fres[i].cpu().numpy() - F[i])) / np.max(np.abs(F[i]))) for i in range(len(DISTANCES))]
     er = [float(np.max(np.abs(refr[i].cpu().numpy() - R[i])) / np.max(np.abs(R[i]))) for i in range(len(DISTANCES))]
     units = len(DISTANCES)
@@ -461,9 +467,9 @@ def cpu_baseline(N, geo, delta, beta, E, M, pix, I0, fres, refr):
     out = {"value": round(cb1, 3), "unit": "Mpixel/s", "cores": 1, "kind": "port",
            "sample": "all %d units of one step on the same %dx%d inputs: %d x (transmission + Fresnel propagation) %.2f s + "
                      "%d x (transmission + refraction) %.2f s, fp64, 1 thread" % (units, N, N, units, tf1, units, tr1),
-           "all_cores": {"value": round(cba, 3), "unit": "Mpixel/s", "cores": ncpu,
-                         "sample": "the same %d units with OpenMP + pocketfft workers on %d threads: Fresnel %.2f s, refraction "
-                                   "%.2f s" % (units, ncpu, tfa, tra)},
+           "all_cores": {"value": round(cba, 3), "unit": "Mpixel/s", "cores": nta,
+                         "sample": "the same %d units with OpenMP + pocketfft workers on %d threads (of %d hardware threads; the "
+                                   "faster of all / half): Fresnel %.2f s, refraction %.2f s" % (units, nta, ncpu, tfa, tra)},
            "host_cpus": os.cpu_count(), "cpu_model": cb.cpu_model(),
            "implementation": "oracle/cpu_baseline.cpp (C++17 -O3 x86-64-v3, OpenMP) + pocketfft via scipy.fft for the 2-D FFTs"}
     ok = max(ef + er) <= PARITY_TOL

@@ -72,8 +72,13 @@ int psx_accumulate_f32(float *acc, const float *img, float scale, const float *c
                        int accumulate, int64_t n, void *stream);
 
 /* The same, also reducing what it adds (Experiment.py:360-361 / 485-486: np.mean of the per-energy reference image feeds
- * the intensity-weighted mean energy): with v[p] = scale*img[p]*exp(sum catt*T[p]),  sums[0] += sum_p v[p] and
- * sums[1] += weight * sum_p v[p]  (device float64[2], caller-zeroed; weight = the energy).  acc may be NULL (sums only). */
+ * the intensity-weighted mean energy): with v[p] = scale*img[p]*exp(sum catt*T[p]) and S = sum_p v[p], the kernel adds S and
+ * weight*S (weight = the energy) into `sums`, a device float64 array of PSX_SUM_SLOTS slots of PSX_SUM_STRIDE doubles
+ * (128 bytes apart, so that the atomics of different workgroups do not serialise on one line), caller-zeroed:
+ *   sum_s sums[s*PSX_SUM_STRIDE + 0] = sum of S over the calls,   sum_s sums[s*PSX_SUM_STRIDE + 1] = sum of weight*S.
+ * acc may be NULL (sums only). */
+#define PSX_SUM_SLOTS 32
+#define PSX_SUM_STRIDE 16
 int psx_accumulate_sum_f32(float *acc, const float *img, float scale, const float *const *T, const double *catt, int nmat,
                            int accumulate, int64_t n, double *sums, double weight, void *stream);
 
@@ -92,7 +97,7 @@ int psx_accumulate_sum_f32(float *acc, const float *img, float scale, const floa
  * workspace         device scratch of psx_refract_workspace_bytes(Nx,Ny) bytes (far-ray list), caller-owned.
  */
 size_t psx_refract_workspace_bytes(int Nx, int Ny);
-/* Gather halo of the tile kernel: 4, 6 or 8 pixels (default 4).  A tile gathers every ray of its window (tile + halo)
+/* Gather halo of the tile kernel: 4, 6 or 8 pixels (default 4); a setting of the CALLING HOST THREAD (one thread per GPU).  A tile gathers every ray of its window (tile + halo)
  * that lands in it, however long; what remains for the slower far-ray replay are the shares whose source lies outside
  * the window of the target's tile.  A pure speed knob: results are identical up to the float-atomics order of those. */
 int psx_refract_set_halo(int halo);

@@ -22,6 +22,8 @@
 #include <complex>
 #include <cstdint>
 #include <cstring>
+#include <memory>
+#include <utility>
 #include <vector>
 
 typedef std::complex<double> cd;
@@ -121,13 +123,22 @@ void cb_transmit_rt(const float *const *T, const double *delta, const double *be
 }
 
 /* fastRefraction v2 (refractionFileNumba2.py:25-86) on (I, phi) [Nx][Ny] float64.  out[Nx][Ny].  Returns 1 when the result
- * holds NaN / >1e50 (RF2:81-82), else 0.  With nthreads > 1 the raster loop runs over row bands with atomic adds (the sums
- * then differ from raster order in the last bits). */
+ * holds NaN / >1e50 (RF2:81-82), else 0.  With nthreads > 1 the raster loop runs over row bands (see below): the sums then
+ * differ from raster order in the last bits. */
 int cb_fast_refraction(const double *I, const double *phi, int Nx, int Ny, double k_refr, double z, double M, double pix_um,
                        double *out, int nthreads) {
     const int mg = 15, Px = Nx + 2 * mg, Py = Ny + 2 * mg;
     const double h = pix_um * 1e-6;
-    std::vector<double> Dx((size_t)Px * Py, 0.0), Dy((size_t)Px * Py, 0.0), Ip((size_t)Px * Py, 0.0), I2((size_t)Px * Py, 0.0);
+    /* uninitialised buffers, zeroed by the threads that will use them (first touch places the pages near their cores) */
+    std::unique_ptr<double[]> Dxb(new double[(size_t)Px * Py]), Dyb(new double[(size_t)Px * Py]), Ipb(new double[(size_t)Px * Py]),
+        I2b(new double[(size_t)Px * Py]);
+    double *Dx = Dxb.get(), *Dy = Dyb.get(), *Ip = Ipb.get(), *I2 = I2b.get();
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int p = 0; p < Px; ++p)
+        for (int q = 0; q < Py; ++q) {
+            const int64_t e = (int64_t)p * Py + q;
+            Dx[e] = 0.0; Dy[e] = 0.0; Ip[e] = 0.0; I2[e] = 0.0;
+        }
 #pragma omp parallel for num_threads(nthreads) schedule(static)
     for (int i = 0; i < Nx; ++i) {
         for (int j = 0; j < Ny; ++j) {
@@ -155,37 +166,48 @@ int cb_fast_refraction(const double *I, const double *phi, int Nx, int Ny, doubl
             Ip[q] = Iv;
         }
     }
-    const bool par = nthreads > 1;
-    auto add = [&](int64_t q, double v) {
-        if (par) {
-#pragma omp atomic
-            I2[q] += v;
-        } else {
-            I2[q] += v;
-        }
-    };
-#pragma omp parallel for num_threads(nthreads) schedule(static)
-    for (int i = 0; i < Px; ++i) {                                          /* RF2:217-263 */
-        for (int j = 0; j < Py; ++j) {
-            const double Iij = Ip[(int64_t)i * Py + j];
-            double dx = Dx[(int64_t)i * Py + j], dy = Dy[(int64_t)i * Py + j];
-            if (dx == 0.0 && dy == 0.0) {
-                add((int64_t)i * Py + j, Iij);
-                continue;
+    /* RF2:217-263, raster order inside a band of rows per thread.  A deposit whose target row lies in the thread's own band is
+     * a plain add; the few that cross a band border are kept in the thread's list and applied, band by band, after a barrier
+     * -- no atomics, and one thread gives exactly the reference's raster order. */
+    const int nt = nthreads < 1 ? 1 : (nthreads > Px ? Px : nthreads);
+    std::vector<std::vector<std::pair<int64_t, double>>> cross(nt);
+#pragma omp parallel num_threads(nt)
+    {
+        const int t = omp_get_thread_num();
+        const int r0 = (int)((int64_t)Px * t / nt), r1 = (int)((int64_t)Px * (t + 1) / nt);
+        auto &mine = cross[t];
+        auto add = [&](int64_t row, int64_t col, double v) {
+            if (row >= r0 && row < r1) I2[row * Py + col] += v;
+            else mine.emplace_back(row * Py + col, v);
+        };
+        for (int i = r0; i < r1; ++i) {
+            for (int j = 0; j < Py; ++j) {
+                const double Iij = Ip[(int64_t)i * Py + j];
+                double dx = Dx[(int64_t)i * Py + j], dy = Dy[(int64_t)i * Py + j];
+                if (dx == 0.0 && dy == 0.0) {
+                    I2[(int64_t)i * Py + j] += Iij;
+                    continue;
+                }
+                int64_t inew = i, jnew = j;
+                if (std::fabs(dx) > 1.0) { const double fl = std::floor(dx); inew = i + (int64_t)fl; dx -= fl; }
+                if (std::fabs(dy) > 1.0) { const double fl = std::floor(dy); jnew = j + (int64_t)fl; dy -= fl; }
+                if (inew < 0 || inew >= Px || jnew < 0 || jnew >= Py) continue;
+                const double ax = std::fabs(dx), ay = std::fabs(dy);
+                add(inew, jnew, Iij * (1.0 - ax) * (1.0 - ay));
+                int64_t ix, jy;
+                if (dx >= 0.0) { if (inew >= Px - 1) continue; ix = inew + 1; } else { if (inew <= 0) continue; ix = inew - 1; }
+                if (dy >= 0.0) { if (jnew >= Py - 1) continue; jy = jnew + 1; } else { if (jnew <= 0) continue; jy = jnew - 1; }
+                add(ix, jnew, Iij * ax * (1.0 - ay));
+                add(ix, jy, Iij * ax * ay);
+                add(inew, jy, Iij * (1.0 - ax) * ay);
             }
-            int64_t inew = i, jnew = j;
-            if (std::fabs(dx) > 1.0) { const double fl = std::floor(dx); inew = i + (int64_t)fl; dx -= fl; }
-            if (std::fabs(dy) > 1.0) { const double fl = std::floor(dy); jnew = j + (int64_t)fl; dy -= fl; }
-            if (inew < 0 || inew >= Px || jnew < 0 || jnew >= Py) continue;
-            const double ax = std::fabs(dx), ay = std::fabs(dy);
-            add(inew * Py + jnew, Iij * (1.0 - ax) * (1.0 - ay));
-            int64_t ix, jy;
-            if (dx >= 0.0) { if (inew >= Px - 1) continue; ix = inew + 1; } else { if (inew <= 0) continue; ix = inew - 1; }
-            if (dy >= 0.0) { if (jnew >= Py - 1) continue; jy = jnew + 1; } else { if (jnew <= 0) continue; jy = jnew - 1; }
-            add(ix * Py + jnew, Iij * ax * (1.0 - ay));
-            add(ix * Py + jy, Iij * ax * ay);
-            add(inew * Py + jy, Iij * (1.0 - ax) * ay);
         }
+#pragma omp barrier
+        for (int u = 0; u < nt; ++u)
+            for (const auto &e : cross[u]) {
+                const int64_t row = e.first / Py;
+                if (row >= r0 && row < r1) I2[e.first] += e.second;
+            }
     }
     int bad = 0;
 #pragma omp parallel for num_threads(nthreads) schedule(static) reduction(| : bad)

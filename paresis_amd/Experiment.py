@@ -232,7 +232,7 @@ class Experiment:
         if self._accs is None or tuple(self._accs.shape[1:]) != N or self._accs.device != dev:
             self._accs = torch.empty((4,) + N, dtype=torch.float32, device=dev)
             self._tmp = torch.empty((2,) + N, dtype=torch.float32, device=dev)
-        sums = torch.zeros(2, dtype=torch.float64, device=dev)      # [sum I_ref, sum E * I_ref] over the energies (EXP:360-361)
+        sums = ops.new_sums(dev)                                    # [sum I_ref, sum E * I_ref] over the energies (EXP:360-361)
         return [out[0], out[1], out[2], out[3]], [self._accs[0], self._accs[1], self._accs[2], self._accs[3]], N, dev, sums
 
     def _close_bins(self):
@@ -302,7 +302,7 @@ class Experiment:
         if ed.get('deferMeanEnergy'):
             self._pending_means.append((sums, npix))
             return
-        self._fold_mean(sums.tolist(), npix)
+        self._fold_mean(ops.fold_sums(sums).tolist(), npix)
 
     def _fold_mean(self, s, npix):
         ed = self.exp_dict
@@ -311,7 +311,7 @@ class Experiment:
     def resolve_mean_energy(self):
         """Fold the deferred per-position sums into exp_dict['meanEnergy'] in call order (one device-to-host copy)."""
         if self._pending_means:
-            vals = torch.stack([t for t, _ in self._pending_means]).tolist()
+            vals = torch.stack([t for t, _ in self._pending_means])[:, :, :2].sum(dim=1).tolist()
             for s, (_, npix) in zip(vals, self._pending_means):
                 self._fold_mean(s, npix)
             self._pending_means = []

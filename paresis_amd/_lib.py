@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libparesis_hip.so")
 PSX_MAX_MAT = 8
 PSX_MAX_DIST = 8
 PSX_MAX_POISSON = 8
+PSX_SUM_SLOTS, PSX_SUM_STRIDE = 32, 16
 ENGINE_AUTO, ENGINE_ROCFFT, ENGINE_LDS = 0, 1, 2
 STATUS_NONFINITE = 1
 ABI_VERSION = 1

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -111,6 +112,23 @@ struct ProfScope {
         psx::ProfScope ps__(name, st);  \
         __VA_ARGS__;                    \
     } while (0)
+
+// Per-device one-time set-up (function attributes such as the dynamic LDS limit belong to the device's copy of the code
+// object): true the first time it is called for `mask` on the CURRENT device.  Nothing in the library caches a device
+// property in a process-wide static, so one process may drive several GPUs (one host thread per GPU).
+inline bool first_on_device(std::atomic<unsigned long long> &mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    return !(mask.fetch_or(bit) & bit);
+}
+
+// compute units of the current device (queried per call: ~0.1 us, no cache to go stale when the device changes)
+inline int current_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 8;
+    return n < 8 ? 8 : n;
+}
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -328,8 +328,7 @@ struct Philox {
 };
 
 // log of the Poisson probability  -L + k log L - log k!  for PTRS's acceptance test.  The three terms are of order
-// L log L and cancel to order 1, so a direct evaluation needs float64 (log, lgamma: ~500 instructions that every wave
-// ends up executing, since 14 % of the candidates take this test).  With x = (k - L)/L and Stirling's series for log k!
+// L log L and cancel to order 1, so a direct float32 evaluation is useless for large means.  With x = (k - L)/L and Stirling's series for log k!
 //     log pmf = -L g(x) - log(2 pi k)/2 - 1/(12 k) + 1/(360 k^3),      g(x) = (1 + x) log(1 + x) - x = x^2/2 - x^3/6 + ...
 // every term is small and float32 is enough (|error| < 1e-4 for k, L >= 64: an acceptance decision can only change when the
 // two sides are that close); small k or L keep the float64 form.
@@ -354,7 +353,9 @@ __device__ __forceinline__ float log_pmf(float k, float L) {
         const float ik = 1.f / k;
         return -L * g - 0.5f * logf(6.2831853f * k) - ik * (1.f / 12.f) + ik * ik * ik * (1.f / 360.f);
     }
-    return (float)(-(double)L + (double)k * log((double)L) - lgamma((double)k + 1.0));
+    // small k or L (10 <= L < 64): the terms are at most a few hundred, float32 leaves an absolute error ~2e-5 in a quantity
+    // that is compared with the log of a uniform -- a decision changes with probability ~1e-5
+    return -L + k * logf(L) - lgammaf(k + 1.f);
 }
 
 // Poisson draw: product-of-uniforms for lam < 10, Hormann's PTRS transformed rejection otherwise (both exact samplers).
@@ -368,8 +369,15 @@ struct PoissonImgs {
     uint64_t seed[PSX_MAX_POISSON];
 };
 
-// everything after the squeeze test of a candidate: the exact acceptance test, then further candidates
-__device__ __noinline__ float poisson_slow(float L, float U0, float V0, uint64_t p, uint64_t seed) {
+// One thread draws 4 consecutive pixels (16-byte load and store), in place; blockIdx.y = image of the batch (the three or
+// four detector images of one energy bin are drawn by ONE launch, each under its own key).  Pixels whose first candidate
+// fails the squeeze go through ONE copy of the exact test + retry loop, one pending pixel per lane at a time (values picked
+// with selects: a dynamically indexed register array would live in scratch memory).
+__device__ __forceinline__ float pick4(const float v[4], int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); }
+
+// everything after the squeeze test of a candidate: the exact acceptance test, then further candidates (PTRS, L >= 10), or
+// the product of uniforms (L < 10)
+__device__ __forceinline__ float poisson_finish(float L, float U0, float V0, uint64_t p, uint64_t seed) {
     Philox g;
     float u[4];
     if (L < 10.f) {
@@ -378,41 +386,44 @@ __device__ __noinline__ float poisson_slow(float L, float U0, float V0, uint64_t
         int k = 0;
         for (uint32_t sub = 1; sub < 64; ++sub) {
             g.next(p, sub, seed, u, 0x5059u);
+            bool done = false;
+#pragma unroll
             for (int i = 0; i < 4; ++i) {
-                prod *= u[i];
-                if (prod <= lim) return (float)k;
-                ++k;
+                if (!done) {
+                    prod *= u[i];
+                    if (prod <= lim) done = true;
+                    else ++k;
+                }
             }
+            if (done) break;
         }
         return (float)k;
     }
     const float slam = sqrtf(L);
     const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
     const float invalpha = 1.1239f + 1.1328f / (b - 3.4f), vr = 0.9277f - 3.6224f / (b - 2.f);
-    float U = U0, V = V0;
+    float U = U0, V = V0, U2 = 0.f, V2 = 0.f;
     uint32_t sub = 1;
-    int have = 0;
+    bool have = false;
+    float res = floorf(L);
     for (int it = 0; it < 128; ++it) {
         const float us = 0.5f - fabsf(U);
         const float k = floorf((2.f * a / us + b) * U + L + 0.43f);
-        if (us >= 0.07f && V <= vr) return k;
+        if (us >= 0.07f && V <= vr) { res = k; break; }
         if (!(k < 0.f || (us < 0.013f && V > us))) {
             const float lhs = logf(V) + logf(invalpha) - logf(a / (us * us) + b);
-            if (lhs <= log_pmf(k, L)) return k;
+            if (lhs <= log_pmf(k, L)) { res = k; break; }
         }
-        if (have == 0) {
+        if (have) {
+            U = U2; V = V2; have = false;
+        } else {
             g.next(p, sub++, seed, u, 0x5059u);
-            have = 2;
+            U = u[0] - 0.5f; V = u[1]; U2 = u[2] - 0.5f; V2 = u[3]; have = true;
         }
-        U = u[4 - 2 * have] - 0.5f;
-        V = u[5 - 2 * have];
-        --have;
     }
-    return floorf(L);
+    return res;
 }
 
-// One thread draws 4 consecutive pixels (16-byte load and store), in place; blockIdx.y = image of the batch (the three or
-// four detector images of one energy bin are drawn by ONE launch, each under its own key).
 __global__ __launch_bounds__(256) void k_poisson(PoissonImgs im, const float *__restrict__ lam_single, int64_t n) {
     float *img = im.img[blockIdx.y];
     const float *lam = lam_single ? lam_single : img;
@@ -423,9 +434,10 @@ __global__ __launch_bounds__(256) void k_poisson(PoissonImgs im, const float *__
         const float4 L4 = reinterpret_cast<const float4 *>(lam)[q];
         const float L[4] = {L4.x, L4.y, L4.z, L4.w};
         Philox g;
-        float u[8];
-        g.next((uint64_t)(2 * q), 0, seed, u, 0x5058u);
-        g.next((uint64_t)(2 * q + 1), 0, seed, u + 4, 0x5058u);
+        float ua[4], ub[4];
+        g.next((uint64_t)(2 * q), 0, seed, ua, 0x5058u);
+        g.next((uint64_t)(2 * q + 1), 0, seed, ub, 0x5058u);
+        const float U[4] = {ua[0] - 0.5f, ua[2] - 0.5f, ub[0] - 0.5f, ub[2] - 0.5f}, V[4] = {ua[1], ua[3], ub[1], ub[3]};
         float res[4];
         unsigned pending = 0;
 #pragma unroll
@@ -434,19 +446,20 @@ __global__ __launch_bounds__(256) void k_poisson(PoissonImgs im, const float *__
             const float slam = sqrtf(Li);
             const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
             const float vr = 0.9277f - 3.6224f / (b - 2.f);
-            const float U = u[2 * i] - 0.5f, V = u[2 * i + 1];
-            const float us = 0.5f - fabsf(U);
-            const float k = floorf((2.f * a / us + b) * U + Li + 0.43f);
-            const bool fast = Li >= 10.f && us >= 0.07f && V <= vr;
+            const float us = 0.5f - fabsf(U[i]);
+            const float k = floorf((2.f * a / us + b) * U[i] + Li + 0.43f);
+            const bool fast = Li >= 10.f && us >= 0.07f && V[i] <= vr;
             res[i] = fast ? k : 0.f;
             if (!fast && Li > 0.f) pending |= 1u << i;
         }
         while (pending) {
             const int i = __builtin_ctz(pending);
             pending &= pending - 1;
-            const float Li = i == 0 ? L[0] : (i == 1 ? L[1] : (i == 2 ? L[2] : L[3]));
-            const float r = poisson_slow(Li, u[2 * i] - 0.5f, u[2 * i + 1], (uint64_t)(4 * q + i), seed);
-            if (i == 0) res[0] = r; else if (i == 1) res[1] = r; else if (i == 2) res[2] = r; else res[3] = r;
+            const float r = poisson_finish(pick4(L, i), pick4(U, i), pick4(V, i), (uint64_t)(4 * q + i), seed);
+            res[0] = i == 0 ? r : res[0];
+            res[1] = i == 1 ? r : res[1];
+            res[2] = i == 2 ? r : res[2];
+            res[3] = i == 3 ? r : res[3];
         }
         reinterpret_cast<float4 *>(img)[q] = make_float4(res[0], res[1], res[2], res[3]);
     }
@@ -459,7 +472,8 @@ __global__ __launch_bounds__(256) void k_poisson(PoissonImgs im, const float *__
             Philox g;
             float u[4];
             g.next((uint64_t)(p >> 1), 0, seed, u, 0x5058u);
-            r = poisson_slow(Li, u[2 * (p & 1)] - 0.5f, u[2 * (p & 1) + 1], (uint64_t)p, seed);
+            const bool odd = p & 1;
+            r = poisson_finish(Li, (odd ? u[2] : u[0]) - 0.5f, odd ? u[3] : u[1], (uint64_t)p, seed);
         }
         img[p] = r;
     }

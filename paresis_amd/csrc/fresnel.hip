@@ -17,13 +17,6 @@ using namespace psx;
 
 namespace {
 
-#define PSX_ROCFFT(expr)                                                                          \
-    do {                                                                                          \
-        rocfft_status s__ = (expr);                                                               \
-        if (s__ != rocfft_status_success)                                                         \
-            return psx::fail(1000 + (int)s__, "%s:%d: %s -> rocfft_status %d", __FILE__, __LINE__, #expr, (int)s__); \
-    } while (0)
-
 template <int NM>
 __global__ __launch_bounds__(256) void k_pad_transmit(const float2 *__restrict__ wave_in, float amp, Mats m,
                                                       float2 *__restrict__ out, int Nx, int Ny, int margin, int Px,
@@ -82,11 +75,16 @@ bool g_rocfft_ready = false;
 
 namespace psx {
 
-int rocfft_engine_create(psx_fresnel_plan *p) {
+int rocfft_ensure_setup() {
     if (!g_rocfft_ready) {
         PSX_ROCFFT(rocfft_setup());
         g_rocfft_ready = true;
     }
+    return 0;
+}
+
+int rocfft_engine_create(psx_fresnel_plan *p) {
+    if (int rc = rocfft_ensure_setup()) return rc;
     RocfftEngine *e = new RocfftEngine();
     p->rf = e;
     const size_t lengths[2] = {(size_t)p->Py, (size_t)p->Px};   // rocFFT lengths are fastest-first

@@ -26,6 +26,8 @@
 // engine finishes the last butterfly and its stores.
 #include <cstdint>
 #include <cstdlib>
+#include <map>
+#include <tuple>
 #include <vector>
 
 #include "fft_pk.hpp"
@@ -751,15 +753,10 @@ __global__ __launch_bounds__(256) void k_source_transposed(const float2 *__restr
     }
 }
 
-// ---- float64 construction of the kernel spectrum FFT_M(IDFT_P(chirp)) ------------------------------------------------
-__global__ void k_cis_table(double2 *t, int n) {   // t[r] = exp(+2 pi i r / n)
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    double s, c;
-    sincospi(2.0 * (double)r / (double)n, &s, &c);
-    t[r] = make_double2(c, s);
-}
-
+// ---- float64 construction of the kernel spectrum FFT_M(IDFT_P(chirp)): chirp -> rocFFT inverse (length P, float64) ->
+// zero-pad per kernel segment -> rocFFT forward (length M, float64, batched over the segments) -> digit-reversed float32
+// table.  (Round 1 evaluated both transforms as direct O(P^2) / O(M P) float64 sums: 1.3 ms per spectrum, as much as a
+// whole bench step, and a 25-energy spectrum visits 75 of them per position.)
 __global__ void k_kern_H(double2 *H, int P, double a, double du) {   // EXP:243-250, FFT order
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
@@ -772,45 +769,31 @@ __global__ void k_kern_H(double2 *H, int P, double a, double du) {   // EXP:243-
     H[i] = make_double2(c, s);
 }
 
-__global__ void k_kern_h(const double2 *H, const double2 *twP, double2 *h, int P) {   // h = IDFT_P(H)
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= P) return;
-    double re = 0.0, im = 0.0;
-    int r = 0;
-    for (int k = 0; k < P; ++k) {
-        const double2 x = H[k], w = twP[r];
-        re += x.x * w.x - x.y * w.y;
-        im += x.x * w.y + x.y * w.x;
-        r += d;
-        if (r >= P) r -= P;
+// The taps h = IDFT_P(H) come out of an unnormalised float64 inverse transform (rocFFT); segment sg of the kernel --
+// taps [off, off + len) -- is laid out zero-padded to M points (and scaled by 1/P) for the forward transform of size M.
+__global__ void k_kern_pad(const double2 *__restrict__ hP, double2 *__restrict__ buf, int P, int M, int Lh, int S, int part) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * S) return;
+    const int sg = t / M, d = t - sg * M;
+    const int off = part ? sg * Lh : 0, len = part ? min(Lh, P - off) : P;
+    double2 v = make_double2(0.0, 0.0);
+    if (d < len) {
+        v = hP[off + d];
+        v.x /= P;
+        v.y /= P;
     }
-    h[d] = make_double2(re / P, im / P);
-}
-
-// FFT_M of the taps h[off .. off+len) zero-padded (the whole kernel, or one segment of the partitioned convolution)
-__global__ void k_kern_Hhat(const double2 *h, const double2 *twM, double2 *Hh, int off, int len, int M) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= M) return;
-    double re = 0.0, im = 0.0;
-    int r = 0;
-    for (int d = 0; d < len; ++d) {
-        const double2 x = h[off + d], w = twM[r];       // conj(w): exp(-2 pi i k d / M)
-        re += x.x * w.x + x.y * w.y;
-        im += x.y * w.x - x.x * w.y;
-        r += k;
-        if (r >= M) r -= M;
-    }
-    Hh[k] = make_double2(re, im);
+    buf[t] = v;
 }
 
 // position p = q1*S1 + q2*R3 + q3 of the in-place DIF output holds frequency k = q1 + 24*q2 + 576*q3
-__global__ void k_kern_perm(const double2 *Hh, float2 *out, int M, int R3) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= M) return;
+__global__ void k_kern_perm(const double2 *__restrict__ Hh, float2 *__restrict__ out, int M, int R3, int S) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * S) return;
+    const int sg = t / M, p = t - sg * M;
     const int S1 = M / RAD;
     const int q1 = p / S1, q2 = (p % S1) / R3, q3 = p % R3;
-    const double2 v = Hh[q1 + RAD * q2 + RAD * RAD * q3];
-    out[p] = make_float2((float)(v.x / M), (float)(v.y / M));
+    const double2 v = Hh[(size_t)sg * M + q1 + RAD * q2 + RAD * RAD * q3];
+    out[t] = make_float2((float)(v.x / M), (float)(v.y / M));
 }
 
 __global__ void k_stage_twiddles(float2 *twA, float2 *twB, int M, int R3) {
@@ -867,26 +850,36 @@ struct AxisTables {
     int N = 0, R3 = 0, M = 0;
     int part = 0, B = 0, Lh = 0, S = 1, NB = 1;     // partitioned convolution (lines that do not fit one transform)
     float2 *twA = nullptr, *twB = nullptr;
+    // float64 transforms of the kernel-spectrum build: taps = IDFT_P(chirp), spectrum = FFT_M(zero-padded taps) x S segments
+    rocfft_plan planP = nullptr, planM = nullptr;
+    rocfft_execution_info infoP = nullptr, infoM = nullptr;
+    void *workP = nullptr, *workM = nullptr;
+    double2 *bufP = nullptr, *bufM = nullptr;       // [P] chirp / taps, [S][M] padded taps / spectra
 };
 
 struct KernEntry {
-    double a, du;
-    int N, M, S;
     float2 *H;          // S spectra of M points
+    int M, S;
     unsigned long long stamp;
 };
+
+// cache key of a kernel spectrum: it depends on these scalars only
+typedef std::tuple<double, double, int, int> KernKey;   // (a, du, N, M)
 
 struct LdsEngine {
     AxisTables ax[2];            // [0]: lines along axis 0 (length Nx), [1]: along axis 1 (length Ny)
     float2 *inter = nullptr;     // [max_dist][Nx/IB][Ny][IB] intermediates (pass-1 line y, sample x)
     size_t inter_elems = 0;
-    float2 *pre = nullptr;       // [Nx][Ny] pre-transmitted wave when nmat exceeds the fused variants
+    float2 *pre = nullptr;       // [Ny][Nx] transmitted source wave, transposed (pass 0)
     float2 *part = nullptr;      // [max_dist][Nx][Ny] partial sums of pass 2 of the partitioned convolution when only |.|^2 is wanted
-    double2 *wH = nullptr, *wh = nullptr, *wHh = nullptr, *twP = nullptr, *twM = nullptr;
-    int twP_n = 0, twM_n = 0;
-    std::vector<KernEntry> cache;
+    // Kernel spectra, keyed by (a, du, N, M).  72 KiB each at 4096^2: the cache is sized for a polychromatic position
+    // (energies x hops x axes: 25 x 3 x 2 = 150 keys visited cyclically -- an LRU smaller than that misses on EVERY lookup),
+    // i.e. effectively unbounded; CACHE_CAP only bounds the memory of a plan fed with ever-changing scalars.
+    std::map<KernKey, KernEntry> cache;
+    size_t cache_bytes = 0;
     unsigned long long clock = 0;
 };
+constexpr size_t CACHE_CAP_BYTES = (size_t)1 << 30;
 
 bool lds_engine_supported(int Nx, int Ny, int margin) {
     // any line length: one transform per line up to N = 4593, the partitioned convolution beyond.  The output windows are
@@ -916,7 +909,31 @@ static int make_axis(AxisTables &t, int N, int margin, size_t &bytes) {
     PSX_HIP(hipMalloc((void **)&t.twB, sizeof(float2) * RAD * t.R3));
     bytes += sizeof(float2) * RAD * (S1 + t.R3);
     k_stage_twiddles<<<(int)cdiv(RAD * S1, 256), 256>>>(t.twA, t.twB, t.M, t.R3);
-    return launch_check("k_stage_twiddles");
+    if (int rc = launch_check("k_stage_twiddles")) return rc;
+    // float64 transforms of the kernel-spectrum build
+    if (int rc = rocfft_ensure_setup()) return rc;
+    const size_t P = (size_t)(N + 2 * margin), M = (size_t)t.M;
+    PSX_ROCFFT(rocfft_plan_create(&t.planP, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
+                                  rocfft_precision_double, 1, &P, 1, nullptr));
+    PSX_ROCFFT(rocfft_plan_create(&t.planM, rocfft_placement_inplace, rocfft_transform_type_complex_forward,
+                                  rocfft_precision_double, 1, &M, (size_t)t.S, nullptr));
+    size_t wP = 0, wM = 0;
+    PSX_ROCFFT(rocfft_plan_get_work_buffer_size(t.planP, &wP));
+    PSX_ROCFFT(rocfft_plan_get_work_buffer_size(t.planM, &wM));
+    PSX_ROCFFT(rocfft_execution_info_create(&t.infoP));
+    PSX_ROCFFT(rocfft_execution_info_create(&t.infoM));
+    if (wP) {
+        PSX_HIP(hipMalloc(&t.workP, wP));
+        PSX_ROCFFT(rocfft_execution_info_set_work_buffer(t.infoP, t.workP, wP));
+    }
+    if (wM) {
+        PSX_HIP(hipMalloc(&t.workM, wM));
+        PSX_ROCFFT(rocfft_execution_info_set_work_buffer(t.infoM, t.workM, wM));
+    }
+    PSX_HIP(hipMalloc((void **)&t.bufP, sizeof(double2) * P));
+    PSX_HIP(hipMalloc((void **)&t.bufM, sizeof(double2) * M * t.S));
+    bytes += wP + wM + sizeof(double2) * (P + M * t.S);
+    return 0;
 }
 
 int lds_engine_create(psx_fresnel_plan *p) {
@@ -928,14 +945,15 @@ int lds_engine_create(psx_fresnel_plan *p) {
     const size_t img = sizeof(float2) * e->inter_elems;
     PSX_HIP(hipMalloc((void **)&e->inter, img * p->max_dist));
     p->bytes += img * p->max_dist;
-    const int Pm = (p->Nx > p->Ny ? p->Nx : p->Ny) + 2 * p->margin;
-    const int Mm = e->ax[0].M > e->ax[1].M ? e->ax[0].M : e->ax[1].M;
-    PSX_HIP(hipMalloc((void **)&e->wH, sizeof(double2) * Pm));
-    PSX_HIP(hipMalloc((void **)&e->wh, sizeof(double2) * Pm));
-    PSX_HIP(hipMalloc((void **)&e->twP, sizeof(double2) * Pm));
-    PSX_HIP(hipMalloc((void **)&e->wHh, sizeof(double2) * Mm));
-    PSX_HIP(hipMalloc((void **)&e->twM, sizeof(double2) * Mm));
-    p->bytes += sizeof(double2) * (3 * (size_t)Pm + 2 * (size_t)Mm);
+    // every buffer a propagate call needs exists from here on: the call itself allocates nothing but kernel spectra it
+    // has not seen yet (and refuses to do that while its stream is being captured into a graph)
+    const size_t npix = (size_t)p->Nx * p->Ny;
+    PSX_HIP(hipMalloc((void **)&e->pre, sizeof(float2) * npix));
+    p->bytes += sizeof(float2) * npix;
+    if (e->ax[1].part && e->ax[1].S > 1) {      // complex partial sums of pass 2 when only |.|^2 leaves the pass
+        PSX_HIP(hipMalloc((void **)&e->part, sizeof(float2) * npix * p->max_dist));
+        p->bytes += sizeof(float2) * npix * p->max_dist;
+    }
     PSX_HIP(hipDeviceSynchronize());
     return 0;
 }
@@ -946,63 +964,78 @@ void lds_engine_destroy(psx_fresnel_plan *p) {
     for (auto &t : e->ax) {
         (void)hipFree(t.twA);
         (void)hipFree(t.twB);
+        if (t.planP) rocfft_plan_destroy(t.planP);
+        if (t.planM) rocfft_plan_destroy(t.planM);
+        if (t.infoP) rocfft_execution_info_destroy(t.infoP);
+        if (t.infoM) rocfft_execution_info_destroy(t.infoM);
+        (void)hipFree(t.workP);
+        (void)hipFree(t.workM);
+        (void)hipFree(t.bufP);
+        (void)hipFree(t.bufM);
     }
-    for (auto &k : e->cache) (void)hipFree(k.H);
+    for (auto &k : e->cache) (void)hipFree(k.second.H);
     (void)hipFree(e->inter);
     (void)hipFree(e->pre);
     (void)hipFree(e->part);
-    (void)hipFree(e->wH);
-    (void)hipFree(e->wh);
-    (void)hipFree(e->wHh);
-    (void)hipFree(e->twP);
-    (void)hipFree(e->twM);
     delete e;
     p->lds = nullptr;
 }
 
 // Kernel spectrum of one (distance, axis): cached, because it depends on scalars only (the reference rebuilds its
-// chirp on every call, EXP:243-248).  Built on `st` in float64; the cache is per plan, so stream order is enough.
-static int kernel_spectrum(psx_fresnel_plan *p, const AxisTables &t, double a, double du, hipStream_t st,
-                           const float2 **out) {
+// chirp on every call, EXP:243-248).  Built on `st` in float64.  A plan -- its cache, its scratch buffers, its
+// intermediates -- serves ONE stream at a time (include/paresis_hip.h, thread model): stream order is then enough to keep a
+// table alive until its readers are done; the one exception, evicting a table to reuse its memory, synchronises the stream.
+static int kernel_spectrum(psx_fresnel_plan *p, AxisTables &t, double a, double du, hipStream_t st, const float2 **out) {
     LdsEngine *e = p->lds;
-    for (auto &k : e->cache)
-        if (k.a == a && k.du == du && k.N == t.N && k.M == t.M) {
-            k.stamp = ++e->clock;
-            *out = k.H;
-            return 0;
-        }
-    KernEntry k{a, du, t.N, t.M, t.S, nullptr, ++e->clock};
-    if (e->cache.size() >= 64) {   // evict the least recently used table
-        size_t lru = 0;
-        for (size_t i = 1; i < e->cache.size(); ++i)
-            if (e->cache[i].stamp < e->cache[lru].stamp) lru = i;
-        k.H = e->cache[lru].H;
-        if (e->cache[lru].M != t.M || e->cache[lru].S != t.S) {
-            PSX_HIP(hipStreamSynchronize(st));
-            (void)hipFree(k.H);
-            k.H = nullptr;
-        }
-        e->cache.erase(e->cache.begin() + lru);
+    const KernKey key(a, du, t.N, t.M);
+    auto it = e->cache.find(key);
+    if (it != e->cache.end()) {
+        it->second.stamp = ++e->clock;
+        *out = it->second.H;
+        return 0;
     }
-    if (!k.H) PSX_HIP(hipMalloc((void **)&k.H, sizeof(float2) * t.M * t.S));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(PSX_E_STATE, "psx_fresnel_propagate: kernel spectrum (a=%g, du=%g) is not cached and cannot be built while "
+                                 "the stream is being captured: run the call once outside the capture first", a, du);
+    KernEntry k{nullptr, t.M, t.S, ++e->clock};
+    const size_t bytes = sizeof(float2) * (size_t)t.M * t.S;
+    if (e->cache_bytes + bytes > CACHE_CAP_BYTES && !e->cache.empty()) {   // evict the least recently used table
+        auto lru = e->cache.begin();
+        for (auto jt = e->cache.begin(); jt != e->cache.end(); ++jt)
+            if (jt->second.stamp < lru->second.stamp) lru = jt;
+        PSX_HIP(hipStreamSynchronize(st));       // its last readers are done
+        if (lru->second.M == t.M && lru->second.S == t.S) {
+            k.H = lru->second.H;
+        } else {
+            (void)hipFree(lru->second.H);
+            e->cache_bytes -= sizeof(float2) * (size_t)lru->second.M * lru->second.S;
+        }
+        e->cache.erase(lru);
+    }
+    if (!k.H) {
+        PSX_HIP(hipMalloc((void **)&k.H, bytes));
+        e->cache_bytes += bytes;
+        p->bytes += bytes;
+    }
     const int P = t.N + 2 * p->margin;
-    if (e->twP_n != P) {
-        PSX_TIMED("k_cis_table", st, k_cis_table<<<(int)cdiv(P, 256), 256, 0, st>>>(e->twP, P));
-        e->twP_n = P;
+    PSX_ROCFFT(rocfft_execution_info_set_stream(t.infoP, st));
+    PSX_ROCFFT(rocfft_execution_info_set_stream(t.infoM, st));
+    PSX_TIMED("k_kern_H", st, k_kern_H<<<(int)cdiv(P, 256), 256, 0, st>>>(t.bufP, P, a, du));
+    {
+        ProfScope ps("kern_ifft_P", st);
+        void *buf = t.bufP;
+        PSX_ROCFFT(rocfft_execute(t.planP, &buf, nullptr, t.infoP));
     }
-    if (e->twM_n != t.M) {
-        PSX_TIMED("k_cis_table", st, k_cis_table<<<(int)cdiv(t.M, 256), 256, 0, st>>>(e->twM, t.M));
-        e->twM_n = t.M;
+    PSX_TIMED("k_kern_pad", st, k_kern_pad<<<(int)cdiv((int64_t)t.M * t.S, 256), 256, 0, st>>>(t.bufP, t.bufM, P, t.M, t.Lh, t.S, t.part));
+    {
+        ProfScope ps("kern_fft_M", st);
+        void *buf = t.bufM;
+        PSX_ROCFFT(rocfft_execute(t.planM, &buf, nullptr, t.infoM));
     }
-    PSX_TIMED("k_kern_H", st, k_kern_H<<<(int)cdiv(P, 256), 256, 0, st>>>(e->wH, P, a, du));
-    PSX_TIMED("k_kern_h", st, k_kern_h<<<(int)cdiv(P, 64), 64, 0, st>>>(e->wH, e->twP, e->wh, P));
-    for (int sg = 0; sg < t.S; ++sg) {      // one spectrum per kernel segment (S = 1: the whole kernel)
-        const int off = t.part ? sg * t.Lh : 0, len = t.part ? std::min(t.Lh, P - off) : P;
-        PSX_TIMED("k_kern_Hhat", st, k_kern_Hhat<<<(int)cdiv(t.M, 64), 64, 0, st>>>(e->wh, e->twM, e->wHh, off, len, t.M));
-        PSX_TIMED("k_kern_perm", st, k_kern_perm<<<(int)cdiv(t.M, 256), 256, 0, st>>>(e->wHh, k.H + (size_t)sg * t.M, t.M, t.R3));
-    }
+    PSX_TIMED("k_kern_perm", st, k_kern_perm<<<(int)cdiv((int64_t)t.M * t.S, 256), 256, 0, st>>>(t.bufM, k.H, t.M, t.R3, t.S));
     if (int rc = launch_check("kernel spectrum")) return rc;
-    e->cache.push_back(k);
+    e->cache.emplace(key, k);
     *out = k.H;
     return 0;
 }
@@ -1011,20 +1044,12 @@ template <int R3, bool CONTIG, bool PART = false>
 static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
     constexpr int M = 576 * R3, LINES = TOT / M;
     constexpr size_t lds_bytes = sizeof(float2) * ((size_t)LINES * (M + M / 32) + (2 * R3 + RAD) * (RAD + 1));   // lines + the three twiddle tables
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_mask{0};
+    if (first_on_device(attr_mask))
         PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG, PART>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_bytes));
-        attr_set = true;
-    }
     // persistent workgroups: one per CU (the LDS footprint allows no more), a multiple of the 8 XCDs
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        PSX_HIP(hipGetDevice(&dev));
-        PSX_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        if (n_cu < 8) n_cu = 8;
-    }
+    const int n_cu = current_cu_count();
     const int nwork = ((la.nlines + LINES - 1) / LINES) * (PART ? la.n_dist * la.NB : (la.dist_inner ? 1 : la.n_dist));
     int nslot = n_cu / 8;
     if (nslot > (nwork + 7) / 8) nslot = (nwork + 7) / 8;
@@ -1064,10 +1089,6 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
     if (nnz == 0) return launch_check("k_source_out");
 
     // ---- pass 0: the transmitted source wave (K1), evaluated once for all distances and stored transposed [Ny][Nx]
-    if (!e->pre) {
-        PSX_HIP(hipMalloc((void **)&e->pre, sizeof(float2) * npix));
-        p->bytes += sizeof(float2) * npix;
-    }
     {
         const int ntiles = (int)(cdiv(p->Nx, 64) * cdiv(p->Ny, 64));
         int vec_ok = p->Ny % 4 == 0 && (uintptr_t)a.wave_in % 16 == 0;
@@ -1120,14 +1141,6 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         lb.n_dist = nnz;
         lb.dist_inner = 0;
         lb.B = e->ax[1].B; lb.Lh = e->ax[1].Lh; lb.S = e->ax[1].S; lb.NB = e->ax[1].NB;
-        if (e->ax[1].part && e->ax[1].S > 1 && !e->part) {     // complex partial sums when only |.|^2 leaves the pass
-            bool need = false;
-            for (int i = 0; i < nnz; ++i) need = need || !(a.wave_out && a.wave_out[nz[i]]);
-            if (need) {
-                PSX_HIP(hipMalloc((void **)&e->part, sizeof(float2) * npix * p->max_dist));
-                p->bytes += sizeof(float2) * npix * p->max_dist;
-            }
-        }
         for (int i = 0; i < PSX_MAX_DIST; ++i) {
             const int k = i < nnz ? i : 0, d = nz[k];
             lb.src[i] = e->inter + (size_t)k * e->inter_elems;

@@ -4,7 +4,16 @@
 
 #include "common.hpp"
 
+#define PSX_ROCFFT(expr)                                                                          \
+    do {                                                                                          \
+        rocfft_status s__ = (expr);                                                               \
+        if (s__ != rocfft_status_success)                                                         \
+            return psx::fail(1000 + (int)s__, "%s:%d: %s -> rocfft_status %d", __FILE__, __LINE__, #expr, (int)s__); \
+    } while (0)
+
 namespace psx {
+
+int rocfft_ensure_setup();   // rocfft_setup() once per process (fresnel.hip)
 
 struct LdsEngine;   // fresnel_lds.hip
 

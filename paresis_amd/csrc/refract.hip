@@ -480,7 +480,8 @@ __global__ __launch_bounds__(256) void k_fastloop(const float *__restrict__ I, c
 
 // Which geometry a call uses.  The wide halo costs ~20 % more source evaluations but keeps rays displaced by up to
 // 8 pixels inside the LDS gather; the far replay (scattered global float atomics, ~0.1 TB/s) is what it avoids.
-int g_refract_geometry = 0;   // 0: GeoSmall (H=4), 1: GeoWide (H=8), 2: GeoMid (H=6)
+// Per HOST THREAD (the ABI's thread model is one host thread per GPU): a second thread driving another GPU keeps its own.
+thread_local int g_refract_geometry = 0;   // 0: GeoSmall (H=4), 1: GeoWide (H=8), 2: GeoMid (H=6)
 
 template <class G>
 size_t workspace_for(int Nx, int Ny, int ndist) {
@@ -499,12 +500,10 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
     auto launch = [&](auto nm, auto hi, auto hp) -> int {
         constexpr int NM = decltype(nm)::value;
         constexpr bool HI = decltype(hi)::value, HP = decltype(hp)::value;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::atomic<unsigned long long> attr_mask{0};
+        if (first_on_device(attr_mask))
             PSX_HIP(hipFuncSetAttribute((const void *)k_refract_near<G, NM, HI, HP>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
-            attr_set = true;
-        }
         PSX_TIMED("k_refract_near", st,
                   k_refract_near<G, NM, HI, HP><<<a.tiles_x * a.tiles_y, G::NT, G::LDS, st>>>(a));
         if (int rc = launch_check("k_refract_near")) return rc;

@@ -55,14 +55,46 @@ __global__ __launch_bounds__(256) void k_accumulate(float *acc, const float *img
 }
 
 // The same with the sum of what was added reduced on the way (EXP:360-361, 485-486: the reference takes np.mean of the
-// per-energy reference image for its intensity-weighted mean energy): sums[0] += S, sums[1] += weight * S, S = sum of v.
-// Wave shuffle reduction in float64, one pair of atomics per workgroup.
+// per-energy reference image for its intensity-weighted mean energy): S = sum of v goes to slot (blockIdx % PSX_SUM_SLOTS) of
+// `sums` -- sums[slot*16 + 0] += S, sums[slot*16 + 1] += weight * S.  The slots are 128 bytes apart: float64 atomics on ONE
+// address retire at ~90 per microsecond chip-wide (16384 blocks on one word took 0.37 ms), on 32 lines they overlap.
+// 4 pixels per thread and trip (16-byte loads and stores) when the maps allow; wave shuffle reduction in float64.
 template <int NM>
 __global__ __launch_bounds__(256) void k_accumulate_sum(float *acc, const float *img, float scale, Mats m, int accumulate,
-                                                        int64_t n, double *sums, double weight) {
+                                                        int64_t n, double *sums, double weight, int vec) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     double s = 0.0;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+    const int64_t nq = vec ? n >> 2 : 0;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {
+        const float4 iv = reinterpret_cast<const float4 *>(img)[q];
+        float v[4] = {scale * iv.x, scale * iv.y, scale * iv.z, scale * iv.w};
+        if (NM > 0) {
+            float4 t[NM > 0 ? NM : 1];
+#pragma unroll
+            for (int i = 0; i < NM; ++i) t[i] = reinterpret_cast<const float4 *>(m.T[i])[q];
+            double la[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                la[0] = fma(m.catt[i], (double)t[i].x, la[0]);
+                la[1] = fma(m.catt[i], (double)t[i].y, la[1]);
+                la[2] = fma(m.catt[i], (double)t[i].z, la[2]);
+                la[3] = fma(m.catt[i], (double)t[i].w, la[3]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= expf((float)la[e]);
+        }
+        if (acc) {
+            float4 *ap = reinterpret_cast<float4 *>(acc) + q;
+            if (accumulate) {
+                const float4 o = *ap;
+                *ap = make_float4(o.x + v[0], o.y + v[1], o.z + v[2], o.w + v[3]);
+            } else {
+                *ap = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        s += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+    }
+    for (int64_t p = nq * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         float v = scale * img[p];
         if (NM > 0) {
             double ph, la;
@@ -79,8 +111,9 @@ __global__ __launch_bounds__(256) void k_accumulate_sum(float *acc, const float 
     __syncthreads();
     if (threadIdx.x == 0) {
         const double t = part[0] + part[1] + part[2] + part[3];
-        atomicAdd(&sums[0], t);
-        atomicAdd(&sums[1], weight * t);
+        double *slot = sums + (size_t)(blockIdx.x % PSX_SUM_SLOTS) * PSX_SUM_STRIDE;
+        atomicAdd(&slot[0], t);
+        atomicAdd(&slot[1], weight * t);
     }
 }
 
@@ -133,7 +166,11 @@ int psx_accumulate_sum_f32(float *acc, const float *img, float scale, const floa
     Mats m;
     if (int rc = pack_mats(m, T, nullptr, catt, nmat)) return rc;
     if (n == 0) return 0;
-    PSX_DISPATCH_NMAT(nmat, PSX_TIMED("k_accumulate_sum", (hipStream_t)stream, k_accumulate_sum<NM><<<ew_grid(n, 256, 4), 256, 0, (hipStream_t)stream>>>(acc, img, scale, m, accumulate, n, sums, weight)));
+    int vec = (uintptr_t)img % 16 == 0 && (uintptr_t)acc % 16 == 0;
+    for (int i = 0; i < nmat && i < PSX_MAX_MAT; ++i) vec = vec && (uintptr_t)T[i] % 16 == 0;
+    int grid = ew_grid(n, 256, 4);
+    if (grid > 1024) grid = 1024;                     // 4 workgroups per CU; 2 x 1024 atomics over 32 lines
+    PSX_DISPATCH_NMAT(nmat, PSX_TIMED("k_accumulate_sum", (hipStream_t)stream, k_accumulate_sum<NM><<<grid, 256, 0, (hipStream_t)stream>>>(acc, img, scale, m, accumulate, n, sums, weight, vec)));
     return launch_check("k_accumulate_sum");
 }
 

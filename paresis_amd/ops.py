@@ -186,14 +186,24 @@ def accumulate(acc, img, scale=1.0, mats=None, add=True):
     return acc
 
 
+def new_sums(device):
+    return torch.zeros((_lib.PSX_SUM_SLOTS, _lib.PSX_SUM_STRIDE), dtype=torch.float64, device=device)
+
+
+def fold_sums(sums):
+    """[sum S, sum weight*S] (float64 tensor of 2, still in HBM) of a new_sums() buffer."""
+    return sums[:, :2].sum(dim=0)
+
+
 def accumulate_sum(acc, img, sums, weight, scale=1.0, mats=None, add=True):
     """accumulate() that also reduces what it adds: sums[0] += sum(v), sums[1] += weight*sum(v), v = scale*img*att
-    (Experiment.py:360-361, 485-486).  sums: float64[2] in HBM.  acc may be None (reduction only)."""
+    (Experiment.py:360-361, 485-486).  sums: float64 [SUM_SLOTS, SUM_STRIDE] in HBM from new_sums() -- the kernel's
+    workgroups add into 32 slots 128 bytes apart; fold_sums() gives the two totals.  acc may be None (reduction only)."""
     mats = _mats(mats)
     _need(img, torch.float32, "img")
     if acc is not None:
         _need(acc, torch.float32, "acc", img.shape)
-    _need(sums, torch.float64, "sums", (2,))
+    _need(sums, torch.float64, "sums", (_lib.PSX_SUM_SLOTS, _lib.PSX_SUM_STRIDE))
     T, cp, ca, n = mats.cargs(tuple(img.shape))
     check(lib().psx_accumulate_sum_f32(_ptr(acc), _ptr(img), c_float(scale), T, ca, n, 1 if add else 0, img.numel(),
                                        _ptr(sums), c_double(weight), _stream()), "psx_accumulate_sum_f32")
