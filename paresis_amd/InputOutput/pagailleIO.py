@@ -39,7 +39,9 @@ def save_tif_image(data, filename):
 def saveEdf(data, filename):
     img = _as_f32(data)
     h, w = img.shape
-    hdr = ("{\nHeaderID = EH:000001:000000:000000 ;\nByteOrder = LowByteFirst ;\nDataType = FloatValue ;\n"
+    # ESRF data format, the header grammar fabio's EdfImage writes: "{\n", lines "key = value ;\n", space padding, "}\n", the
+    # whole header a multiple of 512 bytes; Dim_1 is the FAST axis (columns); raw little-endian float32 follows
+    hdr = ("{\nHeaderID = EH:000001:000000:000000 ;\nImage = 1 ;\nByteOrder = LowByteFirst ;\nDataType = FloatValue ;\n"
            "Dim_1 = %d ;\nDim_2 = %d ;\nSize = %d ;\n" % (w, h, img.nbytes))
     pad = (-(len(hdr) + 2)) % 512
     hdr = hdr + " " * pad + "}\n"
@@ -60,18 +62,42 @@ def save_image(data, filename):
         raise ValueError("unknown image format %r" % ext)
 
 
+_EDF_TYPES = {"FloatValue": "f4", "Float": "f4", "DoubleValue": "f8", "UnsignedShort": "u2", "SignedShort": "i2",
+              "UnsignedInteger": "u4", "SignedInteger": "i4", "UnsignedByte": "u1", "SignedByte": "i1",
+              "UnsignedLong": "u4", "SignedLong": "i4"}
+
+
+def _open_edf(raw):
+    """Any single-frame EDF: header = "{" ... "}\n" (padded to 512-byte blocks), key = value ; lines."""
+    end = raw.index(b"}\n") + 2
+    fields = {}
+    for line in raw[:end].decode("ascii", "replace").split(";"):
+        if "=" in line:
+            k, v = line.split("=", 1)
+            fields[k.strip().lstrip("{").strip()] = v.strip()
+    w, h = int(fields["Dim_1"]), int(fields["Dim_2"])
+    order = "<" if fields.get("ByteOrder", "LowByteFirst") == "LowByteFirst" else ">"
+    dt = np.dtype(order + _EDF_TYPES[fields.get("DataType", "FloatValue")])
+    return np.frombuffer(raw, dtype=dt, count=w * h, offset=end).reshape(h, w).astype(np.float32 if dt.kind == "f" else dt.newbyteorder("="))
+
+
 def openImage(filename):
+    """pagailleIO.py:25-47: EDF / TIFF -> 2-D array.  TIFF files written by other tools (strips, big-endian, integer
+    samples) go through PIL when it is importable; the files this module writes are also read without it."""
     ext = os.path.splitext(filename)[1].lower()
-    raw = open(filename, "rb").read()
     if ext == ".npy":
         return np.load(filename)
+    raw = open(filename, "rb").read()
     if ext == ".edf":
-        end = raw.index(b"}\n") + 2
-        fields = dict(l.split("=", 1) for l in raw[:end].decode("ascii").replace(";", "").splitlines() if "=" in l)
-        w, h = int(fields["Dim_1 "]), int(fields["Dim_2 "])
-        return np.frombuffer(raw, dtype="<f4", count=w * h, offset=end).reshape(h, w).copy()
+        return _open_edf(raw)
+    try:
+        from PIL import Image
+        with Image.open(filename) as im:
+            return np.array(im)
+    except ImportError:
+        pass
     if raw[:4] != b"II*\x00":
-        raise ValueError("only little-endian baseline TIFF written by save_tif_image is supported")
+        raise ValueError("without PIL only little-endian baseline TIFF written by save_tif_image is supported")
     (ifd_off,) = struct.unpack_from("<I", raw, 4)
     (n,) = struct.unpack_from("<H", raw, ifd_off)
     vals = {}

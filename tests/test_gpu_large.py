@@ -221,3 +221,138 @@ def test_16384_partitioned_engine_and_detector():
     assert float((img[40:-40, 40:-40] - 2.25 * ov * ov).abs().max()) < 1e-3     # bin SUM of a uniform image
     noisy = ops.poisson(img * 100, seed=11)
     assert abs(float(noisy.mean()) / (225.0 * ov * ov) - 1) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 2: the places where a regression could hide at the BASELINE sizes ("weak" item 1)
+def test_bench_fresnel_call_4096_four_distances():
+    """bench.py's exact Fresnel call -- 4096^2, ONE call to 4 distances, transmission fused, |.|^2 outputs (the only user of
+    pass 1's distance-inner rounds with 4 distances) -- every one of the 4 images against the rocFFT engine (<= 3e-6) and
+    against the CPU restatement on a 64-wide strip (EXP:219-252)."""
+    from oracle import cpu_baseline as cb
+    from paresis_amd import ops, synth
+    from paresis_amd.getk import getk
+    N, E = 4096, 52.0
+    zs = (1.6, 3.6, 5.2, 7.2)
+    g, T = _membrane(N, 0)
+    wave, _ = _stacks(ops, T)
+    kk = getk(E * 1000)
+    h = g["pix_um"] * 1e-6
+    du = (2 * np.pi / (N * h),) * 2
+    a = [z / (2 * kk * g["M"]) for z in zs]
+    gp = [kk * z / g["M"] for z in zs]
+    amp = float(np.sqrt(7500.0))
+    res = []
+    for eng in (2, 1):
+        plan = ops.FresnelPlan(N, N, max_dist=4, engine=eng)
+        assert plan.engine == eng
+        outs = [torch.empty((N, N), dtype=torch.float32, device="cuda") for _ in zs]
+        plan.propagate(a, gp, du, amp=amp, mats=wave, want_wave=[False] * 4, inten_out=outs)
+        res.append(outs)
+        plan.close()
+    for d in range(4):
+        err = float((res[0][d] - res[1][d]).abs().max() / res[1][d].abs().max())
+        assert err < 3e-6, (d, err)
+    # strip: a wave that does not vary along axis 1 -- the separable operator then acts on axis 0 alone; 64 columns of the
+    # membrane's first column, all 4 distances in one call on the LDS engine, against the float64 restatement
+    d_b = [synth.DELTA_BETA_52KEV[m] for m in ("CuSn", "PMMA")]
+    strip = np.repeat(g["membrane"][:, :, :1], 64, axis=2).copy()
+    Ts = torch.from_numpy(strip).cuda()
+    ws, _ = _stacks(ops, Ts)
+    plan = ops.FresnelPlan(N, 64, max_dist=4, engine=2)
+    outs = [torch.empty((N, 64), dtype=torch.float32, device="cuda") for _ in zs]
+    plan.propagate(a, gp, (du[0], 2 * np.pi / (64 * h)), amp=amp, mats=ws, want_wave=[False] * 4, inten_out=outs)
+    plan.close()
+    for d, z in enumerate(zs):
+        ref = cb.fresnel_intensity(strip, [x[0] for x in d_b], [x[1] for x in d_b], amp, z, E, g["M"], g["pix_um"], 4)
+        assert relmax(outs[d].cpu().numpy(), ref) < 1e-5, d
+
+
+def test_refraction_2048_against_cpu_restatement():
+    """BASELINE config 2 (2048^2, 1 distance): the refraction against the float64 C++ restatement of RF2:25-86 (about a
+    second of CPU at this size), plus the Fresnel propagation of the same inputs."""
+    from oracle import cpu_baseline as cb
+    from paresis_amd import ops, synth
+    from paresis_amd.getk import getk, k_refraction
+    N, E, z = 2048, 52.0, 3.6
+    g, T = _membrane(N, 4)
+    wave, rt = _stacks(ops, T)
+    d_b = [synth.DELTA_BETA_52KEV[m] for m in ("CuSn", "PMMA")]
+    delta, beta = [x[0] for x in d_b], [x[1] for x in d_b]
+    h = g["pix_um"] * 1e-6
+    r, _, _ = ops.refract((N, N), rt, z / k_refraction(E) / (h * g["M"]) / h, (N, N), I0=7500.0)
+    ops.check_status(r.device)
+    ref = cb.refraction_intensity(g["membrane"], delta, beta, 7500.0, z, E, g["M"], g["pix_um"], 8)
+    assert relmax(r.cpu().numpy(), ref) < 1e-5
+    kk = getk(E * 1000)
+    plan = ops.FresnelPlan(N, N, max_dist=1)
+    inten = torch.empty((N, N), dtype=torch.float32, device="cuda")
+    plan.propagate([z / (2 * kk * g["M"])], [kk * z / g["M"]], (2 * np.pi / (N * h),) * 2, amp=float(np.sqrt(7500.0)), mats=wave,
+                   want_wave=[False], inten_out=[inten])
+    plan.close()
+    ref = cb.fresnel_intensity(g["membrane"], delta, beta, float(np.sqrt(7500.0)), z, E, g["M"], g["pix_um"], 8)
+    assert relmax(inten.cpu().numpy(), ref) < 1e-5
+
+
+def test_refraction_16384_properties():
+    """BASELINE config 5's grid through the refraction: flux that stays on the grid is conserved, the distance batch equals
+    the one-distance calls, and a 512-row band equals the same band computed on its own (the gradient stencil and the gather
+    are local: rows far from the band's edges cannot tell the difference)."""
+    from paresis_amd import ops, synth
+    from paresis_amd.getk import k_refraction, k_sample
+    N = 16384
+    pix_um = 6.0 / 4 / (145.2 / 141.6)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    # smooth random membrane-like thickness: low-resolution noise upsampled (a few um of CuSn, gradients of a few pixels)
+    low = torch.rand((1, 1, N // 64, N // 64), device="cuda", generator=gen)
+    Tm = torch.nn.functional.interpolate(low, size=(N, N), mode="bicubic", align_corners=False)[0, 0].clamp_(0, 1).mul_(30e-6).contiguous()
+    T = torch.stack([Tm, torch.full_like(Tm, 6e-3)])
+    del low, Tm
+    k = k_sample(52.0)
+    d = [synth.DELTA_BETA_52KEV[m] for m in ("CuSn", "PMMA")]
+    rt = ops.MaterialStack(T, cphase=[-k * x[0] for x in d], catt=[-2 * k * x[1] for x in d])
+    h = pix_um * 1e-6
+    M = 145.2 / 141.6
+    dsc = [z / k_refraction(52.0) / (h * M) / h for z in (1.6, 7.2)]
+    outs = ops.refract_multi((N, N), rt, dsc, (N, N), I0=470.0)
+    ops.check_status(outs[0].device)
+    I_in, _ = ops.transmit_rt(None, 470.0, rt, want_phi=False)
+    m = 128
+    tot = float(I_in[m:-m, m:-m].sum(dtype=torch.float64))
+    del I_in
+    for o in outs:
+        assert abs(float(o[m:-m, m:-m].sum(dtype=torch.float64)) / tot - 1) < 1e-3
+    single, _, _ = ops.refract((N, N), rt, dsc[1], (N, N), I0=470.0)
+    assert float((outs[1] - single).abs().max() / single.max()) < 1e-6
+    del single
+    # a band on its own
+    r0, r1, guard = 6000, 6512, 96
+    band = ops.MaterialStack(T[:, r0:r1].contiguous(), cphase=rt.cphase, catt=rt.catt)
+    ob, _, _ = ops.refract((r1 - r0, N), band, dsc[1], (r1 - r0, N), I0=470.0)
+    err = float((ob[guard:-guard] - outs[1][r0 + guard:r1 - guard]).abs().max() / outs[1].max())
+    assert err < 1e-6, err
+
+
+def test_integration_md_binding_runs():
+    """The ctypes stub printed in INTEGRATION.md section 2 is executed as printed and compared with the reference's own
+    fastRefraction output (tests/golden/refraction.npz)."""
+    import os
+    import re
+    from paresis_amd import _lib
+    from tests._golden import load
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"## 2\..*?```python\n(.*?)```", text, flags=re.S).group(1)
+    assert "def fastRefraction" in code
+    code = code.replace('ctypes.CDLL("libparesis_hip.so")', 'ctypes.CDLL(%r)' % _lib.LIB_PATH)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#2", "exec"), ns)
+    g = load("refraction.npz")
+    for k in range(int(g["n"])):
+        z, E, M, pix = g["%d/params" % k]
+        I = torch.from_numpy(g["%d/I" % k].astype(np.float32)).cuda()
+        phi = torch.from_numpy(g["%d/phi" % k]).cuda()
+        out, Dx, Dy = ns["fastRefraction"](I, phi, z, E, M, pix)
+        assert relmax(out.cpu().numpy(), g["%d/v2/out" % k]) < 1e-5, k
+        assert relmax(Dx.cpu().numpy(), g["%d/v2/Dx" % k]) < 1e-5
+        assert np.array_equal(I.cpu().numpy() == 0, g["%d/v2/I_after" % k] == 0)        # in-place zeroing of clamped rays

@@ -254,3 +254,75 @@ def test_bench_finds_its_pmc_traffic():
     rows, cols = (bench.pmc_value(prof, k, "WRITE_SIZE_KB") for k in ("k_fresnel_rows", "k_fresnel_cols"))
     assert cols > 1.5 * rows                                         # pass 1 writes complex, pass 2 |.|^2: not mixed up
     assert bench.pmc_profile(2048) is None                           # a profile only serves the grid it was collected on
+
+
+# ---- image formats: what main.py:98-110 writes through fabio in the reference
+def test_tiff_written_here_is_read_by_an_independent_reader(tmp_path):
+    """save_tif_image against PIL (an independent TIFF reader that is in the image): float32 samples, row-major, exact."""
+    from PIL import Image
+    from paresis_amd.InputOutput.pagailleIO import openImage, save_image
+    rng = np.random.default_rng(3)
+    for shape in ((7, 5), (1, 9), (200, 200)):
+        img = (rng.normal(size=shape) * 1e3).astype(np.float32)
+        f = str(tmp_path / ("a%dx%d.tif" % shape))
+        save_image(img, f)
+        with Image.open(f) as im:
+            assert im.mode == "F" and im.size == (shape[1], shape[0])
+            assert np.array_equal(np.array(im), img)
+        assert np.array_equal(openImage(f), img)
+    # and the other way round: a float32 TIFF written by PIL (strips, its own tag order) is read back by openImage
+    f = str(tmp_path / "pil.tif")
+    Image.fromarray(img).save(f)
+    assert np.array_equal(openImage(f), img)
+
+
+def test_image_byte_fixtures(tmp_path):
+    """Hand-checked byte fixtures (tests/golden/image_3x2.{tif,edf}): a 2-row x 3-column float32 image.
+    TIFF: 'II' 42, one IFD of 10 entries (256 width=3, 257 length=2, 258 bits=32, 259 compression=1, 262 photometric=1,
+    273 strip offset=134, 277 samples=1, 278 rows per strip=2, 279 byte count=24, 339 sample format=3 IEEE float), data at 134.
+    EDF: the ESRF header grammar fabio's EdfImage writes -- '{', 'key = value ;' lines, space padding, '}' + newline, header
+    length a multiple of 512 -- with HeaderID, ByteOrder = LowByteFirst, DataType = FloatValue, Dim_1 = columns,
+    Dim_2 = rows, Size = bytes; little-endian float32 rows follow."""
+    import struct
+    from paresis_amd.InputOutput.pagailleIO import save_image
+    img = np.array([[1.5, -2.25, 3.0], [1e-3, 7e4, -0.0]], dtype=np.float32)
+    gold = os.path.join(ROOT, "tests", "golden")
+    for ext in (".tif", ".edf"):
+        f = str(tmp_path / ("x" + ext))
+        save_image(img, f)
+        assert open(f, "rb").read() == open(os.path.join(gold, "image_3x2" + ext), "rb").read(), ext
+    # the EDF fixture through a parser written from the format description alone (not the package's reader)
+    raw = open(os.path.join(gold, "image_3x2.edf"), "rb").read()
+    assert raw[:2] == b"{\n"
+    end = raw.index(b"}\n") + 2
+    assert end % 512 == 0 and len(raw) == end + 24
+    hdr = {}
+    for line in raw[2:end - 2].decode("ascii").split("\n"):
+        if line.strip():
+            assert line.endswith(" ;"), line
+            k, v = line[:-2].split(" = ")
+            hdr[k] = v
+    assert hdr["ByteOrder"] == "LowByteFirst" and hdr["DataType"] == "FloatValue" and hdr["HeaderID"].startswith("EH:")
+    assert (int(hdr["Dim_1"]), int(hdr["Dim_2"]), int(hdr["Size"])) == (3, 2, 24)
+    assert np.array_equal(np.frombuffer(raw[end:], "<f4").reshape(2, 3), img)
+    # the TIFF fixture, field by field
+    t = open(os.path.join(gold, "image_3x2.tif"), "rb").read()
+    assert t[:8] == b"II*\x00\x08\x00\x00\x00" and struct.unpack_from("<H", t, 8)[0] == 10
+    tags = {}
+    for i in range(10):
+        tag, typ, cnt = struct.unpack_from("<HHI", t, 10 + 12 * i)
+        tags[tag] = struct.unpack_from("<I" if typ == 4 else "<H", t, 10 + 12 * i + 8)[0]
+    assert tags == {256: 3, 257: 2, 258: 32, 259: 1, 262: 1, 273: 134, 277: 1, 278: 2, 279: 24, 339: 3}
+    assert np.array_equal(np.frombuffer(t[134:], "<f4").reshape(2, 3), img)
+
+
+def test_edf_reader_accepts_foreign_headers(tmp_path):
+    """openImage on an EDF the way other ESRF tools write it: more keys, other order, big-endian doubles."""
+    from paresis_amd.InputOutput.pagailleIO import openImage
+    img = (np.arange(12).reshape(3, 4) / 7).astype(">f8")
+    hdr = "{\nEDF_DataBlockID = 0.Image.Psd ;\nEDF_BinarySize = 96 ;\nEDF_HeaderSize = 1024 ;\nByteOrder = HighByteFirst ;\n" \
+          "DataType = DoubleValue ;\nDim_1 = 4 ;\nDim_2 = 3 ;\nImage = 0 ;\nHeaderID = EH:000000:000000:000000 ;\nSize = 96 ;\n"
+    hdr = hdr + " " * (1024 - len(hdr) - 2) + "}\n"
+    f = str(tmp_path / "foreign.edf")
+    open(f, "wb").write(hdr.encode("ascii") + img.tobytes())
+    assert np.allclose(openImage(f), img.astype(np.float64))
