@@ -119,6 +119,13 @@ int psx_refract_multi_f32(const float *I_in, float I0, const float *const *T, co
                           float *Dx_out, float *Dy_out, float *I_mut, int Nx, int Ny, int margin, const double *dscale,
                           int ndist, double clamp_x, double clamp_y, unsigned *status, void *workspace, void *stream);
 
+/* Deterministic-order debug mode (the reference's scatter is a single-threaded raster loop, RF2:217-263;
+ * here far rays and psx_fastloop_f32 deposit with global float atomics in arbitrary order).  With on != 0 those deposits go
+ * as 64-bit fixed-point integers into a scratch accumulator image (order-independent sums) and reach the float image with
+ * one add per pixel: two runs of the same call are then bitwise equal.  Costs a hipMalloc, a stream synchronisation and two
+ * extra passes per call -- a debugging aid, off by default.  A setting of the calling host thread. */
+int psx_set_deterministic(int on);
+
 /* The raw scatter loop on explicit displacement fields: fastloopNumba (refractionFileNumba2.py:198-263).
  * I, Dx, Dy, I2 are [Nx][Ny]; I2 is accumulated into (float atomics; order-dependent in the last bits). */
 int psx_fastloop_f32(const float *I, const float *Dx, const float *Dy, float *I2, int Nx, int Ny, void *stream);

@@ -39,6 +39,7 @@ PROTOTYPES = {
     "psx_accumulate_sum_f32": (c_int, [_vp, _vp, c_float, _vpp, _dp, c_int, c_int, c_int64, _vp, c_double, _vp]),
     "psx_refract_workspace_bytes": (c_size_t, [c_int, c_int]),
     "psx_refract_set_halo": (c_int, [c_int]),
+    "psx_set_deterministic": (c_int, [c_int]),
     "psx_refract_f32": (c_int, [_vp, c_float, _vpp, _dp, _dp, c_int, _vp, _vp, c_float, c_int, _vp, _vp, _vp, c_int,
                                 c_int, c_int, c_double, c_double, c_double, _vp, _vp, _vp]),
     "psx_refract_multi_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -414,8 +414,45 @@ __global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // Replay of the far rays with the reference's literal border rules (RF2:235-262) in padded coordinates.
 // One WAVE per list (list = distance * ntiles + tile): a list holds a few dozen records and the kernel is a chain of
 // dependent latencies (count -> records -> atomics), so it wants as many lists in flight per CU as there are wave slots.
+// Deterministic-order debug mode (psx_set_deterministic; SURVEY.md section 5, "race detection"): the reference deposits in
+// raster order, float atomics deposit in whatever order the waves arrive.  In this mode every far-ray deposit goes, as a
+// 64-bit fixed-point integer, into an accumulator image of its own -- integer sums do not depend on the order -- and one add
+// per pixel brings the total into the float image afterwards: two runs are bitwise equal.  The unit is 2^-38 of the power of
+// two above the largest |intensity| on the lists (a max-reduction, itself order-independent).
+struct DetAcc {
+    long long *acc;          // [ndist][Nx*Ny], zeroed
+    const unsigned *mx;      // float bits of the largest |out_scale * I| among the far rays
+};
+
+__device__ __forceinline__ double det_scale(const unsigned *mx) {
+    int ex;
+    frexpf(__uint_as_float(*mx), &ex);
+    return ldexp(1.0, 38 - ex);
+}
+
 template <class G>
-__global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a) {
+__global__ __launch_bounds__(FAR_THREADS) void k_far_max(RefractArgs a, unsigned *mx) {
+    constexpr int TH = G::TH, TW = G::TW;
+    const unsigned nlists = (unsigned)(a.tiles_x * a.tiles_y) * (unsigned)a.ndist;
+    const unsigned lst = blockIdx.x * (FAR_THREADS / 64) + (threadIdx.x >> 6);
+    if (lst >= nlists) return;
+    const unsigned n = a.far_count[lst];
+    const FarRay *list = a.far_list + (size_t)lst * (TH * TW);
+    float m = 0.f;
+    for (unsigned e = threadIdx.x & 63; e < n; e += 64) m = fmaxf(m, fabsf(a.out_scale * list[e].I));
+    if (m > 0.f && m <= 3.0e38f) atomicMax(mx, __float_as_uint(m));     // non-negative floats order like their bits
+}
+
+__global__ __launch_bounds__(256) void k_det_apply(float *out, const long long *acc, const unsigned *mx, int64_t n) {
+    const double inv = 1.0 / det_scale(mx);
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const long long q = acc[p];
+        if (q != 0) out[p] += (float)((double)q * inv);
+    }
+}
+
+template <class G, bool DET = false>
+__global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a, DetAcc det) {
     constexpr int TH = G::TH, TW = G::TW, H = G::H;
     const unsigned nlists = (unsigned)(a.tiles_x * a.tiles_y) * (unsigned)a.ndist;
     const unsigned lst = blockIdx.x * (FAR_THREADS / 64) + (threadIdx.x >> 6);
@@ -423,7 +460,10 @@ __global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a) {
     const unsigned n = a.far_count[lst];
     if (n == 0) return;
     const FarRay *list = a.far_list + (size_t)lst * (TH * TW);
-    float *const I_out = a.I_out[lst / (unsigned)(a.tiles_x * a.tiles_y)];
+    const unsigned dist = lst / (unsigned)(a.tiles_x * a.tiles_y);
+    float *const I_out = a.I_out[dist];
+    const double dscale_fix = DET ? det_scale(det.mx) : 0.0;
+    (void)dist; (void)dscale_fix;
     const int Px = a.Nx + 2 * a.margin, Py = a.Ny + 2 * a.margin;
     for (unsigned e = threadIdx.x & 63; e < n; e += 64) {
         const FarRay fr = list[e];
@@ -442,7 +482,13 @@ __global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a) {
                 if (i >= r0 - H && i < r0 + TH + H && j >= c0 - H && j < c0 + TW + H) return;
                 const float add = a.out_scale * v;
                 if (a.status && !(fabsf(add) <= 3.0e38f)) atomicOr(a.status, PSX_STATUS_NONFINITE);
-                atomicAdd(&I_out[(int64_t)ui * a.Ny + uj], add);
+                if constexpr (DET) {
+                    if (fabsf(add) <= 3.0e38f)
+                        atomicAdd(reinterpret_cast<unsigned long long *>(det.acc + (size_t)dist * a.Nx * a.Ny + (int64_t)ui * a.Ny + uj),
+                                  (unsigned long long)llrint((double)add * dscale_fix));
+                } else {
+                    atomicAdd(&I_out[(int64_t)ui * a.Ny + uj], add);
+                }
             }
         };
         deposit(bi, bj, I * wbi * wbj);
@@ -453,10 +499,32 @@ __global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a) {
     }
 }
 
-// fastloopNumba on explicit displacement maps: literal branch structure, global float atomics.
+__global__ __launch_bounds__(256) void k_absmax(const float *__restrict__ v, int64_t n, unsigned *mx) {
+    float m = 0.f;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const float x = fabsf(v[p]);
+        if (x <= 3.0e38f) m = fmaxf(m, x);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(mx, __float_as_uint(m));
+}
+
+// fastloopNumba on explicit displacement maps: literal branch structure, global float atomics (DET: 64-bit fixed-point
+// deposits into `det.acc`, see the deterministic mode above).
+template <bool DET>
 __global__ __launch_bounds__(256) void k_fastloop(const float *__restrict__ I, const float *__restrict__ Dx,
-                                                       const float *__restrict__ Dy, float *I2, int Nx, int Ny) {
+                                                       const float *__restrict__ Dy, float *I2, int Nx, int Ny, DetAcc det) {
     const int64_t n = (int64_t)Nx * Ny;
+    const double fix = DET ? det_scale(det.mx) : 0.0;
+    auto atomicAdd = [&](float *addr, float v) {       // shadows the builtin inside this kernel
+        if constexpr (DET) {
+            if (fabsf(v) <= 3.0e38f)
+                ::atomicAdd(reinterpret_cast<unsigned long long *>(det.acc + (addr - I2)), (unsigned long long)llrint((double)v * fix));
+        } else {
+            ::atomicAdd(addr, v);
+        }
+    };
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(p / Ny), j = (int)(p - (int64_t)i * Ny);
         const float Iij = I[p];
@@ -482,6 +550,26 @@ __global__ __launch_bounds__(256) void k_fastloop(const float *__restrict__ I, c
 // 8 pixels inside the LDS gather; the far replay (scattered global float atomics, ~0.1 TB/s) is what it avoids.
 // Per HOST THREAD (the ABI's thread model is one host thread per GPU): a second thread driving another GPU keeps its own.
 thread_local int g_refract_geometry = 0;   // 0: GeoSmall (H=4), 1: GeoWide (H=8), 2: GeoMid (H=6)
+thread_local int g_deterministic = 0;      // psx_set_deterministic
+
+// scratch of the deterministic mode: accumulators + the max word, owned for the duration of one call (debug mode: a plain
+// hipMalloc / synchronise / hipFree per call is acceptable there)
+struct DetScratch {
+    long long *acc = nullptr;
+    unsigned *mx = nullptr;
+    int alloc(size_t npix, hipStream_t st) {
+        PSX_HIP(hipMalloc((void **)&acc, sizeof(long long) * npix + 16));
+        mx = reinterpret_cast<unsigned *>(acc + npix);
+        PSX_HIP(hipMemsetAsync(acc, 0, sizeof(long long) * npix + 16, st));
+        return 0;
+    }
+    int release(hipStream_t st) {
+        PSX_HIP(hipStreamSynchronize(st));
+        PSX_HIP(hipFree(acc));
+        acc = nullptr;
+        return 0;
+    }
+};
 
 template <class G>
 size_t workspace_for(int Nx, int Ny, int ndist) {
@@ -508,8 +596,20 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
                   k_refract_near<G, NM, HI, HP><<<a.tiles_x * a.tiles_y, G::NT, G::LDS, st>>>(a));
         if (int rc = launch_check("k_refract_near")) return rc;
         const int nlists = a.tiles_x * a.tiles_y * a.ndist;
-        PSX_TIMED("k_refract_far", st,
-                  k_refract_far<G><<<(nlists + FAR_THREADS / 64 - 1) / (FAR_THREADS / 64), FAR_THREADS, 0, st>>>(a));
+        const int fgrid = (nlists + FAR_THREADS / 64 - 1) / (FAR_THREADS / 64);
+        if (g_deterministic) {
+            const size_t npix = (size_t)a.Nx * a.Ny;
+            DetScratch ds;
+            if (int rc = ds.alloc(npix * a.ndist, st)) return rc;
+            const DetAcc det{ds.acc, ds.mx};
+            PSX_TIMED("k_far_max", st, k_far_max<G><<<fgrid, FAR_THREADS, 0, st>>>(a, ds.mx));
+            PSX_TIMED("k_refract_far", st, k_refract_far<G, true><<<fgrid, FAR_THREADS, 0, st>>>(a, det));
+            for (int d = 0; d < a.ndist; ++d)
+                PSX_TIMED("k_det_apply", st, k_det_apply<<<ew_grid((int64_t)npix, 256), 256, 0, st>>>(a.I_out[d], ds.acc + npix * d, ds.mx, (int64_t)npix));
+            if (int rc = launch_check("deterministic far replay")) return rc;
+            return ds.release(st);
+        }
+        PSX_TIMED("k_refract_far", st, k_refract_far<G><<<fgrid, FAR_THREADS, 0, st>>>(a, DetAcc{nullptr, nullptr}));
         return 0;
     };
     PSX_DISPATCH_NMAT(nmat, {
@@ -591,8 +691,24 @@ int psx_refract_f32(const float *I_in, float I0, const float *const *T, const do
 
 int psx_fastloop_f32(const float *I, const float *Dx, const float *Dy, float *I2, int Nx, int Ny, void *stream) {
     PSX_REQUIRE(I && Dx && Dy && I2 && Nx > 0 && Ny > 0, "psx_fastloop_f32: null pointer or empty grid");
-    PSX_TIMED("k_fastloop", (hipStream_t)stream, k_fastloop<<<ew_grid((int64_t)Nx * Ny, 256), 256, 0, (hipStream_t)stream>>>(I, Dx, Dy, I2, Nx, Ny));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)Nx * Ny;
+    if (g_deterministic) {
+        DetScratch ds;
+        if (int rc = ds.alloc((size_t)n, st)) return rc;
+        PSX_TIMED("k_absmax", st, k_absmax<<<ew_grid(n, 256), 256, 0, st>>>(I, n, ds.mx));
+        PSX_TIMED("k_fastloop", st, k_fastloop<true><<<ew_grid(n, 256), 256, 0, st>>>(I, Dx, Dy, I2, Nx, Ny, DetAcc{ds.acc, ds.mx}));
+        PSX_TIMED("k_det_apply", st, k_det_apply<<<ew_grid(n, 256), 256, 0, st>>>(I2, ds.acc, ds.mx, n));
+        if (int rc = launch_check("k_fastloop (deterministic)")) return rc;
+        return ds.release(st);
+    }
+    PSX_TIMED("k_fastloop", st, k_fastloop<false><<<ew_grid(n, 256), 256, 0, st>>>(I, Dx, Dy, I2, Nx, Ny, DetAcc{nullptr, nullptr}));
     return launch_check("k_fastloop");
+}
+
+int psx_set_deterministic(int on) {
+    g_deterministic = on ? 1 : 0;
+    return 0;
 }
 
 }  // extern "C"

@@ -288,6 +288,12 @@ def darkfield_blur(I2DF, DF, I2, R):
     return out
 
 
+def set_deterministic(on=True):
+    """Deterministic-order debug mode of the scatter paths that use float atomics (far rays, fastloop): order-independent
+    fixed-point deposits, bitwise reproducible results, slower.  Per host thread; off by default."""
+    check(lib().psx_set_deterministic(1 if on else 0), "psx_set_deterministic")
+
+
 def fastloop(I, Dx, Dy, I2):
     """fastloopNumba (refractionFileNumba2.py:198-263) on explicit float32 displacement maps; accumulates into I2."""
     _need(I, torch.float32, "I")

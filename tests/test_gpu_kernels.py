@@ -382,3 +382,46 @@ def test_bad_arguments_raise(ops):
         ops.FresnelPlan(8, 8, margin=15)                                           # reflect margin larger than grid
     with pytest.raises(PsxError):
         ops.refract((2, 2), None, 1.0, (2, 2), phi_in=torch.zeros((2, 2), dtype=torch.float64, device="cuda"))
+
+
+def test_deterministic_order_mode(ops):
+    """psx_set_deterministic: the scatter paths that use float atomics -- the far-ray replay and
+    psx_fastloop_f32 -- deposit through order-independent fixed-point accumulators; two runs are bitwise equal, the result
+    stays within the oracle tolerance and within float rounding of the default mode."""
+    rng = np.random.default_rng(11)
+    Nx, Ny = 300, 260
+    I = rng.uniform(1, 2, (Nx, Ny))
+    phi = np.cumsum(rng.uniform(-30, 30, (Nx, Ny)), axis=0) + np.cumsum(rng.uniform(-30, 30, (Nx, Ny)), axis=1)
+    I32 = I.astype(np.float32).astype(np.float64)
+    ref, Dxr, _ = orc.fast_refraction(I32.copy(), phi.copy(), 1.0, 52.0, 1.0, 1.0)
+    assert np.abs(Dxr).max() > 20                                   # nearly every ray is a far ray
+    dscale = 1.0 / orc.k_refraction(52.0) / (1e-6 * 1.0) / 1e-6
+    It, pt = dev(I32, torch.float32), dev(phi, torch.float64)
+    run = lambda: ops.refract((Nx, Ny), None, dscale, (Nx, Ny), I_in=It, phi_in=pt)[0]
+    plain = run()
+    g = load("refraction.npz")
+    loop_in = [dev(g["loop/" + k], torch.float32) for k in ("I", "Dx", "Dy")]
+    # a larger scatter with many collisions per target for the raw loop
+    Il = torch.rand((512, 384), device="cuda") + 0.5
+    Dxl = (torch.rand((512, 384), device="cuda") - 0.5) * 40
+    Dyl = (torch.rand((512, 384), device="cuda") - 0.5) * 40
+    try:
+        ops.set_deterministic(True)
+        a, b = run(), run()
+        assert torch.equal(a, b)
+        assert relmax(a.cpu().numpy(), ref) < TOL
+        assert float((a - plain).abs().max() / plain.abs().max()) < 2e-6
+        outs = []
+        for _ in range(2):
+            I2 = torch.zeros_like(Il)
+            ops.fastloop(Il, Dxl, Dyl, I2)
+            outs.append(I2)
+        assert torch.equal(outs[0], outs[1])
+        I2 = torch.zeros(g["loop/I"].shape, dtype=torch.float32, device="cuda")
+        ops.fastloop(*loop_in, I2)
+        assert relmax(I2.cpu().numpy(), g["loop/out"]) < TOL
+    finally:
+        ops.set_deterministic(False)
+    I2 = torch.zeros_like(Il)
+    ops.fastloop(Il, Dxl, Dyl, I2)
+    assert float((I2 - outs[0]).abs().max() / outs[0].abs().max()) < 2e-6

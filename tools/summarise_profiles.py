@@ -2,14 +2,15 @@
 """Turns the rocprofv3 outputs under gpurun_out/fin_{stats,fetch,write,sq}/ into the committed summaries in profiles/."""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+sfx = sys.argv[2] if len(sys.argv) > 2 else ""          # "_16384": the run collected with tools/collect_profiles.sh _16384 ...
 os.makedirs("profiles", exist_ok=True)
 newest = lambda pat: sorted(glob.glob(pat) + glob.glob(pat.replace("/runc/*", "/runc_")), key=os.path.getmtime)[-1]
-shutil.copy(newest("gpurun_out/fin_stats/runc/*kernel_stats.csv"), "profiles/%s_kernel_stats.csv" % tag)
+shutil.copy(newest("gpurun_out/fin_stats%s/runc/*kernel_stats.csv" % sfx), "profiles/%s_kernel_stats%s.csv" % (tag, sfx))
 
 
 def agg(d):
-    rows = list(csv.DictReader(open(newest("gpurun_out/%s/runc/*counter_collection.csv" % d))))
+    rows = list(csv.DictReader(open(newest("gpurun_out/%s%s/runc/*counter_collection.csv" % (d, sfx)))))
     out = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
         name = r["Kernel_Name"]
@@ -35,9 +36,9 @@ for k in sorted(set(fetch) | set(write) | set(sq)):
     e.update(sq.get(k, {}))
     summary[k] = e
 json.dump({"note": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ counters each in its own run) of "
-                   "`python3 bench.py --no-cpu-baseline` (the default run: 5 warm-up + 50 timed steps + the 50-step per-kernel event pass) on one MI355X; averages per "
+                   "`python3 bench.py --no-cpu-baseline --positions 0%s` (warm-up + timed steps + the per-kernel event pass) on one MI355X; averages per " % (" (" + sfx.strip("_") + "^2 grid)" if sfx else "") +
                    "launch.  hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE reads half of a wide "
                    "coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section), WRITE_SIZE is exact.",
-           "kernels": summary}, open("profiles/%s_pmc_summary.json" % tag, "w"), indent=1)
+           "kernels": summary}, open("profiles/%s_pmc_summary%s.json" % (tag, sfx), "w"), indent=1)
 for k, e in summary.items():
     print(k, {a: ("%.4g" % b if isinstance(b, float) else b) for a, b in e.items()})
