@@ -79,6 +79,7 @@ struct LineArgs {
     // (complex, same layout as the complex output; it IS the complex output when that is wanted).  H[d] then holds S spectra.
     int B, Lh, S, NB;
     float2 *part[PSX_MAX_DIST];
+    const float2 *w2;       // PAIR: w_2M^{k0} of each 16-point slab, k0 = q1 + 24 q2  (576 entries)
     unsigned long long *stamps;   // optional diagnostics: 32 phase timestamps per workgroup (psx_debug_stamps)
 };
 
@@ -113,9 +114,16 @@ __device__ __forceinline__ void lds_barrier() {
 
 // CONTIG: the samples of a line are adjacent in memory (in_si == 1) -- the lanes of a loader wave then walk along the line;
 // otherwise they walk across the LINES lines of the group (adjacent columns of a row-major image).
-template <int R3, bool CONTIG, bool PART = false>
+// PAIR (partitioned convolution only): the two LDS lines of a round hold the EVEN and the ODD samples of ONE sequence of
+// 2M = 18432 points, and the middle stage couples them with the radix-2 butterfly of a 2M-point transform
+//     X[k] = E[k] + w^k O[k],  X[k+M] = E[k] - w^k O[k]   ...x H...   E'[k] = Y[k] + Y[k+M],  O'[k] = (Y[k] - Y[k+M]) w^-k
+// (E, O = the two M-point spectra the engine computes anyway; w = exp(-2 pi i / 2M)).  One round is then ONE block x segment
+// product of twice the size: a 16384-sample line needs 2 x 2 of them instead of 5 x 3 M-point products for two lines.
+template <int R3, bool CONTIG, bool PART = false, bool PAIR = false>
 __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     constexpr int M = 576 * R3, LINES = TOT / M, S1 = M / RAD, MP = M + M / 32;
+    constexpr int LPG = PAIR ? 1 : LINES;               // image lines per round
+    static_assert(!PAIR || (PART && R3 == 16 && LINES == 2), "PAIR couples the two lines of the R3 = 16 partitioned engine");
     constexpr int SLAB = 16, NSLABS = TOT / SLAB;       // 16 contiguous points per slab in the middle stage
     constexpr int WSLABS = 64 * RAD / SLAB;              // slabs inside the 1536 points one wave owns between barriers
     constexpr int NSLAB = (WSLABS + 63) / 64;            // slab rounds per lane (the last one is partly idle)
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 
     // ---- line groups of this workgroup: XCD x = blockIdx % 8 owns a contiguous chunk of groups (its 32 CUs then read
     // neighbouring columns at the same time: the 128-byte lines of the strided source are shared in that XCD's L2)
-    const int ngroups = (a.nlines + LINES - 1) / LINES;
+    const int ngroups = (a.nlines + LPG - 1) / LPG;
     const int nwork = PART ? ngroups * a.n_dist * a.NB : (a.dist_inner ? ngroups : ngroups * a.n_dist);   // all distances of a call in ONE launch
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     const int cq = nwork >> 3, cr = nwork & 7;
@@ -187,6 +195,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         return AFF ? phys(p0) + j * R3 + ((j * R3) >> 5) : phys(p0 + j * R3);
     };
 
+
     if (tid >= TC) {
         if constexpr (PART) {
             // =========================== loader waves, partitioned convolution ============================================
@@ -207,18 +216,21 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             auto fetch_half = [&](int j, int h) __attribute__((always_inline)) {
                 int d, g;
                 item(j, d, g);
-                const int l = g * LINES + line;
+                const int l = PAIR ? g : g * LINES + line;
                 const int lc = min(l, a.nlines - 1);          // addresses stay inside the image for the idle lines of the last group
                 // PART sources are the blocked intermediate or contiguous lines (in_si == 1): 32-bit element offsets from the line's base
                 const float2 *srcl = a.src[d] + (a.in_blocked ? ((int64_t)(lc / IB) * N) * IB + lc % IB : (int64_t)lc * a.in_sl);
                 const int istep = a.in_blocked ? IB : 1;
                 const int a0 = pb * a.B + P - (ps + 1) * a.Lh;
                 const unsigned tlim = l < a.nlines ? (unsigned)Lw : 0u;
+                int tb = PAIR ? 2 * i0 + line : i0;          // window position of this thread's first sample; opaque, so that the
+                asm volatile("" : "+v"(tb));                 // 72 positions are formed here and not kept across the rounds
                 vm0 = 0u;
                 vm1 = 0u;
 #pragma unroll
                 for (int k = 0; k < NH; ++k) {
-                    const int t = i0 + STEP * (k + NH * h);
+                    // PAIR: LDS line `line` holds the samples of parity `line`, LDS index = window position / 2
+                    const int t = tb + (PAIR ? 2 : 1) * STEP * (k + NH * h);
                     const int te = a0 + t;
                     const bool ok = (unsigned)t < tlim && (unsigned)te < (unsigned)Etot;
                     int jp = te - (P - 1) + mg;                  // index into the padded line, one period either side
@@ -372,8 +384,23 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     // =================================== engine waves =========================================================================
     // stage A and B thread mapping (one butterfly per thread per stage)
     const int lineA = tid / S1, nA = tid % S1;
-    const int remB = tid % S1, q1B = remB / R3, nB = remB % R3, p0B = q1B * S1 + nB;
+    // stage B: thread -> (line, block q1 of S1 points, element n < R3).  PAIR: a wave takes blocks {2w, 2w+1} of BOTH lines
+    // (lanes 0-31 line 0, 32-63 line 1), so that the points it owns between the barriers are the same range of the two lines
+    // the middle stage couples
+    // (the PAIR values are re-derived inside the round loop from an opaque copy of the thread index: hoisted out of it
+    // they would stay live through inverse stage A, which has no register to spare)
+    const int remB = tid % S1, q1B = remB / R3, nB = PAIR ? (tid & 15) : remB % R3, p0B = q1B * S1 + nB;
     v2f *baseA = reinterpret_cast<v2f *>(lds) + lineA * MP;
+    auto stageB_at = [&](v2f *&bB, int &pB) __attribute__((always_inline)) {
+        bB = baseA;
+        pB = p0B;
+        if constexpr (PAIR) {
+            int to = tid;
+            asm volatile("" : "+v"(to));
+            bB = reinterpret_cast<v2f *>(lds) + ((to & 63) >> 5) * MP;
+            pB = (2 * (to >> 6) + ((to & 31) >> 4)) * S1 + (to & 15);
+        }
+    };
     // middle stage: slab of this lane inside the wave's own 96 (round 2: 32 lanes).  Within each half-wave the first 16
     // lanes take the even slabs and the last 16 the odd ones: the 16 lanes of a ds_write_b64 group then carry 16
     // different pad offsets (one pad slot per TWO slabs) and hit 16 different bank pairs instead of 8.
@@ -405,7 +432,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     for (int j = 0; j < nj; ++j) {
         int d, g;
         item(j, d, g);
-        const int l0 = g * LINES;
+        const int l0 = g * LPG;
         PSX_STAMP(2);
 
         // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}
@@ -423,7 +450,21 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         // The kernel spectrum (the engine's only global loads) travels one step ahead of its use: the first slab's 128
         // bytes are requested here, before barrier (1); the second slab's right after the first one's multiply.
         float4 hh[SLAB / 2];
-        {
+        // PAIR: lane u < 48 of wave w couples slab 48 w + u of line 0 with the same slab of line 1; its table is the interleaved
+        // pair (H[k], H[k + M]) per point: 4 points = 4 float4 per chunk; the first chunk travels here, the others under the
+        // arithmetic of the chunk before (a slab pair already holds 64 registers of data)
+        int tp = tid;
+        if constexpr (PAIR) asm volatile("" : "+v"(tp));
+        const int pslab = 48 * (tp >> 6) + (tp & 63);                         // slab index inside a line (PAIR)
+        const bool pact = (tp & 63) < 48;
+        const float4 *hp4 = reinterpret_cast<const float4 *>(a.H[d] + (size_t)(PART ? ps : 0) * 2 * M) + (size_t)(pact ? pslab : 0) * SLAB;
+        v2f w0p = (v2f){1.f, 0.f};
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hh[q] = hp4[q];
+            const float2 w = a.w2[pact ? pslab : 0];
+            w0p = (v2f){w.x, w.y};
+        } else {
             const float4 *h4 = reinterpret_cast<const float4 *>(a.H[d] + (PART ? ps * M : 0) + (slab0 % (M / SLAB)) * SLAB);
 #pragma unroll
             for (int q = 0; q < SLAB / 2; ++q) hh[q] = h4[q];
@@ -434,8 +475,11 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         // ---- 3. forward stage B: radix 24 inside each block of S1, stride R3, twiddle w_S1^{n q}
         {
             v2f v[RAD];
+            v2f *bB;
+            int pB;
+            stageB_at(bB, pB);
 #pragma unroll
-            for (int q = 0; q < RAD; ++q) v[q] = lds_read(baseA + idxB(p0B, q));
+            for (int q = 0; q < RAD; ++q) v[q] = lds_read(bB + idxB(pB, q));
             DftPk<RAD, false>::run(v);
             __builtin_amdgcn_sched_barrier(0);
             // twiddles in two halves: the kernel spectrum of the first slab (hh0, 32 registers) is in flight here
@@ -448,7 +492,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 for (int q = (h == 0 ? 1 : 0); q < RAD / 2; ++q) v[h * (RAD / 2) + q] = pk_cmul(v[h * (RAD / 2) + q], w[q]);
             }
 #pragma unroll
-            for (int q = 0; q < RAD; ++q) baseA[idxB(p0B, q)] = v[q];
+            for (int q = 0; q < RAD; ++q) bB[idxB(pB, q)] = v[q];
         }
         PSX_STAMP(5);
         // From here to the end of inverse stage B every wave works on LDS points that only IT touches: its 64
@@ -461,6 +505,44 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 
         // ---- 4+5. middle stage, slab by slab: forward radix R3 on contiguous chunks, x FFT_M(h_d), inverse radix R3,
         // back to LDS.  Each thread rewrites exactly the slabs it read.
+        if constexpr (PAIR) {
+            if (pact) {
+                v2f *b0 = reinterpret_cast<v2f *>(lds) + phys(pslab * SLAB), *b1 = b0 + MP;
+                v2f f0[SLAB], f1[SLAB];
+#pragma unroll
+                for (int q = 0; q < SLAB; ++q) f0[q] = lds_read(b0 + q);
+#pragma unroll
+                for (int q = 0; q < SLAB; ++q) f1[q] = lds_read(b1 + q);
+                DftPk<SLAB, false>::run(f0);
+                DftPk<SLAB, false>::run(f1);
+                // radix-2 of the 2M-point transform around the product with the kernel spectrum, 4 points per table chunk: chunk
+                // c + 1 is requested (into the other half of hh) before chunk c is used
+                pk_static_for<0, 4>([&](auto cc) __attribute__((always_inline)) {
+                    constexpr int c = decltype(cc)::value;
+                    if constexpr (c < 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) hh[4 * ((c + 1) & 1) + q] = hp4[4 * (c + 1) + q];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    pk_static_for<0, 4>([&](auto qc) __attribute__((always_inline)) {
+                        constexpr int qq = decltype(qc)::value, q = 4 * c + qq, hq = 4 * (c & 1) + qq;
+                        const v2f wq = pk_twiddle<32, q, false>(w0p);       // w^k = w^{k0} exp(-2 pi i q3 / 32), q3 = q
+                        const v2f t = pk_cmul(f1[q], wq);
+                        const v2f x0 = f0[q] + t, x1 = f0[q] - t;
+                        const v2f y0 = pk_cmul(x0, (v2f){hh[hq].x, hh[hq].y}), y1 = pk_cmul(x1, (v2f){hh[hq].z, hh[hq].w});
+                        f0[q] = y0 + y1;
+                        f1[q] = pk_cmulc(y0 - y1, wq);
+                    });
+                });
+                DftPk<SLAB, true>::run(f0);
+#pragma unroll
+                for (int q = 0; q < SLAB; ++q) b0[q] = f0[q];
+                DftPk<SLAB, true>::run(f1);
+#pragma unroll
+                for (int q = 0; q < SLAB; ++q) b1[q] = f1[q];
+            }
+        } else {
         const float2 *Hd = a.H[d] + (PART ? ps * M : 0);
 #pragma unroll
         for (int r = 0; r < NSLAB; ++r) {
@@ -501,6 +583,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 for (int q = 0; q < R3; ++q) base[c * R3 + q] = w[q];
             }
         }
+        }   // !PAIR
         PSX_STAMP(7);
         wave_sync();
         PSX_STAMP(8);
@@ -508,8 +591,11 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         // ---- 6. inverse stage B: conjugate twiddle on the inputs, then the inverse radix-24 butterfly
         {
             v2f v[RAD], w[RAD];
+            v2f *bB;
+            int pB;
+            stageB_at(bB, pB);
 #pragma unroll
-            for (int q = 0; q < RAD; ++q) v[q] = lds_read(baseA + idxB(p0B, q));
+            for (int q = 0; q < RAD; ++q) v[q] = lds_read(bB + idxB(pB, q));
 #pragma unroll
             for (int q = 1; q < RAD; ++q) w[q] = lds_read(rowB + q);
 #pragma unroll
@@ -517,7 +603,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             DftPk<RAD, true>::run(v);
 #pragma unroll
-            for (int q = 0; q < RAD; ++q) baseA[idxB(p0B, q)] = v[q];
+            for (int q = 0; q < RAD; ++q) bB[idxB(pB, q)] = v[q];
         }
         PSX_STAMP(9);
         lds_barrier();                               // (2)
@@ -538,7 +624,8 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             // output sample i = nA + q*S1 - jout (jout = LDS position of output sample 0).  The first index is made opaque
             // so that the 48 per-q addresses are formed here from ONE pointer, not hoisted out of the group loop (they
             // would occupy 96 VGPRs there and spill).
-            int ifirst = nA - (PART ? a.Lh - 1 : N + 2 * mg - 1);      // PART: index inside the output block
+            // PART: index inside the output block; PAIR: LDS line = parity of the position in the 2M-point result
+            int ifirst = (PAIR ? 2 * nA + lineA : nA) - (PART ? a.Lh - 1 : N + 2 * mg - 1);
             asm volatile("" : "+v"(ifirst));
             v2f *wo = reinterpret_cast<v2f *>(a.wave_out[d]);
             float *io = a.inten_out[d];
@@ -551,11 +638,12 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 // a huge offset, i >= N lies past the window).  No compare, no exec-mask bookkeeping per output -- the
                 // scalar unit is shared by the whole CU (0.9 instructions per cycle, tools/salu_bench.hip) and the masked
                 // form of this loop issued 500 scalar instructions per wave.
-                const int l = l0 + __builtin_amdgcn_readfirstlane(lineA);
+                const int l = l0 + (PAIR ? 0 : __builtin_amdgcn_readfirstlane(lineA));
                 const bool lok = l < a.nlines;
                 // element index of output i inside the window: plain rows: i (window = row l); blocked: ((i>>3)*nlines+l)*8 + i%8
                 const int e0 = a.out_blocked ? ((ifirst >> 3) * a.nlines + l) * IB + (ifirst & (IB - 1)) : ifirst;
-                const int estep = a.out_blocked ? (S1 / IB) * a.nlines * IB : S1;
+                constexpr int QS = PAIR ? 2 * S1 : S1;                    // output samples between two outputs of a butterfly
+                const int estep = a.out_blocked ? (QS / IB) * a.nlines * IB : QS;
                 // PART: the window is the output block only -- samples [b*B, b*B + Bv) of the line; in the blocked layout
                 // they are the contiguous range of B/8 sample-blocks (B is a multiple of 8)
                 const int nout = PART ? min(a.B, N - pb * a.B) : N;
@@ -796,6 +884,30 @@ __global__ void k_kern_perm(const double2 *__restrict__ Hh, float2 *__restrict__
     out[t] = make_float2((float)(v.x / M), (float)(v.y / M));
 }
 
+// PAIR: the spectrum of a segment has 2M points; position p of an LDS line meets the bins k(p) and k(p) + M
+__global__ void k_kern_perm_pair(const double2 *__restrict__ Hh, float4 *__restrict__ out, int M, int R3, int S) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * S) return;
+    const int sg = t / M, p = t - sg * M;
+    const int S1 = M / RAD;
+    const int q1 = p / S1, q2 = (p % S1) / R3, q3 = p % R3;
+    const int k = q1 + RAD * q2 + RAD * RAD * q3;
+    const double2 v0 = Hh[(size_t)sg * 2 * M + k], v1 = Hh[(size_t)sg * 2 * M + k + M];
+    const double sc = 1.0 / (2.0 * M);
+    out[t] = make_float4((float)(v0.x * sc), (float)(v0.y * sc), (float)(v1.x * sc), (float)(v1.y * sc));
+}
+
+// w2[slab] = exp(-2 pi i k0 / 2M) for the slab's first point, k0 = q1 + 24 q2, slab = q1 * (S1 / R3) + q2
+__global__ void k_pair_twiddles(float2 *w2, int M, int R3) {
+    const int sl = blockIdx.x * blockDim.x + threadIdx.x;
+    const int S1 = M / RAD, per = S1 / R3;
+    if (sl >= M / R3) return;
+    const int q1 = sl / per, q2 = sl % per;
+    double s, c;
+    sincospi(-(double)(q1 + RAD * q2) / (double)M, &s, &c);       // -2 pi k0 / (2M)
+    w2[sl] = make_float2((float)c, (float)s);
+}
+
 __global__ void k_stage_twiddles(float2 *twA, float2 *twB, int M, int R3) {
     const int S1 = M / RAD;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -825,12 +937,13 @@ int pick_r3(int N, int margin) {
 // Lines longer than that: partition outputs (blocks of B, a multiple of 8) and kernel taps (segments of Lh) so that one
 // block x segment product is an M-point convolution, B + Lh - 1 <= M; fewest products, then fewest segments.
 constexpr int PART_M = 576 * 16;
-void part_geometry(int N, int margin, int &B, int &Lh, int &S, int &NB) {
+// mconv: points of one product -- PART_M, or 2 * PART_M when the two LDS lines are coupled into one transform (PAIR)
+void part_geometry(int N, int margin, int &B, int &Lh, int &S, int &NB, int mconv = 2 * PART_M) {
     const int P = N + 2 * margin;
     long best = -1;
     for (int s = 1; s <= 64; ++s) {
         const int lh = (P + s - 1) / s;
-        const int bmax = (PART_M - lh + 1) / 8 * 8;
+        const int bmax = (mconv - lh + 1) / 8 * 8;
         if (bmax < 8) continue;
         const int nb = (N + bmax - 1) / bmax;
         const long cost = (long)s * nb;
@@ -849,6 +962,8 @@ namespace psx {
 struct AxisTables {
     int N = 0, R3 = 0, M = 0;
     int part = 0, B = 0, Lh = 0, S = 1, NB = 1;     // partitioned convolution (lines that do not fit one transform)
+    int pair = 0, Mconv = 0;                        // part: the two LDS lines coupled into one transform of Mconv = 2M points
+    float2 *w2 = nullptr;                           // pair: slab twiddles
     float2 *twA = nullptr, *twB = nullptr;
     // float64 transforms of the kernel-spectrum build: taps = IDFT_P(chirp), spectrum = FFT_M(zero-padded taps) x S segments
     rocfft_plan planP = nullptr, planM = nullptr;
@@ -889,7 +1004,7 @@ bool lds_engine_supported(int Nx, int Ny, int margin) {
     int64_t span = (int64_t)cdiv(Nx, IB) * IB;                       // samples of a pass-1 line inside one window
     if (!pick_r3(Nx, margin)) {
         int B, Lh, S, NB;
-        part_geometry(Nx, margin, B, Lh, S, NB);
+        part_geometry(Nx, margin, B, Lh, S, NB);      // the coupled-line partition (B is largest there)
         span = B;
     }
     return span * (int64_t)Ny * (int64_t)sizeof(float2) < (1ll << 31);
@@ -898,12 +1013,15 @@ bool lds_engine_supported(int Nx, int Ny, int margin) {
 static int make_axis(AxisTables &t, int N, int margin, size_t &bytes) {
     t.N = N;
     t.R3 = pick_r3(N, margin);
+    static const bool no_pair = getenv("PSX_NO_PAIR") != nullptr;     // diagnostics: the round-1 partition (M-point products)
     if (!t.R3) {
         t.R3 = 16;
         t.part = 1;
-        part_geometry(N, margin, t.B, t.Lh, t.S, t.NB);
+        t.pair = no_pair ? 0 : 1;
+        part_geometry(N, margin, t.B, t.Lh, t.S, t.NB, t.pair ? 2 * PART_M : PART_M);
     }
     t.M = 576 * t.R3;
+    t.Mconv = t.pair ? 2 * t.M : t.M;
     const int S1 = t.M / RAD;
     PSX_HIP(hipMalloc((void **)&t.twA, sizeof(float2) * RAD * S1));
     PSX_HIP(hipMalloc((void **)&t.twB, sizeof(float2) * RAD * t.R3));
@@ -912,7 +1030,13 @@ static int make_axis(AxisTables &t, int N, int margin, size_t &bytes) {
     if (int rc = launch_check("k_stage_twiddles")) return rc;
     // float64 transforms of the kernel-spectrum build
     if (int rc = rocfft_ensure_setup()) return rc;
-    const size_t P = (size_t)(N + 2 * margin), M = (size_t)t.M;
+    if (t.pair) {
+        PSX_HIP(hipMalloc((void **)&t.w2, sizeof(float2) * (t.M / t.R3)));
+        bytes += sizeof(float2) * (t.M / t.R3);
+        k_pair_twiddles<<<(int)cdiv(t.M / t.R3, 256), 256>>>(t.w2, t.M, t.R3);
+        if (int rc = launch_check("k_pair_twiddles")) return rc;
+    }
+    const size_t P = (size_t)(N + 2 * margin), M = (size_t)t.Mconv;
     PSX_ROCFFT(rocfft_plan_create(&t.planP, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
                                   rocfft_precision_double, 1, &P, 1, nullptr));
     PSX_ROCFFT(rocfft_plan_create(&t.planM, rocfft_placement_inplace, rocfft_transform_type_complex_forward,
@@ -964,6 +1088,7 @@ void lds_engine_destroy(psx_fresnel_plan *p) {
     for (auto &t : e->ax) {
         (void)hipFree(t.twA);
         (void)hipFree(t.twB);
+        (void)hipFree(t.w2);
         if (t.planP) rocfft_plan_destroy(t.planP);
         if (t.planM) rocfft_plan_destroy(t.planM);
         if (t.infoP) rocfft_execution_info_destroy(t.infoP);
@@ -987,7 +1112,7 @@ void lds_engine_destroy(psx_fresnel_plan *p) {
 // table alive until its readers are done; the one exception, evicting a table to reuse its memory, synchronises the stream.
 static int kernel_spectrum(psx_fresnel_plan *p, AxisTables &t, double a, double du, hipStream_t st, const float2 **out) {
     LdsEngine *e = p->lds;
-    const KernKey key(a, du, t.N, t.M);
+    const KernKey key(a, du, t.N, t.Mconv);
     auto it = e->cache.find(key);
     if (it != e->cache.end()) {
         it->second.stamp = ++e->clock;
@@ -998,14 +1123,14 @@ static int kernel_spectrum(psx_fresnel_plan *p, AxisTables &t, double a, double 
     if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
         return fail(PSX_E_STATE, "psx_fresnel_propagate: kernel spectrum (a=%g, du=%g) is not cached and cannot be built while "
                                  "the stream is being captured: run the call once outside the capture first", a, du);
-    KernEntry k{nullptr, t.M, t.S, ++e->clock};
-    const size_t bytes = sizeof(float2) * (size_t)t.M * t.S;
+    KernEntry k{nullptr, t.Mconv, t.S, ++e->clock};
+    const size_t bytes = sizeof(float2) * (size_t)t.Mconv * t.S;
     if (e->cache_bytes + bytes > CACHE_CAP_BYTES && !e->cache.empty()) {   // evict the least recently used table
         auto lru = e->cache.begin();
         for (auto jt = e->cache.begin(); jt != e->cache.end(); ++jt)
             if (jt->second.stamp < lru->second.stamp) lru = jt;
         PSX_HIP(hipStreamSynchronize(st));       // its last readers are done
-        if (lru->second.M == t.M && lru->second.S == t.S) {
+        if (lru->second.M == t.Mconv && lru->second.S == t.S) {
             k.H = lru->second.H;
         } else {
             (void)hipFree(lru->second.H);
@@ -1027,38 +1152,42 @@ static int kernel_spectrum(psx_fresnel_plan *p, AxisTables &t, double a, double 
         void *buf = t.bufP;
         PSX_ROCFFT(rocfft_execute(t.planP, &buf, nullptr, t.infoP));
     }
-    PSX_TIMED("k_kern_pad", st, k_kern_pad<<<(int)cdiv((int64_t)t.M * t.S, 256), 256, 0, st>>>(t.bufP, t.bufM, P, t.M, t.Lh, t.S, t.part));
+    PSX_TIMED("k_kern_pad", st, k_kern_pad<<<(int)cdiv((int64_t)t.Mconv * t.S, 256), 256, 0, st>>>(t.bufP, t.bufM, P, t.Mconv, t.Lh, t.S, t.part));
     {
         ProfScope ps("kern_fft_M", st);
         void *buf = t.bufM;
         PSX_ROCFFT(rocfft_execute(t.planM, &buf, nullptr, t.infoM));
     }
-    PSX_TIMED("k_kern_perm", st, k_kern_perm<<<(int)cdiv((int64_t)t.M * t.S, 256), 256, 0, st>>>(t.bufM, k.H, t.M, t.R3, t.S));
+    if (t.pair)
+        PSX_TIMED("k_kern_perm", st, k_kern_perm_pair<<<(int)cdiv((int64_t)t.M * t.S, 256), 256, 0, st>>>(t.bufM, reinterpret_cast<float4 *>(k.H), t.M, t.R3, t.S));
+    else
+        PSX_TIMED("k_kern_perm", st, k_kern_perm<<<(int)cdiv((int64_t)t.M * t.S, 256), 256, 0, st>>>(t.bufM, k.H, t.M, t.R3, t.S));
     if (int rc = launch_check("kernel spectrum")) return rc;
     e->cache.emplace(key, k);
     *out = k.H;
     return 0;
 }
 
-template <int R3, bool CONTIG, bool PART = false>
+template <int R3, bool CONTIG, bool PART = false, bool PAIR = false>
 static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
-    constexpr int M = 576 * R3, LINES = TOT / M;
-    constexpr size_t lds_bytes = sizeof(float2) * ((size_t)LINES * (M + M / 32) + (2 * R3 + RAD) * (RAD + 1));   // lines + the three twiddle tables
+    constexpr int M = 576 * R3, LINES = PAIR ? 1 : TOT / M;        // LINES here: image lines per round
+    constexpr size_t lds_bytes = sizeof(float2) * ((size_t)(TOT / M) * (M + M / 32) + (2 * R3 + RAD) * (RAD + 1));   // lines + the three twiddle tables
     static std::atomic<unsigned long long> attr_mask{0};
     if (first_on_device(attr_mask))
-        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG, PART>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG, PART, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_bytes));
     // persistent workgroups: one per CU (the LDS footprint allows no more), a multiple of the 8 XCDs
     const int n_cu = current_cu_count();
     const int nwork = ((la.nlines + LINES - 1) / LINES) * (PART ? la.n_dist * la.NB : (la.dist_inner ? 1 : la.n_dist));
     int nslot = n_cu / 8;
     if (nslot > (nwork + 7) / 8) nslot = (nwork + 7) / 8;
-    PSX_TIMED(name, st, k_fresnel_lines<R3, CONTIG, PART><<<8 * nslot, T, lds_bytes, st>>>(la));
+    PSX_TIMED(name, st, k_fresnel_lines<R3, CONTIG, PART, PAIR><<<8 * nslot, T, lds_bytes, st>>>(la));
     return launch_check(name);
 }
 
 template <bool CONTIG>
-static int launch_lines_r3(int R3, const LineArgs &la, hipStream_t st, const char *name, bool part = false) {
+static int launch_lines_r3(int R3, const LineArgs &la, hipStream_t st, const char *name, bool part = false, bool pair = false) {
+    if (part && pair) return launch_lines<16, CONTIG, true, true>(la, st, name);
     if (part) return launch_lines<16, CONTIG, true>(la, st, name);
     switch (R3) {
         case 2: return launch_lines<2, CONTIG>(la, st, name);
@@ -1127,7 +1256,8 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
             la.scale[i] = 1.f;
             la.gph[i] = make_float2(1.f, 0.f);
         }
-        if (int rc = launch_lines_r3<true>(e->ax[0].R3, la, st, "k_fresnel_cols", e->ax[0].part)) return rc;
+        la.w2 = e->ax[0].w2;
+        if (int rc = launch_lines_r3<true>(e->ax[0].R3, la, st, "k_fresnel_cols", e->ax[0].part, e->ax[0].pair)) return rc;
     }
 
     // ---- pass 2: lines along axis 1 of the image = columns of the intermediate (strided reads: the second transpose);
@@ -1156,7 +1286,8 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
             const double g = a.gphase ? a.gphase[d] : 0.0;
             lb.gph[i] = make_float2((float)std::cos(g), (float)std::sin(g));   // exact reduction of ~1e11 rad (EXP:250)
         }
-        if (int rc2 = launch_lines_r3<false>(e->ax[1].R3, lb, st, "k_fresnel_rows", e->ax[1].part)) return rc2;
+        lb.w2 = e->ax[1].w2;
+        if (int rc2 = launch_lines_r3<false>(e->ax[1].R3, lb, st, "k_fresnel_rows", e->ax[1].part, e->ax[1].pair)) return rc2;
     }
     return 0;
 }
