@@ -121,7 +121,9 @@ __device__ __forceinline__ void lds_barrier() {
 // product of twice the size: a 16384-sample line needs 2 x 2 of them instead of 5 x 3 M-point products for two lines.
 template <int R3, bool CONTIG, bool PART = false, bool PAIR = false>
 __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
-    constexpr int M = 576 * R3, LINES = TOT / M, S1 = M / RAD, MP = M + M / 32;
+    // PAIR: the second LDS line starts 16 points further, so that a point of line 0 and the same point of line 1 sit 32 banks
+    // apart: stage A then gives adjacent lanes the even and the odd sample of a pair without a bank conflict
+    constexpr int M = 576 * R3, LINES = TOT / M, S1 = M / RAD, MP = M + M / 32 + (PAIR ? 16 : 0);
     constexpr int LPG = PAIR ? 1 : LINES;               // image lines per round
     static_assert(!PAIR || (PART && R3 == 16 && LINES == 2), "PAIR couples the two lines of the R3 = 16 partitioned engine");
     constexpr int SLAB = 16, NSLABS = TOT / SLAB;       // 16 contiguous points per slab in the middle stage
@@ -383,7 +385,9 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 
     // =================================== engine waves =========================================================================
     // stage A and B thread mapping (one butterfly per thread per stage)
-    const int lineA = tid / S1, nA = tid % S1;
+    // PAIR: adjacent lanes take butterfly n of the even line and of the odd line -- their outputs are adjacent samples, so a
+    // wave's stores (and its partial-sum loads) cover whole cache lines
+    const int lineA = PAIR ? (tid & 1) : tid / S1, nA = PAIR ? (tid >> 1) : tid % S1;
     // stage B: thread -> (line, block q1 of S1 points, element n < R3).  PAIR: a wave takes blocks {2w, 2w+1} of BOTH lines
     // (lanes 0-31 line 0, 32-63 line 1), so that the points it owns between the barriers are the same range of the two lines
     // the middle stage couples
@@ -1171,7 +1175,7 @@ static int kernel_spectrum(psx_fresnel_plan *p, AxisTables &t, double a, double 
 template <int R3, bool CONTIG, bool PART = false, bool PAIR = false>
 static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
     constexpr int M = 576 * R3, LINES = PAIR ? 1 : TOT / M;        // LINES here: image lines per round
-    constexpr size_t lds_bytes = sizeof(float2) * ((size_t)(TOT / M) * (M + M / 32) + (2 * R3 + RAD) * (RAD + 1));   // lines + the three twiddle tables
+    constexpr size_t lds_bytes = sizeof(float2) * ((size_t)(TOT / M) * (M + M / 32 + (PAIR ? 16 : 0)) + (2 * R3 + RAD) * (RAD + 1));   // lines + the three twiddle tables
     static std::atomic<unsigned long long> attr_mask{0};
     if (first_on_device(attr_mask))
         PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG, PART, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize,
