@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--positions", type=int, default=64,
                     help="membrane positions of the config-4 batch measured after the timed steps (0 = skip)")
     ap.add_argument("--positions-size", type=int, default=0, help="study grid of the batch (default: --size, at most 4096)")
+    ap.add_argument("--positions-trace", action="store_true",
+                    help="record a HIP event after every position of the batch and report the per-position times of rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -214,8 +216,10 @@ def main():
 
     # ---- BASELINE.json config 4: the membrane-position batch, its own timed region (all ranks take part)
     if a.positions > 0:
+        import contextlib
         pn = a.positions_size or min(N, 4096)
-        out["positions_batch"] = {sim: positions_batch(a, sim, pn, rank, world, dev) for sim in ("Fresnel", "RayT")}
+        with contextlib.redirect_stdout(sys.stderr):     # the mirrors print like the reference; stdout carries the JSON line only
+            out["positions_batch"] = {sim: positions_batch(a, sim, pn, rank, world, dev) for sim in ("Fresnel", "RayT")}
 
     if rank == 0:
         P = N + 30
@@ -351,11 +355,22 @@ def positions_batch(a, sim, N, rank, world, dev):
     if world > 1:                                        # and the gather path (communicator set-up)
         w = torch.zeros(8, device=cpu_dev)
         td.gather(w, [torch.empty_like(w) for _ in range(world)] if rank == 0 else None, dst=0)
+    # The interpreter's cyclic garbage collector would otherwise run a full collection somewhere in the first positions
+    # (hundreds of thousands of objects allocated by the set-up above: ~40-60 ms of host time with the GPU idle -- the
+    # one-off stall DESIGN.md round 1 could not explain).  Collect now, then keep the survivors out of later collections.
+    import gc
+    gc.collect()
+    gc.freeze()
     barrier()
     t0 = time.perf_counter()
     results = {}
-    for p in mine:
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(mine) + 1)] if a.positions_trace else None
+    if marks:
+        marks[0].record()
+    for i, p in enumerate(mine):
         results[p] = position(p)
+        if marks:
+            marks[i + 1].record()
     torch.cuda.synchronize()
     t_comp = time.perf_counter() - t0
     gathered = dist.gather_positions(results, P, rank, world, to_host=False)
@@ -382,6 +397,8 @@ def positions_batch(a, sim, N, rank, world, dev):
            "gathered_bytes": int(sum(v[0].numel() + v[1].numel() for v in gathered.values()) * 4),
            "timed_region": "synthesis + chain + detection + shot noise of every position + the gather onto rank 0 (images stay "
                            "in rank 0's HBM)", "backend": a.backend if world > 1 else None}
+    if marks:
+        res["per_position_ms_rank0"] = [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(len(mine))]
     # rank 0 re-computes positions it did not own (every position when it is alone) and compares with what arrived
     others = [p for p in range(P) if p % world != 0] if world > 1 else list(range(P))
     sample = sorted(set(others[:2] + others[-1:])) if others else []

@@ -106,6 +106,7 @@ class Experiment:
         self._accs = None             # study-grid accumulators [4][Nx][Ny], allocated once
         self._tmp = None
         self._pending_means = []
+        self._sums_pool, self._sums_next = None, 0
         self.darkFieldPropag = None
 
     @classmethod
@@ -225,14 +226,20 @@ class Experiment:
         # position 0 and White is zero elsewhere (the reference detects an all-zero white there: Poisson(0) = 0)
         out = torch.empty((4, nbins, n0, n1), dtype=torch.float32, device=dev)
         if pointNum != 0:
-            out[2:].zero_()
+            ops.fill(out[2:], 0.0)
         N = tuple(int(v) for v in self.exp_dict['studyDimensions'])
         # the four study-grid accumulators live as long as the experiment; the first energy of a bin STORES into them, so they
         # are never cleared (the reference re-allocates zeros after every bin, EXP:396-399)
         if self._accs is None or tuple(self._accs.shape[1:]) != N or self._accs.device != dev:
             self._accs = torch.empty((4,) + N, dtype=torch.float32, device=dev)
-            self._tmp = torch.empty((2,) + N, dtype=torch.float32, device=dev)
-        sums = ops.new_sums(dev)                                    # [sum I_ref, sum E * I_ref] over the energies (EXP:360-361)
+            self._tmp = torch.empty((3,) + N, dtype=torch.float32, device=dev)
+        # [sum I_ref, sum E * I_ref] over the energies (EXP:360-361): one zeroed slot per position from a pool (a torch.zeros
+        # per position would be a PyTorch fill kernel per position)
+        if self._sums_pool is None or self._sums_next >= self._sums_pool.shape[0]:
+            self._sums_pool = torch.zeros((256,) + tuple(ops.new_sums(dev).shape), dtype=torch.float64, device=dev)
+            self._sums_next = 0
+        sums = self._sums_pool[self._sums_next]
+        self._sums_next += 1
         return [out[0], out[1], out[2], out[3]], [self._accs[0], self._accs[1], self._accs[2], self._accs[3]], N, dev, sums
 
     def _close_bins(self):
@@ -282,17 +289,11 @@ class Experiment:
     def _white(self, white, I_scalar, air_rt, plate_att, first):
         """EXP:372-375 / 494-497: the flat-field image of one energy (uniform unless air/plate maps are not)."""
         att = ops.MaterialStack.concat(air_rt, plate_att)
-        if att.n == 0:
-            if first:
-                white.fill_(I_scalar)
-            else:
-                white += I_scalar
+        if first:
+            ops.transmit_rt(None, I_scalar, att, want_phi=False, out=white)      # white = I * exp(-2 k beta T) (uniform without maps)
         else:
-            w = ops.transmit_rt(None, I_scalar, att, want_phi=False)[0]
-            if first:
-                white.copy_(w)
-            else:
-                white += w
+            w = ops.transmit_rt(None, I_scalar, att, want_phi=False, out=self._tmp[2])
+            ops.accumulate(white, w[0], 1.0, None, add=True)
 
     def _finish_mean_energy(self, sums, npix):
         """EXP:360-361,403: intensity-weighted mean energy of the reference image.  One synchronising read of two float64

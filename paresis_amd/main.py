@@ -35,6 +35,11 @@ def run(exp_dict, save=True, saving_format=".tif", backend=None):
         if rank == 0:
             os.makedirs(root + 'membraneThickness/', exist_ok=True)                       # main.py:84-85
         dist.barrier()
+    # everything allocated so far lives as long as the run: keep it out of the cyclic garbage collector's generations, or a
+    # full collection (tens of ms with the GPU idle) lands in one of the first positions
+    import gc
+    gc.collect()
+    gc.freeze()
     print("\nImages calculation")
     results = {}
     for pointNum in dist.my_positions(exp_dict['nbExpPoints'], rank, world):

@@ -158,16 +158,28 @@ def transmit_wave(wave_in, amp, mats, out=None):
     return out
 
 
-def transmit_rt(I_in, I0, mats, phi_in=None, want_phi=True, shape=None):
+def fill(t, value):
+    """t[:] = value through the library's own elementwise kernel (K2 with no input image and no material): the hot loop
+    launches no PyTorch kernel -- the first launch of one (fill, cat, reduce) makes PyTorch load its code object for that
+    kernel family, a one-off 15-40 ms host stall that showed up at membrane position 0 (position loop)."""
+    _need(t, torch.float32, "fill target")
+    check(lib().psx_transmit_rt_f32(None, c_float(value), None, None, None, 0, _ptr(t), None, None, t.numel(), _stream()),
+          "psx_transmit_rt_f32 (fill)")
+    return t
+
+
+def transmit_rt(I_in, I0, mats, phi_in=None, want_phi=True, shape=None, out=None):
     """K2 (Sample.py:347-348): I = I0*I_in*exp(sum catt*T); phi = phi_in + sum cphase*T (float64)."""
     mats = _mats(mats)
-    ref = I_in if I_in is not None else mats.map(0)
+    ref = I_in if I_in is not None else (mats.map(0) if mats.n else out)
     shape = tuple(ref.shape)
     if I_in is not None:
         _need(I_in, torch.float32, "I_in")
     if phi_in is not None:
         _need(phi_in, torch.float64, "phi_in", shape)
-    I_out = torch.empty(shape, dtype=torch.float32, device=ref.device)
+    if out is not None:
+        _need(out, torch.float32, "I_out", shape)
+    I_out = out if out is not None else torch.empty(shape, dtype=torch.float32, device=ref.device)
     phi_out = torch.empty(shape, dtype=torch.float64, device=ref.device) if want_phi else None
     T, cp, ca, n = mats.cargs(shape)
     check(lib().psx_transmit_rt_f32(_ptr(I_in), c_float(I0), T, cp, ca, n, _ptr(I_out), _ptr(phi_in), _ptr(phi_out),
