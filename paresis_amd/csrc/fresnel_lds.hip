@@ -6,7 +6,7 @@
 // circular convolution of period P = N+2*margin along axis 0 followed by one along axis 1.  Each 1-D line convolution
 //     out[n] = sum_{d<P} h[d] * x_per[n + margin - d],   h = IDFT_P(c),   x_per = periodic extension of the reflect pad,
 // is evaluated exactly as a linear convolution through a power-friendly FFT of size M >= N+P-1 (M = 576*R3,
-// R3 in {2,4,8,16}: 9216 for N = 4096) that lives entirely in the 160 KiB LDS of one CU:
+// R3 in {4,8,16}: 9216 for N = 4096) that lives entirely in the 160 KiB LDS of one CU:
 //     line samples -> periodic/reflected images written to LDS ->
 //     in-place DIF stages radix 24, 24, R3 -> multiply by FFT_M(h) (digit-reversed table, 1/M folded in) ->
 //     in-place inverse stages R3, 24, 24 -> the N wanted outputs go straight from registers to HBM.
@@ -933,7 +933,10 @@ __global__ void k_stage_twiddles(float2 *twA, float2 *twB, int M, int R3) {
 
 int pick_r3(int N, int margin) {
     const int need = 2 * N + 2 * margin - 1;   // L = N + P - 1
-    for (int r3 : {2, 4, 8, 16})
+    // R3 = 2 (M = 1152, lines up to N = 561) exists in the kernel but is not used: its stage stride S1 = 48 is no multiple of
+    // 32, so the LDS addressing is not affine and the instance spills 80 VGPRs; M = 2304 serves those grids as well -- they
+    // are one round per CU either way (512^2: 64 groups x 4 distances on 256 CUs)
+    for (int r3 : {4, 8, 16})
         if (576 * r3 >= need) return r3;
     return 0;
 }
@@ -1194,7 +1197,6 @@ static int launch_lines_r3(int R3, const LineArgs &la, hipStream_t st, const cha
     if (part && pair) return launch_lines<16, CONTIG, true, true>(la, st, name);
     if (part) return launch_lines<16, CONTIG, true>(la, st, name);
     switch (R3) {
-        case 2: return launch_lines<2, CONTIG>(la, st, name);
         case 4: return launch_lines<4, CONTIG>(la, st, name);
         case 8: return launch_lines<8, CONTIG>(la, st, name);
         case 16: return launch_lines<16, CONTIG>(la, st, name);
@@ -1244,7 +1246,12 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         la.accumulate = 0; la.stamps = stamp_pass1 ? g_stamps : nullptr;
         la.n_dist = nnz;
         static const bool no_inner = getenv("PSX_NO_DIST_INNER") != nullptr;   // diagnostics: A/B of the work order
-        la.dist_inner = (no_inner || e->ax[0].part) ? 0 : 1;   // one source for all distances
+        // one source for all distances: a workgroup takes the distances of a line group in consecutive rounds and fetches the
+        // group once -- but only when there are enough line groups to occupy every CU that way (small grids: 32 groups of 16
+        // lines at 512^2 would leave 224 CUs idle; there every (distance, group) pair is its own work item)
+        const int lines_per_group = TOT / (576 * e->ax[0].R3);
+        const int ngroups0 = (p->Ny + lines_per_group - 1) / lines_per_group;
+        la.dist_inner = (no_inner || e->ax[0].part || ngroups0 < current_cu_count()) ? 0 : 1;
         la.B = e->ax[0].B; la.Lh = e->ax[0].Lh; la.S = e->ax[0].S; la.NB = e->ax[0].NB;
         for (int i = 0; i < PSX_MAX_DIST; ++i) {
             const int k = i < nnz ? i : 0;
