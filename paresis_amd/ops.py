@@ -113,7 +113,8 @@ _status_words = {}
 
 
 def _workspace(device, nbytes):
-    key = (device.index, "ws")
+    # one scratch buffer per (device, stream): calls issued on different streams may overlap on the GPU
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
