@@ -119,13 +119,21 @@ __device__ __forceinline__ void lds_barrier() {
 //     X[k] = E[k] + w^k O[k],  X[k+M] = E[k] - w^k O[k]   ...x H...   E'[k] = Y[k] + Y[k+M],  O'[k] = (Y[k] - Y[k+M]) w^-k
 // (E, O = the two M-point spectra the engine computes anyway; w = exp(-2 pi i / 2M)).  One round is then ONE block x segment
 // product of twice the size: a 16384-sample line needs 2 x 2 of them instead of 5 x 3 M-point products for two lines.
-template <int R3, bool CONTIG, bool PART = false, bool PAIR = false>
+// DUAL (pass 1 of a call with several distances, R3 = 16): a round is ONE image line and TWO distances.  The line is
+// transformed forward once (stages A and B on LDS line 0, by six of the twelve engine waves); the middle stage reads each
+// spectrum slab once and writes its product with the first distance's kernel spectrum back in place and the product with
+// the second one's into LDS line 1; the inverse stages then run at full width on the two line buffers, one per distance.
+// That is the only way of sharing the forward transform between distances that fits LDS: 4.3 stage-units of work per two
+// (line, distance) results instead of 5.3, and half the samples to fetch and spread per round.
+template <int R3, bool CONTIG, bool PART = false, bool PAIR = false, bool DUAL = false>
 __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     // PAIR: the second LDS line starts 16 points further, so that a point of line 0 and the same point of line 1 sit 32 banks
     // apart: stage A then gives adjacent lanes the even and the odd sample of a pair without a bank conflict
     constexpr int M = 576 * R3, LINES = TOT / M, S1 = M / RAD, MP = M + M / 32 + (PAIR ? 16 : 0);
-    constexpr int LPG = PAIR ? 1 : LINES;               // image lines per round
+    constexpr int LPG = (PAIR || DUAL) ? 1 : LINES;     // image lines per round
+    constexpr int LL = DUAL ? 1 : LINES;                // LDS lines the loaders fill
     static_assert(!PAIR || (PART && R3 == 16 && LINES == 2), "PAIR couples the two lines of the R3 = 16 partitioned engine");
+    static_assert(!DUAL || (!PART && CONTIG && R3 == 16 && LINES == 2), "DUAL: one line x two distances on the R3 = 16 engine");
     constexpr int SLAB = 16, NSLABS = TOT / SLAB;       // 16 contiguous points per slab in the middle stage
     constexpr int WSLABS = 64 * RAD / SLAB;              // slabs inside the 1536 points one wave owns between barriers
     constexpr int NSLAB = (WSLABS + 63) / 64;            // slab rounds per lane (the last one is partly idle)
@@ -143,7 +151,8 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     const int cq = nwork >> 3, cr = nwork & 7;
     const int cstart = xcd * cq + (xcd < cr ? xcd : cr), clen = cq + (xcd < cr ? 1 : 0);
     const int nunits = slot < clen ? (clen - slot + nslot - 1) / nslot : 0;   // units cstart + slot + u*nslot, u < nunits
-    const int nj = PART ? nunits * a.S : (a.dist_inner ? nunits * a.n_dist : nunits);   // rounds of this workgroup
+    const int nsub = DUAL ? (a.n_dist + 1) / 2 : a.n_dist;       // rounds per line group when the distances are taken inside
+    const int nj = PART ? nunits * a.S : (a.dist_inner ? nunits * nsub : nunits);   // rounds of this workgroup
     // round j -> (distance, line group) [, output block, kernel segment]
     int pb = 0, ps = 0;       // PART: block and segment of the round last decoded
     auto item = [&](int j, int &d, int &g) __attribute__((always_inline)) {
@@ -156,8 +165,8 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             d = db / a.NB;
             pb = db - d * a.NB;
         } else if (a.dist_inner) {
-            const int u = j / a.n_dist;
-            d = j - u * a.n_dist;
+            const int u = j / nsub;
+            d = j - u * nsub;                                // DUAL: index of the distance PAIR
             g = cstart + slot + u * nslot;
         } else {
             const int w = cstart + slot + j * nslot;
@@ -280,16 +289,16 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         // Thread lt owns the samples i0 + STEP*k (k < NLD) of ONE line.  STEP is a multiple of 32 (R3 >= 4), so the padded
         // LDS index of sample k is the index of sample 0 plus a compile-time offset.
         const int lt = tid - TC;
-        constexpr int STEP = TL / LINES, NLD = TOT / (2 * TL), PSTEP = STEP + STEP / 32;
-        static_assert(TL % LINES == 0 && NLD * STEP >= (576 * R3 + 1) / 2, "sample ownership does not cover the longest line");
+        constexpr int STEP = TL / LL, NLD = (TOT / LINES) * LL / (2 * TL), PSTEP = STEP + STEP / 32;
+        static_assert(TL % LL == 0 && NLD * STEP >= (576 * R3 + 1) / 2, "sample ownership does not cover the longest line");
         constexpr bool AFFL = (STEP % 32 == 0);
-        const int line = CONTIG ? lt / STEP : lt % LINES, i0 = CONTIG ? lt % STEP : lt / LINES;
+        const int line = CONTIG ? lt / STEP : lt % LL, i0 = CONTIG ? lt % STEP : lt / LL;
         // mirror duty (np.pad 'reflect', EXP:237): thread t < LINES*2*mg re-reads one of the 2*mg samples next to an edge
-        const int nmir = LINES * 2 * mg;
-        const int lm = lt % LINES;
+        const int nmir = LL * 2 * mg;
+        const int lm = lt % LL;
         int im = -1, jm = 0;
         if (lt < nmir) {
-            const int r = lt / LINES;
+            const int r = lt / LL;
             im = r < mg ? r + 1 : N - 1 - 2 * mg + r;                   // 1..mg   |   N-1-mg..N-2
             jm = r < mg ? N + 2 * mg - 1 - im : 2 * N - 3 - im;         // left mirror | right mirror one period earlier
         }
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             item(j, d, g);
             if (a.dist_inner && d != 0) return;                          // same line group as the round before: registers keep it
             const float2 *src = a.src[d];
-            const int l0 = g * LINES;
+            const int l0 = g * LPG;
             const bool line_ok = l0 + line < a.nlines;
             const int64_t pix0 = a.in_blocked
                                      ? ((int64_t)((l0 + line) / IB) * N + i0) * IB + (l0 + line) % IB
@@ -322,12 +331,12 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         auto spread = [&](int j) __attribute__((always_inline)) {       // periodic / mirrored images -> LDS
             int d, g;
             item(j, d, g);
-            const int l0 = g * LINES;
+            const int l0 = g * LPG;
             const bool line_ok = l0 + line < a.nlines;
             for (int jz = a.L + lt; jz < M; jz += TL) {                  // zeros in [L, M) of every line (no division:
                 const int pz = phys(jz);                                 // this burst is issue-bound on ONE wave per SIMD)
 #pragma unroll
-                for (int ln = 0; ln < LINES; ++ln) lds[ln * MP + pz] = make_float2(0.f, 0.f);
+                for (int ln = 0; ln < LL; ++ln) lds[ln * MP + pz] = make_float2(0.f, 0.f);
             }
 #pragma unroll
             for (int k = 0; k < NLD; ++k) {
@@ -344,7 +353,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             }
             if (im >= 0) lds[lm * MP + phys(jm)] = l0 + lm < a.nlines ? xm : make_float2(0.f, 0.f);
             for (int t = lt + TL; t < nmir; t += TL) {                   // margins beyond TL/(2*LINES): rare
-                const int ln = t % LINES, r = t / LINES;
+                const int ln = t % LL, r = t / LL;
                 const int i2 = r < mg ? r + 1 : N - 1 - 2 * mg + r, j2 = r < mg ? N + 2 * mg - 1 - i2 : 2 * N - 3 - i2;
                 float2 x2 = make_float2(0.f, 0.f);
                 if (l0 + ln < a.nlines)
@@ -362,6 +371,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         for (int j = 0; j < nj; ++j) {
             const bool more = j + 1 < nj;
             lds_barrier();                               // (1) engine: forward stage A done
+            if constexpr (DUAL) lds_barrier();           // (1b) engine: forward stage B done (six waves), before the middle stage
             // Issued after barrier (1), not before: issuing strided loads stalls for ~5 us (the texture path hands out one
             // 128-byte line per lane pair) and forward stage A lasts only 3 us -- the engine would wait for the loaders.
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 16] = wall_clock64();
@@ -393,12 +403,12 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     // the middle stage couples
     // (the PAIR values are re-derived inside the round loop from an opaque copy of the thread index: hoisted out of it
     // they would stay live through inverse stage A, which has no register to spare)
-    const int remB = tid % S1, q1B = remB / R3, nB = PAIR ? (tid & 15) : remB % R3, p0B = q1B * S1 + nB;
+    const int remB = tid % S1, q1B = remB / R3, nB = (PAIR || DUAL) ? (tid & 15) : remB % R3, p0B = q1B * S1 + nB;
     v2f *baseA = reinterpret_cast<v2f *>(lds) + lineA * MP;
-    auto stageB_at = [&](v2f *&bB, int &pB) __attribute__((always_inline)) {
+    auto stageB_at = [&](v2f *&bB, int &pB, bool paired) __attribute__((always_inline)) {
         bB = baseA;
         pB = p0B;
-        if constexpr (PAIR) {
+        if (paired) {
             int to = tid;
             asm volatile("" : "+v"(to));
             bB = reinterpret_cast<v2f *>(lds) + ((to & 63) >> 5) * MP;
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     // different pad offsets (one pad slot per TWO slabs) and hit 16 different bank pairs instead of 8.
     const int slabw = ((tid & 63) & 32) + ((tid & 31) < 16 ? 2 * (tid & 31) : 2 * ((tid & 31) - 16) + 1);
     const int slab0 = (tid >> 6) * WSLABS + slabw;
-    const v2f *rowA1 = tw1 + (nA / R3) * TWB_LD, *rowA0 = tw0 + (nA % R3) * TWB_LD, *rowB = twl + nB * TWB_LD;
+    const v2f *rowA1 = tw1 + (nA / R3) * TWB_LD, *rowA0 = tw0 + (nA % R3) * TWB_LD;
     // v[q] *= (or conj-*=) row1[q] * row0[q] for q in [Q0, Q1): half of the 23 twiddles at a time (128-VGPR budget)
     auto twiddle_A = [&](v2f(&v)[RAD], auto q0_tag, auto q1_tag, auto conj_tag) __attribute__((always_inline)) {
         constexpr int Q0 = decltype(q0_tag)::value, Q1 = decltype(q1_tag)::value;
@@ -439,8 +449,8 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         const int l0 = g * LPG;
         PSX_STAMP(2);
 
-        // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}
-        {
+        // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}  (DUAL: LDS line 0 only = engine waves 0..5)
+        if (!DUAL || tid < S1) {
             v2f v[RAD];
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = baseA[idxA(nA, q)];
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         // pair (H[k], H[k + M]) per point: 4 points = 4 float4 per chunk; the first chunk travels here, the others under the
         // arithmetic of the chunk before (a slab pair already holds 64 registers of data)
         int tp = tid;
-        if constexpr (PAIR) asm volatile("" : "+v"(tp));
+        if constexpr (PAIR || DUAL) asm volatile("" : "+v"(tp));
         const int pslab = 48 * (tp >> 6) + (tp & 63);                         // slab index inside a line (PAIR)
         const bool pact = (tp & 63) < 48;
         const float4 *hp4 = reinterpret_cast<const float4 *>(a.H[d] + (size_t)(PART ? ps : 0) * 2 * M) + (size_t)(pact ? pslab : 0) * SLAB;
@@ -468,6 +478,11 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             for (int q = 0; q < 4; ++q) hh[q] = hp4[q];
             const float2 w = a.w2[pact ? pslab : 0];
             w0p = (v2f){w.x, w.y};
+        } else if constexpr (DUAL) {
+            // the whole slab of the FIRST distance's spectrum (16 points = 8 float4); the second one's comes under the arithmetic
+            const float4 *h4 = reinterpret_cast<const float4 *>(a.H[2 * d] + (pact ? pslab : 0) * SLAB);
+#pragma unroll
+            for (int q = 0; q < SLAB / 2; ++q) hh[q] = h4[q];
         } else {
             const float4 *h4 = reinterpret_cast<const float4 *>(a.H[d] + (PART ? ps * M : 0) + (slab0 % (M / SLAB)) * SLAB);
 #pragma unroll
@@ -477,11 +492,13 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         lds_barrier();                               // (1)
         PSX_STAMP(4);
         // ---- 3. forward stage B: radix 24 inside each block of S1, stride R3, twiddle w_S1^{n q}
-        {
+        if (!DUAL || tid < S1) {
             v2f v[RAD];
             v2f *bB;
             int pB;
-            stageB_at(bB, pB);
+            stageB_at(bB, pB, PAIR);
+            const v2f *rowB = twl + (DUAL ? remB % R3 : nB) * TWB_LD;     // DUAL: plain thread map (line 0), n = remB % R3
+            if constexpr (DUAL) pB = (remB / R3) * S1 + remB % R3;
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = lds_read(bB + idxB(pB, q));
             DftPk<RAD, false>::run(v);
@@ -498,6 +515,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 #pragma unroll
             for (int q = 0; q < RAD; ++q) bB[idxB(pB, q)] = v[q];
         }
+        if constexpr (DUAL) lds_barrier();           // (1b) the middle stage's slabs were written by other waves
         PSX_STAMP(5);
         // From here to the end of inverse stage B every wave works on LDS points that only IT touches: its 64
         // radix-24 butterflies of stage B cover 64/R3 whole blocks of S1 points = the 1536 consecutive points
@@ -509,7 +527,41 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 
         // ---- 4+5. middle stage, slab by slab: forward radix R3 on contiguous chunks, x FFT_M(h_d), inverse radix R3,
         // back to LDS.  Each thread rewrites exactly the slabs it read.
-        if constexpr (PAIR) {
+        if constexpr (DUAL) {
+            if (pact) {
+                v2f *b0 = reinterpret_cast<v2f *>(lds) + phys(pslab * SLAB), *b1 = b0 + MP;
+                v2f x[SLAB], y[SLAB];
+#pragma unroll
+                for (int q = 0; q < SLAB; ++q) x[q] = lds_read(b0 + q);
+                DftPk<SLAB, false>::run(x);                              // the spectrum slab, shared by the two distances
+#pragma unroll
+                for (int q = 0; q < SLAB / 2; ++q) {
+                    y[2 * q] = pk_cmul(x[2 * q], (v2f){hh[q].x, hh[q].y});
+                    y[2 * q + 1] = pk_cmul(x[2 * q + 1], (v2f){hh[q].z, hh[q].w});
+                }
+                // second distance's spectrum: its first half travels under the first distance's inverse DFT
+                const float4 *h4b = reinterpret_cast<const float4 *>(a.H[2 * d + 1] + pslab * SLAB);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < SLAB / 4; ++q) hh[q] = h4b[q];
+                __builtin_amdgcn_sched_barrier(0);
+                DftPk<SLAB, true>::run(y);
+#pragma unroll
+                for (int q = 0; q < SLAB; ++q) b0[q] = y[q];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < SLAB / 4; ++q) hh[SLAB / 4 + q] = h4b[SLAB / 4 + q];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < SLAB / 2; ++q) {
+                    x[2 * q] = pk_cmul(x[2 * q], (v2f){hh[q].x, hh[q].y});
+                    x[2 * q + 1] = pk_cmul(x[2 * q + 1], (v2f){hh[q].z, hh[q].w});
+                }
+                DftPk<SLAB, true>::run(x);
+#pragma unroll
+                for (int q = 0; q < SLAB; ++q) b1[q] = x[q];
+            }
+        } else if constexpr (PAIR) {
             if (pact) {
                 v2f *b0 = reinterpret_cast<v2f *>(lds) + phys(pslab * SLAB), *b1 = b0 + MP;
                 v2f f0[SLAB], f1[SLAB];
@@ -597,7 +649,8 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             v2f v[RAD], w[RAD];
             v2f *bB;
             int pB;
-            stageB_at(bB, pB);
+            stageB_at(bB, pB, PAIR || DUAL);
+            const v2f *rowB = twl + nB * TWB_LD;
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = lds_read(bB + idxB(pB, q));
 #pragma unroll
@@ -631,10 +684,12 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             // PART: index inside the output block; PAIR: LDS line = parity of the position in the 2M-point result
             int ifirst = (PAIR ? 2 * nA + lineA : nA) - (PART ? a.Lh - 1 : N + 2 * mg - 1);
             asm volatile("" : "+v"(ifirst));
-            v2f *wo = reinterpret_cast<v2f *>(a.wave_out[d]);
-            float *io = a.inten_out[d];
-            const float sc = a.scale[d];
-            const v2f gp = (v2f){a.gph[d].x, a.gph[d].y};
+            // DUAL: LDS line 0 carries the first distance of the pair, line 1 the second (a wave belongs to one line)
+            const int dd = DUAL ? 2 * d + __builtin_amdgcn_readfirstlane(lineA) : d;
+            v2f *wo = reinterpret_cast<v2f *>(a.wave_out[dd]);
+            float *io = a.inten_out[dd];
+            const float sc = a.scale[dd];
+            const v2f gp = (v2f){a.gph[dd].x, a.gph[dd].y};
             static_assert(S1 % IB == 0 && IB == 8, "blocked output stride; the block index below is i >> 3");
             if constexpr (S1 % 64 == 0) {
                 // A wave's 64 butterflies belong to ONE line, so its outputs go through a buffer descriptor whose range is
@@ -642,7 +697,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 // a huge offset, i >= N lies past the window).  No compare, no exec-mask bookkeeping per output -- the
                 // scalar unit is shared by the whole CU (0.9 instructions per cycle, tools/salu_bench.hip) and the masked
                 // form of this loop issued 500 scalar instructions per wave.
-                const int l = l0 + (PAIR ? 0 : __builtin_amdgcn_readfirstlane(lineA));
+                const int l = l0 + ((PAIR || DUAL) ? 0 : __builtin_amdgcn_readfirstlane(lineA));
                 const bool lok = l < a.nlines;
                 // element index of output i inside the window: plain rows: i (window = row l); blocked: ((i>>3)*nlines+l)*8 + i%8
                 const int e0 = a.out_blocked ? ((ifirst >> 3) * a.nlines + l) * IB + (ifirst & (IB - 1)) : ifirst;
@@ -1175,20 +1230,20 @@ static int kernel_spectrum(psx_fresnel_plan *p, AxisTables &t, double a, double 
     return 0;
 }
 
-template <int R3, bool CONTIG, bool PART = false, bool PAIR = false>
+template <int R3, bool CONTIG, bool PART = false, bool PAIR = false, bool DUAL = false>
 static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
-    constexpr int M = 576 * R3, LINES = PAIR ? 1 : TOT / M;        // LINES here: image lines per round
+    constexpr int M = 576 * R3, LINES = (PAIR || DUAL) ? 1 : TOT / M;        // LINES here: image lines per round
     constexpr size_t lds_bytes = sizeof(float2) * ((size_t)(TOT / M) * (M + M / 32 + (PAIR ? 16 : 0)) + (2 * R3 + RAD) * (RAD + 1));   // lines + the three twiddle tables
     static std::atomic<unsigned long long> attr_mask{0};
     if (first_on_device(attr_mask))
-        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG, PART, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG, PART, PAIR, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_bytes));
     // persistent workgroups: one per CU (the LDS footprint allows no more), a multiple of the 8 XCDs
     const int n_cu = current_cu_count();
     const int nwork = ((la.nlines + LINES - 1) / LINES) * (PART ? la.n_dist * la.NB : (la.dist_inner ? 1 : la.n_dist));
     int nslot = n_cu / 8;
     if (nslot > (nwork + 7) / 8) nslot = (nwork + 7) / 8;
-    PSX_TIMED(name, st, k_fresnel_lines<R3, CONTIG, PART, PAIR><<<8 * nslot, T, lds_bytes, st>>>(la));
+    PSX_TIMED(name, st, k_fresnel_lines<R3, CONTIG, PART, PAIR, DUAL><<<8 * nslot, T, lds_bytes, st>>>(la));
     return launch_check(name);
 }
 
@@ -1249,7 +1304,7 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         // one source for all distances: a workgroup takes the distances of a line group in consecutive rounds and fetches the
         // group once -- but only when there are enough line groups to occupy every CU that way (small grids: 32 groups of 16
         // lines at 512^2 would leave 224 CUs idle; there every (distance, group) pair is its own work item)
-        const int lines_per_group = TOT / (576 * e->ax[0].R3);
+        const int lines_per_group = (e->ax[0].R3 == 16 && nnz >= 2) ? 1 : TOT / (576 * e->ax[0].R3);   // DUAL rounds take one line
         const int ngroups0 = (p->Ny + lines_per_group - 1) / lines_per_group;
         la.dist_inner = (no_inner || e->ax[0].part || ngroups0 < current_cu_count()) ? 0 : 1;
         la.B = e->ax[0].B; la.Lh = e->ax[0].Lh; la.S = e->ax[0].S; la.NB = e->ax[0].NB;
@@ -1268,7 +1323,15 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
             la.gph[i] = make_float2(1.f, 0.f);
         }
         la.w2 = e->ax[0].w2;
-        if (int rc = launch_lines_r3<true>(e->ax[0].R3, la, st, "k_fresnel_cols", e->ax[0].part, e->ax[0].pair)) return rc;
+        static const bool no_dual = getenv("PSX_NO_DUAL") != nullptr;        // diagnostics: A/B of the shared forward transform
+        if (!no_dual && la.dist_inner && nnz >= 2 && e->ax[0].R3 == 16 && !e->ax[0].part) {
+            // one line x two distances per round: the forward transform of a line is shared by the pair
+            if (nnz & 1) {
+                la.H[nnz] = la.H[nnz - 1];
+                la.wave_out[nnz] = nullptr;       // odd count: the last pair's second result is computed and dropped
+            }
+            if (int rc = launch_lines<16, true, false, false, true>(la, st, "k_fresnel_cols")) return rc;
+        } else if (int rc = launch_lines_r3<true>(e->ax[0].R3, la, st, "k_fresnel_cols", e->ax[0].part, e->ax[0].pair)) return rc;
     }
 
     // ---- pass 2: lines along axis 1 of the image = columns of the intermediate (strided reads: the second transpose);

@@ -356,3 +356,28 @@ def test_integration_md_binding_runs():
         assert relmax(out.cpu().numpy(), g["%d/v2/out" % k]) < 1e-5, k
         assert relmax(Dx.cpu().numpy(), g["%d/v2/Dx" % k]) < 1e-5
         assert np.array_equal(I.cpu().numpy() == 0, g["%d/v2/I_after" % k] == 0)        # in-place zeroing of clamped rays
+
+
+def test_shared_forward_rounds_odd_and_even_distance_counts():
+    """Pass 1 of a multi-distance call at N >= 2305 takes one line x two distances per round (shared forward transform);
+    3 distances leave a half-empty last pair, 2 and 4 none: every image equals the one-distance call's, bit for bit (the
+    arithmetic of a (line, distance) result does not depend on which round computes it), and PSX_NO_DUAL-style rounds are
+    covered by the 2048^2 cases, which never pair."""
+    from paresis_amd import ops
+    from paresis_amd.getk import getk
+    N = 3000
+    g, T = _membrane(N, 6)
+    wave, _ = _stacks(ops, T)
+    kk = getk(52000.0)
+    h = g["pix_um"] * 1e-6
+    du = (2 * np.pi / (N * h),) * 2
+    zs = (1.6, 3.6, 5.2, 7.2, 9.0)
+    a = [z / (2 * kk * g["M"]) for z in zs]
+    gp = [kk * z / g["M"] for z in zs]
+    plan = ops.FresnelPlan(N, N, max_dist=5)
+    singles = [plan.propagate([a[i]], [gp[i]], du, amp=50.0, mats=wave)[0] for i in range(5)]
+    for nd in (2, 3, 4, 5):
+        outs = plan.propagate(a[:nd], gp[:nd], du, amp=50.0, mats=wave)
+        for i in range(nd):
+            assert torch.equal(outs[i], singles[i]), (nd, i)
+    plan.close()
