@@ -16,7 +16,7 @@ PSX_MAX_POISSON = 8
 PSX_SUM_SLOTS, PSX_SUM_STRIDE = 32, 16
 ENGINE_AUTO, ENGINE_ROCFFT, ENGINE_LDS = 0, 1, 2
 STATUS_NONFINITE = 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class PsxError(RuntimeError):

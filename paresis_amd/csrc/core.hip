@@ -88,7 +88,7 @@ __global__ void psx_probe_kernel(int *out) { *out = 950; }
 
 extern "C" {
 
-int psx_abi_version(void) { return 1; }
+int psx_abi_version(void) { return 2; }   // 2: psx_accumulate_sum_f32, psx_poisson_multi_f32, psx_set_deterministic; batch vs one-distance refraction wording
 
 const char *psx_last_error(void) { return psx::err_buf(); }
 

@@ -18,8 +18,11 @@
 // (k_source_transposed) that also evaluates the transmitted source wave (K1) -- once per call, for all distances; pass 1
 // (k_fresnel_cols: lines along axis 0) then reads whole lines and writes row y of the intermediate [Ny][Nx]; pass 2
 // (k_fresnel_rows: lines along axis 1) reads the intermediate's columns (the second transpose, 16-byte pieces) and
-// writes the final image.  The distances of a call share each launch (work item = distance x line group); pass 1 repeats
-// its forward stages per distance, because the in-place middle stage consumes the forward spectrum.
+// writes the final image.  The distances of a call share each launch (work item = distance x line group).  Pass 1 shares more:
+// its rounds are ONE line x TWO distances (DUAL) -- forward stages once, the middle stage writes the product with either
+// distance's kernel spectrum into one of the two LDS line buffers, inverse stages at full width.  Lines too long for one
+// transform (N > 4593) run as a partitioned convolution whose rounds couple the two LDS lines into ONE 18432-point transform
+// (PAIR: even samples in line 0, odd in line 1, the radix-2 butterfly of the double-size transform in the middle stage).
 //
 // Each CU runs ONE persistent 16-wave workgroup: 12 engine waves own the butterflies (packed-fp32 arithmetic,
 // fft_pk.hpp), 4 loader waves fetch the next line group from HBM during the transform and spread it into LDS while the
