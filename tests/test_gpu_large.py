@@ -81,10 +81,12 @@ def test_both_engines_agree_4096():
     assert float((outs[0] - outs[1]).abs().max() / outs[0].abs().max()) < 3e-6
 
 
-@pytest.mark.parametrize("shape", [(5000, 5000), (4704, 1500), (1200, 6008), (4594, 4594)])
+@pytest.mark.parametrize("shape", [(5000, 5000), (4704, 1500), (1200, 6008), (4594, 4594), (9800, 320), (320, 12000)])
 def test_partitioned_lds_engine_matches_rocfft_and_oracle(shape):
     """Lines longer than one LDS transform (N > 4593) run as a partitioned convolution -- output blocks x kernel segments,
-    partial sums in HBM -- on one or both axes; checked against the rocFFT engine (complex wave and accumulated
+    partial sums in HBM, the two LDS lines coupled into one 18432-point transform -- on one or both axes: one product per
+    line (5000, 4704, 6008, 4594), one segment x two blocks (9800, 12000), two x two (16384, below); checked against the
+    rocFFT engine (complex wave and accumulated
     intensity, 2 distances in one call) and, on a 300-pixel-wide cut, against the oracle's FFT of the same lines."""
     from paresis_amd import ops
     from paresis_amd.getk import getk

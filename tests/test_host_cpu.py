@@ -326,3 +326,34 @@ def test_edf_reader_accepts_foreign_headers(tmp_path):
     f = str(tmp_path / "foreign.edf")
     open(f, "wb").write(hdr.encode("ascii") + img.tobytes())
     assert np.allclose(openImage(f), img.astype(np.float64))
+
+
+def test_bench_starts_its_own_ranks_and_rejects_a_world_mismatch(monkeypatch):
+    """`bench.py --gpus N` outside torchrun launches N ranks through torch.distributed.run (before touching the GPU) and leaves
+    with the child's exit code; under torchrun a --gpus that disagrees with WORLD_SIZE is refused."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under torchrun with a different world size
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(e.value.code)
