@@ -151,11 +151,11 @@ def getMembraneSegmentedFromFile(sample, dimX, dimY, pixSize, pointNum, supportT
         check(lib().psx_membrane_layer_f32(plan.h, ox, oy, dimX, dimY, plan.margin, plan.margin2, c_double(pixSize * 1e-6),
                                            1 if li else 0, c_void_p(membrane.data_ptr()), st), "psx_membrane_layer_f32")
     if not offs:
-        membrane.zero_()
-    if stacked:
-        support = stack[1].fill_(float(supportThickness) * 1e-6)
-    else:
-        support = torch.full((dimX, dimY), float(supportThickness) * 1e-6, dtype=torch.float32, device=dev)
+        from .. import ops as _ops
+        _ops.fill(membrane, 0.0)
+    from .. import ops
+    support = stack[1] if stacked else torch.empty((dimX, dimY), dtype=torch.float32, device=dev)
+    ops.fill(support, float(supportThickness) * 1e-6)     # the library's own kernel: the position loop launches no PyTorch kernel
     parameters_dic = {'Average sphere radius': (sample.myMeanSphereRadius, 'um'),
                       'Number of layers': (sample.myNbOfLayers, ''),
                       'Support total thickness': (supportThickness, 'um')}
