@@ -122,10 +122,12 @@ __device__ __forceinline__ void lds_barrier() {
 //     X[k] = E[k] + w^k O[k],  X[k+M] = E[k] - w^k O[k]   ...x H...   E'[k] = Y[k] + Y[k+M],  O'[k] = (Y[k] - Y[k+M]) w^-k
 // (E, O = the two M-point spectra the engine computes anyway; w = exp(-2 pi i / 2M)).  One round is then ONE block x segment
 // product of twice the size: a 16384-sample line needs 2 x 2 of them instead of 5 x 3 M-point products for two lines.
-// DUAL (pass 1 of a call with several distances, R3 = 16): a round is ONE image line and TWO distances.  The line is
-// transformed forward once (stages A and B on LDS line 0, by six of the twelve engine waves); the middle stage reads each
-// spectrum slab once and writes its product with the first distance's kernel spectrum back in place and the product with
-// the second one's into LDS line 1; the inverse stages then run at full width on the two line buffers, one per distance.
+// DUAL (pass 1 of a call with several distances): a round is HALF the LDS lines' worth of image lines (one at R3 = 16) and
+// TWO distances.  The lines are transformed forward once (stages A and B on the first half of the LDS lines, by six of the
+// twelve engine waves); the middle stage reads each spectrum slab once and writes its product with the first distance's
+// kernel spectrum back in place and the product with the second one's into the same slab of the second half of the LDS
+// lines; the inverse stages then run at full width on all line buffers, the first half for one distance, the second half
+// for the other.
 // That is the only way of sharing the forward transform between distances that fits LDS: 4.3 stage-units of work per two
 // (line, distance) results instead of 5.3, and half the samples to fetch and spread per round.
 template <int R3, bool CONTIG, bool PART = false, bool PAIR = false, bool DUAL = false>
@@ -133,10 +135,12 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     // PAIR: the second LDS line starts 16 points further, so that a point of line 0 and the same point of line 1 sit 32 banks
     // apart: stage A then gives adjacent lanes the even and the odd sample of a pair without a bank conflict
     constexpr int M = 576 * R3, LINES = TOT / M, S1 = M / RAD, MP = M + M / 32 + (PAIR ? 16 : 0);
-    constexpr int LPG = (PAIR || DUAL) ? 1 : LINES;     // image lines per round
-    constexpr int LL = DUAL ? 1 : LINES;                // LDS lines the loaders fill
+    constexpr int LH = DUAL ? LINES / 2 : LINES;        // DUAL: image lines of a round = half the LDS lines (the other half
+                                                        // receives the second distance's products)
+    constexpr int LPG = PAIR ? 1 : LH;                  // image lines per round
+    constexpr int LL = LH;                              // LDS lines the loaders fill
     static_assert(!PAIR || (PART && R3 == 16 && LINES == 2), "PAIR couples the two lines of the R3 = 16 partitioned engine");
-    static_assert(!DUAL || (!PART && CONTIG && R3 == 16 && LINES == 2), "DUAL: one line x two distances on the R3 = 16 engine");
+    static_assert(!DUAL || (!PART && CONTIG && LINES % 2 == 0), "DUAL: LINES/2 image lines x two distances per round");
     constexpr int SLAB = 16, NSLABS = TOT / SLAB;       // 16 contiguous points per slab in the middle stage
     constexpr int WSLABS = 64 * RAD / SLAB;              // slabs inside the 1536 points one wave owns between barriers
     constexpr int NSLAB = (WSLABS + 63) / 64;            // slab rounds per lane (the last one is partly idle)
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     // the middle stage couples
     // (the PAIR values are re-derived inside the round loop from an opaque copy of the thread index: hoisted out of it
     // they would stay live through inverse stage A, which has no register to spare)
-    const int remB = tid % S1, q1B = remB / R3, nB = (PAIR || DUAL) ? (tid & 15) : remB % R3, p0B = q1B * S1 + nB;
+    const int remB = tid % S1, q1B = remB / R3, nB = (PAIR || DUAL) ? (tid & 31) % R3 : remB % R3, p0B = q1B * S1 + nB;
     v2f *baseA = reinterpret_cast<v2f *>(lds) + lineA * MP;
     auto stageB_at = [&](v2f *&bB, int &pB, bool paired) __attribute__((always_inline)) {
         bB = baseA;
@@ -414,8 +418,11 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         if (paired) {
             int to = tid;
             asm volatile("" : "+v"(to));
-            bB = reinterpret_cast<v2f *>(lds) + ((to & 63) >> 5) * MP;
-            pB = (2 * (to >> 6) + ((to & 31) >> 4)) * S1 + (to & 15);
+            // a half-wave (32 butterflies = 768 points) takes the wave's range of the first LH lines (lanes 0-31) or of the
+            // second LH lines (lanes 32-63); blocks are counted through the concatenated half
+            const int gb = (to >> 6) * (32 / R3) + (to & 31) / R3;          // block inside the half: 24 blocks per line
+            bB = reinterpret_cast<v2f *>(lds) + (gb / RAD + ((to & 63) >> 5) * (PAIR ? 1 : LH)) * MP;
+            pB = (gb % RAD) * S1 + (to & 31) % R3;
         }
     };
     // middle stage: slab of this lane inside the wave's own 96 (round 2: 32 lanes).  Within each half-wave the first 16
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         PSX_STAMP(2);
 
         // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}  (DUAL: LDS line 0 only = engine waves 0..5)
-        if (!DUAL || tid < S1) {
+        if (!DUAL || tid < TC / 2) {
             v2f v[RAD];
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = baseA[idxA(nA, q)];
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             w0p = (v2f){w.x, w.y};
         } else if constexpr (DUAL) {
             // the whole slab of the FIRST distance's spectrum (16 points = 8 float4); the second one's comes under the arithmetic
-            const float4 *h4 = reinterpret_cast<const float4 *>(a.H[2 * d] + (pact ? pslab : 0) * SLAB);
+            const float4 *h4 = reinterpret_cast<const float4 *>(a.H[2 * d] + ((pact ? pslab : 0) % (M / SLAB)) * SLAB);
 #pragma unroll
             for (int q = 0; q < SLAB / 2; ++q) hh[q] = h4[q];
         } else {
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         lds_barrier();                               // (1)
         PSX_STAMP(4);
         // ---- 3. forward stage B: radix 24 inside each block of S1, stride R3, twiddle w_S1^{n q}
-        if (!DUAL || tid < S1) {
+        if (!DUAL || tid < TC / 2) {
             v2f v[RAD];
             v2f *bB;
             int pB;
@@ -532,23 +539,36 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         // back to LDS.  Each thread rewrites exactly the slabs it read.
         if constexpr (DUAL) {
             if (pact) {
-                v2f *b0 = reinterpret_cast<v2f *>(lds) + phys(pslab * SLAB), *b1 = b0 + MP;
+                // slab pslab of the concatenated first LH lines; its second-distance product goes LH lines further
+                const int sline = pslab / (M / SLAB), sp0 = (pslab % (M / SLAB)) * SLAB;
+                v2f *b0 = reinterpret_cast<v2f *>(lds) + sline * MP + phys(sp0), *b1 = b0 + LH * MP;
                 v2f x[SLAB], y[SLAB];
 #pragma unroll
                 for (int q = 0; q < SLAB; ++q) x[q] = lds_read(b0 + q);
-                DftPk<SLAB, false>::run(x);                              // the spectrum slab, shared by the two distances
+                auto dft_chunks = [&](v2f(&f)[SLAB], auto inv_tag) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int c = 0; c < SLAB / R3; ++c) {
+                        v2f w[R3];
+#pragma unroll
+                        for (int q = 0; q < R3; ++q) w[q] = f[c * R3 + q];
+                        DftPk<R3, decltype(inv_tag)::value>::run(w);
+#pragma unroll
+                        for (int q = 0; q < R3; ++q) f[c * R3 + q] = w[q];
+                    }
+                };
+                dft_chunks(x, std::false_type{});                        // the spectrum slab, shared by the two distances
 #pragma unroll
                 for (int q = 0; q < SLAB / 2; ++q) {
                     y[2 * q] = pk_cmul(x[2 * q], (v2f){hh[q].x, hh[q].y});
                     y[2 * q + 1] = pk_cmul(x[2 * q + 1], (v2f){hh[q].z, hh[q].w});
                 }
                 // second distance's spectrum: its first half travels under the first distance's inverse DFT
-                const float4 *h4b = reinterpret_cast<const float4 *>(a.H[2 * d + 1] + pslab * SLAB);
+                const float4 *h4b = reinterpret_cast<const float4 *>(a.H[2 * d + 1] + sp0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < SLAB / 4; ++q) hh[q] = h4b[q];
                 __builtin_amdgcn_sched_barrier(0);
-                DftPk<SLAB, true>::run(y);
+                dft_chunks(y, std::true_type{});
 #pragma unroll
                 for (int q = 0; q < SLAB; ++q) b0[q] = y[q];
                 __builtin_amdgcn_sched_barrier(0);
@@ -560,7 +580,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                     x[2 * q] = pk_cmul(x[2 * q], (v2f){hh[q].x, hh[q].y});
                     x[2 * q + 1] = pk_cmul(x[2 * q + 1], (v2f){hh[q].z, hh[q].w});
                 }
-                DftPk<SLAB, true>::run(x);
+                dft_chunks(x, std::true_type{});
 #pragma unroll
                 for (int q = 0; q < SLAB; ++q) b1[q] = x[q];
             }
@@ -688,7 +708,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             int ifirst = (PAIR ? 2 * nA + lineA : nA) - (PART ? a.Lh - 1 : N + 2 * mg - 1);
             asm volatile("" : "+v"(ifirst));
             // DUAL: LDS line 0 carries the first distance of the pair, line 1 the second (a wave belongs to one line)
-            const int dd = DUAL ? 2 * d + __builtin_amdgcn_readfirstlane(lineA) : d;
+            const int dd = DUAL ? 2 * d + __builtin_amdgcn_readfirstlane(tid >= TC / 2 ? 1 : 0) : d;
             v2f *wo = reinterpret_cast<v2f *>(a.wave_out[dd]);
             float *io = a.inten_out[dd];
             const float sc = a.scale[dd];
@@ -700,7 +720,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 // a huge offset, i >= N lies past the window).  No compare, no exec-mask bookkeeping per output -- the
                 // scalar unit is shared by the whole CU (0.9 instructions per cycle, tools/salu_bench.hip) and the masked
                 // form of this loop issued 500 scalar instructions per wave.
-                const int l = l0 + ((PAIR || DUAL) ? 0 : __builtin_amdgcn_readfirstlane(lineA));
+                const int l = l0 + (PAIR ? 0 : __builtin_amdgcn_readfirstlane(DUAL ? lineA % LH : lineA));
                 const bool lok = l < a.nlines;
                 // element index of output i inside the window: plain rows: i (window = row l); blocked: ((i>>3)*nlines+l)*8 + i%8
                 const int e0 = a.out_blocked ? ((ifirst >> 3) * a.nlines + l) * IB + (ifirst & (IB - 1)) : ifirst;
@@ -774,10 +794,11 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                         }
                     }
                 }
-            } else if (l0 + lineA < a.nlines) {
+            } else if (l0 + (DUAL ? lineA % LH : lineA) < a.nlines) {
                 // short lines (R3 <= 4): a wave straddles lines, per-lane pointers and masks
-                const int64_t ob = a.out_blocked ? ((int64_t)(ifirst >> 3) * a.nlines + (l0 + lineA)) * IB + (ifirst & (IB - 1))
-                                                 : (int64_t)(l0 + lineA) * a.out_ld + ifirst;
+                const int lsh = l0 + (DUAL ? lineA % LH : lineA);
+                const int64_t ob = a.out_blocked ? ((int64_t)(ifirst >> 3) * a.nlines + lsh) * IB + (ifirst & (IB - 1))
+                                                 : (int64_t)lsh * a.out_ld + ifirst;
                 const int64_t oq = a.out_blocked ? (int64_t)(S1 / IB) * a.nlines * IB : (int64_t)S1;
                 if (wo) wo += ob;
                 if (io) io += ob;
@@ -1235,7 +1256,7 @@ static int kernel_spectrum(psx_fresnel_plan *p, AxisTables &t, double a, double 
 
 template <int R3, bool CONTIG, bool PART = false, bool PAIR = false, bool DUAL = false>
 static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
-    constexpr int M = 576 * R3, LINES = (PAIR || DUAL) ? 1 : TOT / M;        // LINES here: image lines per round
+    constexpr int M = 576 * R3, LINES = PAIR ? 1 : (DUAL ? TOT / M / 2 : TOT / M);        // LINES here: image lines per round
     constexpr size_t lds_bytes = sizeof(float2) * ((size_t)(TOT / M) * (M + M / 32 + (PAIR ? 16 : 0)) + (2 * R3 + RAD) * (RAD + 1));   // lines + the three twiddle tables
     static std::atomic<unsigned long long> attr_mask{0};
     if (first_on_device(attr_mask))
@@ -1307,7 +1328,8 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         // one source for all distances: a workgroup takes the distances of a line group in consecutive rounds and fetches the
         // group once -- but only when there are enough line groups to occupy every CU that way (small grids: 32 groups of 16
         // lines at 512^2 would leave 224 CUs idle; there every (distance, group) pair is its own work item)
-        const int lines_per_group = (e->ax[0].R3 == 16 && nnz >= 2) ? 1 : TOT / (576 * e->ax[0].R3);   // DUAL rounds take one line
+        const int lds_lines = TOT / (576 * e->ax[0].R3);
+        const int lines_per_group = (nnz >= 2 && !e->ax[0].part) ? lds_lines / 2 : lds_lines;   // shared-forward rounds take half the LDS lines
         const int ngroups0 = (p->Ny + lines_per_group - 1) / lines_per_group;
         la.dist_inner = (no_inner || e->ax[0].part || ngroups0 < current_cu_count()) ? 0 : 1;
         la.B = e->ax[0].B; la.Lh = e->ax[0].Lh; la.S = e->ax[0].S; la.NB = e->ax[0].NB;
@@ -1327,13 +1349,19 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         }
         la.w2 = e->ax[0].w2;
         static const bool no_dual = getenv("PSX_NO_DUAL") != nullptr;        // diagnostics: A/B of the shared forward transform
-        if (!no_dual && la.dist_inner && nnz >= 2 && e->ax[0].R3 == 16 && !e->ax[0].part) {
+        if (!no_dual && la.dist_inner && nnz >= 2 && !e->ax[0].part) {
             // one line x two distances per round: the forward transform of a line is shared by the pair
             if (nnz & 1) {
                 la.H[nnz] = la.H[nnz - 1];
                 la.wave_out[nnz] = nullptr;       // odd count: the last pair's second result is computed and dropped
             }
-            if (int rc = launch_lines<16, true, false, false, true>(la, st, "k_fresnel_cols")) return rc;
+            int rc = 0;
+            switch (e->ax[0].R3) {
+                case 4: rc = launch_lines<4, true, false, false, true>(la, st, "k_fresnel_cols"); break;
+                case 8: rc = launch_lines<8, true, false, false, true>(la, st, "k_fresnel_cols"); break;
+                default: rc = launch_lines<16, true, false, false, true>(la, st, "k_fresnel_cols"); break;
+            }
+            if (rc) return rc;
         } else if (int rc = launch_lines_r3<true>(e->ax[0].R3, la, st, "k_fresnel_cols", e->ax[0].part, e->ax[0].pair)) return rc;
     }
 

@@ -360,14 +360,14 @@ def test_integration_md_binding_runs():
         assert np.array_equal(I.cpu().numpy() == 0, g["%d/v2/I_after" % k] == 0)        # in-place zeroing of clamped rays
 
 
-def test_shared_forward_rounds_odd_and_even_distance_counts():
-    """Pass 1 of a multi-distance call at N >= 2305 takes one line x two distances per round (shared forward transform);
-    3 distances leave a half-empty last pair, 2 and 4 none: every image equals the one-distance call's, bit for bit (the
-    arithmetic of a (line, distance) result does not depend on which round computes it), and PSX_NO_DUAL-style rounds are
-    covered by the 2048^2 cases, which never pair."""
+@pytest.mark.parametrize("N", [3000, 2000, 1100])
+def test_shared_forward_rounds_odd_and_even_distance_counts(N):
+    """Pass 1 of a multi-distance call shares the forward transform between the two distances of a round (one image line per
+    round at N >= 2305, two at N >= 1153, four below); 3 or 5 distances leave a half-empty last pair, 2 and 4 none: every
+    image equals the one-distance call's, bit for bit (the arithmetic of a (line, distance) result does not depend on which
+    round computes it)."""
     from paresis_amd import ops
     from paresis_amd.getk import getk
-    N = 3000
     g, T = _membrane(N, 6)
     wave, _ = _stacks(ops, T)
     kk = getk(52000.0)
