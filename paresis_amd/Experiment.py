@@ -272,6 +272,14 @@ class Experiment:
         ed = self.exp_dict
         return self.mySource.source_dict["mySize"] * ed['distObjectToDetector'] / (ed['distSourceToMembrane'] + ed['distMembraneToObject']) / self.myDetector.det_param['myPixelSize'] * ed['overSampling']   # EXP:380
 
+    def _zero_unvisited_bins(self, stacks, nvisited, pointNum):
+        """Bins no energy ever closed (thresholds denser than the spectrum) stay all-zero in the reference (np.zeros,
+        EXP:302-305); the stacks here are uninitialised memory until a bin's detection writes them."""
+        nbins = stacks[0].shape[0]
+        if nvisited < nbins:
+            for k in ((0, 1, 2, 3) if pointNum == 0 else (0, 1)):
+                ops.fill(stacks[k][nvisited:], 0.0)
+
     def _detect_bin(self, ibin, pointNum, stacks, accs):
         """EXP:378-401 / 501-521: detection of the accumulated images of one energy bin.  The detector operator writes
         straight into the output stacks and the shot noise of the bin's images is ONE launch, each image under the key of
@@ -366,6 +374,7 @@ class Experiment:
                 self._detect_bin(ibin, pointNum, stacks, accs)                            # EXP:378-401
                 ibin += 1
                 first = True
+        self._zero_unvisited_bins(stacks, ibin, pointNum)
         self._finish_mean_energy(sums, N[0] * N[1])
         return tuple(stacks)
 
@@ -436,6 +445,7 @@ class Experiment:
                 self._detect_bin(ibin, pointNum, stacks, accs)                            # EXP:501-521
                 ibin += 1
                 first = True
+        self._zero_unvisited_bins(stacks, ibin, pointNum)
         if not ed.get('deferStatus'):
             ops.check_status(dev, "computeSampleAndReferenceImages_RT")                   # RF2:81-82, checked once
         self._finish_mean_energy(sums, N[0] * N[1])
