@@ -250,3 +250,27 @@ def test_cpu_baseline_from_thickness_maps():
         assert relmax(f, np.abs(orc.wave_propagation(w, z, 52.0, geo["M"], (N, N), geo["pix_um"])) ** 2) < 1e-11
         I, phi, _ = orc.set_wave_rt(np.full((N, N), 7500.0), g64, delta, beta, 52.0, 0)
         assert relmax(r, orc.fast_refraction(I, phi, z, 52.0, geo["M"], geo["pix_um"])[0]) < 1e-11
+
+
+def test_cpu_baseline_matches_the_python_oracle_on_random_cases():
+    """Property check of the two independent restatements against each other (C++/OpenMP vs numpy + scalar C): random
+    ragged shapes, phases steep enough to throw rays far beyond the margin and past the clamp, several thread counts."""
+    from hypothesis import given, settings, strategies as st
+    from oracle import cpu_baseline as cb
+
+    @settings(max_examples=25, deadline=None, derandomize=True)
+    @given(nx=st.integers(16, 70), ny=st.integers(16, 70), seed=st.integers(0, 10 ** 6), steep=st.floats(0.01, 40.0),   # margin 15 <= N - 1: one reflection
+           z=st.floats(0.05, 60.0), threads=st.sampled_from([1, 2, 3, 7]))
+    def check(nx, ny, seed, steep, z, threads):
+        rng = np.random.default_rng(seed)
+        I = rng.uniform(0.5, 2.0, (nx, ny))
+        phi = np.cumsum(rng.uniform(-steep, steep, (nx, ny)), axis=0) + np.cumsum(rng.uniform(-steep, steep, (nx, ny)), axis=1)
+        ref, _, _ = orc.fast_refraction(I.copy(), phi.copy(), z, 52.0, 1.02, 1.3)
+        out = cb.fast_refraction(I, phi, z, 52.0, 1.02, 1.3, threads)
+        assert relmax(out, ref) < 1e-10
+        w = rng.normal(size=(nx, ny)) + 1j * rng.normal(size=(nx, ny))
+        a = cb.wave_propagation(w, z, 52.0, 1.02, 1.3, threads)
+        b = orc.wave_propagation(w, z, 52.0, 1.02, (nx, ny), 1.3)
+        assert relmax(a, b) < 1e-10
+
+    check()
