@@ -383,3 +383,28 @@ def test_shared_forward_rounds_odd_and_even_distance_counts(N):
         for i in range(nd):
             assert torch.equal(outs[i], singles[i]), (nd, i)
     plan.close()
+
+
+@pytest.mark.parametrize("shape,nd", [((2400, 600), 3), ((1200, 1100), 2), ((700, 1300), 4), ((2310, 300), 2), ((300, 2310), 3)])
+def test_fresnel_multi_distance_ragged_grids_against_the_oracle(shape, nd):
+    """Non-square grids through a multi-distance call: the two axes use different transform sizes, pass 1 pairs distances
+    (or not: too few line groups to fill the chip at 300 lines) -- every complex field against the float64 oracle."""
+    from paresis_amd import ops
+    from paresis_amd.getk import getk
+    Nx, Ny = shape
+    gen = torch.Generator(device="cuda").manual_seed(Nx * 7 + Ny)
+    w = torch.complex(1.0 + 0.3 * torch.randn(Nx, Ny, device="cuda", generator=gen),
+                      0.3 * torch.randn(Nx, Ny, device="cuda", generator=gen)).to(torch.complex64)
+    kk = getk(52000.0)
+    pix = 2.9
+    h = pix * 1e-6
+    du = (2 * np.pi / (Nx * h), 2 * np.pi / (Ny * h))
+    zs = (0.8, 3.6, 7.2, 11.0)[:nd]
+    M = 1.02
+    plan = ops.FresnelPlan(Nx, Ny, max_dist=nd)
+    outs = plan.propagate([z / (2 * kk * M) for z in zs], [kk * z / M for z in zs], du, wave_in=w)
+    plan.close()
+    w64 = w.cpu().numpy().astype(np.complex128)
+    for z, o in zip(zs, outs):
+        ref = orc.wave_propagation(w64, z, 52.0, M, (Nx, Ny), pix)
+        assert relmax(o.cpu().numpy(), ref) < 1e-5, (shape, z)
