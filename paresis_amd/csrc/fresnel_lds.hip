@@ -1248,7 +1248,11 @@ static int kernel_spectrum(psx_fresnel_plan *p, AxisTables &t, double a, double 
         PSX_TIMED("k_kern_perm", st, k_kern_perm_pair<<<(int)cdiv((int64_t)t.M * t.S, 256), 256, 0, st>>>(t.bufM, reinterpret_cast<float4 *>(k.H), t.M, t.R3, t.S));
     else
         PSX_TIMED("k_kern_perm", st, k_kern_perm<<<(int)cdiv((int64_t)t.M * t.S, 256), 256, 0, st>>>(t.bufM, k.H, t.M, t.R3, t.S));
-    if (int rc = launch_check("kernel spectrum")) return rc;
+    if (int rc = launch_check("kernel spectrum")) {
+        (void)hipFree(k.H);                       // not cached: give the table back
+        e->cache_bytes -= bytes;
+        return rc;
+    }
     e->cache.emplace(key, k);
     *out = k.H;
     return 0;

@@ -606,8 +606,9 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
             PSX_TIMED("k_refract_far", st, k_refract_far<G, true><<<fgrid, FAR_THREADS, 0, st>>>(a, det));
             for (int d = 0; d < a.ndist; ++d)
                 PSX_TIMED("k_det_apply", st, k_det_apply<<<ew_grid((int64_t)npix, 256), 256, 0, st>>>(a.I_out[d], ds.acc + npix * d, ds.mx, (int64_t)npix));
-            if (int rc = launch_check("deterministic far replay")) return rc;
-            return ds.release(st);
+            const int rc_det = launch_check("deterministic far replay");
+            const int rc_rel = ds.release(st);            // the scratch goes back also when a launch failed
+            return rc_det ? rc_det : rc_rel;
         }
         PSX_TIMED("k_refract_far", st, k_refract_far<G><<<fgrid, FAR_THREADS, 0, st>>>(a, DetAcc{nullptr, nullptr}));
         return 0;
@@ -699,8 +700,9 @@ int psx_fastloop_f32(const float *I, const float *Dx, const float *Dy, float *I2
         PSX_TIMED("k_absmax", st, k_absmax<<<ew_grid(n, 256), 256, 0, st>>>(I, n, ds.mx));
         PSX_TIMED("k_fastloop", st, k_fastloop<true><<<ew_grid(n, 256), 256, 0, st>>>(I, Dx, Dy, I2, Nx, Ny, DetAcc{ds.acc, ds.mx}));
         PSX_TIMED("k_det_apply", st, k_det_apply<<<ew_grid(n, 256), 256, 0, st>>>(I2, ds.acc, ds.mx, n));
-        if (int rc = launch_check("k_fastloop (deterministic)")) return rc;
-        return ds.release(st);
+        const int rc_det = launch_check("k_fastloop (deterministic)");
+        const int rc_rel = ds.release(st);
+        return rc_det ? rc_det : rc_rel;
     }
     PSX_TIMED("k_fastloop", st, k_fastloop<false><<<ew_grid(n, 256), 256, 0, st>>>(I, Dx, Dy, I2, Nx, Ny, DetAcc{nullptr, nullptr}));
     return launch_check("k_fastloop");
