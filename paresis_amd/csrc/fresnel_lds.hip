@@ -767,11 +767,19 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 if (wo && emit) {
                     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wo + wbase, 0, welems * 8, 0x00020000);
                     int off = e0 * 8;
+                    if (gp.x == 1.f && gp.y == 0.f) {     // pass 1 (and z-independent callers): no global phase to apply
 #pragma unroll
-                    for (int q = 0; q < RAD; ++q) {
-                        const v2f r = pk_cmul_s(v[q], gp);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, r), rs, off, 0, 0);
-                        off += estep * 8;
+                        for (int q = 0; q < RAD; ++q) {
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v[q]), rs, off, 0, 0);
+                            off += estep * 8;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < RAD; ++q) {
+                            const v2f r = pk_cmul_s(v[q], gp);
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, r), rs, off, 0, 0);
+                            off += estep * 8;
+                        }
                     }
                 }
                 if (io && emit) {
