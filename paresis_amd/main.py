@@ -2,7 +2,7 @@
 """XML-driven entry point (mirror of CodePython/main.py:20-115).
 
     python -m paresis_amd.main [--experiment NAME] [--type RayT|Fresnel] [--oversampling N] [--points N]
-                               [--out DIR] [--format .tif|.edf|.npy] [--xml DIR] [--no-noise] [--seed S]
+                               [--out DIR] [--format .tif|.edf|.npy] [--xml DIR] [--no-noise] [--seed S] [--backend nccl|gloo]
 
 With torchrun (one process per GPU) the membrane positions are strided over the ranks and the detector images are
 gathered on rank 0 over RCCL (paresis_amd/dist.py); results do not depend on the number of GPUs because every position
@@ -98,6 +98,9 @@ def main(argv=None):
     ap.add_argument("--xml", default=None)
     ap.add_argument("--no-noise", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"],
+                    help="torch.distributed backend under torchrun (default: nccl = RCCL on a GPU node; gloo rehearses several "
+                         "ranks on one GPU)")
     a = ap.parse_args(argv)
     exp_dict = {'experimentName': a.experiment, 'filepath': a.out if a.out.endswith('/') else a.out + '/',
                 'overSampling': a.oversampling, 'nbExpPoints': a.points, 'simulation_type': a.type,
@@ -105,7 +108,7 @@ def main(argv=None):
     if a.xml:
         exp_dict['xmlDir'] = a.xml
     os.makedirs(exp_dict['filepath'], exist_ok=True)
-    run(exp_dict, save=True, saving_format=a.format)
+    run(exp_dict, save=True, saving_format=a.format, backend=a.backend)
 
 
 if __name__ == "__main__":
