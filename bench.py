@@ -366,9 +366,12 @@ def positions_batch(a, sim, N, rank, world, dev):
 
     for p in (P + 1 + rank, P + 1 + world + rank):       # untimed: plans, sphere list on the GPU, allocator pools
         position(p)
-    if world > 1:                                        # and the gather path (communicator set-up)
-        w = torch.zeros(8, device=cpu_dev)
-        td.gather(w, [torch.empty_like(w) for _ in range(world)] if rank == 0 else None, dst=0)
+    if world > 1:
+        # and the gather path at its full size: communicator and peer connections, the packing kernels, and the caching
+        # allocator's blocks for the staging buffers (a first-time hipMalloc of ~2 GiB on rank 0 would land in the timed region)
+        warm = position(P + 1 + rank)
+        dist.gather_positions({p: warm for p in mine}, P, rank, world, to_host=False)
+        del warm
     # The interpreter's cyclic garbage collector would otherwise run a full collection somewhere in the first positions
     # (hundreds of thousands of objects allocated by the set-up above: ~40-60 ms of host time with the GPU idle -- the
     # one-off stall DESIGN.md round 1 could not explain).  Collect now, then keep the survivors out of later collections.
@@ -409,6 +412,7 @@ def positions_batch(a, sim, N, rank, world, dev):
            "per_rank_compute_ms": [round(float(t[1]) * 1e3, 3) for t in per_rank],
            "gather_ms": round(max(float(t[2]) for t in per_rank) * 1e3, 3),
            "gathered_bytes": int(sum(v[0].numel() + v[1].numel() for v in gathered.values()) * 4),
+           "gather_wire_bytes": dist.last_gather.get("wire_bytes"), "gather_packed_u16": dist.last_gather.get("packed"),
            "timed_region": "synthesis + chain + detection + shot noise of every position + the gather onto rank 0 (images stay "
                            "in rank 0's HBM)", "backend": a.backend if world > 1 else None}
     if marks:

@@ -182,6 +182,17 @@ int psx_poisson_f32(const float *lam, float *out, int64_t n, uint64_t seed, void
  * psx_poisson_f32(imgs[i], imgs[i], n, seeds[i]) would leave it. */
 #define PSX_MAX_POISSON 8
 int psx_poisson_multi_f32(float *const *imgs, const uint64_t *seeds, int nimg, int64_t n, void *stream);
+/* Photon-count images as 16-bit integers for the gather of the per-position stacks (main.py:63-110 keeps every position's
+ * images on one host; here they cross xGMI once): dst[p] = src[p] for counts below 65535; a larger count leaves the escape
+ * code 65535 in dst and the pair (index0 + p, count) in exc[cap][2], *exc_count counting them (both device memory, the count
+ * zeroed by the caller; index0 + n < 2^32).  *overflow (a device int the caller zeroed) is raised when some src[p] is not an
+ * integer in [0, 2^24] or the table is full -- the caller then moves the float32 image instead, so the round trip is lossless
+ * or not taken.  psx_unpack_counts_u16 is the inverse over a whole buffer: widen n pixels, then write back the exceptions
+ * whose index is below n (cap = 0: none). */
+int psx_pack_counts_u16(const float *src, uint16_t *dst, int64_t n, int64_t index0, int32_t *exc, int32_t *exc_count, int cap,
+                        int *overflow, void *stream);
+int psx_unpack_counts_u16(const uint16_t *src, float *dst, int64_t n, const int32_t *exc, const int32_t *exc_count, int cap,
+                          void *stream);
 
 /* ---- dark-field refraction, second half: the per-pixel variable-width Gaussian re-splat of
  * fastRefractionDF (refractionFileNumba2.py:168-186).  I2DF: refracted dark-field intensity, DF: dark-field width in

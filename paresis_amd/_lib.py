@@ -60,6 +60,8 @@ PROTOTYPES = {
     "psx_resize_f32": (c_int, [_vp, c_int, c_int, _vp, c_int, c_int, _vp]),
     "psx_poisson_f32": (c_int, [_vp, _vp, c_int64, c_uint64, _vp]),
     "psx_poisson_multi_f32": (c_int, [_vpp, POINTER(c_uint64), c_int, c_int64, _vp]),
+    "psx_pack_counts_u16": (c_int, [_vp, _vp, c_int64, c_int64, _vp, _vp, c_int, _vp, _vp]),
+    "psx_unpack_counts_u16": (c_int, [_vp, _vp, c_int64, _vp, _vp, c_int, _vp]),
     "psx_status_scan_f32": (c_int, [_vp, c_int64, _vp, _vp]),
     "psx_darkfield_workspace_bytes": (c_size_t, [c_int, c_int]),
     "psx_darkfield_blur_f32": (c_int, [_vp, _vp, _vp, _vp, c_int, c_int, c_int, _vp, _vp]),

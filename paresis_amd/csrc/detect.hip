@@ -307,6 +307,71 @@ __global__ __launch_bounds__(256) void k_resize(const float *__restrict__ img, i
     }
 }
 
+// ---- photon-count images as 16-bit integers (the gather of main.py's per-position stacks moves half the bytes) ----------
+// dst[p] = src[p] for counts below 65535; a larger count leaves the escape code 65535 and an entry (index0 + p, count) in the
+// exception table exc[cap][2] (rare: caustic peaks).  *overflow is raised when some src[p] is not an integer in [0, 2^24] or
+// the table is full -- dst is then not a copy of src and the caller sends the float32 image instead.  Eight pixels per
+// thread: two 16-byte loads, one 16-byte store.
+__global__ __launch_bounds__(256) void k_pack_u16(const float *__restrict__ src, uint16_t *__restrict__ dst, int64_t n,
+                                                  int64_t index0, int32_t *__restrict__ exc, int32_t *__restrict__ exc_count,
+                                                  int cap, int *__restrict__ overflow) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    auto cvt = [&](float x, int64_t p) {
+        const float c = fminf(fmaxf(x, 0.f), 16777216.f);
+        unsigned q = (unsigned)c;
+        bad |= !((float)q == x);                     // NaN, inf, negatives, fractions and counts above 2^24 all land here
+        if (q >= 65535u) {
+            const int e = atomicAdd(exc_count, 1);
+            if (e < cap) {
+                exc[2 * e] = (int32_t)(index0 + p);
+                exc[2 * e + 1] = (int32_t)q;
+            } else {
+                bad = true;
+            }
+            q = 65535u;
+        }
+        return q;
+    };
+    const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    const int64_t n8 = vec ? n / 8 : 0;
+    for (int64_t g = t0; g < n8; g += stride) {
+        const float4 a = reinterpret_cast<const float4 *>(src)[2 * g], b = reinterpret_cast<const float4 *>(src)[2 * g + 1];
+        uint4 o;
+        o.x = cvt(a.x, 8 * g) | (cvt(a.y, 8 * g + 1) << 16);
+        o.y = cvt(a.z, 8 * g + 2) | (cvt(a.w, 8 * g + 3) << 16);
+        o.z = cvt(b.x, 8 * g + 4) | (cvt(b.y, 8 * g + 5) << 16);
+        o.w = cvt(b.z, 8 * g + 6) | (cvt(b.w, 8 * g + 7) << 16);
+        reinterpret_cast<uint4 *>(dst)[g] = o;
+    }
+    for (int64_t p = n8 * 8 + t0; p < n; p += stride) dst[p] = (uint16_t)cvt(src[p], p);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(overflow, 1);
+}
+
+__global__ __launch_bounds__(256) void k_unpack_u16(const uint16_t *__restrict__ src, float *__restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    const int64_t n8 = vec ? n / 8 : 0;
+    for (int64_t g = t0; g < n8; g += stride) {
+        const uint4 q = reinterpret_cast<const uint4 *>(src)[g];
+        reinterpret_cast<float4 *>(dst)[2 * g] = make_float4((float)(q.x & 0xffffu), (float)(q.x >> 16), (float)(q.y & 0xffffu), (float)(q.y >> 16));
+        reinterpret_cast<float4 *>(dst)[2 * g + 1] = make_float4((float)(q.z & 0xffffu), (float)(q.z >> 16), (float)(q.w & 0xffffu), (float)(q.w >> 16));
+    }
+    for (int64_t p = n8 * 8 + t0; p < n; p += stride) dst[p] = (float)src[p];
+}
+
+// the escaped counts go back in (after k_unpack_u16 on the same stream)
+__global__ __launch_bounds__(256) void k_unpack_exceptions(float *__restrict__ dst, int64_t n, const int32_t *__restrict__ exc,
+                                                           const int32_t *__restrict__ exc_count, int cap) {
+    const int m = min(*exc_count, cap);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < m; e += gridDim.x * blockDim.x) {
+        const int64_t p = (uint32_t)exc[2 * e];
+        if (p < n) dst[p] = (float)(uint32_t)exc[2 * e + 1];
+    }
+}
+
 // ---- Philox4x32-10 counter-based generator -----------------------------------------------------------------------
 struct Philox {
     uint32_t c[4], k[2];
@@ -690,6 +755,26 @@ int psx_poisson_multi_f32(float *const *imgs, const uint64_t *seeds, int nimg, i
     if (n == 0) return 0;
     PSX_TIMED("k_poisson", (hipStream_t)stream, k_poisson<<<dim3(ew_grid(n, 256, 4), nimg), 256, 0, (hipStream_t)stream>>>(im, nullptr, n));
     return launch_check("k_poisson");
+}
+
+int psx_pack_counts_u16(const float *src, uint16_t *dst, int64_t n, int64_t index0, int32_t *exc, int32_t *exc_count, int cap,
+                        int *overflow, void *stream) {
+    PSX_REQUIRE(src && dst && exc && exc_count && overflow && n >= 0 && cap >= 0 && index0 >= 0,
+                "psx_pack_counts_u16: null pointer or negative size");
+    PSX_REQUIRE(index0 + n <= (int64_t)0xffffffffLL, "psx_pack_counts_u16: the exception table holds 32-bit pixel indices");
+    if (n == 0) return 0;
+    PSX_TIMED("k_pack_u16", (hipStream_t)stream, k_pack_u16<<<ew_grid(n, 256, 8), 256, 0, (hipStream_t)stream>>>(src, dst, n, index0, exc, exc_count, cap, overflow));
+    return launch_check("k_pack_u16");
+}
+
+int psx_unpack_counts_u16(const uint16_t *src, float *dst, int64_t n, const int32_t *exc, const int32_t *exc_count, int cap,
+                          void *stream) {
+    PSX_REQUIRE(src && dst && n >= 0 && cap >= 0 && (cap == 0 || (exc && exc_count)), "psx_unpack_counts_u16: null pointer or negative size");
+    if (n == 0) return 0;
+    PSX_TIMED("k_unpack_u16", (hipStream_t)stream, k_unpack_u16<<<ew_grid(n, 256, 8), 256, 0, (hipStream_t)stream>>>(src, dst, n));
+    if (cap > 0)
+        PSX_TIMED("k_unpack_exceptions", (hipStream_t)stream, k_unpack_exceptions<<<ew_grid(cap, 256, 4), 256, 0, (hipStream_t)stream>>>(dst, n, exc, exc_count, cap));
+    return launch_check("k_unpack_u16");
 }
 
 }  // extern "C"

@@ -52,41 +52,123 @@ def owner(position, world):
     return position % world
 
 
-def gather_positions(results, n_positions, rank, world, dst=0, to_host=True):
+last_gather = {}          # what the last gather_positions() moved: {"packed": bool, "wire_bytes": bytes received by dst}
+
+
+class _CountsWire:
+    """One rank's contribution as bytes: [n 16-bit counts | pad to 8 | exception count, 0 (int32) | cap x (index, count)
+    (int32)].  Counts >= 65535 are escaped into the exception table (rare: caustic peaks), so the packing is lossless for
+    any integer image below 2^24 whose bright pixels fit the table (one per 256 pixels)."""
+
+    def __init__(self, n, device, like=None):
+        self.n = n
+        self.cap = max(64, n // 256)
+        self.off = (2 * n + 7) // 8 * 8
+        self.bytes = torch.empty(self.off + 8 + 8 * self.cap, dtype=torch.uint8, device=device) if like is None else like
+        self.counts = self.bytes[:2 * n].view(torch.int16)
+        self.head = self.bytes[self.off:self.off + 8].view(torch.int32)
+        self.exc = self.bytes[self.off + 8:].view(torch.int32)
+
+    def pack(self, img, index0, flag):
+        """Counts of img into slots [index0, index0 + img.numel()); flag raised when img cannot be packed."""
+        out = self.counts[index0:index0 + img.numel()]
+        if img.device != out.device:                      # gloo rehearsal of images computed on the GPU
+            img = img.to(out.device)
+        img = img.contiguous().view(-1)
+        if img.is_cuda:                                   # HIP kernel; the host restatement below serves the gloo rehearsal
+            from . import ops
+            ops.pack_counts(img, out, index0, self.exc, self.head[:1], flag)
+            return
+        q = img.clamp(0, 16777216).to(torch.int32)
+        if not bool((q.to(torch.float32) == img).all()):
+            flag.fill_(1)
+        big = torch.nonzero(q >= 65535).view(-1)
+        e0 = int(self.head[0])
+        self.head[0] = e0 + big.numel()
+        if e0 + big.numel() > self.cap:
+            flag.fill_(1)
+        else:
+            tab = self.exc.view(-1, 2)
+            tab[e0:e0 + big.numel(), 0] = (big + index0).to(torch.int32)
+            tab[e0:e0 + big.numel(), 1] = q[big]
+        out.copy_(q.clamp(max=65535).to(torch.int16))     # two's complement wrap: the uint16 bit pattern
+
+    def unpack(self):
+        if self.bytes.is_cuda:
+            from . import ops
+            return ops.unpack_counts(self.counts, torch.empty(self.n, dtype=torch.float32, device=self.bytes.device),
+                                     self.exc, self.head[:1])
+        out = (self.counts.to(torch.int32) & 0xFFFF).to(torch.float32)
+        m = min(int(self.head[0]), self.cap)
+        tab = self.exc.view(-1, 2)[:m]
+        out[tab[:, 0].to(torch.int64)] = tab[:, 1].to(torch.float32)
+        return out
+
+
+def gather_positions(results, n_positions, rank, world, dst=0, to_host=True, pack=True):
     """results: {position: tuple of tensors} computed on this rank.  Returns on `dst` a dict with every position
     (tensors on the host, or left in `dst`'s HBM with to_host=False), {} elsewhere.
 
     ONE fixed-shape gather for the whole run: every rank contributes the Sample/Reference stacks of its positions
     [rounds][2][nbins][n][n] (slot t = position t*world + rank, zeros when it has none) -- 7 point-to-point transfers into
-    rank `dst` over xGMI, no ring."""
+    rank `dst` over xGMI, no ring.  `dst`'s inbound links bound it, so with pack=True detector images that are photon
+    counts (integers: the shot-noise output) cross as 16-bit integers plus a short table of the pixels above 65534, half
+    the bytes, and are widened again on `dst`; the packing checks every pixel and any rank finding something else makes ALL
+    ranks send float32, so what arrives is bit for bit what was computed either way."""
     host = lambda tup: tuple(t.detach().cpu() if isinstance(t, torch.Tensor) and to_host else t for t in tup)
+    last_gather.clear()
     if world == 1:
         return {p: host(v) for p, v in results.items()}
     out = {}
+    dev = _dev()
     rounds = (n_positions + world - 1) // world
     proto = None
     for v in results.values():
         proto = v
         break
-    shape_t = torch.zeros(4, dtype=torch.int64, device=_dev())
+    shape_t = torch.zeros(4, dtype=torch.int64, device=dev)
     if proto is not None:
         shape_t[:3] = torch.tensor(proto[0].shape, dtype=torch.int64)
         shape_t[3] = 1
     td.all_reduce(shape_t, op=td.ReduceOp.MAX)          # ranks without work learn the stack shape
     shape = tuple(int(v) for v in shape_t[:3])
-    mine = torch.empty((rounds, 2) + shape, dtype=torch.float32, device=_dev())
-    for t in range(rounds):
-        p = t * world + rank
-        if p in results:
-            mine[t, 0].copy_(results[p][0])
-            mine[t, 1].copy_(results[p][1])
-        else:
-            mine[t].zero_()
+    per_img = shape[0] * shape[1] * shape[2]
+    n_all = rounds * 2 * per_img
+    wire = None
+    if pack and n_all < 2 ** 31:
+        wire = _CountsWire(n_all, dev)
+        wire.head.zero_()
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        for t in range(rounds):
+            p = t * world + rank
+            if p in results:
+                wire.pack(results[p][0], (2 * t) * per_img, flag)
+                wire.pack(results[p][1], (2 * t + 1) * per_img, flag)
+            else:
+                wire.counts[2 * t * per_img:(2 * t + 2) * per_img].zero_()
+        td.all_reduce(flag, op=td.ReduceOp.MAX)          # one image that is not photon counts anywhere: everybody sends float32
+        if int(flag.item()):
+            wire = None
+    packed = wire is not None
+    if packed:
+        mine = wire.bytes
+    else:
+        mine = torch.empty((rounds, 2) + shape, dtype=torch.float32, device=dev)
+        for t in range(rounds):
+            p = t * world + rank
+            if p in results:
+                mine[t, 0].copy_(results[p][0])
+                mine[t, 1].copy_(results[p][1])
+            else:
+                mine[t].zero_()
     bucket = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
     td.gather(mine, bucket, dst=dst)
+    last_gather.update(packed=packed, wire_bytes=(world - 1) * mine.numel() * mine.element_size() if rank == dst else 0)
     if rank == dst:
         if to_host:
             bucket = [b.cpu() for b in bucket]
+        if packed:
+            bucket = [_CountsWire(n_all, b.device, like=b).unpack().view((rounds, 2) + shape) for b in bucket]
         for r in range(world):
             for t in range(rounds):
                 q = t * world + r

@@ -466,6 +466,34 @@ def poisson_multi(imgs, seeds):
     return imgs
 
 
+def pack_counts(src, dst, index0, exc, exc_count, overflow):
+    """dst (int16 storage, read as uint16) = src as 16-bit photon counts; counts >= 65535 leave the escape code 65535 and
+    (index0 + p, count) in the exception table exc (int32 [cap, 2]; exc_count int32 [1] counts them); overflow (int32 [1])
+    is raised when src is not all integers in [0, 2^24] or the table is full -- dst is then not to be used."""
+    _need(src, torch.float32, "src")
+    _need(dst, torch.int16, "dst", src.shape)
+    _need(exc, torch.int32, "exc")
+    _need(exc_count, torch.int32, "exc_count")
+    _need(overflow, torch.int32, "overflow")
+    check(lib().psx_pack_counts_u16(_ptr(src), _ptr(dst), src.numel(), int(index0), _ptr(exc), _ptr(exc_count),
+                                    exc.numel() // 2, _ptr(overflow), _stream()), "psx_pack_counts_u16")
+    return dst
+
+
+def unpack_counts(src, dst, exc=None, exc_count=None):
+    """dst (float32) = the 16-bit counts of src (int16 storage, read as uint16), then the exceptions of pack_counts."""
+    _need(src, torch.int16, "src")
+    _need(dst, torch.float32, "dst", src.shape)
+    cap = 0
+    if exc is not None:
+        _need(exc, torch.int32, "exc")
+        _need(exc_count, torch.int32, "exc_count")
+        cap = exc.numel() // 2
+    check(lib().psx_unpack_counts_u16(_ptr(src), _ptr(dst), src.numel(), _ptr(exc) if cap else None,
+                                      _ptr(exc_count) if cap else None, cap, _stream()), "psx_unpack_counts_u16")
+    return dst
+
+
 def status_scan(img):
     _need(img, torch.float32, "img")
     check(lib().psx_status_scan_f32(_ptr(img), img.numel(), _ptr(status_word(img.device)), _stream()),

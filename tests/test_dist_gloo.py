@@ -14,7 +14,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_positions, q):
+def _worker(rank, world, port, n_positions, q, kind="counts"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     from paresis_amd import dist
@@ -23,28 +23,47 @@ def _worker(rank, world, port, n_positions, q):
     mine = dist.my_positions(n_positions, r, w)
     # stand-in for computeSampleAndReferenceImages: images that encode (position, kind); position 0 has Propag/White too
     results = {}
-    for p in mine:
+    # "counts": integer images up to 65535 (cross as 16-bit); "fractions": noise-free images (float32 on the wire);
+    # "one_rank_fractions": only rank 1 holds a non-integer pixel -- every rank must then fall back together
+    def images(p):
         S = torch.full((2, 5, 7), 10.0 * p + 1.0)
         R = torch.full((2, 5, 7), 10.0 * p + 2.0)
-        results[p] = (S, R, torch.full((2, 5, 7), 3.0), torch.full((2, 5, 7), 4.0)) if p == 0 else (S, R)
+        S[0, 0, 1], R[1, 0, 0], R[0, 1, 1], S[1, 4, 6] = 65535.0, 32768.0, 65536.0 + p, 16777216.0    # escapes included
+        if kind == "fractions" or (kind == "one_rank_fractions" and p == 1):
+            S[1, 2, 3] = 0.25
+        if kind == "too_large" and p == 2:
+            R[0, 1, 2] = 16777218.0                       # an integer in float32, beyond the packed range
+        if kind == "many_bright" and p == 3:
+            S[:] = 70000.0                                # more escapes than the table holds
+        return S, R
+    for p in mine:
+        S, R = images(p)
+        results[p] = (S, R, torch.full((2, 5, 7), 3.5), torch.full((2, 5, 7), 4.0)) if p == 0 else (S, R)
     out = dist.gather_positions(results, n_positions, r, w)
+    packed = dist.last_gather.get("packed")
     dist.finish()
     if r == 0:
-        ok = sorted(out) == list(range(n_positions))
+        ok = sorted(out) == list(range(n_positions)) and packed == (kind == "counts")
+        ok = ok and dist.last_gather["wire_bytes"] == (3 * 2 * 70 * 2 + 8 + 8 * 64 if packed else 3 * 2 * 70 * 4)
         for p in range(n_positions):
-            ok = ok and float(out[p][0][0, 0, 0]) == 10.0 * p + 1.0 and float(out[p][1][1, 4, 6]) == 10.0 * p + 2.0
-        ok = ok and len(out[0]) == 4 and float(out[0][3][0, 0, 0]) == 4.0
+            S, R = images(p)
+            ok = ok and torch.equal(out[p][0], S) and torch.equal(out[p][1], R) and out[p][0].dtype == torch.float32
+        ok = ok and len(out[0]) == 4 and float(out[0][3][0, 0, 0]) == 4.0 and float(out[0][2][0, 0, 0]) == 3.5
         q.put(bool(ok))
     else:
         q.put(out == {})
     torch.distributed.destroy_process_group()
 
 
-def test_gather_positions_world2():
+import pytest
+
+
+@pytest.mark.parametrize("kind", ["counts", "fractions", "one_rank_fractions", "too_large", "many_bright"])
+def test_gather_positions_world2(kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 5, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 5, q, kind)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

@@ -425,3 +425,52 @@ def test_deterministic_order_mode(ops):
     I2 = torch.zeros_like(Il)
     ops.fastloop(Il, Dxl, Dyl, I2)
     assert float((I2 - outs[0]).abs().max() / outs[0].abs().max()) < 2e-6
+
+
+def test_pack_counts_roundtrip_and_overflow(ops):
+    """psx_pack_counts_u16 / psx_unpack_counts_u16 (the gather of the per-position stacks moves photon counts as 16-bit
+    integers): exact round trip for every count 0..65534 and, through the exception table, for larger counts up to 2^24;
+    vector body and scalar tail, unaligned starts, a non-zero index base; the flag is raised by a fraction, a negative,
+    2^24 + 2, NaN and inf -- wherever it sits -- and by a full table, and by nothing else."""
+    from paresis_amd._lib import PsxError
+    g = torch.Generator(device="cuda").manual_seed(5)
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for n, off in ((65536 + 8 * 300 + 5, 0), (4099, 1), (7, 0), (1 << 20, 3)):
+        src = torch.randint(0, 65535, (n + off,), generator=g, device="cuda").to(torch.float32)
+        if n >= 65536:
+            src[off:off + 65536] = torch.arange(65536, device="cuda", dtype=torch.float32)
+        s = src[off:]
+        bright = torch.randint(0, n, (min(20, n),), generator=g, device="cuda")
+        s[bright] = torch.randint(65535, 1 << 24, (bright.numel(),), generator=g, device="cuda").to(torch.float32)
+        s[n - 1] = 16777216.0
+        exc = torch.zeros((64, 2), dtype=torch.int32, device="cuda")
+        packed = torch.empty(n + off, dtype=torch.int16, device="cuda")[off:]
+        cnt.zero_()
+        ops.pack_counts(s, packed, 0, exc, cnt, flag)
+        assert int(flag.item()) == 0 and 1 <= int(cnt.item()) <= 22
+        small = s < 65535
+        assert torch.equal((packed.to(torch.int32) & 0xFFFF)[small], s.to(torch.int32)[small])
+        assert bool(((packed.to(torch.int32) & 0xFFFF)[~small] == 65535).all())
+        back = ops.unpack_counts(packed, torch.empty(n + off, dtype=torch.float32, device="cuda")[off:], exc, cnt)
+        assert torch.equal(back, s)
+        # two images into one buffer: the second one's exceptions carry its index base
+        both = torch.empty(2 * n, dtype=torch.int16, device="cuda")
+        cnt.zero_()
+        ops.pack_counts(s, both[:n], 0, exc, cnt, flag)
+        ops.pack_counts(s.flip(0).contiguous(), both[n:], n, exc, cnt, flag)
+        back = ops.unpack_counts(both, torch.empty(2 * n, dtype=torch.float32, device="cuda"), exc, cnt)
+        assert int(flag.item()) == 0 and torch.equal(back[:n], s) and torch.equal(back[n:], s.flip(0))
+        for bad in (0.5, -1.0, 16777218.0, float("nan"), float("inf"), 1e30):
+            for where in (0, n // 2, n - 1):
+                t = s.clone()
+                t[where] = bad
+                flag.zero_(); cnt.zero_()
+                ops.pack_counts(t, packed, 0, exc, cnt, flag)
+                assert int(flag.item()) == 1, (bad, where)
+        flag.zero_(); cnt.zero_()
+        ops.pack_counts(s, packed, 0, exc[:1], cnt, flag)                 # a one-entry table: full
+        assert int(flag.item()) == (1 if int(cnt.item()) > 1 else 0) and int(cnt.item()) >= 2
+        flag.zero_()
+    with pytest.raises(PsxError):
+        ops.pack_counts(torch.zeros(4, device="cuda"), torch.zeros(5, dtype=torch.int16, device="cuda"), 0, exc, cnt, flag)
