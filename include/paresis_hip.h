@@ -221,6 +221,13 @@ int psx_membrane_plan_create(const double *x, const double *y, const double *r, 
 int psx_membrane_plan_destroy(psx_membrane_plan *plan);
 int psx_membrane_layer_f32(psx_membrane_plan *plan, int offx, int offy, int dimX, int dimY, int margin, int margin2,
                            double scale, int accumulate, float *out, void *stream);
+/* Every layer of a membrane position in ONE launch (getMembraneFromFile.py:139-159 loops over nbOfLayers offsets and adds
+ * into one float64 map): the chords of all nlayers offsets (offx, offy: HOST arrays) are summed in float64 and stored
+ * once; nlayers = 0 stores zeros.  support (may be NULL) is the position's second map, the uniform support thickness
+ * (getMembraneFromFile.py:163), filled with support_value by the same launch. */
+int psx_membrane_layers_f32(psx_membrane_plan *plan, int nlayers, const int *offx, const int *offy, int dimX, int dimY,
+                            int margin, int margin2, double scale, int accumulate, float *out, float *support,
+                            float support_value, void *stream);
 
 /* ---- per-kernel timing (bench.py's roofline leg) ----------------------------------------------------------------------
  * psx_profile_enable(1) clears the log and makes every kernel launch of the library record a HIP event pair on the

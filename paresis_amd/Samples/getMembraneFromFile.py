@@ -146,16 +146,14 @@ def getMembraneSegmentedFromFile(sample, dimX, dimY, pixSize, pointNum, supportT
     # the caller needs no torch.stack copy; geom[0].base-style access: the stack is returned as the third list entry
     stack = torch.empty((2, dimX, dimY), dtype=torch.float32, device=dev) if stacked else None
     membrane = stack[0] if stacked else torch.empty((dimX, dimY), dtype=torch.float32, device=dev)
-    st = c_void_p(torch.cuda.current_stream().cuda_stream)
-    for li, (ox, oy) in enumerate(offs):
-        check(lib().psx_membrane_layer_f32(plan.h, ox, oy, dimX, dimY, plan.margin, plan.margin2, c_double(pixSize * 1e-6),
-                                           1 if li else 0, c_void_p(membrane.data_ptr()), st), "psx_membrane_layer_f32")
-    if not offs:
-        from .. import ops as _ops
-        _ops.fill(membrane, 0.0)
-    from .. import ops
     support = stack[1] if stacked else torch.empty((dimX, dimY), dtype=torch.float32, device=dev)
-    ops.fill(support, float(supportThickness) * 1e-6)     # the library's own kernel: the position loop launches no PyTorch kernel
+    st = c_void_p(torch.cuda.current_stream().cuda_stream)
+    # every layer and the uniform support map in ONE launch of the library (the position loop launches no PyTorch kernel)
+    ox = (ctypes.c_int * max(1, len(offs)))(*[int(o[0]) for o in offs])
+    oy = (ctypes.c_int * max(1, len(offs)))(*[int(o[1]) for o in offs])
+    check(lib().psx_membrane_layers_f32(plan.h, len(offs), ox, oy, dimX, dimY, plan.margin, plan.margin2,
+                                        c_double(pixSize * 1e-6), 0, c_void_p(membrane.data_ptr()), c_void_p(support.data_ptr()),
+                                        ctypes.c_float(float(supportThickness) * 1e-6), st), "psx_membrane_layers_f32")
     parameters_dic = {'Average sphere radius': (sample.myMeanSphereRadius, 'um'),
                       'Number of layers': (sample.myNbOfLayers, ''),
                       'Support total thickness': (supportThickness, 'um')}

@@ -69,6 +69,8 @@ PROTOTYPES = {
     "psx_membrane_plan_create": (c_int, [_dp, _dp, _dp, c_int64, _vpp]),
     "psx_membrane_plan_destroy": (c_int, [_vp]),
     "psx_membrane_layer_f32": (c_int, [_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_int, _vp, _vp]),
+    "psx_membrane_layers_f32": (c_int, [_vp, c_int, POINTER(c_int), POINTER(c_int), c_int, c_int, c_int, c_int, c_double, c_int,
+                                        _vp, _vp, c_float, _vp]),
     "psx_debug_stamps": (c_int, [_vp]),
     "psx_profile_enable": (c_int, [c_int]),
     "psx_profile_summary": (c_int, [ctypes.c_char_p, c_size_t]),

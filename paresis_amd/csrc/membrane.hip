@@ -76,78 +76,142 @@ struct CellSphere {
     double x, y, r;     // pixels of the list frame (par / pixSize)
 };
 
-__global__ __launch_bounds__(256) void k_membrane_cells(const CellSphere *__restrict__ spheres,
-                                                        const int *__restrict__ cell_off, int ncx, int ncy, double x0,
-                                                        double y0, int rmax_int, int offx, int offy,
-                                                        float *__restrict__ out, int dimX, int dimY, int margin,
-                                                        int margin2, int tiles_y, double scale, int accumulate) {
-    __shared__ Sphere sh[64];
-    __shared__ int shcnt;
+// ---- all layers of a position in ONE launch, sphere-centric ------------------------------------------------------------
+// A pixel-centric tile (k_membrane above, one or four pixels per lane walking the tile's spheres) spends its float64 chord
+// sequences at ~10-20 % lane occupancy: a sphere is ~10 pixels wide, a wave's pixels are 64.  Here a workgroup owns a
+// 32 x 32 tile of 64-bit fixed-point accumulators in LDS (2^-36 pixel; integer adds commute, so the map is bitwise
+// reproducible whatever the order) and 16 lanes take ONE sphere: a lane per window column, a loop over the window rows
+// clipped to the tile, ds_add_u64 per chord.  Staging is by "job" = (layer, cell row of the list frame): a half-wave
+// compacts the spheres of one job whose window meets the tile, eight jobs per round -- both layers of the usual two-layer
+// membrane in one round -- into one flat list.  The layers of a position (same list, one integer offset each,
+// getMembraneFromFile.py:139-142) are summed before the single store, and the uniform support map is written by the same launch.
+constexpr int ML_MAX = 8;        // layers per launch
+constexpr int ML_SEGS = 8;       // jobs staged per round
+constexpr int ML_CAP = 32;       // spheres per job and batch
+constexpr int ML_FRAC = 36;      // fractional bits of the accumulators: chords below 2^14 pixels, sums below 2^27
+
+struct LayerArgs {
+    int offx[ML_MAX], offy[ML_MAX];
+    int nlayers, rows;           // rows: upper bound of the cell rows one layer's tile window can meet
+};
+
+struct StagedSphere {
+    double xf, yf, r2;
+    int xi, yi, radInt, pad;
+};
+
+// sqrt of a positive float64 from the float32 reciprocal square root and one Newton step in float64 (relative error
+// ~2e-14; the library's correctly rounded sqrt costs three times the instructions and the result is stored as float32)
+__device__ __forceinline__ double chord_sqrt(double t) {
+    const float tf = fmaxf((float)t, 1e-30f);
+    const double y = (double)__builtin_amdgcn_rsqf(tf);
+    const double s0 = t * y, h0 = 0.5 * y;
+    const double r = fma(-s0, h0, 0.5);
+    return fma(s0, r, s0);
+}
+
+__global__ __launch_bounds__(256) void k_membrane_layers(const CellSphere *__restrict__ spheres,
+                                                         const int *__restrict__ cell_off, int ncx, int ncy, double x0,
+                                                         double y0, int rmax_int, LayerArgs la, float *__restrict__ out,
+                                                         float *__restrict__ support, float support_value, int dimX,
+                                                         int dimY, int margin, int margin2, int tiles_y, double scale,
+                                                         int accumulate) {
+    __shared__ unsigned long long acc[MT * MT];
+    __shared__ StagedSphere flat[ML_SEGS * ML_CAP];
+    __shared__ int shcnt[ML_SEGS], shrem[ML_SEGS];
     const int tile = blockIdx.x, t0 = (tile / tiles_y) * MT, c0 = (tile % tiles_y) * MT;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 columns x 8 rows; each thread owns 4 rows
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    const int py = c0 + tx + margin;
-    // cells whose spheres can reach this tile: |centre - pixel| <= radInt + 1/2 on each axis
-    const double xlo = (double)(offx + t0 + margin - rmax_int - 1) - x0, xhi = (double)(offx + t0 + margin + MT + rmax_int + 1) - x0;
-    const double ylo = (double)(offy + c0 + margin - rmax_int - 1) - y0, yhi = (double)(offy + c0 + margin + MT + rmax_int + 1) - y0;
-    const int cx0 = max(0, (int)floor(xlo / MT)), cx1 = min(ncx - 1, (int)floor(xhi / MT));
-    const int cy0 = max(0, (int)floor(ylo / MT)), cy1 = min(ncy - 1, (int)floor(yhi / MT));
-    for (int cx = cx0; cx <= cx1 && cy0 <= cy1; ++cx) {
-        const int beg = cell_off[cx * ncy + cy0], end = cell_off[cx * ncy + cy1 + 1];
-        for (int base = beg; base < end; base += 64) {
-            const int nraw = min(64, end - base);
-            __syncthreads();
-            if (threadIdx.x < 64) {                  // the first wave stages and compacts: only spheres whose window meets the tile
-                Sphere sp = {};
-                bool hit = false;
-                if (threadIdx.x < nraw) {
-                    const CellSphere cs = spheres[base + threadIdx.x];
-                    sp.xf = cs.x - (double)offx;                                   // getMembraneFromFile.py:141-142
-                    sp.yf = cs.y - (double)offy;
-                    sp.r = cs.r;
-                    sp.xi = (int)rint(sp.xf);                                      // np.round: half to even
-                    sp.yi = (int)rint(sp.yf);
-                    const bool ok = cs.r > 0.0 && margin2 < sp.xi && sp.xi < dimX + margin + margin2 && margin2 < sp.yi &&
-                                    sp.yi < dimY + margin + margin2;               // :152
-                    sp.radInt = (int)floor(cs.r) + 1;
-                    // window [xi - radInt, xi + radInt) against the tile's pixels [t0 + margin, t0 + margin + MT)
-                    hit = ok && sp.xi + sp.radInt > t0 + margin && sp.xi - sp.radInt < t0 + margin + MT &&
-                          sp.yi + sp.radInt > c0 + margin && sp.yi - sp.radInt < c0 + margin + MT;
-                }
-                const unsigned long long m = __ballot(hit);
-                if (hit) sh[__popcll(m & ((1ull << threadIdx.x) - 1ull))] = sp;
-                if (threadIdx.x == 0) shcnt = __popcll(m);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, hl = lane & 31;
+    const int seg = 2 * wave + half;                 // the job slot this half-wave stages
+    const int grp = tid >> 4, col = tid & 15;        // splat: 16 lanes per sphere
+    const int njobs = la.nlayers * la.rows;
+    const int tx0 = t0 + margin, ty0 = c0 + margin;  // the tile on the margin-extended grid
+    for (int k = tid; k < MT * MT; k += 256) acc[k] = 0ull;
+    for (int j0 = 0; j0 < njobs; j0 += ML_SEGS) {
+        // this half-wave's job: layer l, cell row cx0(l) + g, the spheres of cells [cy0, cy1] of that row
+        const int job = j0 + seg, l = min(job / la.rows, ML_MAX - 1), g = job % la.rows;
+        const int offx = la.offx[l], offy = la.offy[l];
+        int beg = 0, end = 0;
+        if (job < njobs) {
+            // cells whose spheres can reach this tile: |centre - pixel| <= radInt + 1/2 on each axis
+            const double xlo = (double)(offx + tx0 - rmax_int - 1) - x0, xhi = (double)(offx + tx0 + MT + rmax_int + 1) - x0;
+            const double ylo = (double)(offy + ty0 - rmax_int - 1) - y0, yhi = (double)(offy + ty0 + MT + rmax_int + 1) - y0;
+            const int cx = max(0, (int)floor(xlo / MT)) + g, cx1 = min(ncx - 1, (int)floor(xhi / MT));
+            const int cy0 = max(0, (int)floor(ylo / MT)), cy1 = min(ncy - 1, (int)floor(yhi / MT));
+            if (cx <= cx1 && cy0 <= cy1) {
+                beg = cell_off[cx * ncy + cy0];
+                end = cell_off[cx * ncy + cy1 + 1];
+            }
+        }
+        bool more = true;
+        for (int b0 = 0; more; b0 += ML_CAP) {
+            StagedSphere sp = {};
+            bool hit = false;
+            if (beg + b0 + hl < end) {
+                const CellSphere cs = spheres[beg + b0 + hl];
+                sp.xf = cs.x - (double)offx;                                       // getMembraneFromFile.py:141-142
+                sp.yf = cs.y - (double)offy;
+                sp.r2 = cs.r * cs.r;
+                sp.xi = (int)rint(sp.xf);                                          // np.round: half to even
+                sp.yi = (int)rint(sp.yf);
+                const bool ok = cs.r > 0.0 && margin2 < sp.xi && sp.xi < dimX + margin + margin2 && margin2 < sp.yi &&
+                                sp.yi < dimY + margin + margin2;                   // :152
+                sp.radInt = (int)floor(cs.r) + 1;
+                // window [xi - radInt, xi + radInt) against the tile's pixels [tx0, tx0 + MT)
+                hit = ok && sp.xi + sp.radInt > tx0 && sp.xi - sp.radInt < tx0 + MT && sp.yi + sp.radInt > ty0 &&
+                      sp.yi - sp.radInt < ty0 + MT;
+            }
+            const unsigned mh = (unsigned)(__ballot(hit) >> (32 * half));
+            __syncthreads();                         // the previous batch has been splatted (and acc is zeroed)
+            if (hl == 0) {
+                shcnt[seg] = __popc(mh);
+                shrem[seg] = max(0, end - beg - b0 - ML_CAP);
             }
             __syncthreads();
-            const int cnt = shcnt;
-            for (int s = 0; s < cnt; ++s) {
-                const Sphere sp = sh[s];
-                const int jj = py - sp.yi;
-                if (jj < -sp.radInt || jj >= sp.radInt) continue;
-                const double dy = (double)py - sp.yf;
+            int base = 0, total = 0;
+            more = false;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int px = t0 + ty + 8 * k + margin;
-                    const int ii = px - sp.xi;
-                    if (ii >= -sp.radInt && ii < sp.radInt) {
-                        const double dx = (double)px - sp.xf;
-                        // getMembraneFromFile.py:157-159 takes dist = sqrt(dx^2 + dy^2), tests dist < r and adds 2 sqrt(r^2 - dist^2);
-                        // comparing the squares saves one of the two float64 square roots and moves the chord by one rounding
-                        // of dist^2 (below 1e-9 of the membrane thickness, also at a sphere's rim)
-                        const double d2 = dx * dx + dy * dy, r2 = sp.r * sp.r;
-                        if (d2 < r2) acc[k] += 2.0 * sqrt(r2 - d2);
+            for (int q = 0; q < ML_SEGS; ++q) {
+                const int c = shcnt[q];
+                base += q < seg ? c : 0;
+                total += c;
+                more = more || shrem[q] > 0;
+            }
+            if (hit) flat[base + __popc(mh & ((1u << hl) - 1u))] = sp;
+            __syncthreads();
+            for (int s = grp; s < total; s += 16) {
+                const StagedSphere c = flat[s];
+                // window rows clipped to the tile; columns: one per lane of the group, 16 at a time
+                const int i_lo = max(c.xi - c.radInt, tx0), i_hi = min(c.xi + c.radInt, tx0 + MT);
+                for (int pyc = c.yi - c.radInt + col; pyc < c.yi + c.radInt; pyc += 16) {
+                    const int j = pyc - ty0;
+                    if (j < 0 || j >= MT) continue;
+                    // getMembraneFromFile.py:157-159 takes dist = sqrt(dx^2 + dy^2), tests dist < r and adds
+                    // 2 sqrt(r^2 - dist^2); comparing the squares saves one of the two square roots and moves the chord by
+                    // one rounding of dist^2 (below 1e-9 of the membrane thickness, also at a sphere's rim)
+                    const double dy = (double)pyc - c.yf;
+                    const double dy2 = dy * dy;
+                    for (int pxr = i_lo; pxr < i_hi; ++pxr) {
+                        const double dx = (double)pxr - c.xf;
+                        const double d2 = fma(dx, dx, dy2);
+                        if (d2 < c.r2) {
+                            // 2 sqrt(.) in units of 2^-ML_FRAC pixel, rounded to nearest through the 2^52 + 2^51 offset
+                            const double v = fma(chord_sqrt(c.r2 - d2), (double)(2ull << ML_FRAC), 6755399441055744.0);
+                            atomicAdd(&acc[(pxr - tx0) * MT + j], (unsigned long long)(__double_as_longlong(v) - 0x4338000000000000ll));
+                        }
                     }
                 }
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = t0 + ty + 8 * k, j = c0 + tx;
+    __syncthreads();
+    const double unit = scale / (double)(1ull << ML_FRAC);
+    for (int k = tid; k < MT * MT; k += 256) {
+        const int i = t0 + k / MT, j = c0 + k % MT;
         if (i < dimX && j < dimY) {
-            const float v = (float)(acc[k] * scale);
+            const float v = (float)((double)acc[k] * unit);
             const int64_t p = (int64_t)i * dimY + j;
             out[p] = accumulate ? out[p] + v : v;
+            if (support) support[p] = support_value;
         }
     }
 }
@@ -221,15 +285,33 @@ int psx_membrane_plan_destroy(psx_membrane_plan *p) {
     return 0;
 }
 
-int psx_membrane_layer_f32(psx_membrane_plan *p, int offx, int offy, int dimX, int dimY, int margin, int margin2,
-                           double scale, int accumulate, float *out, void *stream) {
-    PSX_REQUIRE(p != nullptr && out != nullptr && dimX > 0 && dimY > 0 && margin >= 0, "psx_membrane_layer_f32: bad argument");
+int psx_membrane_layers_f32(psx_membrane_plan *p, int nlayers, const int *offx, const int *offy, int dimX, int dimY, int margin,
+                            int margin2, double scale, int accumulate, float *out, float *support, float support_value,
+                            void *stream) {
+    PSX_REQUIRE(p != nullptr && out != nullptr && dimX > 0 && dimY > 0 && margin >= 0, "psx_membrane_layers_f32: bad argument");
+    PSX_REQUIRE(nlayers >= 0 && (nlayers == 0 || (offx && offy)), "psx_membrane_layers_f32: null offsets");
     hipStream_t st = (hipStream_t)stream;
     const int tiles_x = (int)cdiv(dimX, MT), tiles_y = (int)cdiv(dimY, MT);
-    PSX_TIMED("k_membrane", st, k_membrane_cells<<<tiles_x * tiles_y, 256, 0, st>>>(p->spheres, p->cell_off, p->ncx, p->ncy, p->x0, p->y0,
-                                                                                    p->rmax_int, offx, offy, out, dimX, dimY, margin,
-                                                                                    margin2, tiles_y, scale, accumulate));
-    return launch_check("k_membrane");
+    // ML_MAX layers per launch; later launches add to the map (and leave the support alone)
+    for (int l0 = 0; l0 == 0 || l0 < nlayers; l0 += ML_MAX) {
+        LayerArgs la = {};
+        la.nlayers = std::min(ML_MAX, nlayers - l0);
+        la.rows = (MT + 2 * (p->rmax_int + 1)) / MT + 2;       // a window of that many pixels meets at most this many 32-pixel cells
+        for (int l = 0; l < la.nlayers; ++l) {
+            la.offx[l] = offx[l0 + l];
+            la.offy[l] = offy[l0 + l];
+        }
+        PSX_TIMED("k_membrane", st, k_membrane_layers<<<tiles_x * tiles_y, 256, 0, st>>>(
+                      p->spheres, p->cell_off, p->ncx, p->ncy, p->x0, p->y0, p->rmax_int, la, out, l0 == 0 ? support : nullptr,
+                      support_value, dimX, dimY, margin, margin2, tiles_y, scale, (accumulate || l0 > 0) ? 1 : 0));
+        if (int rc = launch_check("k_membrane")) return rc;
+    }
+    return 0;
+}
+
+int psx_membrane_layer_f32(psx_membrane_plan *p, int offx, int offy, int dimX, int dimY, int margin, int margin2,
+                           double scale, int accumulate, float *out, void *stream) {
+    return psx_membrane_layers_f32(p, 1, &offx, &offy, dimX, dimY, margin, margin2, scale, accumulate, out, nullptr, 0.f, stream);
 }
 
 // xf, yf, rad: HOST arrays (pixels of the margin-extended grid).  out: DEVICE [dimX][dimY] float32.

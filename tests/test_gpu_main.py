@@ -116,6 +116,31 @@ def test_membrane_entry_points_agree():
                 assert float((a - b).abs().max()) <= 1e-12 + 2e-7 * float(a.abs().max()), (dimX, dimY, ox, oy)
                 if (ox, oy) == (margin2, margin2):
                     assert float(a.max()) > 1.0            # something was rendered
+            # every layer in one launch (psx_membrane_layers_f32): float64 sum over the layers against the host-binned
+            # layers added one by one, for 0, 1, 3 and 11 layers (more than one launch holds); the support map is filled by
+            # the same launch
+            offs = [(margin2 + 13 * k, margin2 + 7 * k * k) for k in range(11)]
+            for nl in (0, 1, 3, 11):
+                a = torch.zeros((dimX, dimY), dtype=torch.float32, device="cuda")
+                b = torch.full((dimX, dimY), 7.0, dtype=torch.float32, device="cuda")
+                sup = torch.zeros((dimX, dimY), dtype=torch.float32, device="cuda")
+                ref64 = np.zeros((dimX, dimY))
+                for ox, oy in offs[:nl]:
+                    a.zero_()
+                    xf, yf = np.ascontiguousarray(x - ox), np.ascontiguousarray(y - oy)
+                    check(lib().psx_membrane_f32(xf.ctypes.data_as(DP), yf.ctypes.data_as(DP), r.ctypes.data_as(DP), len(r), dimX,
+                                                 dimY, margin, margin2, c_double(pix * 1e-6), 0, c_void_p(a.data_ptr()), st), "host")
+                    ref64 += a.cpu().numpy().astype(np.float64)
+                oxs = (ctypes.c_int * max(1, nl))(*[o[0] for o in offs[:nl]])
+                oys = (ctypes.c_int * max(1, nl))(*[o[1] for o in offs[:nl]])
+                check(lib().psx_membrane_layers_f32(plan, nl, oxs, oys, dimX, dimY, margin, margin2, c_double(pix * 1e-6), 0,
+                                                    c_void_p(b.data_ptr()), c_void_p(sup.data_ptr()), ctypes.c_float(0.006), st),
+                      "layers")
+                torch.cuda.synchronize()
+                assert np.abs(b.cpu().numpy() - ref64).max() <= 1e-12 + 3e-7 * max(ref64.max(), 1e-30), (dimX, dimY, nl)
+                assert bool((sup == np.float32(0.006)).all())
+                if nl == 0:
+                    assert float(b.abs().max()) == 0.0
         finally:
             lib().psx_membrane_plan_destroy(plan)
 
