@@ -105,7 +105,7 @@ class _CountsWire:
         return out
 
 
-def gather_positions(results, n_positions, rank, world, dst=0, to_host=True, pack=True):
+def gather_positions(results, n_positions, rank, world, dst=0, to_host=True, pack=True, force_collectives=False):
     """results: {position: tuple of tensors} computed on this rank.  Returns on `dst` a dict with every position
     (tensors on the host, or left in `dst`'s HBM with to_host=False), {} elsewhere.
 
@@ -114,10 +114,11 @@ def gather_positions(results, n_positions, rank, world, dst=0, to_host=True, pac
     rank `dst` over xGMI, no ring.  `dst`'s inbound links bound it, so with pack=True detector images that are photon
     counts (integers: the shot-noise output) cross as 16-bit integers plus a short table of the pixels above 65534, half
     the bytes, and are widened again on `dst`; the packing checks every pixel and any rank finding something else makes ALL
-    ranks send float32, so what arrives is bit for bit what was computed either way."""
+    ranks send float32, so what arrives is bit for bit what was computed either way.  force_collectives: take the
+    collective path in a one-rank group too (the tests drive RCCL itself that way on a one-GPU box)."""
     host = lambda tup: tuple(t.detach().cpu() if isinstance(t, torch.Tensor) and to_host else t for t in tup)
     last_gather.clear()
-    if world == 1:
+    if world == 1 and not force_collectives:
         return {p: host(v) for p, v in results.items()}
     out = {}
     dev = _dev()

@@ -223,3 +223,53 @@ def test_main_two_ranks_match_one(tmp_path):
         for a, b in zip(one[p][:2], two[p]):
             assert np.array_equal(a.numpy(), b), p
     assert len(glob.glob(out + "/Fresnel_*/membraneThickness/*.tif")) == 5
+
+
+_RCCL_ONE_RANK = r'''
+import os, sys, torch
+import torch.distributed as td
+sys.path.insert(0, os.getcwd())
+from paresis_amd import dist
+torch.cuda.set_device(0)
+td.init_process_group(backend="nccl", rank=0, world_size=1)
+g = torch.Generator(device="cuda").manual_seed(3)
+def images(p, frac=False):
+    S = torch.randint(0, 60000, (2, 64, 96), generator=g, device="cuda").to(torch.float32)
+    R = torch.randint(0, 60000, (2, 64, 96), generator=g, device="cuda").to(torch.float32)
+    S[0, 1, 2], R[1, 3, 4] = 70000.0 + p, 65535.0
+    if frac:
+        R[0, 0, 0] = 0.5
+    return S, R
+for frac in (False, True):
+    res = {p: images(p, frac and p == 2) for p in range(3)}
+    res[0] = res[0] + (torch.full((2, 64, 96), 3.5, device="cuda"), torch.full((2, 64, 96), 4.0, device="cuda"))
+    for to_host in (False, True):
+        out = dist.gather_positions(res, 3, 0, 1, to_host=to_host, force_collectives=True)
+        assert dist.last_gather["packed"] == (not frac), dist.last_gather
+        assert sorted(out) == [0, 1, 2] and len(out[0]) == 4
+        for p in range(3):
+            for a, b in zip(out[p][:2], res[p][:2]):
+                assert a.is_cuda != to_host and torch.equal(a.cpu(), b.cpu()), (frac, to_host, p)
+td.barrier()
+td.destroy_process_group()
+print("RCCL-ONE-RANK-OK")
+'''
+
+
+def test_gather_path_on_rccl_one_rank(tmp_path):
+    """The collectives of dist.gather_positions on the backend the 8-GPU run uses (RCCL), in a one-rank group -- all a
+    one-GPU box allows: the byte-typed gather of the packed counts, the int32 / int64 all_reduce(MAX), the float32
+    fallback, images left in HBM or brought to the host."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(_RCCL_ONE_RANK)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, str(script)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
