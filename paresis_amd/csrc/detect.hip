@@ -28,6 +28,16 @@ struct BandOp {
                            // monotonic where the reflect pad folds the axis back)
     float *w = nullptr;    // [n_out][W] device (row-major: the axis-0 pass reads a row with scalar loads)
     float *wT = nullptr;   // [W][n_out] device (transposed: the contiguous pass reads it coalesced)
+    std::vector<int> h_start;   // host copy of start[] (row tiles of the fused pair are laid out from it)
+};
+
+// A contiguous-axis operator followed by an axis-0 operator in ONE pass (k_band_pair): per tile of RT output rows the
+// rows [x, y) of the input image that the axis-0 operator reads for them.
+struct BandPair {
+    bool ok = false;
+    int RT = 0, n_rtiles = 0, mid_rows = 0, span_ld = 0;
+    int2 *r_tile = nullptr;     // [n_rtiles] device
+    size_t lds = 0;
 };
 
 struct psx_detector_plan {
@@ -36,6 +46,9 @@ struct psx_detector_plan {
     float *t1 = nullptr;     // [Nx][fy.n_out]
     float *t2 = nullptr;     // [fx.n_out][fy.n_out]   (only with a PSF)
     float *t3 = nullptr;     // [fx.n_out][ny]         (only with a PSF)
+    BandPair front, back;    // fused (contiguous axis, axis 0) pairs; front writes t2p, back reads it
+    float *t2p = nullptr;    // [fx.n_out][pitch2], pitch2 = fy.n_out rounded up to 4 (16-byte rows for the back pair's loads)
+    int pitch2 = 0;
     size_t bytes = 0;
 };
 
@@ -290,6 +303,123 @@ __global__ __launch_bounds__(256) void k_band_rows(const float *__restrict__ in,
                     if (k < lim) acc = fmaf(wr[k], x[b][k], acc);
                 if (r0 + b < r_end) out[(int64_t)r * C + c] = acc;
             }
+        }
+    }
+}
+
+// ---- a contiguous-axis operator and an axis-0 operator in one pass ------------------------------------------------------
+// out = R (C in^T)^T for a tile of RT output rows x 256 output columns: the rows [ilo, ihi) of `in` that R reads for the
+// tile are staged through LDS eight at a time (16-byte loads, all of a thread's loads in flight before the first LDS
+// write), C is applied from LDS with the column's weights in registers, and the results stay in LDS (mid[row][256]) until R
+// combines them -- the intermediate image of the two-pass form (34 MB written and read again per 4096^2 image for the front
+// pair, 17 MB for the PSF pair) never exists.  Tiles are walked by a grid-stride loop (column blocks of a row tile are
+// neighbours in the walk: they share input rows in L2).
+constexpr int PAIR_MIT = 5;      // float4 per lane and staged row: spans up to 1280 floats
+
+struct PairArgs {
+    const float *in;
+    float *out;
+    int in_pitch, out_pitch;
+    const int *c_start;
+    const int2 *c_blk;
+    const float *c_wT;
+    int c_W, Cin, Cout;
+    const int *r_start;
+    const float *r_w;
+    int r_W, Rin, Rout;
+    const int2 *r_tile;
+    int RT, n_rtiles, span_ld, mid_rows;
+};
+
+template <int WC, int MIT>
+__global__ __launch_bounds__(256) void k_band_pair(PairArgs a) {
+    constexpr int H = 2, RG = 4 * H;                                 // two rows per wave and round
+    extern __shared__ __attribute__((aligned(16))) float sdet[];     // stage [RG][span_ld] | mid [mid_rows][256] | wsh [RT][r_W] | ssh [RT]
+    float *mid = sdet + RG * a.span_ld;
+    float *wsh = mid + a.mid_rows * 256;
+    int *ssh = reinterpret_cast<int *>(wsh + a.RT * a.r_W);
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    // a workgroup keeps its column block: the column's weights and the staged span are set up once
+    const int cbk = blockIdx.x;
+    const int c = cbk * 256 + threadIdx.x;
+    const bool live = c < a.Cout;
+    const int cl = live ? c : a.Cout - 1;
+    const int s0 = a.c_blk[cbk].x & ~3, s1 = a.c_blk[cbk].y;
+    const int n4 = (s1 - s0 + 3) >> 2;                                 // float4 per row (<= 64 * MIT, checked by the host)
+    const int off = a.c_start[cl] - s0;
+    float w[WC];
+#pragma unroll
+    for (int k = 0; k < WC; ++k) w[k] = k < a.c_W ? a.c_wT[(int64_t)k * a.Cout + cl] : 0.f;
+    float4 v[H][MIT];
+    auto fetch = [&](int i0, int ihi) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const int i = min(i0 + wv + 4 * h, ihi - 1);
+            const float4 *row = reinterpret_cast<const float4 *>(a.in + (int64_t)i * a.in_pitch + s0);
+#pragma unroll
+            for (int m = 0; m < MIT; ++m) {
+                const int t4 = ln + 64 * m;
+                // rows are padded to whole float4s (in_pitch % 4 == 0); beyond the axis: zeros (a band wider than the axis)
+                v[h][m] = (t4 < n4 && s0 + 4 * t4 < a.in_pitch) ? row[t4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    for (int rt = blockIdx.y; rt < a.n_rtiles; rt += gridDim.y) {
+        const int ilo = a.r_tile[rt].x, ihi = a.r_tile[rt].y;
+        const int r0 = rt * a.RT, r1 = min(a.Rout, r0 + a.RT);
+        // the axis-0 operator's rows of this tile: weights and first input row, read back from LDS as broadcasts
+        float wpre = 0.f;
+        int spre = 0;
+        if ((int)threadIdx.x < (r1 - r0) * a.r_W) wpre = a.r_w[(int64_t)r0 * a.r_W + threadIdx.x];
+        if ((int)threadIdx.x < r1 - r0) spre = a.r_start[r0 + threadIdx.x];
+        fetch(ilo, ihi);
+        for (int i0 = ilo; i0 < ihi; i0 += RG) {
+            __syncthreads();                                           // the previous round's (and tile's) reads are done
+            if (i0 == ilo) {
+                if ((int)threadIdx.x < a.RT * a.r_W) wsh[threadIdx.x] = wpre;
+                if ((int)threadIdx.x < a.RT) ssh[threadIdx.x] = spre;
+            }
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+#pragma unroll
+                for (int m = 0; m < MIT; ++m) {
+                    const int t4 = ln + 64 * m;
+                    if (t4 < n4) {
+                        float4 x = v[h][m];
+                        const int e = s0 + 4 * t4;                     // columns at and beyond Cin are pitch padding, not data
+                        if (e + 3 >= a.Cin) {
+                            x.x = e < a.Cin ? x.x : 0.f;
+                            x.y = e + 1 < a.Cin ? x.y : 0.f;
+                            x.z = e + 2 < a.Cin ? x.z : 0.f;
+                            x.w = 0.f;
+                        }
+                        *reinterpret_cast<float4 *>(sdet + (wv + 4 * h) * a.span_ld + 4 * t4) = x;
+                    }
+                }
+            __syncthreads();
+            if (i0 + RG < ihi) fetch(i0 + RG, ihi);                    // the next round's rows fly during this round's arithmetic
+#pragma unroll
+            for (int rr = 0; rr < RG; ++rr) {
+                if (i0 + rr < ihi) {
+                    const float *x = sdet + rr * a.span_ld + off;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < WC; ++k)
+                        if (k < a.c_W) acc = fmaf(w[k], x[k], acc);   // off + k < span for every k < W by construction
+                    mid[(i0 + rr - ilo) * 256 + threadIdx.x] = acc;
+                }
+            }
+        }
+        // each thread reads back only what it wrote (its own column of mid): no barrier needed before the axis-0 operator
+        for (int r = r0; r < r1; ++r) {
+            const int st = ssh[r - r0];
+            const float *wr = wsh + (r - r0) * a.r_W;
+            const int lim = min(a.r_W, a.Rin - st);
+            const float *col = mid + (st - ilo) * 256 + threadIdx.x;
+            float acc = 0.f;
+#pragma unroll 4
+            for (int k = 0; k < lim; ++k) acc = fmaf(wr[k], col[k * 256], acc);
+            if (live) a.out[(int64_t)r * a.out_pitch + c] = acc;
         }
     }
 }
@@ -575,6 +705,7 @@ int psx_detector_plan_create(int Nx, int Ny, int ov, int nx, int ny, int margin,
         compose_axis(N, ov, n, margin, sigma_src, sigma_psf, st, w, op.W, stage);
         op.n_out = (int)st.size();
         op.n_in = stage == STAGE_BACK ? n + 2 * margin : N;
+        op.h_start = st;
         std::vector<float> wT((size_t)op.W * op.n_out);
         for (int o = 0; o < op.n_out; ++o)
             for (int k = 0; k < op.W; ++k) wT[(size_t)k * op.n_out + o] = w[(size_t)o * op.W + k];
@@ -608,6 +739,39 @@ int psx_detector_plan_create(int Nx, int Ny, int ov, int nx, int ny, int margin,
     if (!rc) rc = scratch(&p->t1, (size_t)Nx * (size_t)p->fy.n_out);
     if (!rc && psf) rc = scratch(&p->t2, (size_t)p->fx.n_out * (size_t)p->fy.n_out);
     if (!rc && psf) rc = scratch(&p->t3, (size_t)p->fx.n_out * (size_t)ny);
+    // the fused (contiguous axis, axis 0) pairs: tiles of RT output rows, the largest RT whose LDS footprint leaves four
+    // workgroups per CU; a geometry that does not fit (very wide bands) keeps the four-pass form
+    auto pair = [&](BandPair &pr, const BandOp &C, const BandOp &R) -> int {
+        pr.ok = false;
+        if (C.W > 16 || C.span + 3 + 3 > 4 * 64 * PAIR_MIT) return 0;
+        pr.span_ld = (C.span + 3 + 3 + 4) / 4 * 4;
+        for (int RT : {16, 8, 4}) {
+            std::vector<int2> tiles;
+            int mid = 1;
+            for (int r0 = 0; r0 < R.n_out; r0 += RT) {
+                int lo = R.n_in, hi = 0;
+                for (int r = r0; r < std::min(R.n_out, r0 + RT); ++r) {
+                    lo = std::min(lo, R.h_start[r]);
+                    hi = std::max(hi, std::min(R.h_start[r] + R.W, R.n_in));
+                }
+                tiles.push_back(make_int2(lo, hi));
+                mid = std::max(mid, hi - lo);
+            }
+            const size_t lds = sizeof(float) * (8 * (size_t)pr.span_ld + (size_t)mid * 256 + (size_t)RT * R.W + RT);
+            if ((lds > 40 * 1024 || RT * R.W > 256) && RT > 4) continue;
+            if (RT * R.W > 256) return 0;
+            if (lds > 64 * 1024) return 0;
+            pr.RT = RT; pr.n_rtiles = (int)tiles.size(); pr.mid_rows = mid; pr.lds = lds;
+            if (int e = up((void **)&pr.r_tile, tiles.data(), sizeof(int2) * tiles.size())) return e;
+            pr.ok = true;
+            return 0;
+        }
+        return 0;
+    };
+    if (!rc) rc = pair(p->front, p->fy, p->fx);
+    if (!rc && psf) rc = pair(p->back, p->by, p->bx);
+    p->pitch2 = (p->fy.n_out + 3) / 4 * 4;
+    if (!rc && psf && p->front.ok && p->back.ok) rc = scratch(&p->t2p, (size_t)p->fx.n_out * (size_t)p->pitch2);
     if (rc) {
         psx_detector_plan_destroy(p);
         return rc;
@@ -643,6 +807,9 @@ int psx_detector_plan_destroy(psx_detector_plan *p) {
     (void)hipFree(p->t1);
     (void)hipFree(p->t2);
     (void)hipFree(p->t3);
+    (void)hipFree(p->t2p);
+    (void)hipFree(p->front.r_tile);
+    (void)hipFree(p->back.r_tile);
     delete p;
     return 0;
 }
@@ -714,10 +881,42 @@ int band_rows(const BandOp &op, const float *in, float *out, int C, hipStream_t 
 
 }  // namespace
 
+namespace {
+
+int band_pair(const BandPair &pr, const BandOp &C, const BandOp &R, const float *in, int in_pitch, float *out, int out_pitch,
+              hipStream_t st) {
+    PairArgs a;
+    a.in = in; a.out = out; a.in_pitch = in_pitch; a.out_pitch = out_pitch;
+    a.c_start = C.start; a.c_blk = C.blk; a.c_wT = C.wT; a.c_W = C.W; a.Cin = C.n_in; a.Cout = C.n_out;
+    a.r_start = R.start; a.r_w = R.w; a.r_W = R.W; a.Rin = R.n_in; a.Rout = R.n_out;
+    a.r_tile = pr.r_tile; a.RT = pr.RT; a.n_rtiles = pr.n_rtiles; a.span_ld = pr.span_ld; a.mid_rows = pr.mid_rows;
+    // column blocks x row strips; a workgroup walks the row tiles of its strip (its column set-up is done once)
+    const int cb = (C.n_out + 255) / 256;
+    const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / pr.lds);
+    const int strips = std::max(1, std::min(a.n_rtiles, current_cu_count() * std::max(1, per_cu) / cb));
+    const dim3 grid(cb, strips);
+    if (C.W <= 8) PSX_TIMED("k_band_pair", st, k_band_pair<8, PAIR_MIT><<<grid, 256, pr.lds, st>>>(a));
+    else PSX_TIMED("k_band_pair", st, k_band_pair<16, PAIR_MIT><<<grid, 256, pr.lds, st>>>(a));
+    return launch_check("k_band_pair");
+}
+
+bool four_pass_forced() {
+    static const bool v = [] { const char *e = getenv("PSX_DETECT_4PASS"); return e && *e && *e != '0'; }();
+    return v;
+}
+
+}  // namespace
+
 int psx_detect_f32(psx_detector_plan *p, const float *img, float *out, void *stream) {
     PSX_REQUIRE(p && img && out, "psx_detect_f32: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const bool psf = p->bx.n_out != 0;
+    // two fused passes (k_band_pair) when the rows of the image are 16-byte aligned and the bands fit its tiles
+    if (p->front.ok && (!psf || (p->back.ok && p->t2p)) && p->Ny % 4 == 0 && (uintptr_t)img % 16 == 0 && !four_pass_forced()) {
+        if (!psf) return band_pair(p->front, p->fy, p->fx, img, p->Ny, out, p->fy.n_out, st);
+        if (int rc = band_pair(p->front, p->fy, p->fx, img, p->Ny, p->t2p, p->pitch2, st)) return rc;
+        return band_pair(p->back, p->by, p->bx, p->t2p, p->pitch2, out, p->ny, st);
+    }
     // front operator: contiguous axis first (the only pass over the full-resolution image), then axis 0
     if (int rc = band_cols(p->fy, img, p->t1, p->Nx, st)) return rc;
     if (int rc = band_rows(p->fx, p->t1, psf ? p->t2 : out, p->fy.n_out, st)) return rc;

@@ -327,11 +327,13 @@ def test_detector_golden(ops):
 
 
 @pytest.mark.parametrize("case", [(1100, 1204, 2, 1.3, 1.2), (1101, 1203, 3, 0.0, 0.8), (1600, 2052, 4, 2.6, 0.0),
-                                  (700, 520, 1, 0.9, 1.7), (2400, 600, 2, 9.0, 3.1)])
+                                  (700, 520, 1, 0.9, 1.7), (2400, 600, 2, 9.0, 3.1), (1024, 1536, 2, 0.5, 0.0),
+                                  (520, 2052, 4, 0.3, 2.0), (2048, 2048, 2, 0.036, 1.2)])
 def test_detector_multi_block_grids(ops, case):
-    """The two-stage banded detector kernels on grids of several 256-output blocks, aligned (16-byte staging) and
-    unaligned rows, with and without each blur: against the dense composite operator of the host builder (the one the
-    CPU suite holds to the oracle), applied in float64."""
+    """The banded detector kernels on grids of several 256-output blocks: the fused (contiguous axis, axis 0) pairs where
+    the rows are 16-byte aligned and the bands fit (front only, front + PSF, the bench geometry) and the four-pass form
+    elsewhere (unaligned rows, wide source blur), with and without each blur: against the dense composite operator of the
+    host builder (the one the CPU suite holds to the oracle), applied in float64."""
     Nx, Ny, ov, sig_src, sig_psf = case
     nx, ny = Nx // ov, Ny // ov
     rng = np.random.default_rng(Nx + Ny)

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Diagnostic: the detector operator alone (Detector.detection without noise) at the bench size; kernels by name under
+rocprofv3 --kernel-trace --stats.    python tools/time_detector.py [N] [ov] [sigma_src, study pixels; bench: 0.036]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from paresis_amd import ops
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+ov = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+sig = float(sys.argv[3]) if len(sys.argv) > 3 else 1.3
+img = torch.rand((N, N), device="cuda") + 0.5
+plan = ops.DetectorPlan(N, N, ov, N // ov, N // ov, sig, 1.2, device=img.device)
+out = torch.empty((N // ov, N // ov), device="cuda")
+for _ in range(3):
+    plan.detect(img, out=out)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50):
+    plan.detect(img, out=out)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 50
+print("detector %dx%d -> %dx%d: %.1f us per image (%.2f TB/s of the %d MB that must move)"
+      % (N, N, N // ov, N // ov, dt * 1e6, (img.numel() + out.numel()) * 4 / dt / 1e12, (img.numel() + out.numel()) * 4 >> 20))
