@@ -625,6 +625,11 @@ __global__ __launch_bounds__(256) void k_poisson(PoissonImgs im, const float *__
     const uint64_t seed = im.seed[blockIdx.y];
     const int64_t nq = n >> 2;
     const bool vec = ((uintptr_t)img % 16 == 0) && ((uintptr_t)lam % 16 == 0);
+    __shared__ float4 wq_all[4][256];                  // per wave: the pending pixels of a round (mean, candidate, owner)
+    __shared__ float wr_all[4][256];                   // their draws
+    const int lane = threadIdx.x & 63;
+    float4 *wq = wq_all[threadIdx.x >> 6];
+    float *wr = wr_all[threadIdx.x >> 6];
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < (vec ? nq : 0); q += (int64_t)gridDim.x * blockDim.x) {
         const float4 L4 = reinterpret_cast<const float4 *>(lam)[q];
         const float L[4] = {L4.x, L4.y, L4.z, L4.w};
@@ -647,14 +652,37 @@ __global__ __launch_bounds__(256) void k_poisson(PoissonImgs im, const float *__
             res[i] = fast ? k : 0.f;
             if (!fast && Li > 0.f) pending |= 1u << i;
         }
-        while (pending) {
-            const int i = __builtin_ctz(pending);
-            pending &= pending - 1;
-            const float r = poisson_finish(pick4(L, i), pick4(U, i), pick4(V, i), (uint64_t)(4 * q + i), seed);
-            res[0] = i == 0 ? r : res[0];
-            res[1] = i == 1 ? r : res[1];
-            res[2] = i == 2 ? r : res[2];
-            res[3] = i == 3 ? r : res[3];
+        // The pixels the squeeze did not settle (~14 %) are dealt out again over the wave: left with their owners, a wave
+        // would run the exact test as often as its unluckiest lane has pending pixels (3-4 times, a sixth of the lanes
+        // alive); packed through LDS it runs it once or twice with the lanes full.  A draw is a function of (pixel, key)
+        // alone, so who computes it changes nothing.
+        int slot[4];
+        int total = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned long long m = __ballot((pending >> i) & 1u);
+            slot[i] = total + __popcll(m & ((1ull << lane) - 1ull));
+            total += __popcll(m);
+            if ((pending >> i) & 1u) {
+                wq[slot[i]] = make_float4(L[i], U[i], V[i], __uint_as_float((unsigned)(lane * 4 + i)));
+            }
+        }
+        if (total) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // the lanes still in the loop (all of them except in an image's last round) share the entries
+            const unsigned long long act = __ballot(true);
+            const int nact = __popcll(act), rank = __popcll(act & ((1ull << lane) - 1ull));
+            for (int e = rank; e < total; e += nact) {
+                const float4 t = wq[e];
+                const unsigned who = __float_as_uint(t.w);
+                const int64_t qo = q + ((int)(who >> 2) - lane);                // the owner's quad: lanes hold consecutive quads
+                wr[e] = poisson_finish(t.x, t.y, t.z, (uint64_t)(4 * qo + (who & 3u)), seed);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if ((pending >> i) & 1u) res[i] = wr[slot[i]];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // read before the next quad's entries land
         }
         reinterpret_cast<float4 *>(img)[q] = make_float4(res[0], res[1], res[2], res[3]);
     }

@@ -374,6 +374,17 @@ def test_poisson_statistics(ops):
     b = ops.poisson(torch.full((64, 64), 20.0, dtype=torch.float32, device="cuda"), seed=7)
     c = ops.poisson(torch.full((64, 64), 20.0, dtype=torch.float32, device="cuda"), seed=8)
     assert torch.equal(a, b) and not torch.equal(a, c)
+    # a draw is a function of (pixel, key) alone: the 16-byte path (four pixels per thread, the pending ones dealt out over
+    # the wave) and the scalar path (a misaligned image) give the same image, whatever the size does to the last wave
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for n in (4 * 64 * 3 + 4 * 17, 1 << 20, 4 * 5 + 3, 300007):
+        lam = torch.rand(n, generator=g, device="cuda") * torch.tensor([0.0, 3.0, 40.0, 30000.0], device="cuda")[torch.randint(0, 4, (n,), generator=g, device="cuda")]
+        buf = torch.empty(n + 4, dtype=torch.float32, device="cuda")
+        mis = buf[1:1 + n]
+        mis.copy_(lam)
+        x = ops.poisson(lam.clone(), seed=99)
+        ops.poisson_multi([mis], [99])
+        assert torch.equal(x, mis), n
 
 
 def test_bad_arguments_raise(ops):
