@@ -35,6 +35,7 @@ extern "C" {
 
 #define PSX_MAX_MAT 8
 #define PSX_MAX_DIST 8
+#define PSX_MAX_SRC 16    /* source waves per psx_fresnel_propagate_sources / images per psx_accumulate_many_f32 call */
 
 #define PSX_E_ARG (-1)      /* bad argument (null pointer, size, count) */
 #define PSX_E_STATE (-2)    /* plan/shape mismatch */
@@ -81,6 +82,13 @@ int psx_accumulate_f32(float *acc, const float *img, float scale, const float *c
 #define PSX_SUM_STRIDE 16
 int psx_accumulate_sum_f32(float *acc, const float *img, float scale, const float *const *T, const double *catt, int nmat,
                            int accumulate, int64_t n, double *sums, double weight, void *stream);
+/* The same for the images of n_img <= PSX_MAX_SRC energies in ONE pass (the energies of a detector bin): acc (+)= sum over e of
+ * scale[e] * imgs[e] * exp(sum_i catt[e*nmat + i] * T[i]), added in the order of e exactly as one psx_accumulate_sum_f32 call
+ * per energy would (bit-identical float32 result); sums (may be NULL) += (sum of all terms, sum of weight[e] * term).
+ * acc may be NULL (sums only).  imgs, scale, catt, weight: host arrays. */
+int psx_accumulate_many_f32(float *acc, const float *const *imgs, const float *scale, int n_img, const float *const *T,
+                            const double *catt, int nmat, int accumulate, int64_t n, double *sums, const double *weight,
+                            void *stream);
 
 /* ---- K9-K13: fastRefraction (refractionFileNumba2.py:25-86; variant v1: refractionFileNumba.py:11-68) ----------
  * Source intensity  I_src = I0 * I_in * exp(sum catt*T)          (I_in may be NULL = ones; fused K2)
@@ -158,6 +166,17 @@ int psx_fresnel_propagate(psx_fresnel_plan *plan, const psx_c64 *wave_in, float 
                           const double *cphase, const double *catt, int nmat, int n_dist, const double *a,
                           const double *gphase, double du_x, double du_y, psx_c64 *const *wave_out,
                           float *const *inten_out, const float *inten_scale, int accumulate, void *stream);
+/* The same for n_src <= PSX_MAX_SRC source waves over the SAME thickness maps in one call -- the energies of a detector bin
+ * (EXP:317-361 loops over them): source s has its own input wave wave_in[s] (the array or an entry may be NULL = unit wave),
+ * amplitude amp[s] and coefficients cphase/catt[s*nmat + i]; pair (s, d) has its own a, gphase, outputs and scale at index
+ * s*n_dist + d.  Every pair's result is exactly what psx_fresnel_propagate gives for that source (nothing is accumulated:
+ * each pair owns its output).  On grids too small to fill the chip (fewer line groups than CUs) the LDS engine runs the
+ * whole batch in three launches -- the pairs are one more axis of its work items -- when n_src*n_dist <= 32; otherwise the
+ * sources are taken one after the other.  The first batched call of a plan allocates its batch buffers (not under capture). */
+int psx_fresnel_propagate_sources(psx_fresnel_plan *plan, int n_src, int n_dist, const psx_c64 *const *wave_in, const float *amp,
+                                  const float *const *T, const double *cphase, const double *catt, int nmat, const double *a,
+                                  const double *gphase, double du_x, double du_y, psx_c64 *const *wave_out,
+                                  float *const *inten_out, const float *inten_scale, void *stream);
 
 /* ---- K14-K19: Detector.detection (Detector.py:79-119), resize (:185-198), create_gaussian_shape (:201-220) -----
  * reflect-pad 15*ov -> source blur (sigma_src study px, 0 = none) -> ov x ov block SUM -> PSF blur (sigma_psf detector

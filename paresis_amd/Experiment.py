@@ -18,7 +18,7 @@ import time
 import numpy as np
 import torch
 
-from . import _xml, ops
+from . import _lib, _xml, ops
 from ._lib import PsxError
 from ._tensors import device, is_scalar, to_dev
 from .Detector import Detector
@@ -103,6 +103,7 @@ class Experiment:
         self.imagePropagBeforeDetection = []
         self._fresnel_plan = None
         self._bins_ready = False      # thresholds validated and closed with the last spectrum energy (EXP:296-301)
+        self._etmp = None             # per-energy intensity scratch [energies of a bin][Nx][Ny] (batched energy chain)
         self._accs = None             # study-grid accumulators [4][Nx][Ny], allocated once
         self._tmp = None
         self._pending_means = []
@@ -326,6 +327,84 @@ class Experiment:
             self._pending_means = []
         return self.exp_dict.get('meanEnergy', 0)
 
+    # Small study grids (the ones the reference itself is run on) cannot fill the chip: a line kernel is ~25 us of start-up
+    # and drain whatever it computes, and a polychromatic position is 7 launches per energy.  There the energies of a
+    # detector bin go through the chain TOGETHER (psx_fresnel_propagate_sources, psx_accumulate_many_f32): 7 launches per
+    # bin.  On large grids a launch per energy costs nothing and the per-energy loop keeps its fused accumulation.
+    BATCH_ENERGIES_MAX_PIXELS = 1200 * 1200
+
+    def _batch_energies(self, N, plan):
+        flag = self.exp_dict.get('batchEnergies')
+        if flag is not None:
+            return bool(flag) and len(self.mySource.mySpectrum) > 1
+        return (len(self.mySource.mySpectrum) > 1 and N[0] * N[1] <= self.BATCH_ENERGIES_MAX_PIXELS and
+                plan.engine == _lib.ENGINE_LDS)
+
+    def _bins_of_spectrum(self):
+        """EXP:378: the energies of each detector bin, in spectrum order (a bin closes at the first energy above its
+        threshold minus half a sampling step; energies after the last threshold are computed and never detected)."""
+        thr, half = self.myDetector.det_param["myBinsThersholds"], self.mySource.source_dict["myEnergySampling"] / 2
+        bins, cur, ibin = [], [], 0
+        for ie, (E, flux) in enumerate(self.mySource.mySpectrum):
+            cur.append((ie, E, flux))
+            if ibin < len(thr) and E > thr[ibin] - half:
+                bins.append(cur)
+                cur, ibin = [], ibin + 1
+        return bins, cur
+
+    def _fresnel_bins_batched(self, pointNum, stacks, accs, plan, plate, air, N, sums):
+        """The Fresnel chain of one position (EXP:317-401) with the energies of each bin taken together.  Same operations on
+        the same numbers as the per-energy loop; the per-energy intensities go through a scratch stack and are summed in
+        spectrum order."""
+        ed = self.exp_dict
+        accS, accR, accP, white = accs
+        dSM, dMO, dOD, M = ed['distSourceToMembrane'], ed['distMembraneToObject'], ed['distObjectToDetector'], ed['magnification']
+        bins, leftover = self._bins_of_spectrum()
+        nmax = max(len(b) for b in bins + [leftover]) if (bins or leftover) else 0
+        if self._etmp is None or self._etmp.shape[0] < nmax or tuple(self._etmp.shape[1:]) != N:
+            self._etmp = torch.empty((nmax,) + N, dtype=torch.float32, device=accS.device)
+        for ibin, energies in enumerate(bins):
+            ne = len(energies)
+            Es = [E for _, E, _ in energies]
+            I0 = [self._incident(flux, E, ie) for ie, E, flux in energies]
+            amp = [float(np.sqrt(v)) for v in I0]                                          # EXP:334
+            air_w = [air.stack_wave(E, phase=False) if air is not None else None for E in Es]
+            plate_att = [plate.stack_rt(E, phase=False) for E in Es] if plate is not None else None
+            mem = [ops.MaterialStack.concat(aw, self.myMembrane.stack_wave(E)) for aw, E in zip(air_w, Es)]   # EXP:323,338
+            smp = [self.mySampleofInterest.stack_wave(E) for E in Es]
+            sc = [(self._fresnel_scalars(dMO, E, (dSM + dMO) / dSM), self._fresnel_scalars(dOD + dMO, E, M),
+                   self._fresnel_scalars(dOD, E, M)) for E in Es]
+            du = sc[0][0][2]
+            tmp = [self._etmp[k] for k in range(ne)]
+            # EXP:341 + EXP:349: membrane exit wave -> sample plane (complex field) and -> detector (|.|^2), every energy
+            wbs = plan.propagate_sources([[c[0][0], c[1][0]] for c in sc], [[c[0][1], c[1][1]] for c in sc], du, amp=amp,
+                                         mats=mem, want_wave=[True, False], inten_out=[[None, t] for t in tmp])
+            self.waveSampleBeforeSample = wbs[-1][0]
+            # EXP:355-361: plate attenuation, sum over the bin's energies and the image sums for the mean energy
+            ops.accumulate_many(accR, tmp, sums, Es, mats=plate_att, add=False)
+            # EXP:344 + EXP:348: through the sample, on to the detector
+            plan.propagate_sources([[c[2][0]] for c in sc], [[c[2][1]] for c in sc], du, wave_in=[w[0] for w in wbs], mats=smp,
+                                   want_wave=[False], inten_out=[[t] for t in tmp])
+            ops.accumulate_many(accS, tmp, None, [0.0] * ne, mats=plate_att, add=False)
+            if pointNum == 0:                                                              # EXP:363-375
+                smp0 = [ops.MaterialStack.concat(aw, sm) for aw, sm in zip(air_w, smp)]
+                plan.propagate_sources([[c[2][0]] for c in sc], [[c[2][1]] for c in sc], du, amp=amp, mats=smp0,
+                                       want_wave=[False], inten_out=[[t] for t in tmp])
+                ops.accumulate_many(accP, tmp, None, [0.0] * ne, mats=plate_att, add=False)
+                for k, E in enumerate(Es):
+                    air_rt = air.stack_rt(E, phase=False) if air is not None else None
+                    self._white(white, I0[k], air_rt, plate_att[k] if plate_att is not None else None, k == 0)
+            self._detect_bin(ibin, pointNum, stacks, accs)                                 # EXP:378-401
+        if leftover:
+            # energies above the last threshold: the reference still propagates them (the field it leaves behind is theirs)
+            E = leftover[-1][1]
+            I0 = self._incident(leftover[-1][2], E, leftover[-1][0])
+            air_w = air.stack_wave(E, phase=False) if air is not None else None
+            a1, g1, du = self._fresnel_scalars(dMO, E, (dSM + dMO) / dSM)
+            self.waveSampleBeforeSample = plan.propagate([a1], [g1], du, amp=float(np.sqrt(I0)),
+                                                         mats=ops.MaterialStack.concat(air_w, self.myMembrane.stack_wave(E)))[0]
+        return len(bins)
+
     def computeSampleAndReferenceImages_Fresnel(self, pointNum):
         """Experiment.py:279-405.  Returns (SampleImage, ReferenceImage, PropagImage, detectedWhite), each
         [nbins, n, n] float32 in HBM."""
@@ -336,6 +415,11 @@ class Experiment:
         plate, air = self.myPlate, (None if ed['inVacuum'] else self.myAirVolume)
         tmp = self._tmp[0]
         dSM, dMO, dOD, M = ed['distSourceToMembrane'], ed['distMembraneToObject'], ed['distObjectToDetector'], ed['magnification']
+        if self._batch_energies(N, plan):
+            nvisited = self._fresnel_bins_batched(pointNum, stacks, accs, plan, plate, air, N, sums)
+            self._zero_unvisited_bins(stacks, nvisited, pointNum)
+            self._finish_mean_energy(sums, N[0] * N[1])
+            return tuple(stacks)
         ibin = 0
         first = True                     # first energy of the current bin: its images are stored, the later ones added
         for ie, (currentEnergy, flux) in enumerate(self.mySource.mySpectrum):

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libparesis_hip.so")
 PSX_MAX_MAT = 8
 PSX_MAX_DIST = 8
 PSX_MAX_POISSON = 8
+PSX_MAX_SRC = 16
 PSX_SUM_SLOTS, PSX_SUM_STRIDE = 32, 16
 ENGINE_AUTO, ENGINE_ROCFFT, ENGINE_LDS = 0, 1, 2
 STATUS_NONFINITE = 1
@@ -37,6 +38,7 @@ PROTOTYPES = {
     "psx_transmit_rt_f32": (c_int, [_vp, c_float, _vpp, _dp, _dp, c_int, _vp, _vp, _vp, c_int64, _vp]),
     "psx_accumulate_f32": (c_int, [_vp, _vp, c_float, _vpp, _dp, c_int, c_int, c_int64, _vp]),
     "psx_accumulate_sum_f32": (c_int, [_vp, _vp, c_float, _vpp, _dp, c_int, c_int, c_int64, _vp, c_double, _vp]),
+    "psx_accumulate_many_f32": (c_int, [_vp, _vpp, _fp, c_int, _vpp, _dp, c_int, c_int, c_int64, _vp, _dp, _vp]),
     "psx_refract_workspace_bytes": (c_size_t, [c_int, c_int]),
     "psx_refract_set_halo": (c_int, [c_int]),
     "psx_set_deterministic": (c_int, [c_int]),
@@ -52,6 +54,8 @@ PROTOTYPES = {
     "psx_fresnel_plan_bytes": (c_size_t, [_vp]),
     "psx_fresnel_propagate": (c_int, [_vp, _vp, c_float, _vpp, _dp, _dp, c_int, c_int, _dp, _dp, c_double, c_double,
                                       _vpp, _vpp, _fp, c_int, _vp]),
+    "psx_fresnel_propagate_sources": (c_int, [_vp, c_int, c_int, _vpp, _fp, _vpp, _dp, _dp, c_int, _dp, _dp, c_double, c_double,
+                                              _vpp, _vpp, _fp, _vp]),
     "psx_detector_plan_create": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double, _vpp]),
     "psx_detector_plan_destroy": (c_int, [_vp]),
     "psx_detect_f32": (c_int, [_vp, _vp, _vp, _vp]),

@@ -239,4 +239,42 @@ int psx_fresnel_propagate(psx_fresnel_plan *plan, const psx_c64 *wave_in, float 
     return plan->engine == PSX_ENGINE_LDS ? lds_engine_propagate(plan, pa) : rocfft_engine_propagate(plan, pa);
 }
 
+int psx_fresnel_propagate_sources(psx_fresnel_plan *plan, int n_src, int n_dist, const psx_c64 *const *wave_in, const float *amp,
+                                  const float *const *T, const double *cphase, const double *catt, int nmat, const double *a,
+                                  const double *gphase, double du_x, double du_y, psx_c64 *const *wave_out,
+                                  float *const *inten_out, const float *inten_scale, void *stream) {
+    PSX_REQUIRE(plan != nullptr, "psx_fresnel_propagate_sources: null plan");
+    PSX_REQUIRE(n_src >= 1 && n_src <= PSX_MAX_SRC, "psx_fresnel_propagate_sources: n_src=%d outside [1,%d]", n_src, PSX_MAX_SRC);
+    PSX_REQUIRE(n_dist >= 1 && n_dist <= plan->max_dist, "psx_fresnel_propagate_sources: n_dist=%d outside [1,%d]", n_dist,
+                plan->max_dist);
+    PSX_REQUIRE(a != nullptr && amp != nullptr, "psx_fresnel_propagate_sources: null distance or amplitude table");
+    PSX_REQUIRE(wave_out || inten_out, "psx_fresnel_propagate_sources: no output requested");
+    for (int v = 0; v < n_src * n_dist; ++v) {
+        const bool w = wave_out && wave_out[v], i = inten_out && inten_out[v];
+        PSX_REQUIRE(w || i, "psx_fresnel_propagate_sources: source %d, distance %d has no output", v / n_dist, v % n_dist);
+        PSX_REQUIRE(std::isfinite(a[v]), "psx_fresnel_propagate_sources: a[%d] is not finite", v);
+    }
+    SourcesArgs sa;
+    if (int rc = pack_mats(sa.maps, T, nullptr, nullptr, nmat)) return rc;
+    sa.n_src = n_src; sa.n_dist = n_dist; sa.wave_in = (const float2 *const *)wave_in; sa.amp = amp;
+    sa.cphase = cphase; sa.catt = catt; sa.a = a; sa.gphase = gphase; sa.du_x = du_x; sa.du_y = du_y;
+    sa.wave_out = (float2 *const *)wave_out; sa.inten_out = inten_out; sa.inten_scale = inten_scale;
+    sa.stream = (hipStream_t)stream;
+    if (plan->engine == PSX_ENGINE_LDS) return lds_engine_propagate_sources(plan, sa);
+    for (int s = 0; s < n_src; ++s) {                    // rocFFT engine: one source at a time
+        PropArgs pa;
+        if (int rc = pack_mats(pa.m, T, cphase ? cphase + (size_t)s * nmat : nullptr, catt ? catt + (size_t)s * nmat : nullptr, nmat))
+            return rc;
+        pa.wave_in = wave_in ? (const float2 *)wave_in[s] : nullptr; pa.amp = amp[s]; pa.n_dist = n_dist;
+        pa.a = a + (size_t)s * n_dist; pa.gphase = gphase ? gphase + (size_t)s * n_dist : nullptr;
+        pa.du_x = du_x; pa.du_y = du_y;
+        pa.wave_out = wave_out ? (float2 *const *)wave_out + (size_t)s * n_dist : nullptr;
+        pa.inten_out = inten_out ? inten_out + (size_t)s * n_dist : nullptr;
+        pa.inten_scale = inten_scale ? inten_scale + (size_t)s * n_dist : nullptr;
+        pa.accumulate = 0; pa.stream = (hipStream_t)stream;
+        if (int rc = rocfft_engine_propagate(plan, pa)) return rc;
+    }
+    return 0;
+}
+
 }  // extern "C"

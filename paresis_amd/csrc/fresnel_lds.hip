@@ -59,29 +59,33 @@ constexpr int IB = 8;
 
 __host__ __device__ constexpr int phys(int p) { return p + (p >> 5); }   // one pad slot per 32: conflict-free slabs
 
+// (distance, source) pairs one line launch can carry: the PSX_MAX_DIST distances of one source wave, or -- a batch of source
+// waves, e.g. the energies of a detector bin -- up to MAX_LINE (source, distance) pairs, each with its own input and tables
+constexpr int MAX_LINE = 32;
+
 struct LineArgs {
     int n_dist;             // distances merged into this launch: work item w = d * ngroups + g  (d-th table / buffers, group g)
     int dist_inner;         // 1: every distance reads the SAME source (pass 1): a workgroup takes the n_dist work items of a
                             // line group in consecutive rounds and its loaders fetch the group once, spreading it n_dist times
-    const float2 *src[PSX_MAX_DIST];        // input wave of each distance
+    const float2 *src[MAX_LINE];        // input wave of each distance
     int N, nlines, margin, P, L;
     int64_t in_si, in_sl;   // sample i of line l is element i*in_si + l*in_sl of src ...
     int in_blocked;         // ... or, blocked: element ((l / IB)*N + i)*IB + l % IB  (the intermediate, see IB)
     int64_t out_ld;         // output sample i of line l goes to l*out_ld + i ...
     int out_blocked;        // ... or, blocked: element ((i / IB)*nlines + l)*IB + i % IB
     const float2 *twA, *twB;   // [n][24] stage twiddles
-    const float2 *H[PSX_MAX_DIST];          // kernel spectrum FFT_M(h) of each distance, digit-reversed, 1/M folded in
-    float2 *wave_out[PSX_MAX_DIST];         // complex result (pass 1: the blocked intermediate) or null
-    float *inten_out[PSX_MAX_DIST];         // scale * |result|^2 or null
-    float scale[PSX_MAX_DIST];
-    float2 gph[PSX_MAX_DIST];               // global phase factor exp(i k z / M) of the complex result
+    const float2 *H[MAX_LINE];          // kernel spectrum FFT_M(h) of each distance, digit-reversed, 1/M folded in
+    float2 *wave_out[MAX_LINE];         // complex result (pass 1: the blocked intermediate) or null
+    float *inten_out[MAX_LINE];         // scale * |result|^2 or null
+    float scale[MAX_LINE];
+    float2 gph[MAX_LINE];               // global phase factor exp(i k z / M) of the complex result
     int accumulate;
     // Partitioned convolution (PART instantiations; lines too long for one M-point transform in LDS): the N outputs of a
     // line are cut into NB blocks of B, the P-tap kernel into S segments of Lh (B + Lh - 1 <= M); a work unit is
     // (distance, line group, block) and takes S consecutive rounds, one per segment, whose results add up in `part`
     // (complex, same layout as the complex output; it IS the complex output when that is wanted).  H[d] then holds S spectra.
     int B, Lh, S, NB;
-    float2 *part[PSX_MAX_DIST];
+    float2 *part[MAX_LINE];
     const float2 *w2;       // PAIR: w_2M^{k0} of each 16-point slab, k0 = q1 + 24 q2  (576 entries)
     unsigned long long *stamps;   // optional diagnostics: 32 phase timestamps per workgroup (psx_debug_stamps)
 };
@@ -849,11 +853,11 @@ __global__ __launch_bounds__(256) void k_source_out(const float2 *__restrict__ s
 // distances, and pass 1 of the line engine then reads whole lines contiguously.  64x64 tiles through LDS: the thickness
 // maps are read along y (their fast axis), the wave is written along x.
 template <int NM>
-__global__ __launch_bounds__(256) void k_source_transposed(const float2 *__restrict__ src, float amp, Mats m,
-                                                           float2 *__restrict__ out, int Nx, int Ny, int vec_ok) {
+__device__ __forceinline__ void source_transposed_tile(const float2 *__restrict__ src, float amp, const Mats &m,
+                                                       float2 *__restrict__ out, int Nx, int Ny, int vec_ok, int tile_index) {
     __shared__ float2 tile[64][65];
     const int ntx = (Ny + 63) / 64;                       // tiles along y
-    const int y0 = (blockIdx.x % ntx) * 64, x0 = (blockIdx.x / ntx) * 64;
+    const int y0 = (tile_index % ntx) * 64, x0 = (tile_index / ntx) * 64;
     // read phase: a thread takes 4 consecutive y of one image row per pass (one 16-byte load per thickness map), a wave
     // 4 rows x 64 y; 4 passes cover the 64 rows of the tile.  Full tiles of maps whose rows are 16-byte aligned only.
     const bool vec = vec_ok && x0 + 64 <= Nx && y0 + 64 <= Ny;   // vec_ok: Ny % 4 == 0, 16-byte aligned maps (and input wave)
@@ -930,6 +934,39 @@ __global__ __launch_bounds__(256) void k_source_transposed(const float2 *__restr
         const int y = y0 + ty + 4 * r, x = x0 + tx;
         if (x < Nx && y < Ny) out[(int64_t)y * Nx + x] = tile[tx][ty + 4 * r];
     }
+}
+
+template <int NM>
+__global__ __launch_bounds__(256) void k_source_transposed(const float2 *__restrict__ src, float amp, Mats m,
+                                                           float2 *__restrict__ out, int Nx, int Ny, int vec_ok) {
+    source_transposed_tile<NM>(src, amp, m, out, Nx, Ny, vec_ok, blockIdx.x);
+}
+
+// The same for a batch of source waves over the SAME thickness maps -- the energies of a detector bin (EXP:317-361): source
+// e = blockIdx.y has its own input wave, amplitude and coefficients and writes plane e of `out`.
+struct SrcBatch {
+    const float2 *src[PSX_MAX_SRC];
+    float amp[PSX_MAX_SRC];
+    double cphase[PSX_MAX_SRC][PSX_MAX_MAT], catt[PSX_MAX_SRC][PSX_MAX_MAT];
+};
+
+struct MapPtrs {
+    const float *T[PSX_MAX_MAT];
+};
+
+template <int NM>
+__global__ __launch_bounds__(256) void k_source_transposed_batch(SrcBatch b, MapPtrs maps, float2 *__restrict__ out,
+                                                                 size_t out_stride, int Nx, int Ny, int vec_ok) {
+    const int e = blockIdx.y;
+    Mats m;
+    m.n = NM;
+#pragma unroll
+    for (int i = 0; i < (NM > 0 ? NM : 1); ++i) {
+        m.T[i] = maps.T[i];
+        m.cphase[i] = b.cphase[e][i];
+        m.catt[i] = b.catt[e][i];
+    }
+    source_transposed_tile<NM>(b.src[e], b.amp[e], m, out + (size_t)e * out_stride, Nx, Ny, vec_ok, blockIdx.x);
 }
 
 // ---- float64 construction of the kernel spectrum FFT_M(IDFT_P(chirp)): chirp -> rocFFT inverse (length P, float64) ->
@@ -1081,6 +1118,8 @@ struct LdsEngine {
     size_t inter_elems = 0;
     float2 *pre = nullptr;       // [Ny][Nx] transmitted source wave, transposed (pass 0)
     float2 *part = nullptr;      // [max_dist][Nx][Ny] partial sums of pass 2 of the partitioned convolution when only |.|^2 is wanted
+    float2 *pre_b = nullptr;     // [PSX_MAX_SRC][Ny][Nx], [MAX_LINE][inter_elems]: the same two for a batch of source waves,
+    float2 *inter_b = nullptr;   // allocated by the first batched call (psx_fresnel_propagate_sources)
     // Kernel spectra, keyed by (a, du, N, M).  72 KiB each at 4096^2: the cache is sized for a polychromatic position
     // (energies x hops x axes: 25 x 3 x 2 = 150 keys visited cyclically -- an LRU smaller than that misses on EVERY lookup),
     // i.e. effectively unbounded; CACHE_CAP only bounds the memory of a plan fed with ever-changing scalars.
@@ -1196,6 +1235,8 @@ void lds_engine_destroy(psx_fresnel_plan *p) {
     (void)hipFree(e->inter);
     (void)hipFree(e->pre);
     (void)hipFree(e->part);
+    (void)hipFree(e->pre_b);
+    (void)hipFree(e->inter_b);
     delete e;
     p->lds = nullptr;
 }
@@ -1409,5 +1450,115 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
     return 0;
 }
 
-}  // namespace psx
+// ---- a batch of source waves in ONE launch per pass ------------------------------------------------------------------------
+// The energies of a detector bin (EXP:317-361) differ in input wave, coefficients and chirp but share grid, maps and work
+// buffers' shape.  On a grid that fills the chip a launch per energy costs nothing; on the grids the reference itself is run
+// on (a few hundred pixels) a line kernel is ~25 us of start-up and drain whatever it computes, and a 25-energy position is
+// 175 of them.  Here every (source, distance) pair is one more "distance" of the line kernels -- own source plane, own kernel
+// spectrum, own outputs (the work item (pair, line group) of the small-grid order) -- and the pre-pass takes the source index
+// as a grid axis: three launches for up to PSX_MAX_SRC sources.  Results are exactly those of one propagate call per source
+// (same kernels, same arithmetic); nothing is accumulated here -- every pair has its own output.
+int lds_engine_propagate_sources(psx_fresnel_plan *p, const SourcesArgs &a) {
+    LdsEngine *e = p->lds;
+    hipStream_t st = a.stream;
+    const int V = a.n_src * a.n_dist;
+    const size_t npix = (size_t)p->Nx * p->Ny;
+    // one launch per pass only pays where a launch is mostly overhead and the generic (pair, group) work order applies
+    const int lds_lines = TOT / (576 * e->ax[0].R3);
+    const int ngroups0 = (p->Ny + lds_lines - 1) / lds_lines;
+    bool batched = a.n_src > 1 && !e->ax[0].part && !e->ax[1].part && ngroups0 < current_cu_count() && V <= MAX_LINE &&
+                   a.n_src <= PSX_MAX_SRC;
+    for (int v = 0; v < V && batched; ++v) batched = a.a[v] != 0.0;         // z == 0 pairs take the one-source path
+    if (!batched) {
+        for (int s = 0; s < a.n_src; ++s) {
+            PropArgs pa;
+            pa.wave_in = a.wave_in ? a.wave_in[s] : nullptr;
+            pa.amp = a.amp[s];
+            pa.m = a.maps;
+            for (int i = 0; i < a.maps.n; ++i) {
+                pa.m.cphase[i] = a.cphase ? a.cphase[(size_t)s * a.maps.n + i] : 0.0;
+                pa.m.catt[i] = a.catt ? a.catt[(size_t)s * a.maps.n + i] : 0.0;
+            }
+            pa.n_dist = a.n_dist; pa.a = a.a + (size_t)s * a.n_dist; pa.gphase = a.gphase ? a.gphase + (size_t)s * a.n_dist : nullptr;
+            pa.du_x = a.du_x; pa.du_y = a.du_y;
+            pa.wave_out = a.wave_out ? a.wave_out + (size_t)s * a.n_dist : nullptr;
+            pa.inten_out = a.inten_out ? a.inten_out + (size_t)s * a.n_dist : nullptr;
+            pa.inten_scale = a.inten_scale ? a.inten_scale + (size_t)s * a.n_dist : nullptr;
+            pa.accumulate = 0; pa.stream = st;
+            if (int rc = lds_engine_propagate(p, pa)) return rc;
+        }
+        return 0;
+    }
+    if (!e->pre_b) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cs);
+        if (cs != hipStreamCaptureStatusNone)
+            return fail(PSX_E_STATE, "psx_fresnel_propagate_sources: the batch buffers are allocated by the first call; make it before capturing");
+        PSX_HIP(hipMalloc((void **)&e->pre_b, sizeof(float2) * npix * PSX_MAX_SRC));
+        PSX_HIP(hipMalloc((void **)&e->inter_b, sizeof(float2) * e->inter_elems * MAX_LINE));
+        p->bytes += sizeof(float2) * (npix * PSX_MAX_SRC + e->inter_elems * MAX_LINE);
+    }
+    // ---- pass 0: the transmitted source wave of every source, transposed
+    {
+        SrcBatch b = {};
+        MapPtrs mp = {};
+        int vec_ok = p->Ny % 4 == 0;
+        for (int i = 0; i < a.maps.n && i < PSX_MAX_MAT; ++i) {
+            mp.T[i] = a.maps.T[i];
+            vec_ok = vec_ok && ((uintptr_t)a.maps.T[i] % 16 == 0);
+        }
+        for (int s = 0; s < a.n_src; ++s) {
+            b.src[s] = a.wave_in ? a.wave_in[s] : nullptr;
+            vec_ok = vec_ok && ((uintptr_t)b.src[s] % 16 == 0);
+            b.amp[s] = a.amp[s];
+            for (int i = 0; i < a.maps.n; ++i) {
+                b.cphase[s][i] = a.cphase ? a.cphase[(size_t)s * a.maps.n + i] : 0.0;
+                b.catt[s][i] = a.catt ? a.catt[(size_t)s * a.maps.n + i] : 0.0;
+            }
+        }
+        const dim3 grid((unsigned)(cdiv(p->Nx, 64) * cdiv(p->Ny, 64)), (unsigned)a.n_src);
+        PSX_DISPATCH_NMAT(a.maps.n, PSX_TIMED("k_source_transposed", st, k_source_transposed_batch<NM><<<grid, 256, 0, st>>>(
+                                                                              b, mp, e->pre_b, npix, p->Nx, p->Ny, vec_ok)));
+        if (int rc = launch_check("k_source_transposed")) return rc;
+    }
+    // ---- pass 1 and pass 2: pair v = (source v / n_dist, distance v % n_dist) is "distance" v of the line kernels
+    LineArgs la;
+    la.N = p->Nx; la.nlines = p->Ny; la.margin = p->margin; la.P = p->Px; la.L = p->Nx + p->Px - 1;
+    la.in_si = 1; la.in_sl = p->Nx; la.in_blocked = 0; la.out_ld = 0; la.out_blocked = 1;
+    la.twA = e->ax[0].twA; la.twB = e->ax[0].twB;
+    la.accumulate = 0; la.stamps = nullptr; la.n_dist = V; la.dist_inner = 0;
+    la.B = e->ax[0].B; la.Lh = e->ax[0].Lh; la.S = e->ax[0].S; la.NB = e->ax[0].NB; la.w2 = e->ax[0].w2;
+    LineArgs lb;
+    lb.N = p->Ny; lb.nlines = p->Nx; lb.margin = p->margin; lb.P = p->Py; lb.L = p->Ny + p->Py - 1;
+    lb.in_si = 0; lb.in_sl = 0; lb.in_blocked = 1; lb.out_ld = p->Ny; lb.out_blocked = 0;
+    lb.twA = e->ax[1].twA; lb.twB = e->ax[1].twB;
+    lb.accumulate = 0; lb.stamps = nullptr; lb.n_dist = V; lb.dist_inner = 0;
+    lb.B = e->ax[1].B; lb.Lh = e->ax[1].Lh; lb.S = e->ax[1].S; lb.NB = e->ax[1].NB; lb.w2 = e->ax[1].w2;
+    for (int i = 0; i < MAX_LINE; ++i) {
+        const int v = i < V ? i : 0;
+        la.src[i] = e->pre_b + (size_t)(v / a.n_dist) * npix;
+        la.wave_out[i] = e->inter_b + (size_t)v * e->inter_elems;
+        la.part[i] = la.wave_out[i];
+        la.inten_out[i] = nullptr;
+        la.scale[i] = 1.f;
+        la.gph[i] = make_float2(1.f, 0.f);
+        lb.src[i] = la.wave_out[i];
+        lb.wave_out[i] = a.wave_out ? a.wave_out[v] : nullptr;
+        lb.part[i] = lb.wave_out[i];
+        lb.inten_out[i] = a.inten_out ? a.inten_out[v] : nullptr;
+        lb.scale[i] = a.inten_scale ? a.inten_scale[v] : 1.f;
+        const double g = a.gphase ? a.gphase[v] : 0.0;
+        lb.gph[i] = make_float2((float)std::cos(g), (float)std::sin(g));
+        if (i < V) {
+            if (int rc = kernel_spectrum(p, e->ax[0], a.a[v], a.du_x, st, &la.H[i])) return rc;
+            if (int rc = kernel_spectrum(p, e->ax[1], a.a[v], a.du_y, st, &lb.H[i])) return rc;
+        } else {
+            la.H[i] = la.H[0];
+            lb.H[i] = lb.H[0];
+        }
+    }
+    if (int rc = launch_lines_r3<true>(e->ax[0].R3, la, st, "k_fresnel_cols")) return rc;
+    return launch_lines_r3<false>(e->ax[1].R3, lb, st, "k_fresnel_rows");
+}
 
+}  // namespace psx

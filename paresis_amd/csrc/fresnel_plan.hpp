@@ -54,6 +54,22 @@ struct PropArgs {
     hipStream_t stream;
 };
 
+// a batch of source waves over the same thickness maps (psx_fresnel_propagate_sources); arrays indexed [source] or
+// [source * n_dist + distance], coefficients [source * maps.n + material]
+struct SourcesArgs {
+    int n_src, n_dist;
+    const float2 *const *wave_in;   // may be NULL (unit waves), entries may be NULL
+    const float *amp;
+    Mats maps;                      // T and n; its coefficients are not used
+    const double *cphase, *catt;
+    const double *a, *gphase;
+    double du_x, du_y;
+    float2 *const *wave_out;
+    float *const *inten_out;
+    const float *inten_scale;
+    hipStream_t stream;
+};
+
 int rocfft_engine_create(psx_fresnel_plan *p);
 void rocfft_engine_destroy(psx_fresnel_plan *p);
 int rocfft_engine_propagate(psx_fresnel_plan *p, const PropArgs &a);
@@ -62,6 +78,7 @@ bool lds_engine_supported(int Nx, int Ny, int margin);
 int lds_engine_create(psx_fresnel_plan *p);
 void lds_engine_destroy(psx_fresnel_plan *p);
 int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a);
+int lds_engine_propagate_sources(psx_fresnel_plan *p, const SourcesArgs &a);
 
 // psi(p) = amp * wave_in * transmission at UN-padded pixel p
 template <int NM>

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void k_accumulate(float *acc, const float *img
 template <int NM>
 __global__ __launch_bounds__(256) void k_accumulate_sum(float *acc, const float *img, float scale, Mats m, int accumulate,
                                                         int64_t n, double *sums, double weight, int vec) {
+#pragma clang fp contract(off)                 // every product and sum rounded on its own: k_accumulate_many repeats them bit for bit
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     double s = 0.0;
     const int64_t nq = vec ? n >> 2 : 0;
@@ -81,9 +82,9 @@ __global__ __launch_bounds__(256) void k_accumulate_sum(float *acc, const float 
                 la[3] = fma(m.catt[i], (double)t[i].w, la[3]);
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= expf((float)la[e]);
-        }
-        if (acc) {
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * expf((float)la[e]);             // rounded products and sums (no fma
+        }                                                                              // contraction): k_accumulate_many
+        if (acc) {                                                                     // reproduces them bit for bit
             float4 *ap = reinterpret_cast<float4 *>(acc) + q;
             if (accumulate) {
                 const float4 o = *ap;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void k_accumulate_sum(float *acc, const float 
         if (NM > 0) {
             double ph, la;
             mats_eval<NM>(m, p, ph, la);
-            v *= expf((float)la);
+            v = v * expf((float)la);
         }
         if (acc) acc[p] = accumulate ? acc[p] + v : v;
         s += (double)v;
@@ -114,6 +115,89 @@ __global__ __launch_bounds__(256) void k_accumulate_sum(float *acc, const float 
         double *slot = sums + (size_t)(blockIdx.x % PSX_SUM_SLOTS) * PSX_SUM_STRIDE;
         atomicAdd(&slot[0], t);
         atomicAdd(&slot[1], weight * t);
+    }
+}
+
+// The same for the images of several energies in ONE pass (the energies of a detector bin, EXP:351-361): acc (+)= sum over e
+// of scale[e] * img_e * exp(sum_i catt[e][i] * T_i), added in the order of e exactly as one k_accumulate_sum launch per energy
+// would (the float32 sums are bit-identical); sums += (sum of every term, sum of weight[e] * term).
+struct ImgBatch {
+    const float *img[PSX_MAX_SRC];
+    float scale[PSX_MAX_SRC];
+    double weight[PSX_MAX_SRC];
+    double catt[PSX_MAX_SRC][PSX_MAX_MAT];
+    const float *T[PSX_MAX_MAT];
+    int n_img;
+};
+
+template <int NM>
+__global__ __launch_bounds__(256) void k_accumulate_many(float *acc, ImgBatch b, int accumulate, int64_t n, double *sums, int vec) {
+#pragma clang fp contract(off)
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double s0 = 0.0, s1 = 0.0;
+    const int64_t nq = vec ? n >> 2 : 0;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {
+        float4 t[NM > 0 ? NM : 1];
+#pragma unroll
+        for (int i = 0; i < NM; ++i) t[i] = reinterpret_cast<const float4 *>(b.T[i])[q];
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (acc && accumulate) o = reinterpret_cast<const float4 *>(acc)[q];
+        for (int e = 0; e < b.n_img; ++e) {
+            const float4 iv = reinterpret_cast<const float4 *>(b.img[e])[q];
+            const float sc = b.scale[e];
+            float v[4] = {sc * iv.x, sc * iv.y, sc * iv.z, sc * iv.w};
+            if (NM > 0) {
+                double la[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    const double c = b.catt[e][i];
+                    la[0] = fma(c, (double)t[i].x, la[0]);
+                    la[1] = fma(c, (double)t[i].y, la[1]);
+                    la[2] = fma(c, (double)t[i].z, la[2]);
+                    la[3] = fma(c, (double)t[i].w, la[3]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = v[k] * expf((float)la[k]);
+            }
+            if (e == 0 && !accumulate) o = make_float4(v[0], v[1], v[2], v[3]);
+            else o = make_float4(o.x + v[0], o.y + v[1], o.z + v[2], o.w + v[3]);
+            const double t4 = ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+            s0 += t4;
+            s1 = fma(b.weight[e], t4, s1);
+        }
+        if (acc) reinterpret_cast<float4 *>(acc)[q] = o;
+    }
+    for (int64_t p = nq * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        float o = (acc && accumulate) ? acc[p] : 0.f;
+        for (int e = 0; e < b.n_img; ++e) {
+            float v = b.scale[e] * b.img[e][p];
+            if (NM > 0) {
+                double la = 0.0;
+#pragma unroll
+                for (int i = 0; i < NM; ++i) la = fma(b.catt[e][i], (double)b.T[i][p], la);
+                v = v * expf((float)la);
+            }
+            o = (e == 0 && !accumulate) ? v : o + v;
+            s0 += (double)v;
+            s1 = fma(b.weight[e], (double)v, s1);
+        }
+        if (acc) acc[p] = o;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_down(s0, o, 64);
+        s1 += __shfl_down(s1, o, 64);
+    }
+    __shared__ double part[4][2];
+    if ((threadIdx.x & 63) == 0) {
+        part[threadIdx.x >> 6][0] = s0;
+        part[threadIdx.x >> 6][1] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && sums) {
+        double *slot = sums + (size_t)(blockIdx.x % PSX_SUM_SLOTS) * PSX_SUM_STRIDE;
+        atomicAdd(&slot[0], part[0][0] + part[1][0] + part[2][0] + part[3][0]);
+        atomicAdd(&slot[1], part[0][1] + part[1][1] + part[2][1] + part[3][1]);
     }
 }
 
@@ -172,6 +256,35 @@ int psx_accumulate_sum_f32(float *acc, const float *img, float scale, const floa
     if (grid > 1024) grid = 1024;                     // 4 workgroups per CU; 2 x 1024 atomics over 32 lines
     PSX_DISPATCH_NMAT(nmat, PSX_TIMED("k_accumulate_sum", (hipStream_t)stream, k_accumulate_sum<NM><<<grid, 256, 0, (hipStream_t)stream>>>(acc, img, scale, m, accumulate, n, sums, weight, vec)));
     return launch_check("k_accumulate_sum");
+}
+
+int psx_accumulate_many_f32(float *acc, const float *const *imgs, const float *scale, int n_img, const float *const *T,
+                            const double *catt, int nmat, int accumulate, int64_t n, double *sums, const double *weight,
+                            void *stream) {
+    PSX_REQUIRE(imgs && n_img >= 1 && n_img <= PSX_MAX_SRC && n >= 0, "psx_accumulate_many_f32: 1..%d images", PSX_MAX_SRC);
+    PSX_REQUIRE(acc || sums, "psx_accumulate_many_f32: neither an accumulator nor sums requested");
+    Mats m;
+    if (int rc = pack_mats(m, T, nullptr, nullptr, nmat)) return rc;
+    if (n == 0) return 0;
+    ImgBatch b = {};
+    b.n_img = n_img;
+    int vec = (uintptr_t)acc % 16 == 0;
+    for (int i = 0; i < nmat && i < PSX_MAX_MAT; ++i) {
+        b.T[i] = T[i];
+        vec = vec && (uintptr_t)T[i] % 16 == 0;
+    }
+    for (int e = 0; e < n_img; ++e) {
+        PSX_REQUIRE(imgs[e] != nullptr, "psx_accumulate_many_f32: null image %d", e);
+        b.img[e] = imgs[e];
+        vec = vec && (uintptr_t)imgs[e] % 16 == 0;
+        b.scale[e] = scale ? scale[e] : 1.f;
+        b.weight[e] = weight ? weight[e] : 0.0;
+        for (int i = 0; i < nmat; ++i) b.catt[e][i] = catt ? catt[(size_t)e * nmat + i] : 0.0;
+    }
+    int grid = ew_grid(n, 256, 4);
+    if (grid > 1024) grid = 1024;
+    PSX_DISPATCH_NMAT(nmat, PSX_TIMED("k_accumulate_sum", (hipStream_t)stream, k_accumulate_many<NM><<<grid, 256, 0, (hipStream_t)stream>>>(acc, b, accumulate, n, sums, vec)));
+    return launch_check("k_accumulate_many");
 }
 
 int psx_status_scan_f32(const float *img, int64_t n, unsigned *status, void *stream) {

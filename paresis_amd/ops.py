@@ -223,6 +223,36 @@ def accumulate_sum(acc, img, sums, weight, scale=1.0, mats=None, add=True):
     return acc
 
 
+def accumulate_many(acc, imgs, sums, weights, scales=None, mats=None, add=True):
+    """accumulate_sum() over the images of several energies in ONE pass per PSX_MAX_SRC images, added in list order exactly
+    as one accumulate_sum call per image would: acc (+)= sum_e scales[e] * imgs[e] * att_e, sums += (sum, sum of
+    weights[e] * term).  mats[e]: MaterialStack of image e (same maps, own attenuation coefficients) or None."""
+    ne = len(imgs)
+    mats = [_mats(None)] * ne if mats is None else [_mats(m) for m in mats]
+    scales = [1.0] * ne if scales is None else [float(v) for v in scales]
+    shape = tuple(imgs[0].shape)
+    for i, t in enumerate(imgs):
+        _need(t, torch.float32, "imgs[%d]" % i, shape)
+    if acc is not None:
+        _need(acc, torch.float32, "acc", shape)
+    if sums is not None:
+        _need(sums, torch.float64, "sums", (_lib.PSX_SUM_SLOTS, _lib.PSX_SUM_STRIDE))
+    nm = mats[0].n
+    T = mats[0].cargs(shape)[0]
+    for m in mats[1:]:
+        if m.n != nm or any(m.map(i).data_ptr() != mats[0].map(i).data_ptr() for i in range(nm)):
+            raise PsxError("accumulate_many: every image must use the same thickness maps")
+    for e0 in range(0, ne, _lib.PSX_MAX_SRC):
+        el = range(e0, min(ne, e0 + _lib.PSX_MAX_SRC))
+        n = len(el)
+        check(lib().psx_accumulate_many_f32(
+            _ptr(acc), (c_void_p * n)(*[imgs[e].data_ptr() for e in el]), (c_float * n)(*[scales[e] for e in el]), n, T,
+            (c_double * max(1, n * nm))(*[c for e in el for c in mats[e].catt]), nm, 1 if (add or e0 > 0) else 0,
+            imgs[0].numel(), _ptr(sums), (c_double * n)(*[float(weights[e]) for e in el]), _stream()),
+            "psx_accumulate_many_f32")
+    return acc
+
+
 # ----------------------------------------------------------------------------------------------- refraction
 def refract(shape, mats, dscale, clamp, margin=15, I_in=None, I0=1.0, phi_in=None, out=None, out_scale=1.0, add=False,
             want_D=False, I_mut=None):
@@ -368,6 +398,50 @@ class FresnelPlan:
                                           (c_double * nd)(*[float(v) for v in gphase]), c_double(du[0]), c_double(du[1]),
                                           wo, io, (c_float * nd)(*inten_scale), 1 if add else 0, _stream()),
               "psx_fresnel_propagate")
+        return waves
+
+
+    def propagate_sources(self, a, gphase, du, wave_in=None, amp=None, mats=None, want_wave=None, inten_out=None,
+                          inten_scale=None):
+        """Several source waves over the SAME thickness maps in one call (the energies of a detector bin, EXP:317-361):
+        a[s][d], gphase[s][d]; wave_in[s] (or None), amp[s]; mats[s]: MaterialStack of source s (same maps, own coefficients);
+        want_wave[d]; inten_out[s][d] (float32 image or None), inten_scale[s][d].  Every (source, distance) result is what
+        propagate() gives for that source; nothing is accumulated.  Returns waves[s][d] (None where not wanted).  More than
+        PSX_MAX_SRC sources are taken in chunks."""
+        ns, nd = len(a), len(a[0])
+        shape = (self.Nx, self.Ny)
+        mats = [_mats(None)] * ns if mats is None else [_mats(m) for m in mats]
+        amp = [1.0] * ns if amp is None else [float(v) for v in amp]
+        want_wave = [True] * nd if want_wave is None else list(want_wave)
+        inten_out = [[None] * nd for _ in range(ns)] if inten_out is None else [list(r) for r in inten_out]
+        inten_scale = [[1.0] * nd for _ in range(ns)] if inten_scale is None else [[float(v) for v in r] for r in inten_scale]
+        nm = mats[0].n
+        T = mats[0].cargs(shape)[0]
+        for m in mats[1:]:
+            if m.n != nm or any(m.map(i).data_ptr() != mats[0].map(i).data_ptr() for i in range(nm)):
+                raise PsxError("propagate_sources: every source must use the same thickness maps")
+        waves = [[torch.empty(shape, dtype=torch.complex64, device=self.device) if w else None for w in want_wave]
+                 for _ in range(ns)]
+        for s0 in range(0, ns, _lib.PSX_MAX_SRC):
+            sl = range(s0, min(ns, s0 + _lib.PSX_MAX_SRC))
+            n = len(sl)
+            for s in sl:
+                if wave_in is not None and wave_in[s] is not None:
+                    _need(wave_in[s], torch.complex64, "wave_in[%d]" % s, shape)
+                for d, t in enumerate(inten_out[s]):
+                    if t is not None:
+                        _need(t, torch.float32, "inten_out[%d][%d]" % (s, d), shape)
+            wi = (c_void_p * n)(*[(wave_in[s].data_ptr() if wave_in is not None and wave_in[s] is not None else None) for s in sl])
+            wo = (c_void_p * (n * nd))(*[(waves[s][d].data_ptr() if waves[s][d] is not None else None) for s in sl for d in range(nd)])
+            io = (c_void_p * (n * nd))(*[(inten_out[s][d].data_ptr() if inten_out[s][d] is not None else None) for s in sl for d in range(nd)])
+            check(lib().psx_fresnel_propagate_sources(
+                self._h, n, nd, wi, (c_float * n)(*[amp[s] for s in sl]), T,
+                (c_double * max(1, n * nm))(*[c for s in sl for c in mats[s].cphase]),
+                (c_double * max(1, n * nm))(*[c for s in sl for c in mats[s].catt]), nm,
+                (c_double * (n * nd))(*[float(a[s][d]) for s in sl for d in range(nd)]),
+                (c_double * (n * nd))(*[float(gphase[s][d]) for s in sl for d in range(nd)]), c_double(du[0]), c_double(du[1]),
+                wo, io, (c_float * (n * nd))(*[inten_scale[s][d] for s in sl for d in range(nd)]), _stream()),
+                "psx_fresnel_propagate_sources")
         return waves
 
 

@@ -487,3 +487,65 @@ def test_pack_counts_roundtrip_and_overflow(ops):
         flag.zero_()
     with pytest.raises(PsxError):
         ops.pack_counts(torch.zeros(4, device="cuda"), torch.zeros(5, dtype=torch.int16, device="cuda"), 0, exc, cnt, flag)
+
+
+@pytest.mark.parametrize("case", [(200, 312, 5, 2, 2), (512, 512, 25, 1, 2), (96, 130, 3, 2, 1), (640, 384, 18, 2, 2)])
+def test_propagate_sources_matches_one_call_per_source(ops, case):
+    """psx_fresnel_propagate_sources (the energies of a detector bin in three launches on small grids): every (source,
+    distance) result is bit for bit what psx_fresnel_propagate gives for that source -- own input wave, amplitude,
+    coefficients, chirp, phase and scale; more sources than one launch holds; a z = 0 pair (one-source path); both engines."""
+    Nx, Ny, ns, nd, engine = case
+    g = torch.Generator(device="cuda").manual_seed(Nx + ns)
+    T = torch.rand((2, Nx, Ny), generator=g, device="cuda") * 1e-4
+    mats = [ops.MaterialStack(T, cphase=[-3e4 * (1 + 0.1 * s), 2e4 / (1 + s)], catt=[-30.0 * (1 + s), -5.0]) for s in range(ns)]
+    waves_in = [torch.complex(torch.rand((Nx, Ny), generator=g, device="cuda"), torch.rand((Nx, Ny), generator=g, device="cuda"))
+                if s % 2 else None for s in range(ns)]
+    amp = [1.0 + 0.25 * s for s in range(ns)]
+    a = [[2.0e-12 * (1 + s) * (1 + 0.5 * d) for d in range(nd)] for s in range(ns)]
+    if nd == 2 and ns == 3:
+        a[1][0] = 0.0                                      # z == 0 (EXP:233-234): the batch falls back to one source at a time
+    gph = [[1.0e9 * (s + 1) + 0.3 * d for d in range(nd)] for s in range(ns)]
+    du = (2 * np.pi / (Nx * 1e-6), 2 * np.pi / (Ny * 1e-6))
+    scale = [[0.5 + s + d for d in range(nd)] for s in range(ns)]
+    plan = ops.FresnelPlan(Nx, Ny, max_dist=2, engine=engine)
+    ref_w, ref_i = [], []
+    for s in range(ns):
+        io = [torch.empty((Nx, Ny), device="cuda") for _ in range(nd)]
+        ref_w.append(plan.propagate(a[s], gph[s], du, wave_in=waves_in[s], amp=amp[s], mats=mats[s], want_wave=[True] * nd,
+                                    inten_out=io, inten_scale=scale[s]))
+        ref_i.append(io)
+    io = [[torch.empty((Nx, Ny), device="cuda") for _ in range(nd)] for _ in range(ns)]
+    got = plan.propagate_sources(a, gph, du, wave_in=waves_in, amp=amp, mats=mats, want_wave=[True] * nd, inten_out=io,
+                                 inten_scale=scale)
+    for s in range(ns):
+        for d in range(nd):
+            assert torch.equal(got[s][d], ref_w[s][d]), (s, d)
+            assert torch.equal(io[s][d], ref_i[s][d]), (s, d)
+    # intensity only, no complex output
+    io2 = [[torch.empty((Nx, Ny), device="cuda") for _ in range(nd)] for _ in range(ns)]
+    plan.propagate_sources(a, gph, du, wave_in=waves_in, amp=amp, mats=mats, want_wave=[False] * nd, inten_out=io2,
+                           inten_scale=scale)
+    assert all(torch.equal(io2[s][d], ref_i[s][d]) for s in range(ns) for d in range(nd))
+    plan.close()
+
+
+def test_accumulate_many_matches_one_call_per_image(ops):
+    """psx_accumulate_many_f32: the float32 image is bit for bit the chain of psx_accumulate_sum_f32 calls, the float64 sums
+    agree to rounding; more images than one launch holds, aligned and ragged sizes, with and without attenuation maps."""
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for shape, ne, with_maps in (((300, 412), 5, True), ((127, 33), 20, True), ((256, 256), 3, False)):
+        T = torch.rand((2,) + shape, generator=g, device="cuda") * 1e-3
+        imgs = [torch.rand(shape, generator=g, device="cuda") * 100 for _ in range(ne)]
+        mats = [ops.MaterialStack(T, catt=[-40.0 * (e + 1), -3.0]) if with_maps else None for e in range(ne)]
+        weights = [20.0 + 2 * e for e in range(ne)]
+        scales = [1.0 + 0.1 * e for e in range(ne)]
+        for add in (False, True):
+            a1 = torch.full(shape, 7.0, device="cuda")
+            a2 = a1.clone()
+            s1, s2 = ops.new_sums(a1.device), ops.new_sums(a1.device)
+            for e in range(ne):
+                ops.accumulate_sum(a1, imgs[e], s1, weights[e], scale=scales[e], mats=mats[e], add=add or e > 0)
+            ops.accumulate_many(a2, imgs, s2, weights, scales=scales, mats=mats, add=add)
+            assert torch.equal(a1, a2), (shape, add)
+            f1, f2 = ops.fold_sums(s1), ops.fold_sums(s2)
+            assert torch.allclose(f1, f2, rtol=1e-12, atol=0), (f1, f2)
