@@ -126,6 +126,16 @@ int psx_refract_multi_f32(const float *I_in, float I0, const float *const *T, co
                           int nmat, const double *phi_in, float *const *I_out, float out_scale, int accumulate,
                           float *Dx_out, float *Dy_out, float *I_mut, int Nx, int Ny, int margin, const double *dscale,
                           int ndist, double clamp_x, double clamp_y, unsigned *status, void *workspace, void *stream);
+/* A batch of n <= PSX_MAX_SRC refractions over the SAME thickness maps in one launch per kernel -- the energies of a detector
+ * bin (Experiment.py:448-486 loops over them): refraction e has its own input image I_in[e] (all or none; none = the uniform
+ * I0[e]), coefficients cphase/catt[e*nmat + i], displacement scale dscale[e] and output image I_out[e]; one distance each, no
+ * displacement maps.  Every image is what psx_refract_f32 gives for that refraction (far rays apart: float atomics).
+ * workspace: psx_refract_batch_workspace_bytes(Nx, Ny, n) bytes. */
+size_t psx_refract_batch_workspace_bytes(int Nx, int Ny, int n);
+int psx_refract_batch_f32(int n, const float *const *I_in, const float *I0, const float *const *T, const double *cphase,
+                          const double *catt, int nmat, float *const *I_out, float out_scale, int accumulate, int Nx, int Ny,
+                          int margin, const double *dscale, double clamp_x, double clamp_y, unsigned *status, void *workspace,
+                          void *stream);
 
 /* Deterministic-order debug mode (the reference's scatter is a single-threaded raster loop, RF2:217-263;
  * here far rays and psx_fastloop_f32 deposit with global float atomics in arbitrary order).  With on != 0 those deposits go

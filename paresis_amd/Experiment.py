@@ -338,7 +338,7 @@ class Experiment:
         if flag is not None:
             return bool(flag) and len(self.mySource.mySpectrum) > 1
         return (len(self.mySource.mySpectrum) > 1 and N[0] * N[1] <= self.BATCH_ENERGIES_MAX_PIXELS and
-                plan.engine == _lib.ENGINE_LDS)
+                (plan is None or plan.engine == _lib.ENGINE_LDS))
 
     def _bins_of_spectrum(self):
         """EXP:378: the energies of each detector bin, in spectrum order (a bin closes at the first energy above its
@@ -469,6 +469,52 @@ class Experiment:
         h = self.exp_dict['studyPixelSize'] * 1e-6
         return z / k_refraction(Energy) / (h * self.exp_dict['magnification']) / h
 
+    def _rt_bins_batched(self, pointNum, stacks, accs, plate, air, N, sums, clamp):
+        """The ray-tracing chain of one position (EXP:448-521) with the energies of each bin taken together
+        (psx_refract_batch_f32: one launch per kernel for up to 8 energies); samples without dark field only."""
+        ed = self.exp_dict
+        accS, accR, accP, white = accs
+        dMO, dOD = ed['distMembraneToObject'], ed['distObjectToDetector']
+        bins, leftover = self._bins_of_spectrum()
+        nmax = max([len(b) for b in bins] + [1])
+        if self._etmp is None or self._etmp.shape[0] < 2 * nmax or tuple(self._etmp.shape[1:]) != N:
+            self._etmp = torch.empty((2 * nmax,) + N, dtype=torch.float32, device=accS.device)
+        for ibin, energies in enumerate(bins):
+            ne = len(energies)
+            Es = [E for _, E, _ in energies]
+            I0 = [self._incident(flux, E, ie) for ie, E, flux in energies]
+            air_rt = [air.stack_rt(E, phase=False) if air is not None else None for E in Es]
+            plate_att = [plate.stack_rt(E, phase=False) for E in Es] if plate is not None else None
+            mem = [self.myMembrane.stack_rt(E) for E in Es]
+            smp = [self.mySampleofInterest.stack_rt(E) for E in Es]
+            mem_phase = [m.with_coeffs(catt=[0.0] * m.n) for m in mem]
+            Ibs = [self._etmp[k] for k in range(ne)]
+            tmp = [self._etmp[nmax + k] for k in range(ne)]
+            # EXP:463 + 466: membrane transmission fused into the first refraction, every energy
+            ops.refract_batch(N, [ops.MaterialStack.concat(a, m) for a, m in zip(air_rt, mem)],
+                              [self._dscale(dMO, E) for E in Es], clamp, I0=I0, outs=Ibs)
+            self.IntensitySampleBeforeSample = Ibs[-1]
+            # EXP:474 reference images: refracted again with the membrane phase only; EXP:480-486 their attenuated sum
+            ops.refract_batch(N, mem_phase, [self._dscale(dOD, E) for E in Es], clamp, I_in=Ibs, outs=tmp)
+            ops.accumulate_many(accR, tmp, sums, Es, mats=plate_att, add=False)
+            # EXP:469 + 473 sample images: sample attenuation and membrane+sample phase fused into the refraction
+            ops.refract_batch(N, [ops.MaterialStack.concat(mp, sm) for mp, sm in zip(mem_phase, smp)],
+                              [self._dscale(dOD, E) for E in Es], clamp, I_in=Ibs, outs=tmp)
+            ops.accumulate_many(accS, tmp, None, [0.0] * ne, mats=plate_att, add=False)
+            if pointNum == 0:                                                             # EXP:488-498
+                if ne > 1:
+                    ops.refract_batch(N, [ops.MaterialStack.concat(a, sm) for a, sm in zip(air_rt[:-1], smp[:-1])],
+                                      [self._dscale(dOD, E) for E in Es[:-1]], clamp, I0=I0[:-1], outs=tmp[:-1])
+                # the last energy of the bin leaves the displacement maps behind (EXP:492), like the per-energy loop
+                _, self.Dxreal, self.Dyreal = ops.refract(N, ops.MaterialStack.concat(air_rt[-1], smp[-1]),
+                                                          self._dscale(dOD, Es[-1]), clamp, I0=I0[-1], out=tmp[ne - 1],
+                                                          want_D=True)
+                ops.accumulate_many(accP, tmp, None, [0.0] * ne, mats=plate_att, add=False)
+                for k in range(ne):
+                    self._white(white, I0[k], air_rt[k], plate_att[k] if plate_att is not None else None, k == 0)
+            self._detect_bin(ibin, pointNum, stacks, accs)                                # EXP:501-521
+        return len(bins)
+
     def computeSampleAndReferenceImages_RT(self, pointNum):
         """Experiment.py:407-526.  Returns (SampleImage, ReferenceImage, PropagImage, detectedWhite, Dxreal, Dyreal,
         darkFieldPropag); Dxreal/Dyreal are the PADDED [N+30, N+30] maps of the last energy (point 0 only)."""
@@ -484,6 +530,15 @@ class Experiment:
             self.darkFieldPropag = torch.zeros(N, dtype=torch.float32, device=dev)        # scalar dark field: stays zero
         dMO, dOD = ed['distMembraneToObject'], ed['distObjectToDetector']
         clamp = (N[0], N[1])                                                              # RF2:61-64
+        if not scattering and self._batch_energies(N, None):
+            nvisited = self._rt_bins_batched(pointNum, stacks, accs, plate, air, N, sums, clamp)
+            self._zero_unvisited_bins(stacks, nvisited, pointNum)
+            if not ed.get('deferStatus'):
+                ops.check_status(dev, "computeSampleAndReferenceImages_RT")               # RF2:81-82, checked once
+            self._finish_mean_energy(sums, N[0] * N[1])
+            if not ed.get('deferMeanEnergy'):
+                print("Mean detected energy in reference image", ed['meanEnergy'])
+            return stacks[0], stacks[1], stacks[2], stacks[3], self.Dxreal, self.Dyreal, self.darkFieldPropag
         ibin = 0
         first = True
         for ie, (currentEnergy, flux) in enumerate(self.mySource.mySpectrum):

@@ -146,12 +146,17 @@ class AnalyticalSample(Sample):
     # --------------------------------------------------------------------------------------- coefficients
     def _coeff(self, table, energy):
         """The reference looks delta/beta up by exact float equality on the energy and keeps 0 when nothing matches
-        (Sample.py:266-277)."""
+        (Sample.py:266-277; the last matching row wins).  The rows of a material are indexed once (a 25-energy position
+        otherwise walks every table for every energy: thousands of comparisons per position); the index follows the list it
+        was built from (same object, same length)."""
         out = np.zeros(len(self.myMaterials))
+        cache = self.__dict__.setdefault("_coeff_index", {})
         for imat in range(len(self.myMaterials)):
-            for energyData, value in table[imat]:
-                if energyData == energy:
-                    out[imat] = value
+            rows = table[imat]
+            hit = cache.get(id(rows))
+            if hit is None or hit[0] is not rows or hit[1] != len(rows):
+                hit = cache[id(rows)] = (rows, len(rows), {e: v for e, v in rows})
+            out[imat] = hit[2].get(energy, 0.0)
         return out
 
     def stack_wave(self, energy, phase=True, att=True):

@@ -47,6 +47,9 @@ PROTOTYPES = {
     "psx_refract_multi_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "psx_refract_multi_f32": (c_int, [_vp, c_float, _vpp, _dp, _dp, c_int, _vp, _vpp, c_float, c_int, _vp, _vp, _vp,
                                       c_int, c_int, c_int, _dp, c_int, c_double, c_double, _vp, _vp, _vp]),
+    "psx_refract_batch_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "psx_refract_batch_f32": (c_int, [c_int, _vpp, _fp, _vpp, _dp, _dp, c_int, _vpp, c_float, c_int, c_int, c_int, c_int, _dp,
+                                      c_double, c_double, _vp, _vp, _vp]),
     "psx_fastloop_f32": (c_int, [_vp, _vp, _vp, _vp, c_int, c_int, _vp]),
     "psx_fresnel_plan_create": (c_int, [c_int, c_int, c_int, c_int, c_int, _vpp]),
     "psx_fresnel_plan_destroy": (c_int, [_vp]),

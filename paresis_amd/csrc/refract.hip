@@ -109,7 +109,7 @@ __device__ __forceinline__ int xcd_tile(int b, int nt) {
 }
 
 template <class G, int NM, bool HAS_I, bool HAS_PHI>
-__global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_refract_near(RefractArgs a) {
+__device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     constexpr int TH = G::TH, TW = G::TW, H = G::H, SR = G::SR, SC = G::SC, GR = G::GR, GC = G::GC, NTHREADS = G::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *sphi = (double *)smem;                                        // [SR][SC]
@@ -411,6 +411,53 @@ __global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     if (a.status && __any(any_bad) && (tid & 63) == 0) atomicOr(a.status, PSX_STATUS_NONFINITE);
 }
 
+template <class G, int NM, bool HAS_I, bool HAS_PHI>
+__global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_refract_near(RefractArgs a) {
+    refract_near_body<G, NM, HAS_I, HAS_PHI>(a);
+}
+
+// A batch of refractions in one launch -- the energies of a detector bin (EXP:448-486): refraction e = blockIdx.y has its own
+// argument block (input intensity or uniform I0, coefficients, displacement scale, output image, far-ray lists) in the
+// kernel-argument segment, which holds REFRACT_TAB of them; the kernels read theirs in place (scalar loads at a computed
+// offset -- a copy of the block would live in scratch memory).
+constexpr int REFRACT_TAB = 8;
+struct RefractTab {
+    RefractArgs e[REFRACT_TAB];
+};
+static_assert(sizeof(RefractTab) <= 4096, "kernel arguments are limited to 4 KiB");
+
+// The block of refraction e as a LOCAL structure whose arrays are only ever touched at compile-time indices (one distance,
+// NM materials): it is scalarised into registers.  Handing the bodies a reference into the argument segment at a run-time
+// offset instead made the compiler re-load the arguments wherever they are used (six times the kernel time), and a plain
+// copy of the block lives in scratch memory (its distance arrays are indexed by a loop variable).
+template <int NM>
+__device__ __forceinline__ RefractArgs one_distance_block(const RefractTab &t, int e) {
+    const RefractArgs &s = t.e[e];
+    RefractArgs a;
+    a.I_in = s.I_in; a.I0 = s.I0; a.phi_in = nullptr;
+    a.m.n = NM;
+#pragma unroll
+    for (int i = 0; i < (NM > 0 ? NM : 1); ++i) {
+        a.m.T[i] = s.m.T[i];
+        a.m.cphase[i] = s.m.cphase[i];
+        a.m.catt[i] = s.m.catt[i];
+    }
+    a.I_out[0] = s.I_out[0]; a.dscale[0] = s.dscale[0]; a.ndist = 1;
+    a.out_scale = s.out_scale; a.accumulate = s.accumulate;
+    a.Dx_out = nullptr; a.Dy_out = nullptr; a.I_mut = nullptr;
+    a.Nx = s.Nx; a.Ny = s.Ny; a.margin = s.margin; a.clamp_xf = s.clamp_xf; a.clamp_yf = s.clamp_yf;
+    a.status = s.status; a.far_count = s.far_count; a.far_list = s.far_list;
+    a.tiles_x = s.tiles_x; a.tiles_y = s.tiles_y; a.tile_cap = s.tile_cap; a.stamps = nullptr;
+    return a;
+}
+
+template <class G, int NM, bool HAS_I>
+__global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_refract_near_batch(RefractTab t) {
+    const RefractArgs a = one_distance_block<NM>(t, blockIdx.y);
+    refract_near_body<G, NM, HAS_I, false>(a);
+}
+
+
 // Replay of the far rays with the reference's literal border rules (RF2:235-262) in padded coordinates.
 // One WAVE per list (list = distance * ntiles + tile): a list holds a few dozen records and the kernel is a chain of
 // dependent latencies (count -> records -> atomics), so it wants as many lists in flight per CU as there are wave slots.
@@ -451,8 +498,8 @@ __global__ __launch_bounds__(256) void k_det_apply(float *out, const long long *
     }
 }
 
-template <class G, bool DET = false>
-__global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a, DetAcc det) {
+template <class G, bool DET = false, bool ONE = false>      // ONE: a single distance (its index is then a constant)
+__device__ __forceinline__ void refract_far_body(const RefractArgs &a, const DetAcc &det) {
     constexpr int TH = G::TH, TW = G::TW, H = G::H;
     const unsigned nlists = (unsigned)(a.tiles_x * a.tiles_y) * (unsigned)a.ndist;
     const unsigned lst = blockIdx.x * (FAR_THREADS / 64) + (threadIdx.x >> 6);
@@ -460,8 +507,8 @@ __global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a, DetA
     const unsigned n = a.far_count[lst];
     if (n == 0) return;
     const FarRay *list = a.far_list + (size_t)lst * (TH * TW);
-    const unsigned dist = lst / (unsigned)(a.tiles_x * a.tiles_y);
-    float *const I_out = a.I_out[dist];
+    const unsigned dist = ONE ? 0u : lst / (unsigned)(a.tiles_x * a.tiles_y);
+    float *const I_out = a.I_out[ONE ? 0 : dist];
     const double dscale_fix = DET ? det_scale(det.mx) : 0.0;
     (void)dist; (void)dscale_fix;
     const int Px = a.Nx + 2 * a.margin, Py = a.Ny + 2 * a.margin;
@@ -498,6 +545,18 @@ __global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a, DetA
         deposit(bi, nj, I * wbi * wnj);
     }
 }
+
+template <class G, bool DET = false>
+__global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a, DetAcc det) {
+    refract_far_body<G, DET>(a, det);
+}
+
+template <class G>
+__global__ __launch_bounds__(FAR_THREADS) void k_refract_far_batch(RefractTab t) {
+    const RefractArgs a = one_distance_block<0>(t, blockIdx.y);
+    refract_far_body<G, false, true>(a, DetAcc{nullptr, nullptr});
+}
+
 
 __global__ __launch_bounds__(256) void k_absmax(const float *__restrict__ v, int64_t n, unsigned *mx) {
     float m = 0.f;
@@ -624,6 +683,39 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
     return launch_check("k_refract_far");
 }
 
+template <class G>
+int launch_refract_batch(RefractTab &t, int n, bool has_I, int nmat, void *workspace, hipStream_t st) {
+    const int tiles_x = (int)cdiv(t.e[0].Nx, G::TH), tiles_y = (int)cdiv(t.e[0].Ny, G::TW);
+    const size_t nt = (size_t)tiles_x * tiles_y;
+    for (int e = 0; e < REFRACT_TAB; ++e) {
+        RefractArgs &a = t.e[e];
+        a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.tile_cap = G::TH * G::TW;
+        const int k = e < n ? e : 0;
+        a.far_count = (unsigned *)workspace + (size_t)k * nt;
+        a.far_list = (FarRay *)((char *)workspace + 16 * ((sizeof(unsigned) * nt * REFRACT_TAB + 15) / 16)) + (size_t)k * nt * a.tile_cap;
+    }
+    int rc_launch = 0;
+    auto launch = [&](auto nm, auto hi) -> int {
+        constexpr int NM = decltype(nm)::value;
+        constexpr bool HI = decltype(hi)::value;
+        static std::atomic<unsigned long long> attr_mask{0};
+        if (first_on_device(attr_mask))
+            PSX_HIP(hipFuncSetAttribute((const void *)k_refract_near_batch<G, NM, HI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)G::LDS));
+        PSX_TIMED("k_refract_near", st, k_refract_near_batch<G, NM, HI><<<dim3((unsigned)nt, (unsigned)n), G::NT, G::LDS, st>>>(t));
+        if (int rc = launch_check("k_refract_near")) return rc;
+        const int fgrid = ((int)nt + FAR_THREADS / 64 - 1) / (FAR_THREADS / 64);
+        PSX_TIMED("k_refract_far", st, k_refract_far_batch<G><<<dim3((unsigned)fgrid, (unsigned)n), FAR_THREADS, 0, st>>>(t));
+        return launch_check("k_refract_far");
+    };
+    PSX_DISPATCH_NMAT(nmat, {
+        using N_ = std::integral_constant<int, NM>;
+        if (has_I) rc_launch = launch(N_{}, std::true_type{});
+        else rc_launch = launch(N_{}, std::false_type{});
+    });
+    return rc_launch;
+}
+
 }  // namespace
 
 extern "C" {
@@ -710,6 +802,67 @@ int psx_fastloop_f32(const float *I, const float *Dx, const float *Dy, float *I2
 
 int psx_set_deterministic(int on) {
     g_deterministic = on ? 1 : 0;
+    return 0;
+}
+
+size_t psx_refract_batch_workspace_bytes(int Nx, int Ny, int n) {
+    const int chunks = (std::max(n, 1) + REFRACT_TAB - 1) / REFRACT_TAB;
+    return (size_t)chunks * psx_refract_multi_workspace_bytes(Nx, Ny, REFRACT_TAB);
+}
+
+int psx_refract_batch_f32(int n, const float *const *I_in, const float *I0, const float *const *T, const double *cphase,
+                          const double *catt, int nmat, float *const *I_out, float out_scale, int accumulate, int Nx, int Ny,
+                          int margin, const double *dscale, double clamp_x, double clamp_y, unsigned *status, void *workspace,
+                          void *stream) {
+    PSX_REQUIRE(n >= 1 && n <= PSX_MAX_SRC, "psx_refract_batch_f32: %d refractions, 1..%d supported per call", n, PSX_MAX_SRC);
+    PSX_REQUIRE(I_out != nullptr && dscale != nullptr && workspace != nullptr, "psx_refract_batch_f32: null outputs, scales or workspace");
+    PSX_REQUIRE(nmat > 0, "psx_refract_batch_f32: the phase comes from the thickness maps (nmat > 0)");
+    const bool has_I = I_in != nullptr && I_in[0] != nullptr;
+    PSX_REQUIRE(has_I || I0 != nullptr, "psx_refract_batch_f32: neither input images nor uniform intensities");
+    for (int e = 0; e < n; ++e) {
+        PSX_REQUIRE(I_out[e] != nullptr, "psx_refract_batch_f32: null output image %d", e);
+        PSX_REQUIRE(!has_I || I_in[e] != nullptr, "psx_refract_batch_f32: input images for all refractions or for none (%d)", e);
+        for (int f = 0; f < e; ++f) PSX_REQUIRE(I_out[f] != I_out[e], "psx_refract_batch_f32: refractions %d and %d share an output image", f, e);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (g_deterministic) {                    // debug mode: one refraction at a time through the scratch accumulators
+        const size_t one = psx_refract_workspace_bytes(Nx, Ny);
+        (void)one;
+        for (int e = 0; e < n; ++e)
+            if (int rc = psx_refract_f32(has_I ? I_in[e] : nullptr, I0 ? I0[e] : 1.f, T, cphase ? cphase + (size_t)e * nmat : nullptr,
+                                         catt ? catt + (size_t)e * nmat : nullptr, nmat, nullptr, I_out[e], out_scale, accumulate,
+                                         nullptr, nullptr, nullptr, Nx, Ny, margin, dscale[e], clamp_x, clamp_y, status, workspace, stream))
+                return rc;
+        return 0;
+    }
+    PSX_REQUIRE(Nx >= 3 && Ny >= 3, "psx_refract_batch_f32: grid %dx%d too small for the edge_order=2 gradient", Nx, Ny);
+    PSX_REQUIRE((int64_t)Nx * Ny < (1ll << 31), "psx_refract_batch_f32: grid %dx%d exceeds int32 pixel indices", Nx, Ny);
+    PSX_REQUIRE(margin >= 8 && margin <= 4096, "psx_refract_batch_f32: margin %d must be >= 8 (the widest gather halo)", margin);
+    const size_t chunk_ws = psx_refract_multi_workspace_bytes(Nx, Ny, REFRACT_TAB);
+    for (int e0 = 0; e0 < n; e0 += REFRACT_TAB) {           // REFRACT_TAB argument blocks fit one launch
+        const int m = std::min(REFRACT_TAB, n - e0);
+        RefractTab t = {};
+        for (int k = 0; k < REFRACT_TAB; ++k) {
+            const int e = e0 + (k < m ? k : 0);
+            RefractArgs &a = t.e[k];
+            if (int rc = pack_mats(a.m, T, cphase ? cphase + (size_t)e * nmat : nullptr, catt ? catt + (size_t)e * nmat : nullptr, nmat))
+                return rc;
+            a.ndist = 1;
+            a.I_in = has_I ? I_in[e] : nullptr; a.I0 = I0 ? I0[e] : 1.f;
+            for (int d = 0; d < PSX_MAX_DIST; ++d) {
+                a.I_out[d] = I_out[e];
+                a.dscale[d] = dscale[e];
+            }
+            a.phi_in = nullptr; a.out_scale = out_scale; a.accumulate = accumulate;
+            a.Dx_out = nullptr; a.Dy_out = nullptr; a.I_mut = nullptr; a.Nx = Nx; a.Ny = Ny; a.margin = margin;
+            a.clamp_xf = (float)clamp_x; a.clamp_yf = (float)clamp_y; a.status = status; a.stamps = nullptr;
+        }
+        void *ws = (char *)workspace + (size_t)(e0 / REFRACT_TAB) * chunk_ws;     // every chunk its own far-ray lists
+        const int rc = g_refract_geometry == 1   ? launch_refract_batch<GeoWide>(t, m, has_I, nmat, ws, st)
+                       : g_refract_geometry == 2 ? launch_refract_batch<GeoMid>(t, m, has_I, nmat, ws, st)
+                                                 : launch_refract_batch<GeoSmall>(t, m, has_I, nmat, ws, st);
+        if (rc) return rc;
+    }
     return 0;
 }
 

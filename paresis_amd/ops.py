@@ -284,6 +284,44 @@ def refract(shape, mats, dscale, clamp, margin=15, I_in=None, I0=1.0, phi_in=Non
     return out, Dx, Dy
 
 
+def refract_batch(shape, mats, dscales, clamp, margin=15, I_in=None, I0=None, outs=None, out_scale=1.0, add=False):
+    """Several refractions over the SAME thickness maps in one launch per kernel (the energies of a detector bin,
+    EXP:448-486): mats[e] (same maps, own coefficients), dscales[e], I_in[e] (all or None) or the uniform I0[e], outs[e].
+    Every image is what refract() gives for that refraction.  Returns the list of output images."""
+    ne = len(mats)
+    mats = [_mats(m) for m in mats]
+    Nx, Ny = int(shape[0]), int(shape[1])
+    dev = mats[0].map(0).device
+    nm = mats[0].n
+    T = mats[0].cargs((Nx, Ny))[0]
+    for m in mats[1:]:
+        if m.n != nm or any(m.map(i).data_ptr() != mats[0].map(i).data_ptr() for i in range(nm)):
+            raise PsxError("refract_batch: every refraction must use the same thickness maps")
+    if I_in is not None:
+        for e, t in enumerate(I_in):
+            _need(t, torch.float32, "I_in[%d]" % e, (Nx, Ny))
+    if outs is None:
+        if add:
+            raise PsxError("add=True needs existing output images")
+        outs = [torch.empty((Nx, Ny), dtype=torch.float32, device=dev) for _ in range(ne)]
+    for e, t in enumerate(outs):
+        _need(t, torch.float32, "outs[%d]" % e, (Nx, Ny))
+    I0 = [1.0] * ne if I0 is None else [float(v) for v in I0]
+    for e0 in range(0, ne, _lib.PSX_MAX_SRC):
+        el = range(e0, min(ne, e0 + _lib.PSX_MAX_SRC))
+        n = len(el)
+        ws = _workspace(dev, lib().psx_refract_batch_workspace_bytes(Nx, Ny, n))
+        check(lib().psx_refract_batch_f32(
+            n, (c_void_p * n)(*[I_in[e].data_ptr() for e in el]) if I_in is not None else None,
+            (c_float * n)(*[I0[e] for e in el]), T,
+            (c_double * (n * nm))(*[c for e in el for c in mats[e].cphase]),
+            (c_double * (n * nm))(*[c for e in el for c in mats[e].catt]), nm,
+            (c_void_p * n)(*[outs[e].data_ptr() for e in el]), c_float(out_scale), 1 if add else 0, Nx, Ny, int(margin),
+            (c_double * n)(*[float(dscales[e]) for e in el]), c_double(clamp[0]), c_double(clamp[1]),
+            _ptr(status_word(dev)), _ptr(ws), _stream()), "psx_refract_batch_f32")
+    return outs
+
+
 def refract_multi(shape, mats, dscales, clamp, margin=15, I_in=None, I0=1.0, phi_in=None, outs=None, out_scale=1.0,
                   add=False):
     """A propagation-distance batch of K9-K13: len(dscales) refractions of the SAME source (I_in/I0, mats, phi_in) in

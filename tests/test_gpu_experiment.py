@@ -76,6 +76,30 @@ def test_energy_batched_chain_matches_energy_loop():
     assert relmax(outs[True, 0][0].cpu().numpy(), g[t + "Sample"]) < TOL
 
 
+def test_energy_batched_rt_chain_matches_energy_loop():
+    """The ray-tracing chain with the energies of a bin taken together (psx_refract_batch_f32) against the per-energy loop:
+    same images (far rays are summed by float atomics in both), same displacement maps, same mean energy."""
+    g = load("experiment.npz")
+    cfg = experiment_cfg(g, "poly/RT", orc.Obj)
+    outs = {}
+    for batched in (True, False):
+        exp = build_experiment(cfg, "RT")
+        exp.exp_dict["batchEnergies"] = batched
+        for point in (0, 1):
+            exp.myMembrane.myGeometry = g["poly/RT/p%d/membrane" % point]
+            exp.exp_dict["meanEnergy"] = 0
+            out = exp.computeSampleAndReferenceImages(point)
+            outs[batched, point] = [a.clone() for a in out[:6]] + [exp.exp_dict["meanEnergy"]]
+    for point in (0, 1):
+        b, l = outs[True, point], outs[False, point]
+        for k in range(4 if point == 0 else 2):
+            assert relmax(b[k].cpu().numpy(), l[k].cpu().numpy()) < 2e-6, (point, k)
+        assert abs(b[6] - l[6]) < 1e-9 * abs(l[6])
+    assert torch.equal(outs[True, 0][4], outs[False, 0][4]) and torch.equal(outs[True, 0][5], outs[False, 0][5])
+    t = "poly/RT/p0/"
+    assert relmax(outs[True, 0][0].cpu().numpy(), g[t + "Sample"]) < TOL
+
+
 def test_reference_named_functions():
     """The module-level functions keep the reference's names, argument order and return arity."""
     from paresis_amd import refractionFileNumba as RF1

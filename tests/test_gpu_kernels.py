@@ -549,3 +549,31 @@ def test_accumulate_many_matches_one_call_per_image(ops):
             assert torch.equal(a1, a2), (shape, add)
             f1, f2 = ops.fold_sums(s1), ops.fold_sums(s2)
             assert torch.allclose(f1, f2, rtol=1e-12, atol=0), (f1, f2)
+
+
+def test_refract_batch_matches_one_call_per_refraction(ops):
+    """psx_refract_batch_f32 (the energies of a detector bin, one launch per kernel for eight of them): every image equals
+    the psx_refract_f32 result for that refraction -- bit for bit while all rays stay inside the gather halo, within float
+    rounding once far rays are replayed with float atomics; uniform input and per-refraction input images; more refractions
+    than one launch (and one call) holds."""
+    g = torch.Generator(device="cuda").manual_seed(8)
+    Nx, Ny = 210, 333
+    x = torch.linspace(-1, 1, Nx, device="cuda")[:, None]
+    y = torch.linspace(-1, 1, Ny, device="cuda")[None, :]
+    T = torch.stack([(1 - x * x).clamp(min=0) * (1 - y * y).clamp(min=0) * 2e-4,
+                     torch.rand((Nx, Ny), generator=g, device="cuda") * 2e-6]).to(torch.float32).contiguous()
+    for ne, strength in ((5, 1.0), (19, 1.0), (3, 60.0)):
+        mats = [ops.MaterialStack(T, cphase=[-4e4 * strength / (1 + 0.2 * e), -3e4 / (1 + e)], catt=[-50.0 * (e + 1), -10.0])
+                for e in range(ne)]
+        dsc = [0.8 + 0.1 * e for e in range(ne)]
+        I0 = [100.0 + e for e in range(ne)]
+        Iin = [torch.rand((Nx, Ny), generator=g, device="cuda") + 0.5 for _ in range(ne)]
+        for with_in in (False, True):
+            ref = [ops.refract((Nx, Ny), mats[e], dsc[e], (Nx, Ny), I_in=Iin[e] if with_in else None, I0=I0[e])[0] for e in range(ne)]
+            got = ops.refract_batch((Nx, Ny), mats, dsc, (Nx, Ny), I_in=Iin if with_in else None, I0=I0)
+            for e in range(ne):
+                if strength == 1.0:
+                    assert torch.equal(got[e], ref[e]), (ne, with_in, e)
+                else:
+                    assert float((got[e] - ref[e]).abs().max() / ref[e].abs().max()) < 2e-6, (ne, with_in, e)
+    ops.check_status(T.device, "refract batch")
