@@ -55,6 +55,7 @@ PROTOTYPES = {
     "psx_fresnel_plan_destroy": (c_int, [_vp]),
     "psx_fresnel_plan_engine": (c_int, [_vp]),
     "psx_fresnel_plan_bytes": (c_size_t, [_vp]),
+    "psx_fresnel_plan_work_queue": (c_int, [_vp, c_int]),
     "psx_fresnel_propagate": (c_int, [_vp, _vp, c_float, _vpp, _dp, _dp, c_int, c_int, _dp, _dp, c_double, c_double,
                                       _vpp, _vpp, _fp, c_int, _vp]),
     "psx_fresnel_propagate_sources": (c_int, [_vp, c_int, c_int, _vpp, _fp, _vpp, _dp, _dp, c_int, _dp, _dp, c_double, c_double,

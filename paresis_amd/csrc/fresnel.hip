@@ -217,6 +217,12 @@ int psx_fresnel_plan_engine(const psx_fresnel_plan *p) { return p ? p->engine : 
 
 size_t psx_fresnel_plan_bytes(const psx_fresnel_plan *p) { return p ? p->bytes : 0; }
 
+int psx_fresnel_plan_work_queue(psx_fresnel_plan *p, int on) {
+    PSX_REQUIRE(p != nullptr, "psx_fresnel_plan_work_queue: null plan");
+    if (p->engine == PSX_ENGINE_LDS) lds_engine_work_queue(p, on);
+    return 0;
+}
+
 int psx_fresnel_propagate(psx_fresnel_plan *plan, const psx_c64 *wave_in, float amp, const float *const *T,
                           const double *cphase, const double *catt, int nmat, int n_dist, const double *a,
                           const double *gphase, double du_x, double du_y, psx_c64 *const *wave_out,

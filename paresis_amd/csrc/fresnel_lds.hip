@@ -87,6 +87,7 @@ struct LineArgs {
     int B, Lh, S, NB;
     float2 *part[MAX_LINE];
     const float2 *w2;       // PAIR: w_2M^{k0} of each 16-point slab, k0 = q1 + 24 q2  (576 entries)
+    unsigned *queue;        // work queue of the one-transform passes: next unit of each XCD's chunk at [16 x], workgroups done at [128]
     unsigned long long *stamps;   // optional diagnostics: 32 phase timestamps per workgroup (psx_debug_stamps)
 };
 
@@ -134,7 +135,7 @@ __device__ __forceinline__ void lds_barrier() {
 // for the other.
 // That is the only way of sharing the forward transform between distances that fits LDS: 4.3 stage-units of work per two
 // (line, distance) results instead of 5.3, and half the samples to fetch and spread per round.
-template <int R3, bool CONTIG, bool PART = false, bool PAIR = false, bool DUAL = false>
+template <int R3, bool CONTIG, bool PART = false, bool PAIR = false, bool DUAL = false, bool QUEUE = false>
 __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     // PAIR: the second LDS line starts 16 points further, so that a point of line 0 and the same point of line 1 sit 32 banks
     // apart: stage A then gives adjacent lanes the even and the odd sample of a pair without a bank conflict
@@ -163,7 +164,17 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     const int cstart = xcd * cq + (xcd < cr ? xcd : cr), clen = cq + (xcd < cr ? 1 : 0);
     const int nunits = slot < clen ? (clen - slot + nslot - 1) / nslot : 0;   // units cstart + slot + u*nslot, u < nunits
     const int nsub = DUAL ? (a.n_dist + 1) / 2 : a.n_dist;       // rounds per line group when the distances are taken inside
-    const int nj = PART ? nunits * a.S : (a.dist_inner ? nunits * nsub : nunits);   // rounds of this workgroup
+    const int nj = PART ? nunits * a.S : (a.dist_inner ? nunits * nsub : nunits);   // rounds of this workgroup (static order)
+    // One-transform passes take their units from a QUEUE instead (DYN): the workgroups of an XCD claim the units of the XCD's
+    // chunk one after the other (an atomic counter per XCD), two units ahead of the engine.  A static share per workgroup
+    // assumes that all 256 workgroups start together: one CU busy with anything else (the copy kernels of an RCCL transfer,
+    // another stream) makes one workgroup start when the first of the others ends and DOUBLES the pass
+    // (tools/contention_probe.py: one foreign workgroup, +48 % on a position).  From the queue a late workgroup finds nothing
+    // left and the pass loses that CU's share only.  uq: ring of the units claimed (index inside the chunk, -1: chunk empty).
+    constexpr bool DYN = QUEUE;                          // its own instantiations: the engine waves have no register to spare
+    static_assert(!QUEUE || !PART, "the queue serves the one-transform passes");
+    const int nsubr = a.dist_inner ? nsub : 1;                   // rounds per unit
+    int *const uq = reinterpret_cast<int *>(lds + LINES * MP + (2 * R3 + RAD) * (RAD + 1));   // behind the three twiddle tables
     // round j -> (distance, line group) [, output block, kernel segment]
     int pb = 0, ps = 0;       // PART: block and segment of the round last decoded
     auto item = [&](int j, int &d, int &g) __attribute__((always_inline)) {
@@ -178,12 +189,18 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         } else if (a.dist_inner) {
             const int u = j / nsub;
             d = j - u * nsub;                                // DUAL: index of the distance PAIR
-            g = cstart + slot + u * nslot;
+            g = cstart + (DYN ? uq[u & 3] : slot + u * nslot);
         } else {
-            const int w = cstart + slot + j * nslot;
+            const int w = cstart + (DYN ? uq[j & 3] : slot + j * nslot);
             d = w / ngroups;
             g = w - d * ngroups;
         }
+    };
+    // is round j a round at all?  (uniform: every thread reads the same ring entry, written at least one barrier earlier)
+    auto valid = [&](int j) __attribute__((always_inline)) { return DYN ? uq[(j / nsubr) & 3] >= 0 : j < nj; };
+    auto claim = [&]() __attribute__((always_inline)) {
+        const unsigned k = atomicAdd(&a.queue[16 * xcd], 1u);
+        return k < (unsigned)clen ? (int)k : -1;
     };
 
     // Stage B's twiddles w_S1^{n q} (n < R3, q < 24: 3 KiB) live in LDS behind the line buffers, rows padded to 25 so that
@@ -193,6 +210,9 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     // w_576^{n1 q} * w_M^{n0 q}: a [24][24] and an [R3][24] table (rows R3*n1 and n0 of the global table), 7.8 KiB, at the
     // price of one more complex multiply per point and stage (+46 packed instructions per butterfly).  With all three
     // tables in LDS the engine's only global loads are the kernel spectrum's.
+    // the first two units of this workgroup: one atomic, in flight while the twiddle tables are copied
+    unsigned first2 = 0u;
+    if (DYN && tid == TC) first2 = atomicAdd(&a.queue[16 * xcd], 2u);
     constexpr int TWB_LD = RAD + 1;
     v2f *twl = reinterpret_cast<v2f *>(lds) + LINES * MP;          // [R3][25]  stage B
     v2f *tw1 = twl + R3 * TWB_LD;                                  // [24][25]  stage A, n1 part
@@ -205,6 +225,14 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     for (int idx = tid; idx < RAD * RAD; idx += T) {
         const float2 w = a.twA[(size_t)(idx / RAD) * R3 * RAD + idx % RAD];     // row n = R3 * n1
         tw1[(idx / RAD) * TWB_LD + idx % RAD] = (v2f){w.x, w.y};
+    }
+
+    if constexpr (DYN) {
+        if (tid == TC) {                                 // the first loader thread runs the queue
+            uq[0] = first2 < (unsigned)clen ? (int)first2 : -1;
+            uq[1] = first2 + 1u < (unsigned)clen ? (int)(first2 + 1u) : -1;
+        }
+        lds_barrier();                                   // the first two units are known to every wave
     }
 
     // LDS index of butterfly element j: with S1 a multiple of 32 (and R3 | 32) the pad term of phys() is affine in j, so
@@ -374,15 +402,18 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             }
         };
 
-        if (nj > 0) {
+        if (valid(0)) {
             fetch(0);
             spread(0);
         }
         lds_barrier();                                   // (0) first group is in LDS
-        for (int j = 0; j < nj; ++j) {
-            const bool more = j + 1 < nj;
+        for (int j = 0; valid(j); ++j) {
+            const bool more = valid(j + 1);
             lds_barrier();                               // (1) engine: forward stage A done
             if constexpr (DUAL) lds_barrier();           // (1b) engine: forward stage B done (six waves), before the middle stage
+            // the unit after next: claimed during the first round of a unit, visible to every wave after barrier (2), first
+            // read (as "is there a next round") in the last round of the next unit
+            if (DYN && lt == 0 && j % nsubr == 0) uq[(j / nsubr + 2) & 3] = uq[(j / nsubr + 1) & 3] >= 0 ? claim() : -1;
             // Issued after barrier (1), not before: issuing strided loads stalls for ~5 us (the texture path hands out one
             // 128-byte line per lane pair) and forward stage A lasts only 3 us -- the engine would wait for the loaders.
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 16] = wall_clock64();
@@ -400,6 +431,15 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 19] = wall_clock64();
             lds_barrier();                               // (4) next group is in LDS
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 20] = wall_clock64();
+        }
+        if (DYN && lt == 0) {
+            // the last workgroup to leave re-arms the queue for the next launch (every claim of this launch has been made)
+            __threadfence();
+            if (atomicAdd(&a.queue[128], 1u) == gridDim.x - 1) {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) atomicExch(&a.queue[16 * x], 0u);
+                atomicExch(&a.queue[128], 0u);
+            }
         }
         return;
     }
@@ -457,7 +497,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 0] = wall_clock64();
     lds_barrier();                                       // (0) first group is in LDS
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 1] = wall_clock64();
-    for (int j = 0; j < nj; ++j) {
+    for (int j = 0; valid(j); ++j) {
         int d, g;
         item(j, d, g);
         const int l0 = g * LPG;
@@ -1118,6 +1158,8 @@ struct LdsEngine {
     size_t inter_elems = 0;
     float2 *pre = nullptr;       // [Ny][Nx] transmitted source wave, transposed (pass 0)
     float2 *part = nullptr;      // [max_dist][Nx][Ny] partial sums of pass 2 of the partitioned convolution when only |.|^2 is wanted
+    unsigned *queue = nullptr;   // [2][144]: work queues of pass 1 and pass 2 (zero between launches: the kernels re-arm them)
+    bool use_queue = false;      // psx_fresnel_plan_work_queue
     float2 *pre_b = nullptr;     // [PSX_MAX_SRC][Ny][Nx], [MAX_LINE][inter_elems]: the same two for a batch of source waves,
     float2 *inter_b = nullptr;   // allocated by the first batched call (psx_fresnel_propagate_sources)
     // Kernel spectra, keyed by (a, du, N, M).  72 KiB each at 4096^2: the cache is sized for a polychromatic position
@@ -1128,6 +1170,10 @@ struct LdsEngine {
     unsigned long long clock = 0;
 };
 constexpr size_t CACHE_CAP_BYTES = (size_t)1 << 30;
+
+void lds_engine_work_queue(psx_fresnel_plan *p, int on) {
+    if (p->lds) p->lds->use_queue = on != 0;
+}
 
 bool lds_engine_supported(int Nx, int Ny, int margin) {
     // any line length: one transform per line up to N = 4593, the partitioned convolution beyond.  The output windows are
@@ -1207,6 +1253,8 @@ int lds_engine_create(psx_fresnel_plan *p) {
     const size_t npix = (size_t)p->Nx * p->Ny;
     PSX_HIP(hipMalloc((void **)&e->pre, sizeof(float2) * npix));
     p->bytes += sizeof(float2) * npix;
+    PSX_HIP(hipMalloc((void **)&e->queue, sizeof(unsigned) * 2 * 144));
+    PSX_HIP(hipMemset(e->queue, 0, sizeof(unsigned) * 2 * 144));
     if (e->ax[1].part && e->ax[1].S > 1) {      // complex partial sums of pass 2 when only |.|^2 leaves the pass
         PSX_HIP(hipMalloc((void **)&e->part, sizeof(float2) * npix * p->max_dist));
         p->bytes += sizeof(float2) * npix * p->max_dist;
@@ -1237,6 +1285,7 @@ void lds_engine_destroy(psx_fresnel_plan *p) {
     (void)hipFree(e->part);
     (void)hipFree(e->pre_b);
     (void)hipFree(e->inter_b);
+    (void)hipFree(e->queue);
     delete e;
     p->lds = nullptr;
 }
@@ -1307,20 +1356,23 @@ static int kernel_spectrum(psx_fresnel_plan *p, AxisTables &t, double a, double 
     return 0;
 }
 
-template <int R3, bool CONTIG, bool PART = false, bool PAIR = false, bool DUAL = false>
+template <int R3, bool CONTIG, bool PART = false, bool PAIR = false, bool DUAL = false, bool QUEUE = false>
 static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
+    if constexpr (!PART && !QUEUE) {
+        if (la.queue) return launch_lines<R3, CONTIG, PART, PAIR, DUAL, true>(la, st, name);
+    }
     constexpr int M = 576 * R3, LINES = PAIR ? 1 : (DUAL ? TOT / M / 2 : TOT / M);        // LINES here: image lines per round
-    constexpr size_t lds_bytes = sizeof(float2) * ((size_t)(TOT / M) * (M + M / 32 + (PAIR ? 16 : 0)) + (2 * R3 + RAD) * (RAD + 1));   // lines + the three twiddle tables
+    constexpr size_t lds_bytes = sizeof(float2) * ((size_t)(TOT / M) * (M + M / 32 + (PAIR ? 16 : 0)) + (2 * R3 + RAD) * (RAD + 1)) + 16;   // lines + the three twiddle tables + the unit ring
     static std::atomic<unsigned long long> attr_mask{0};
     if (first_on_device(attr_mask))
-        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG, PART, PAIR, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG, PART, PAIR, DUAL, QUEUE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_bytes));
     // persistent workgroups: one per CU (the LDS footprint allows no more), a multiple of the 8 XCDs
     const int n_cu = current_cu_count();
     const int nwork = ((la.nlines + LINES - 1) / LINES) * (PART ? la.n_dist * la.NB : (la.dist_inner ? 1 : la.n_dist));
     int nslot = n_cu / 8;
     if (nslot > (nwork + 7) / 8) nslot = (nwork + 7) / 8;
-    PSX_TIMED(name, st, k_fresnel_lines<R3, CONTIG, PART, PAIR, DUAL><<<8 * nslot, T, lds_bytes, st>>>(la));
+    PSX_TIMED(name, st, k_fresnel_lines<R3, CONTIG, PART, PAIR, DUAL, QUEUE><<<8 * nslot, T, lds_bytes, st>>>(la));
     return launch_check(name);
 }
 
@@ -1376,6 +1428,7 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         la.in_si = 1; la.in_sl = p->Nx; la.in_blocked = 0; la.out_ld = 0; la.out_blocked = 1;
         la.twA = e->ax[0].twA; la.twB = e->ax[0].twB;
         la.accumulate = 0; la.stamps = stamp_pass1 ? g_stamps : nullptr;
+        la.queue = e->use_queue ? e->queue : nullptr;
         la.n_dist = nnz;
         static const bool no_inner = getenv("PSX_NO_DIST_INNER") != nullptr;   // diagnostics: A/B of the work order
         // one source for all distances: a workgroup takes the distances of a line group in consecutive rounds and fetches the
@@ -1426,6 +1479,7 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         lb.in_si = 0; lb.in_sl = 0; lb.in_blocked = 1; lb.out_ld = p->Ny; lb.out_blocked = 0;
         lb.twA = e->ax[1].twA; lb.twB = e->ax[1].twB;
         lb.accumulate = a.accumulate; lb.stamps = stamp_pass1 ? nullptr : g_stamps;
+        lb.queue = e->use_queue ? e->queue + 144 : nullptr;
         lb.n_dist = nnz;
         lb.dist_inner = 0;
         lb.B = e->ax[1].B; lb.Lh = e->ax[1].Lh; lb.S = e->ax[1].S; lb.NB = e->ax[1].NB;
@@ -1526,13 +1580,13 @@ int lds_engine_propagate_sources(psx_fresnel_plan *p, const SourcesArgs &a) {
     la.N = p->Nx; la.nlines = p->Ny; la.margin = p->margin; la.P = p->Px; la.L = p->Nx + p->Px - 1;
     la.in_si = 1; la.in_sl = p->Nx; la.in_blocked = 0; la.out_ld = 0; la.out_blocked = 1;
     la.twA = e->ax[0].twA; la.twB = e->ax[0].twB;
-    la.accumulate = 0; la.stamps = nullptr; la.n_dist = V; la.dist_inner = 0;
+    la.accumulate = 0; la.stamps = nullptr; la.n_dist = V; la.dist_inner = 0; la.queue = e->use_queue ? e->queue : nullptr;
     la.B = e->ax[0].B; la.Lh = e->ax[0].Lh; la.S = e->ax[0].S; la.NB = e->ax[0].NB; la.w2 = e->ax[0].w2;
     LineArgs lb;
     lb.N = p->Ny; lb.nlines = p->Nx; lb.margin = p->margin; lb.P = p->Py; lb.L = p->Ny + p->Py - 1;
     lb.in_si = 0; lb.in_sl = 0; lb.in_blocked = 1; lb.out_ld = p->Ny; lb.out_blocked = 0;
     lb.twA = e->ax[1].twA; lb.twB = e->ax[1].twB;
-    lb.accumulate = 0; lb.stamps = nullptr; lb.n_dist = V; lb.dist_inner = 0;
+    lb.accumulate = 0; lb.stamps = nullptr; lb.n_dist = V; lb.dist_inner = 0; lb.queue = e->use_queue ? e->queue + 144 : nullptr;
     lb.B = e->ax[1].B; lb.Lh = e->ax[1].Lh; lb.S = e->ax[1].S; lb.NB = e->ax[1].NB; lb.w2 = e->ax[1].w2;
     for (int i = 0; i < MAX_LINE; ++i) {
         const int v = i < V ? i : 0;

@@ -78,6 +78,7 @@ bool lds_engine_supported(int Nx, int Ny, int margin);
 int lds_engine_create(psx_fresnel_plan *p);
 void lds_engine_destroy(psx_fresnel_plan *p);
 int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a);
+void lds_engine_work_queue(psx_fresnel_plan *p, int on);
 int lds_engine_propagate_sources(psx_fresnel_plan *p, const SourcesArgs &a);
 
 // psi(p) = amp * wave_in * transmission at UN-padded pixel p

@@ -399,6 +399,11 @@ class FresnelPlan:
         self.engine = lib().psx_fresnel_plan_engine(self._h)
         self.bytes = lib().psx_fresnel_plan_bytes(self._h)
 
+    def work_queue(self, on=True):
+        """Line groups through a queue instead of static shares (psx_fresnel_plan_work_queue): for runs whose transfers or
+        other streams share the GPU with the propagations."""
+        check(lib().psx_fresnel_plan_work_queue(self._h, 1 if on else 0), "psx_fresnel_plan_work_queue")
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             lib().psx_fresnel_plan_destroy(self._h)

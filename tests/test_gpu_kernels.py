@@ -577,3 +577,40 @@ def test_refract_batch_matches_one_call_per_refraction(ops):
                 else:
                     assert float((got[e] - ref[e]).abs().max() / ref[e].abs().max()) < 2e-6, (ne, with_in, e)
     ops.check_status(T.device, "refract batch")
+
+
+@pytest.mark.parametrize("case", [(200, 312, 2), (1300, 900, 1), (2100, 2100, 4), (2100, 2100, 3), (640, 384, 2)])
+def test_work_queue_gives_the_same_images(ops, case):
+    """psx_fresnel_plan_work_queue: line groups handed out through a queue (per-XCD atomic counters) instead of static
+    shares -- small grids (fewer groups than CUs: some workgroups find the queue empty), the shared-forward rounds of a
+    several-distance pass 1 (even and odd counts), a batch of sources; bit for bit the same images, repeatedly (the last
+    workgroup re-arms the queue for the next launch)."""
+    Nx, Ny, nd = case
+    g = torch.Generator(device="cuda").manual_seed(Nx)
+    T = torch.rand((1, Nx, Ny), generator=g, device="cuda") * 1e-4
+    mats = ops.MaterialStack(T, cphase=[-2e4], catt=[-20.0])
+    a = [3.0e-12 * (1 + 0.7 * d) for d in range(nd)]
+    gph = [1.0e8 + d for d in range(nd)]
+    du = (2 * np.pi / (Nx * 1e-6), 2 * np.pi / (Ny * 1e-6))
+    plan = ops.FresnelPlan(Nx, Ny, max_dist=4, engine=2)
+
+    def run():
+        io = [torch.empty((Nx, Ny), device="cuda") for _ in range(nd)]
+        w = plan.propagate(a, gph, du, amp=2.0, mats=mats, want_wave=[True] * nd, inten_out=io)
+        return w, io
+
+    w0, i0 = run()
+    plan.work_queue(True)
+    for rep in range(3):
+        w1, i1 = run()
+        for d in range(nd):
+            assert torch.equal(w0[d], w1[d]) and torch.equal(i0[d], i1[d]), (case, rep, d)
+    if nd <= 2:
+        ms = [ops.MaterialStack(T, cphase=[-2e4 * (1 + s)], catt=[-20.0]) for s in range(5)]
+        aa = [[v * (1 + s) for v in a] for s in range(5)]
+        gg = [gph] * 5
+        q = plan.propagate_sources(aa, gg, du, amp=[1.0] * 5, mats=ms)
+        plan.work_queue(False)
+        r = plan.propagate_sources(aa, gg, du, amp=[1.0] * 5, mats=ms)
+        assert all(torch.equal(q[s][d], r[s][d]) for s in range(5) for d in range(nd))
+    plan.close()
