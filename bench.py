@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI, the real thing) or gloo (rehearsal of "
                          "the multi-rank control flow with several ranks on ONE GPU; collectives then go through host copies)")
+    ap.add_argument("--gather", default="overlap", choices=["overlap", "final"],
+                    help="positions batch on several ranks: gather round by round behind the computation (default) or once at the end")
     ap.add_argument("--positions", type=int, default=64,
                     help="membrane positions of the config-4 batch measured after the timed steps (0 = skip)")
     ap.add_argument("--positions-size", type=int, default=0, help="study grid of the batch (default: --size, at most 4096)")
@@ -233,7 +235,14 @@ def main():
         import contextlib
         pn = a.positions_size or min(N, 4096)
         with contextlib.redirect_stdout(sys.stderr):     # the mirrors print like the reference; stdout carries the JSON line only
-            out["positions_batch"] = {sim: positions_batch(a, sim, pn, rank, world, dev) for sim in ("Fresnel", "RayT")}
+            out["positions_batch"] = {}
+            for sim in ("Fresnel", "RayT"):
+                try:
+                    out["positions_batch"][sim] = positions_batch(a, sim, pn, rank, world, dev)
+                except Exception as exc:              # the step's line above is measured already: keep it, report the batch as failed
+                    import traceback
+                    traceback.print_exc()
+                    out["positions_batch"][sim] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     if rank == 0:
         P = N + 30
@@ -343,8 +352,9 @@ def main():
 
 def positions_batch(a, sim, N, rank, world, dev):
     """BASELINE.json config 4: `--positions` membrane positions strided over the ranks, the full loop of main.py:63-110 per
-    position (membrane synthesis with seed(pointNum), chain, detection, shot noise) and ONE RCCL gather of every position's
-    Sample/Reference stacks onto rank 0, all inside the timed region (barrier + synchronize on both sides, MAX over ranks)."""
+    position (membrane synthesis with seed(pointNum), chain, detection, shot noise) and the RCCL gather of every position's
+    Sample/Reference stacks onto rank 0 -- round by round behind the computation (--gather overlap, default) or once at the
+    end (--gather final) -- all inside the timed region (barrier + synchronize on both sides, MAX over ranks)."""
     import torch
     import torch.distributed as td
     from paresis_amd import dist, ops, synth
@@ -366,11 +376,37 @@ def positions_batch(a, sim, N, rank, world, dev):
 
     for p in (P + 1 + rank, P + 1 + world + rank):       # untimed: plans, sphere list on the GPU, allocator pools
         position(p)
+    nbins = exp._close_bins()
+    dims = exp.myDetector.det_param["myDimensions"]
+    stack_shape = (nbins, int(dims[0]), int(dims[1]))
+    overlap = world > 1 and a.gather == "overlap"
+    if overlap and sim == "Fresnel":
+        exp._plan().work_queue(True)      # the transfer's copy kernels share the GPU with the line kernels from here on
+
+    def gather_all(positions_fn):
+        """Computes this rank's positions and brings every position's stacks to rank 0: round by round behind the computation
+        (dist.PositionGatherer) or in one gather at the end.  Returns (gathered, seconds of computation issued + finished)."""
+        t1 = time.perf_counter()
+        if overlap:
+            gat = dist.PositionGatherer(P, rank, world, to_host=False, shape=stack_shape)
+            for p in mine:
+                gat.add(p, positions_fn(p))
+            ev = torch.cuda.Event()
+            ev.record()
+            ev.synchronize()              # this rank's computation (not the rounds in flight on RCCL's stream)
+            tc = time.perf_counter() - t1
+            return gat.finish(), tc
+        results = {p: positions_fn(p) for p in mine}
+        torch.cuda.synchronize()
+        tc = time.perf_counter() - t1
+        return dist.gather_positions(results, P, rank, world, to_host=False), tc
+
     if world > 1:
-        # and the gather path at its full size: communicator and peer connections, the packing kernels, and the caching
-        # allocator's blocks for the staging buffers (a first-time hipMalloc of ~2 GiB on rank 0 would land in the timed region)
+        # the whole gather path once at its full size, untimed: communicator and peer connections, the packing kernels, and
+        # the caching allocator's blocks for the staging buffers (a first-time hipMalloc of ~2 GiB on rank 0 would land in
+        # the timed region)
         warm = position(P + 1 + rank)
-        dist.gather_positions({p: warm for p in mine}, P, rank, world, to_host=False)
+        gather_all(lambda p: warm)
         del warm
     # The interpreter's cyclic garbage collector would otherwise run a full collection somewhere in the first positions
     # (hundreds of thousands of objects allocated by the set-up above: ~40-60 ms of host time with the GPU idle -- the
@@ -380,17 +416,19 @@ def positions_batch(a, sim, N, rank, world, dev):
     gc.freeze()
     barrier()
     t0 = time.perf_counter()
-    results = {}
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(mine) + 1)] if a.positions_trace else None
     if marks:
         marks[0].record()
-    for i, p in enumerate(mine):
-        results[p] = position(p)
+    done = [0]
+
+    def timed_position(p):
+        out = position(p)
         if marks:
-            marks[i + 1].record()
-    torch.cuda.synchronize()
-    t_comp = time.perf_counter() - t0
-    gathered = dist.gather_positions(results, P, rank, world, to_host=False)
+            done[0] += 1
+            marks[done[0]].record()
+        return out
+
+    gathered, t_comp = gather_all(timed_position)
     barrier()
     dt = time.perf_counter() - t0
     exp.resolve_mean_energy()
@@ -413,6 +451,7 @@ def positions_batch(a, sim, N, rank, world, dev):
            "gather_ms": round(max(float(t[2]) for t in per_rank) * 1e3, 3),
            "gathered_bytes": int(sum(v[0].numel() + v[1].numel() for v in gathered.values()) * 4),
            "gather_wire_bytes": dist.last_gather.get("wire_bytes"), "gather_packed_u16": dist.last_gather.get("packed"),
+           "gather_overlapped": bool(dist.last_gather.get("overlapped")),
            "timed_region": "synthesis + chain + detection + shot noise of every position + the gather onto rank 0 (images stay "
                            "in rank 0's HBM)", "backend": a.backend if world > 1 else None}
     if marks:

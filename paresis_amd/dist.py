@@ -180,6 +180,100 @@ def gather_positions(results, n_positions, rank, world, dst=0, to_host=True, pac
     return out if rank == dst else {}
 
 
+class PositionGatherer:
+    """gather_positions() in pieces, overlapped with the computation: as soon as a rank has finished its position of
+    round t (positions t*world .. t*world + world - 1, one per rank) it packs the two stacks and issues the gather of that
+    round WITHOUT waiting for it (async_op); RCCL moves round t while the GPU computes round t + 1, and only the last
+    round's transfer is exposed.  With the work queue of the Fresnel plan on (psx_fresnel_plan_work_queue), the copy
+    kernels of the transfer cost the computation a few per cent (tools/contention_probe.py).
+
+    Every round crosses as 16-bit photon counts (see gather_positions); a round that cannot (non-integer images, too many
+    bright pixels) is flagged, and finish() then repeats the whole gather in float32 -- all ranks together, after one
+    all_reduce of the flag.  Every rank issues the same collectives in the same order whatever positions it owns."""
+
+    def __init__(self, n_positions, rank, world, dst=0, to_host=False, shape=None, force_collectives=False):
+        """shape: (nbins, n0, n1) of a detector stack -- known to every rank from the experiment; a rank that owns no
+        position cannot learn it any other way (a collective for it would come in a different order on the other ranks)."""
+        self.P, self.rank, self.world, self.dst, self.to_host = n_positions, rank, world, dst, to_host
+        self.rounds = (n_positions + world - 1) // world
+        self.results, self.work, self.wires, self.buckets = {}, [], [], []
+        self.local = world == 1 and not force_collectives             # nothing to move
+        self.force = force_collectives
+        self.shape = tuple(int(v) for v in shape) if shape is not None else None
+        self.flag = None
+        self.next_round = 0
+
+    def _issue(self, t):
+        dev = _dev()
+        per_img = self.shape[0] * self.shape[1] * self.shape[2]
+        wire = _CountsWire(2 * per_img, dev)
+        wire.head.zero_()
+        p = t * self.world + self.rank
+        if p in self.results:
+            wire.pack(self.results[p][0], 0, self.flag)
+            wire.pack(self.results[p][1], per_img, self.flag)
+        else:
+            wire.counts.zero_()
+        bucket = [torch.empty_like(wire.bytes) for _ in range(self.world)] if self.rank == self.dst else None
+        self.work.append(td.gather(wire.bytes, bucket, dst=self.dst, async_op=True))
+        self.wires.append(wire)
+        self.buckets.append(bucket)
+
+    def add(self, p, images):
+        """images: the tuple computeSampleAndReferenceImages returned for position p (owned by this rank)."""
+        self.results[p] = images
+        if self.local:
+            return
+        if self.shape is None:
+            self.shape = tuple(images[0].shape)
+        if tuple(images[0].shape) != self.shape or tuple(images[1].shape) != self.shape:
+            raise ValueError("PositionGatherer: stack of shape %s, expected %s" % (tuple(images[0].shape), self.shape))
+        if self.flag is None:
+            self.flag = torch.zeros(1, dtype=torch.int32, device=_dev())
+        while self.next_round < self.rounds and self.next_round * self.world + self.rank <= p:
+            self._issue(self.next_round)
+            self.next_round += 1
+
+    def finish(self):
+        """Waits for the rounds in flight; returns on dst {position: images} (every position), {} elsewhere."""
+        host = lambda tup: tuple(t.detach().cpu() if isinstance(t, torch.Tensor) and self.to_host else t for t in tup)
+        last_gather.clear()
+        if self.local:
+            return {p: host(v) for p, v in self.results.items()}
+        if self.shape is None:
+            raise ValueError("PositionGatherer: a rank without positions needs the stack shape (constructor argument)")
+        if self.flag is None:
+            self.flag = torch.zeros(1, dtype=torch.int32, device=_dev())
+        while self.next_round < self.rounds:                            # rounds this rank has no position in
+            self._issue(self.next_round)
+            self.next_round += 1
+        for w in self.work:
+            w.wait()
+        td.all_reduce(self.flag, op=td.ReduceOp.MAX)
+        if int(self.flag.item()):                                       # something was not photon counts: float32, all together
+            return gather_positions(self.results, self.P, self.rank, self.world, dst=self.dst, to_host=self.to_host, pack=False,
+                                    force_collectives=self.force)
+        out = {}
+        wire_bytes = 0
+        if self.rank == self.dst:
+            per_img = self.shape[0] * self.shape[1] * self.shape[2]
+            for t in range(self.rounds):
+                for r in range(self.world):
+                    q = t * self.world + r
+                    if q >= self.P:
+                        continue
+                    b = self.buckets[t][r]
+                    wire_bytes += b.numel() if r != self.rank else 0
+                    if self.to_host:
+                        b = b.cpu()
+                    img = _CountsWire(2 * per_img, b.device, like=b).unpack().view((2,) + self.shape)
+                    out[q] = (img[0], img[1])
+            if 0 in self.results:                                        # Propag / White / Dx,Dy exist for position 0 only
+                out[0] = host(self.results[0])
+        last_gather.update(packed=True, wire_bytes=wire_bytes, overlapped=True)
+        return out if self.rank == self.dst else {}
+
+
 def _dev():
     if td.get_backend() == "nccl":
         return torch.device("cuda", torch.cuda.current_device())

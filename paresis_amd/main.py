@@ -41,19 +41,25 @@ def run(exp_dict, save=True, saving_format=".tif", backend=None):
     gc.collect()
     gc.freeze()
     print("\nImages calculation")
-    results = {}
+    # the detector stacks go to rank 0 round by round while the next positions are computed (dist.PositionGatherer); the
+    # Fresnel plan then hands out its line groups through a queue, so that the transfer's copy kernels cost it a few per cent
+    dims = experiment.myDetector.det_param["myDimensions"]
+    gatherer = dist.PositionGatherer(exp_dict['nbExpPoints'], rank, world, to_host=True,
+                                     shape=(experiment._close_bins(), int(dims[0]), int(dims[1])))
+    if world > 1 and sim == "Fresnel":
+        experiment._plan().work_queue(True)
     for pointNum in dist.my_positions(exp_dict['nbExpPoints'], rank, world):
         experiment.myMembrane.myGeometry = []
         experiment.myMembrane.getMyGeometry(experiment.exp_dict['studyDimensions'], experiment.myMembrane.membranePixelSize,
                                             experiment.exp_dict['overSampling'], pointNum, exp_dict['nbExpPoints'])   # main.py:64-65
         print("\nCalculations point", pointNum)
         out = experiment.computeSampleAndReferenceImages(pointNum)
-        results[pointNum] = out
+        gatherer.add(pointNum, out)
         if save and exp_dict.get('saveMembrane', True):
             # main.py:98: every rank writes the membrane maps of its own positions (one node, one file system: no gather)
             save_image(experiment.myMembrane.myGeometry[0], root + 'membraneThickness/' + exp_dict['experimentName'] +
                        '_sampling' + str(exp_dict['overSampling']) + '_' + str(pointNum) + saving_format)
-    gathered = dist.gather_positions(results, exp_dict['nbExpPoints'], rank, world)
+    gathered = gatherer.finish()
     experiment.resolve_mean_energy()
     if rank == 0 and save:
         os.makedirs(root, exist_ok=True)

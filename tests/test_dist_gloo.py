@@ -14,7 +14,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_positions, q, kind="counts"):
+def _worker(rank, world, port, n_positions, q, kind="counts", overlapped=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     from paresis_amd import dist
@@ -39,12 +39,20 @@ def _worker(rank, world, port, n_positions, q, kind="counts"):
     for p in mine:
         S, R = images(p)
         results[p] = (S, R, torch.full((2, 5, 7), 3.5), torch.full((2, 5, 7), 4.0)) if p == 0 else (S, R)
-    out = dist.gather_positions(results, n_positions, r, w)
+    if overlapped:                    # round by round, each gather issued as soon as the rank's position of the round exists
+        gat = dist.PositionGatherer(n_positions, r, w, to_host=True, shape=(2, 5, 7))
+        for p in mine:
+            gat.add(p, results[p])
+        out = gat.finish()
+    else:
+        out = dist.gather_positions(results, n_positions, r, w)
     packed = dist.last_gather.get("packed")
     dist.finish()
     if r == 0:
         ok = sorted(out) == list(range(n_positions)) and packed == (kind == "counts")
-        ok = ok and dist.last_gather["wire_bytes"] == (3 * 2 * 70 * 2 + 8 + 8 * 64 if packed else 3 * 2 * 70 * 4)
+        per_round = 2 * 70 * 2 + 8 + 8 * 64
+        ok = ok and dist.last_gather["wire_bytes"] == ((2 * per_round if overlapped else 3 * 2 * 70 * 2 + 8 + 8 * 64) if packed
+                                                       else 3 * 2 * 70 * 4)
         for p in range(n_positions):
             S, R = images(p)
             ok = ok and torch.equal(out[p][0], S) and torch.equal(out[p][1], R) and out[p][0].dtype == torch.float32
@@ -58,12 +66,13 @@ def _worker(rank, world, port, n_positions, q, kind="counts"):
 import pytest
 
 
+@pytest.mark.parametrize("overlapped", [False, True])
 @pytest.mark.parametrize("kind", ["counts", "fractions", "one_rank_fractions", "too_large", "many_bright"])
-def test_gather_positions_world2(kind):
+def test_gather_positions_world2(kind, overlapped):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 5, q, kind)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 5, q, kind, overlapped)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

@@ -250,6 +250,16 @@ for frac in (False, True):
         for p in range(3):
             for a, b in zip(out[p][:2], res[p][:2]):
                 assert a.is_cuda != to_host and torch.equal(a.cpu(), b.cpu()), (frac, to_host, p)
+    # the same round by round, each gather issued without waiting (async_op on RCCL's stream)
+    for to_host in (False, True):
+        gat = dist.PositionGatherer(3, 0, 1, to_host=to_host, shape=(2, 64, 96), force_collectives=True)
+        for p in range(3):
+            gat.add(p, res[p])
+        out = gat.finish()
+        assert dist.last_gather["packed"] == (not frac) and sorted(out) == [0, 1, 2] and len(out[0]) == 4
+        for p in range(3):
+            for a, b in zip(out[p][:2], res[p][:2]):
+                assert a.is_cuda != to_host and torch.equal(a.cpu(), b.cpu()), (frac, to_host, p)
 td.barrier()
 td.destroy_process_group()
 print("RCCL-ONE-RANK-OK")
