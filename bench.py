@@ -121,6 +121,8 @@ def main():
     rt_mats = ops.MaterialStack(T, cphase=[-k * d for d in delta], catt=[-2 * k * b for b in beta])
     engine = {"auto": _lib.ENGINE_AUTO, "rocfft": _lib.ENGINE_ROCFFT, "lds": _lib.ENGINE_LDS}[a.engine]
     plan = ops.FresnelPlan(N, N, max_dist=len(DISTANCES), engine=engine)
+    if os.environ.get("PSX_WORK_QUEUE"):            # A/B of the line kernels' work queue on the step itself (default: static shares)
+        plan.work_queue(True)
     kk = getk(E * 1000)
     aa = [z / (2 * kk * M) for z in DISTANCES]
     gp = [kk * z / M for z in DISTANCES]

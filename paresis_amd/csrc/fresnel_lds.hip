@@ -411,16 +411,22 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             const bool more = valid(j + 1);
             lds_barrier();                               // (1) engine: forward stage A done
             if constexpr (DUAL) lds_barrier();           // (1b) engine: forward stage B done (six waves), before the middle stage
-            // the unit after next: claimed during the first round of a unit, visible to every wave after barrier (2), first
-            // read (as "is there a next round") in the last round of the next unit
-            if (DYN && lt == 0 && j % nsubr == 0) uq[(j / nsubr + 2) & 3] = uq[(j / nsubr + 1) & 3] >= 0 ? claim() : -1;
             // Issued after barrier (1), not before: issuing strided loads stalls for ~5 us (the texture path hands out one
             // 128-byte line per lane pair) and forward stage A lasts only 3 us -- the engine would wait for the loaders.
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 16] = wall_clock64();
+            // the unit after next: claimed during the first round of a unit.  The atomic goes out AHEAD of the round's loads and
+            // nobody waits for it here (memory returns in order: behind the loads it would come back last and hold up the
+            // spread; stored at once it would hold up the loads by a round trip); its result is stored with the spread below:
+            // visible to every wave after barrier (4), first read -- "is there a round after the next" -- at the top of the
+            // next iteration
+            int claimed = -1;
+            const bool claiming = DYN && lt == 0 && j % nsubr == 0;
+            if (claiming && uq[(j / nsubr + 1) & 3] >= 0) claimed = claim();
             if (more) fetch(j + 1);
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 17] = wall_clock64();
             lds_barrier();                               // (2) engine: wave-private stages done
             lds_barrier();                               // (3) engine: inverse stage A holds all of LDS in registers
+            if (claiming) uq[(j / nsubr + 2) & 3] = claimed;
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 18] = wall_clock64();
             // the spread sits between two barriers the engine waits at: it goes first on its SIMD (a loader wave would
             // otherwise get every fourth issue slot).  The fetch keeps normal priority: hurrying the strided loads only
