@@ -163,7 +163,7 @@ int psx_fresnel_plan_engine(const psx_fresnel_plan *plan);
 /* bytes of device memory the plan owns */
 size_t psx_fresnel_plan_bytes(const psx_fresnel_plan *plan);
 /* on != 0: the LDS engine's one-transform passes (N <= 4593) hand their line groups to the workgroups through a queue (an
- * atomic counter per XCD) instead of equal static shares.  Static shares are ~2 % faster on a GPU the call has to itself, and
+ * atomic counter per XCD) instead of equal static shares.  Static shares are ~3 % faster on a GPU the call has to itself, and
  * TWICE as slow as soon as one CU is busy with anything else when a pass starts (its 256 workgroups need a whole CU each:
  * the one that cannot start waits for another to finish its whole share) -- e.g. the copy kernels of an RCCL transfer that
  * overlaps the computation.  Same results bit for bit.  Default off; no effect on the other engine paths. */
