@@ -162,8 +162,9 @@ int psx_fresnel_plan_destroy(psx_fresnel_plan *plan);
 int psx_fresnel_plan_engine(const psx_fresnel_plan *plan);
 /* bytes of device memory the plan owns */
 size_t psx_fresnel_plan_bytes(const psx_fresnel_plan *plan);
-/* on != 0: the LDS engine's one-transform passes (N <= 4593) hand their line groups to the workgroups through a queue (an
- * atomic counter per XCD) instead of equal static shares.  Static shares are ~3 % faster on a GPU the call has to itself, and
+/* on != 0: the LDS engine's one-transform passes (N <= 4593) hand their line groups to the workgroups through queues (the
+ * share of a workgroup is an atomic counter it claims from; a workgroup whose share is done steals from the others of its
+ * XCD) instead of equal static shares.  Static shares are ~4 % faster on a GPU the call has to itself, and
  * TWICE as slow as soon as one CU is busy with anything else when a pass starts (its 256 workgroups need a whole CU each:
  * the one that cannot start waits for another to finish its whole share) -- e.g. the copy kernels of an RCCL transfer that
  * overlaps the computation.  Same results bit for bit.  Default off; no effect on the other engine paths. */

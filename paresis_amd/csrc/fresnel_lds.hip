@@ -87,7 +87,7 @@ struct LineArgs {
     int B, Lh, S, NB;
     float2 *part[MAX_LINE];
     const float2 *w2;       // PAIR: w_2M^{k0} of each 16-point slab, k0 = q1 + 24 q2  (576 entries)
-    unsigned *queue;        // work queue of the one-transform passes: next unit of each XCD's chunk at [16 x], workgroups done at [128]
+    unsigned *queue;        // work queues of the one-transform passes (null: static shares): the counter of workgroup w at [16 w], workgroups done at [16 * 256]
     unsigned long long *stamps;   // optional diagnostics: 32 phase timestamps per workgroup (psx_debug_stamps)
 };
 
@@ -165,12 +165,15 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     const int nunits = slot < clen ? (clen - slot + nslot - 1) / nslot : 0;   // units cstart + slot + u*nslot, u < nunits
     const int nsub = DUAL ? (a.n_dist + 1) / 2 : a.n_dist;       // rounds per line group when the distances are taken inside
     const int nj = PART ? nunits * a.S : (a.dist_inner ? nunits * nsub : nunits);   // rounds of this workgroup (static order)
-    // One-transform passes take their units from a QUEUE instead (DYN): the workgroups of an XCD claim the units of the XCD's
-    // chunk one after the other (an atomic counter per XCD), two units ahead of the engine.  A static share per workgroup
-    // assumes that all 256 workgroups start together: one CU busy with anything else (the copy kernels of an RCCL transfer,
-    // another stream) makes one workgroup start when the first of the others ends and DOUBLES the pass
-    // (tools/contention_probe.py: one foreign workgroup, +48 % on a position).  From the queue a late workgroup finds nothing
-    // left and the pass loses that CU's share only.  uq: ring of the units claimed (index inside the chunk, -1: chunk empty).
+    // One-transform passes can take their units from QUEUES instead (DYN).  A static share per workgroup assumes that all 256
+    // workgroups start together: one CU busy with anything else (the copy kernels of an RCCL transfer, another stream) makes
+    // one workgroup start when the first of the others ends and DOUBLES the pass (tools/contention_probe.py: one foreign
+    // workgroup, +48 % on a position).  Here the share of workgroup s of an XCD -- units s, s + 32, ... of the XCD's chunk,
+    // as in the static order -- is a queue of its own (one atomic counter): the owner claims from it, two units ahead of the
+    // engine, and a workgroup whose own queue has run dry STEALS from the queues of the others (loader wave 0 looks at all
+    // of them at once).  On a quiet GPU everybody finishes its own share at the same moment and finds nothing to steal; a
+    // workgroup that starts late finds its share taken and leaves.  uq: ring of the units claimed (index inside the chunk,
+    // -1: nothing left).
     constexpr bool DYN = QUEUE;                          // its own instantiations: the engine waves have no register to spare
     static_assert(!QUEUE || !PART, "the queue serves the one-transform passes");
     const int nsubr = a.dist_inner ? nsub : 1;                   // rounds per unit
@@ -198,9 +201,32 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     };
     // is round j a round at all?  (uniform: every thread reads the same ring entry, written at least one barrier earlier)
     auto valid = [&](int j) __attribute__((always_inline)) { return DYN ? uq[(j / nsubr) & 3] >= 0 : j < nj; };
-    auto claim = [&]() __attribute__((always_inline)) {
-        const unsigned k = atomicAdd(&a.queue[16 * xcd], 1u);
-        return k < (unsigned)clen ? (int)k : -1;
+    // queue of slot v of this XCD: its counter (64 bytes apart) and the length of its share
+    auto qcount = [&](int v) __attribute__((always_inline)) { return &a.queue[16 * (xcd + 8 * v)]; };
+    auto share = [&](int v) __attribute__((always_inline)) { return v < clen ? (clen - v + nslot - 1) / nslot : 0; };
+    // loader wave 0 as a whole: one unit from somebody else's queue, or -1.  `dry` is set when every queue was seen empty.
+    bool dry = false, own_dry = false;
+    auto steal = [&]() __attribute__((always_inline)) {
+        const int ln = tid & 63;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const int v = ln;                                       // lane v looks at queue v (nslot <= 32)
+            bool avail = false;
+            if (v < nslot && v != slot)
+                avail = __hip_atomic_load(qcount(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)share(v);
+            const unsigned long long m = __ballot(avail);
+            if (m == 0ull) {
+                dry = true;
+                return -1;
+            }
+            // the first queue with something left after my own, cyclically (thieves spread over the victims)
+            const unsigned long long hi = m >> ((slot + 1) & 63);
+            const int pick = hi ? (slot + 1 + __builtin_ctzll(hi)) : __builtin_ctzll(m);
+            unsigned k = 0u;
+            if (ln == 0) k = atomicAdd(qcount(pick), 1u);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (k < (unsigned)share(pick)) return pick + (int)k * nslot;
+        }
+        return -1;
     };
 
     // Stage B's twiddles w_S1^{n q} (n < R3, q < 24: 3 KiB) live in LDS behind the line buffers, rows padded to 25 so that
@@ -212,7 +238,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     // tables in LDS the engine's only global loads are the kernel spectrum's.
     // the first two units of this workgroup: one atomic, in flight while the twiddle tables are copied
     unsigned first2 = 0u;
-    if (DYN && tid == TC) first2 = atomicAdd(&a.queue[16 * xcd], 2u);
+    if (DYN && tid == TC) first2 = atomicAdd(qcount(slot), 2u);
     constexpr int TWB_LD = RAD + 1;
     v2f *twl = reinterpret_cast<v2f *>(lds) + LINES * MP;          // [R3][25]  stage B
     v2f *tw1 = twl + R3 * TWB_LD;                                  // [24][25]  stage A, n1 part
@@ -229,8 +255,8 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 
     if constexpr (DYN) {
         if (tid == TC) {                                 // the first loader thread runs the queue
-            uq[0] = first2 < (unsigned)clen ? (int)first2 : -1;
-            uq[1] = first2 + 1u < (unsigned)clen ? (int)(first2 + 1u) : -1;
+            uq[0] = first2 < (unsigned)share(slot) ? slot + (int)first2 * nslot : -1;
+            uq[1] = first2 + 1u < (unsigned)share(slot) ? slot + (int)(first2 + 1u) * nslot : -1;
         }
         lds_barrier();                                   // the first two units are known to every wave
     }
@@ -414,19 +440,28 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             // Issued after barrier (1), not before: issuing strided loads stalls for ~5 us (the texture path hands out one
             // 128-byte line per lane pair) and forward stage A lasts only 3 us -- the engine would wait for the loaders.
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 16] = wall_clock64();
-            // the unit after next: claimed during the first round of a unit.  The atomic goes out AHEAD of the round's loads and
-            // nobody waits for it here (memory returns in order: behind the loads it would come back last and hold up the
-            // spread; stored at once it would hold up the loads by a round trip); its result is stored with the spread below:
-            // visible to every wave after barrier (4), first read -- "is there a round after the next" -- at the top of the
-            // next iteration
-            int claimed = -1;
-            const bool claiming = DYN && lt == 0 && j % nsubr == 0;
-            if (claiming && uq[(j / nsubr + 1) & 3] >= 0) claimed = claim();
+            // the unit after next: claimed during the first round of a unit, by loader wave 0.  The atomic on the workgroup's own
+            // queue goes out AHEAD of the round's loads and nobody waits for it here (memory returns in order: behind the loads
+            // it would come back last and hold up the spread; consumed at once it would hold up the loads by a round trip); its
+            // result is looked at with the spread below -- visible to every wave after barrier (4), first read, as "is there a
+            // round after the next", at the top of the next iteration.
+            const bool claiming = DYN && lt < 64 && j % nsubr == 0 && uq[(j / nsubr + 1) & 3] >= 0;   // wave-uniform
+            unsigned mine = 0xffffffffu;
+            if (claiming && !own_dry && lt == 0) mine = atomicAdd(qcount(slot), 1u);
             if (more) fetch(j + 1);
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 17] = wall_clock64();
             lds_barrier();                               // (2) engine: wave-private stages done
             lds_barrier();                               // (3) engine: inverse stage A holds all of LDS in registers
-            if (claiming) uq[(j / nsubr + 2) & 3] = claimed;
+            if (DYN && lt < 64 && j % nsubr == 0) {
+                int unit = -1;
+                if (claiming) {
+                    const unsigned k = __builtin_amdgcn_readfirstlane(mine);
+                    if (k < (unsigned)share(slot)) unit = slot + (int)k * nslot;
+                    else own_dry = true;
+                    if (unit < 0 && !dry) unit = steal();             // two round trips, the whole wave: own queue empty only
+                }
+                if (lt == 0) uq[(j / nsubr + 2) & 3] = unit;
+            }
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 18] = wall_clock64();
             // the spread sits between two barriers the engine waits at: it goes first on its SIMD (a loader wave would
             // otherwise get every fourth issue slot).  The fetch keeps normal priority: hurrying the strided loads only
@@ -438,13 +473,17 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             lds_barrier();                               // (4) next group is in LDS
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 20] = wall_clock64();
         }
-        if (DYN && lt == 0) {
-            // the last workgroup to leave re-arms the queue for the next launch (every claim of this launch has been made)
-            __threadfence();
-            if (atomicAdd(&a.queue[128], 1u) == gridDim.x - 1) {
-#pragma unroll
-                for (int x = 0; x < 8; ++x) atomicExch(&a.queue[16 * x], 0u);
-                atomicExch(&a.queue[128], 0u);
+        if (DYN && lt < 64) {
+            // the last workgroup to leave re-arms the queues for the next launch (every claim of this launch has been made)
+            unsigned prev = 0u;
+            if (lt == 0) {
+                __threadfence();
+                prev = atomicAdd(&a.queue[16 * 256], 1u);
+            }
+            prev = __builtin_amdgcn_readfirstlane(prev);
+            if (prev == gridDim.x - 1) {
+                for (int w = lt; w < (int)gridDim.x; w += 64) atomicExch(&a.queue[16 * w], 0u);
+                if (lt == 0) atomicExch(&a.queue[16 * 256], 0u);
             }
         }
         return;
@@ -1158,13 +1197,15 @@ struct KernEntry {
 // cache key of a kernel spectrum: it depends on these scalars only
 typedef std::tuple<double, double, int, int> KernKey;   // (a, du, N, M)
 
+constexpr int QUEUE_WORDS = 16 * 257;     // a counter per workgroup (<= 256, 64 bytes apart) + the count of workgroups done
+
 struct LdsEngine {
     AxisTables ax[2];            // [0]: lines along axis 0 (length Nx), [1]: along axis 1 (length Ny)
     float2 *inter = nullptr;     // [max_dist][Nx/IB][Ny][IB] intermediates (pass-1 line y, sample x)
     size_t inter_elems = 0;
     float2 *pre = nullptr;       // [Ny][Nx] transmitted source wave, transposed (pass 0)
     float2 *part = nullptr;      // [max_dist][Nx][Ny] partial sums of pass 2 of the partitioned convolution when only |.|^2 is wanted
-    unsigned *queue = nullptr;   // [2][144]: work queues of pass 1 and pass 2 (zero between launches: the kernels re-arm them)
+    unsigned *queue = nullptr;   // [2][QUEUE_WORDS]: work queues of pass 1 and pass 2 (zero between launches: the kernels re-arm them)
     bool use_queue = false;      // psx_fresnel_plan_work_queue
     float2 *pre_b = nullptr;     // [PSX_MAX_SRC][Ny][Nx], [MAX_LINE][inter_elems]: the same two for a batch of source waves,
     float2 *inter_b = nullptr;   // allocated by the first batched call (psx_fresnel_propagate_sources)
@@ -1259,8 +1300,8 @@ int lds_engine_create(psx_fresnel_plan *p) {
     const size_t npix = (size_t)p->Nx * p->Ny;
     PSX_HIP(hipMalloc((void **)&e->pre, sizeof(float2) * npix));
     p->bytes += sizeof(float2) * npix;
-    PSX_HIP(hipMalloc((void **)&e->queue, sizeof(unsigned) * 2 * 144));
-    PSX_HIP(hipMemset(e->queue, 0, sizeof(unsigned) * 2 * 144));
+    PSX_HIP(hipMalloc((void **)&e->queue, sizeof(unsigned) * 2 * QUEUE_WORDS));
+    PSX_HIP(hipMemset(e->queue, 0, sizeof(unsigned) * 2 * QUEUE_WORDS));
     if (e->ax[1].part && e->ax[1].S > 1) {      // complex partial sums of pass 2 when only |.|^2 leaves the pass
         PSX_HIP(hipMalloc((void **)&e->part, sizeof(float2) * npix * p->max_dist));
         p->bytes += sizeof(float2) * npix * p->max_dist;
@@ -1485,7 +1526,7 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         lb.in_si = 0; lb.in_sl = 0; lb.in_blocked = 1; lb.out_ld = p->Ny; lb.out_blocked = 0;
         lb.twA = e->ax[1].twA; lb.twB = e->ax[1].twB;
         lb.accumulate = a.accumulate; lb.stamps = stamp_pass1 ? nullptr : g_stamps;
-        lb.queue = e->use_queue ? e->queue + 144 : nullptr;
+        lb.queue = e->use_queue ? e->queue + QUEUE_WORDS : nullptr;
         lb.n_dist = nnz;
         lb.dist_inner = 0;
         lb.B = e->ax[1].B; lb.Lh = e->ax[1].Lh; lb.S = e->ax[1].S; lb.NB = e->ax[1].NB;
@@ -1592,7 +1633,7 @@ int lds_engine_propagate_sources(psx_fresnel_plan *p, const SourcesArgs &a) {
     lb.N = p->Ny; lb.nlines = p->Nx; lb.margin = p->margin; lb.P = p->Py; lb.L = p->Ny + p->Py - 1;
     lb.in_si = 0; lb.in_sl = 0; lb.in_blocked = 1; lb.out_ld = p->Ny; lb.out_blocked = 0;
     lb.twA = e->ax[1].twA; lb.twB = e->ax[1].twB;
-    lb.accumulate = 0; lb.stamps = nullptr; lb.n_dist = V; lb.dist_inner = 0; lb.queue = e->use_queue ? e->queue + 144 : nullptr;
+    lb.accumulate = 0; lb.stamps = nullptr; lb.n_dist = V; lb.dist_inner = 0; lb.queue = e->use_queue ? e->queue + QUEUE_WORDS : nullptr;
     lb.B = e->ax[1].B; lb.Lh = e->ax[1].Lh; lb.S = e->ax[1].S; lb.NB = e->ax[1].NB; lb.w2 = e->ax[1].w2;
     for (int i = 0; i < MAX_LINE; ++i) {
         const int v = i < V ? i : 0;
