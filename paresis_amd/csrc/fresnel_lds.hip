@@ -206,6 +206,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     auto share = [&](int v) __attribute__((always_inline)) { return v < clen ? (clen - v + nslot - 1) / nslot : 0; };
     // loader wave 0 as a whole: one unit from somebody else's queue, or -1.  `dry` is set when every queue was seen empty.
     bool dry = false, own_dry = false;
+    const int myshare = share(slot);
     auto steal = [&]() __attribute__((always_inline)) {
         const int ln = tid & 63;
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -255,8 +256,8 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 
     if constexpr (DYN) {
         if (tid == TC) {                                 // the first loader thread runs the queue
-            uq[0] = first2 < (unsigned)share(slot) ? slot + (int)first2 * nslot : -1;
-            uq[1] = first2 + 1u < (unsigned)share(slot) ? slot + (int)(first2 + 1u) * nslot : -1;
+            uq[0] = first2 < (unsigned)myshare ? slot + (int)first2 * nslot : -1;
+            uq[1] = first2 + 1u < (unsigned)myshare ? slot + (int)(first2 + 1u) * nslot : -1;
         }
         lds_barrier();                                   // the first two units are known to every wave
     }
@@ -433,8 +434,12 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             spread(0);
         }
         lds_barrier();                                   // (0) first group is in LDS
-        for (int j = 0; valid(j); ++j) {
-            const bool more = valid(j + 1);
+        // ucur, usub: unit of round j (as the workgroup's u-th unit) and the round inside it -- counted, not divided
+        int ucur = 0, usub = 0;
+        auto ring_ok = [&](int u) __attribute__((always_inline)) { return uq[u & 3] >= 0; };
+        for (int j = 0; DYN ? ring_ok(ucur) : j < nj; ++j) {
+            const bool last_sub = usub + 1 == nsubr;
+            const bool more = DYN ? ring_ok(last_sub ? ucur + 1 : ucur) : j + 1 < nj;
             lds_barrier();                               // (1) engine: forward stage A done
             if constexpr (DUAL) lds_barrier();           // (1b) engine: forward stage B done (six waves), before the middle stage
             // Issued after barrier (1), not before: issuing strided loads stalls for ~5 us (the texture path hands out one
@@ -443,25 +448,16 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             // the unit after next: claimed during the first round of a unit, by loader wave 0.  The atomic on the workgroup's own
             // queue goes out AHEAD of the round's loads and nobody waits for it here (memory returns in order: behind the loads
             // it would come back last and hold up the spread; consumed at once it would hold up the loads by a round trip); its
-            // result is looked at with the spread below -- visible to every wave after barrier (4), first read, as "is there a
+            // result is looked at AFTER the spread below -- visible to every wave after barrier (4), first read, as "is there a
             // round after the next", at the top of the next iteration.
-            const bool claiming = DYN && lt < 64 && j % nsubr == 0 && uq[(j / nsubr + 1) & 3] >= 0;   // wave-uniform
+            const bool qround = DYN && lt < 64 && usub == 0;                               // wave-uniform
+            const bool claiming = qround && ring_ok(ucur + 1);
             unsigned mine = 0xffffffffu;
             if (claiming && !own_dry && lt == 0) mine = atomicAdd(qcount(slot), 1u);
             if (more) fetch(j + 1);
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 17] = wall_clock64();
             lds_barrier();                               // (2) engine: wave-private stages done
             lds_barrier();                               // (3) engine: inverse stage A holds all of LDS in registers
-            if (DYN && lt < 64 && j % nsubr == 0) {
-                int unit = -1;
-                if (claiming) {
-                    const unsigned k = __builtin_amdgcn_readfirstlane(mine);
-                    if (k < (unsigned)share(slot)) unit = slot + (int)k * nslot;
-                    else own_dry = true;
-                    if (unit < 0 && !dry) unit = steal();             // two round trips, the whole wave: own queue empty only
-                }
-                if (lt == 0) uq[(j / nsubr + 2) & 3] = unit;
-            }
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 18] = wall_clock64();
             // the spread sits between two barriers the engine waits at: it goes first on its SIMD (a loader wave would
             // otherwise get every fourth issue slot).  The fetch keeps normal priority: hurrying the strided loads only
@@ -469,6 +465,22 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             __builtin_amdgcn_s_setprio(3);
             if (more) spread(j + 1);
             __builtin_amdgcn_s_setprio(0);
+            if (qround) {
+                int unit = -1;
+                if (claiming) {
+                    const unsigned k = __builtin_amdgcn_readfirstlane(mine);
+                    if (k < (unsigned)myshare) unit = slot + (int)k * nslot;
+                    else own_dry = true;
+                    if (unit < 0 && !dry) unit = steal();             // two round trips, the whole wave: own queue empty only
+                }
+                if (lt == 0) uq[(ucur + 2) & 3] = unit;
+            }
+            if (last_sub) {
+                usub = 0;
+                ++ucur;
+            } else {
+                ++usub;
+            }
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 19] = wall_clock64();
             lds_barrier();                               // (4) next group is in LDS
             if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 20] = wall_clock64();
@@ -542,10 +554,15 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 0] = wall_clock64();
     lds_barrier();                                       // (0) first group is in LDS
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 1] = wall_clock64();
-    for (int j = 0; valid(j); ++j) {
+    int eu = 0, es = 0;                                  // unit of round j and the round inside it (counted, not divided)
+    for (int j = 0; DYN ? uq[eu & 3] >= 0 : j < nj; ++j) {
         int d, g;
         item(j, d, g);
         const int l0 = g * LPG;
+        if (++es == nsubr) {
+            es = 0;
+            ++eu;
+        }
         PSX_STAMP(2);
 
         // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}  (DUAL: LDS line 0 only = engine waves 0..5)
