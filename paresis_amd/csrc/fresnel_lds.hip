@@ -600,7 +600,13 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 #pragma unroll
             for (int q = 0; q < SLAB / 2; ++q) hh[q] = h4[q];
         } else {
-            const float4 *h4 = reinterpret_cast<const float4 *>(a.H[d] + (PART ? ps * M : 0) + (slab0 % (M / SLAB)) * SLAB);
+            int sl = slab0;
+            if constexpr (R3 < 16) {                 // re-derived here (as above): the hoisted 64-bit offset was spilled
+                int to = tid;
+                asm volatile("" : "+v"(to));
+                sl = (to >> 6) * WSLABS + ((to & 63) & 32) + ((to & 31) < 16 ? 2 * (to & 31) : 2 * ((to & 31) - 16) + 1);
+            }
+            const float4 *h4 = reinterpret_cast<const float4 *>(a.H[d] + (PART ? ps * M : 0) + (unsigned)((sl % (M / SLAB)) * SLAB));
 #pragma unroll
             for (int q = 0; q < SLAB / 2; ++q) hh[q] = h4[q];
         }
@@ -644,9 +650,15 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         // ---- 4+5. middle stage, slab by slab: forward radix R3 on contiguous chunks, x FFT_M(h_d), inverse radix R3,
         // back to LDS.  Each thread rewrites exactly the slabs it read.
         if constexpr (DUAL) {
-            if (pact) {
-                // slab pslab of the concatenated first LH lines; its second-distance product goes LH lines further
-                const int sline = pslab / (M / SLAB), sp0 = (pslab % (M / SLAB)) * SLAB;
+            // the slab index once more from an opaque copy of the thread index: kept live across forward stage B it is spilled
+            // at R3 < 16 (and comes back behind a full memory wait)
+            int tq = tid;
+            if constexpr (R3 < 16) asm volatile("" : "+v"(tq));
+            const int mslab = R3 < 16 ? 48 * (tq >> 6) + (tq & 63) : pslab;
+            const bool mact = R3 < 16 ? (tq & 63) < 48 : pact;
+            if (mact) {
+                // slab mslab of the concatenated first LH lines; its second-distance product goes LH lines further
+                const int sline = mslab / (M / SLAB), sp0 = (mslab % (M / SLAB)) * SLAB;
                 v2f *b0 = reinterpret_cast<v2f *>(lds) + sline * MP + phys(sp0), *b1 = b0 + LH * MP;
                 v2f x[SLAB], y[SLAB];
 #pragma unroll
@@ -811,7 +823,16 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             // so that the 48 per-q addresses are formed here from ONE pointer, not hoisted out of the group loop (they
             // would occupy 96 VGPRs there and spill).
             // PART: index inside the output block; PAIR: LDS line = parity of the position in the 2M-point result
-            int ifirst = (PAIR ? 2 * nA + lineA : nA) - (PART ? a.Lh - 1 : N + 2 * mg - 1);
+            // (R3 < 16: formed from an opaque copy of nA as well -- hoisted out of the group loop it has no register left and
+            // comes back from scratch memory once a round, behind a full memory wait)
+            int nAo = nA, lineAo = lineA;
+            if constexpr (R3 < 16 && !PAIR) {
+                int to = tid;
+                asm volatile("" : "+v"(to));
+                nAo = to % S1;
+                lineAo = to / S1;
+            }
+            int ifirst = (PAIR ? 2 * nA + lineA : nAo) - (PART ? a.Lh - 1 : N + 2 * mg - 1);
             asm volatile("" : "+v"(ifirst));
             // DUAL: LDS line 0 carries the first distance of the pair, line 1 the second (a wave belongs to one line)
             const int dd = DUAL ? 2 * d + __builtin_amdgcn_readfirstlane(tid >= TC / 2 ? 1 : 0) : d;
@@ -826,7 +847,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 // a huge offset, i >= N lies past the window).  No compare, no exec-mask bookkeeping per output -- the
                 // scalar unit is shared by the whole CU (0.9 instructions per cycle, tools/salu_bench.hip) and the masked
                 // form of this loop issued 500 scalar instructions per wave.
-                const int l = l0 + (PAIR ? 0 : __builtin_amdgcn_readfirstlane(DUAL ? lineA % LH : lineA));
+                const int l = l0 + (PAIR ? 0 : __builtin_amdgcn_readfirstlane(DUAL ? lineAo % LH : lineAo));
                 const bool lok = l < a.nlines;
                 // element index of output i inside the window: plain rows: i (window = row l); blocked: ((i>>3)*nlines+l)*8 + i%8
                 const int e0 = a.out_blocked ? ((ifirst >> 3) * a.nlines + l) * IB + (ifirst & (IB - 1)) : ifirst;
@@ -908,9 +929,9 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                         }
                     }
                 }
-            } else if (l0 + (DUAL ? lineA % LH : lineA) < a.nlines) {
+            } else if (l0 + (DUAL ? lineAo % LH : lineAo) < a.nlines) {
                 // short lines (R3 <= 4): a wave straddles lines, per-lane pointers and masks
-                const int lsh = l0 + (DUAL ? lineA % LH : lineA);
+                const int lsh = l0 + (DUAL ? lineAo % LH : lineAo);
                 const int64_t ob = a.out_blocked ? ((int64_t)(ifirst >> 3) * a.nlines + lsh) * IB + (ifirst & (IB - 1))
                                                  : (int64_t)lsh * a.out_ld + ifirst;
                 const int64_t oq = a.out_blocked ? (int64_t)(S1 / IB) * a.nlines * IB : (int64_t)S1;
