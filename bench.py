@@ -385,11 +385,13 @@ def positions_batch(a, sim, N, rank, world, dev):
     if overlap and sim == "Fresnel":
         exp._plan().work_queue(True)      # the transfer's copy kernels share the GPU with the line kernels from here on
 
+    mode = {"overlap": overlap}
+
     def gather_all(positions_fn):
         """Computes this rank's positions and brings every position's stacks to rank 0: round by round behind the computation
         (dist.PositionGatherer) or in one gather at the end.  Returns (gathered, seconds of computation issued + finished)."""
         t1 = time.perf_counter()
-        if overlap:
+        if mode["overlap"]:
             gat = dist.PositionGatherer(P, rank, world, to_host=False, shape=stack_shape)
             for p in mine:
                 gat.add(p, positions_fn(p))
@@ -408,7 +410,15 @@ def positions_batch(a, sim, N, rank, world, dev):
         # the caching allocator's blocks for the staging buffers (a first-time hipMalloc of ~2 GiB on rank 0 would land in
         # the timed region)
         warm = position(P + 1 + rank)
-        gather_all(lambda p: warm)
+        try:
+            gather_all(lambda p: warm)
+        except Exception:                  # the overlapped form failed where every rank fails alike (an API it lacks): one gather at the end
+            if not mode["overlap"]:
+                raise
+            import traceback
+            traceback.print_exc()
+            mode["overlap"] = False
+            gather_all(lambda p: warm)
         del warm
     # The interpreter's cyclic garbage collector would otherwise run a full collection somewhere in the first positions
     # (hundreds of thousands of objects allocated by the set-up above: ~40-60 ms of host time with the GPU idle -- the
