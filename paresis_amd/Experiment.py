@@ -331,7 +331,8 @@ class Experiment:
     # and drain whatever it computes, and a polychromatic position is 7 launches per energy.  There the energies of a
     # detector bin go through the chain TOGETHER (psx_fresnel_propagate_sources, psx_accumulate_many_f32): 7 launches per
     # bin.  On large grids a launch per energy costs nothing and the per-energy loop keeps its fused accumulation.
-    BATCH_ENERGIES_MAX_PIXELS = 1200 * 1200
+    BATCH_ENERGIES_MAX_PIXELS = 1137 * 1137        # lines of up to 1137 samples take the 2304-point transform, 8 to a round: fewer
+                                                   # line groups than CUs, the case the batched library calls serve in one launch
 
     def _batch_energies(self, N, plan):
         flag = self.exp_dict.get('batchEnergies')
