@@ -27,6 +27,11 @@ from .Sample import AnalyticalSample
 from .Source import Source
 
 
+def _rebased(base, rows):
+    """ops.MaterialBatch of cached coefficient rows (cphase rows, catt rows) over this position's maps."""
+    return ops.MaterialBatch(base, rows[0], rows[1])
+
+
 class Experiment:
     def __init__(self, exp_dict):
         """Experiment.py:26-137: XML -> objects -> geometry; exp_dict carries experimentName, overSampling,
@@ -103,6 +108,7 @@ class Experiment:
         self.imagePropagBeforeDetection = []
         self._fresnel_plan = None
         self._bins_ready = False      # thresholds validated and closed with the last spectrum energy (EXP:296-301)
+        self._tables = None           # (state key, per-bin energy tables) of the batched chains
         self._etmp = None             # per-energy intensity scratch [energies of a bin][Nx][Ny] (batched energy chain)
         self._accs = None             # study-grid accumulators [4][Nx][Ny], allocated once
         self._tmp = None
@@ -353,6 +359,57 @@ class Experiment:
                 cur, ibin = [], ibin + 1
         return bins, cur
 
+    def _bin_tables(self, sim, plate, air):
+        """Everything of the batched chains that depends on the energy only -- incident intensities, coefficient rows of every
+        material stack the chain uses, chirp scalars / displacement scales -- per detector bin, built once per experiment
+        state (the per-energy loop of the reference recomputes them for every membrane position) and re-based on each
+        position's maps (ops.MaterialBatch.rebase)."""
+        ed, spec = self.exp_dict, self.mySource.mySpectrum
+        objs = (self.myMembrane, self.mySampleofInterest, air, plate)
+        key = (sim, id(spec), len(spec), tuple(spec[0]), tuple(spec[-1]), tuple(self.myDetector.det_param["myBinsThersholds"]),
+               self.mySource.source_dict["myEnergySampling"], ed['distSourceToMembrane'], ed['distMembraneToObject'],
+               ed['distObjectToDetector'], ed['magnification'], ed['meanShotCount'], ed['overSampling'], ed['studyPixelSize'],
+               tuple(ed['studyDimensions']), self.myDetector.det_param['myScintillatorMaterial'],
+               self.myDetector.det_param['myScintillatorThickness'], id(self.myDetector.beta), len(self.myDetector.mySpectralEfficiency),
+               tuple((id(o.delta), id(o.beta), len(o.delta), len(o.beta)) if o is not None else None for o in objs))
+        if self._tables is not None and self._tables[0] == key:
+            return self._tables[1]
+        dSM, dMO, dOD, M = ed['distSourceToMembrane'], ed['distMembraneToObject'], ed['distObjectToDetector'], ed['magnification']
+        rows = lambda stacks: ([st.cphase for st in stacks], [st.catt for st in stacks])
+        bins, leftover = self._bins_of_spectrum()
+        out = []
+        for energies in bins:
+            Es = [E for _, E, _ in energies]
+            t = {"Es": Es, "I0": [self._incident(flux, E, ie) for ie, E, flux in energies]}
+            t["amp"] = [float(np.sqrt(v)) for v in t["I0"]]                                  # EXP:334
+            t["plate"] = rows([plate.stack_rt(E, phase=False) for E in Es]) if plate is not None else None
+            t["air_rt"] = rows([air.stack_rt(E, phase=False) for E in Es]) if air is not None else None
+            if sim == "Fresnel":
+                air_w = [air.stack_wave(E, phase=False) if air is not None else None for E in Es]
+                smp = [self.mySampleofInterest.stack_wave(E) for E in Es]
+                t["mem"] = rows([ops.MaterialStack.concat(aw, self.myMembrane.stack_wave(E)) for aw, E in zip(air_w, Es)])
+                t["smp"] = rows(smp)
+                t["smp0"] = rows([ops.MaterialStack.concat(aw, sm) for aw, sm in zip(air_w, smp)])
+                sc = [(self._fresnel_scalars(dMO, E, (dSM + dMO) / dSM), self._fresnel_scalars(dOD + dMO, E, M),
+                       self._fresnel_scalars(dOD, E, M)) for E in Es]
+                t["du"] = sc[0][0][2]
+                t["aA"], t["gA"] = [[c[0][0], c[1][0]] for c in sc], [[c[0][1], c[1][1]] for c in sc]
+                t["aB"], t["gB"] = [[c[2][0]] for c in sc], [[c[2][1]] for c in sc]
+            else:
+                air_rt = [air.stack_rt(E, phase=False) if air is not None else None for E in Es]
+                mem = [self.myMembrane.stack_rt(E) for E in Es]
+                smp = [self.mySampleofInterest.stack_rt(E) for E in Es]
+                mem_phase = [m.with_coeffs(catt=[0.0] * m.n) for m in mem]
+                t["mem_air"] = rows([ops.MaterialStack.concat(a_, m) for a_, m in zip(air_rt, mem)])
+                t["mem_phase"] = rows(mem_phase)
+                t["both"] = rows([ops.MaterialStack.concat(mp, sm) for mp, sm in zip(mem_phase, smp)])
+                t["air_smp"] = rows([ops.MaterialStack.concat(a_, sm) for a_, sm in zip(air_rt, smp)])
+                t["dsMO"] = [self._dscale(dMO, E) for E in Es]
+                t["dsOD"] = [self._dscale(dOD, E) for E in Es]
+            out.append(t)
+        self._tables = (key, (out, leftover))
+        return out, leftover
+
     def _fresnel_bins_batched(self, pointNum, stacks, accs, plan, plate, air, N, sums):
         """The Fresnel chain of one position (EXP:317-401) with the energies of each bin taken together.  Same operations on
         the same numbers as the per-energy loop; the per-energy intensities go through a scratch stack and are summed in
@@ -360,41 +417,38 @@ class Experiment:
         ed = self.exp_dict
         accS, accR, accP, white = accs
         dSM, dMO, dOD, M = ed['distSourceToMembrane'], ed['distMembraneToObject'], ed['distObjectToDetector'], ed['magnification']
-        bins, leftover = self._bins_of_spectrum()
-        nmax = max(len(b) for b in bins + [leftover]) if (bins or leftover) else 0
+        tables, leftover = self._bin_tables("Fresnel", plate, air)
+        nmax = max([len(t["Es"]) for t in tables] + [1])
         if self._etmp is None or self._etmp.shape[0] < nmax or tuple(self._etmp.shape[1:]) != N:
             self._etmp = torch.empty((nmax,) + N, dtype=torch.float32, device=accS.device)
-        for ibin, energies in enumerate(bins):
-            ne = len(energies)
-            Es = [E for _, E, _ in energies]
-            I0 = [self._incident(flux, E, ie) for ie, E, flux in energies]
-            amp = [float(np.sqrt(v)) for v in I0]                                          # EXP:334
-            air_w = [air.stack_wave(E, phase=False) if air is not None else None for E in Es]
-            plate_att = [plate.stack_rt(E, phase=False) for E in Es] if plate is not None else None
-            mem = [ops.MaterialStack.concat(aw, self.myMembrane.stack_wave(E)) for aw, E in zip(air_w, Es)]   # EXP:323,338
-            smp = [self.mySampleofInterest.stack_wave(E) for E in Es]
-            sc = [(self._fresnel_scalars(dMO, E, (dSM + dMO) / dSM), self._fresnel_scalars(dOD + dMO, E, M),
-                   self._fresnel_scalars(dOD, E, M)) for E in Es]
-            du = sc[0][0][2]
+        # this position's maps under the cached coefficient rows (any energy serves: only the maps are taken)
+        E0 = self.mySource.mySpectrum[0][0]
+        air_w0 = air.stack_wave(E0, phase=False) if air is not None else None
+        smp_b = self.mySampleofInterest.stack_wave(E0)
+        mem_b = ops.MaterialStack.concat(air_w0, self.myMembrane.stack_wave(E0))
+        smp0_b = ops.MaterialStack.concat(air_w0, smp_b)
+        plate_b = plate.stack_rt(E0, phase=False) if plate is not None else None
+        for ibin, t in enumerate(tables):
+            Es, ne = t["Es"], len(t["Es"])
+            plate_att = _rebased(plate_b, t["plate"]) if plate is not None else None
             tmp = [self._etmp[k] for k in range(ne)]
             # EXP:341 + EXP:349: membrane exit wave -> sample plane (complex field) and -> detector (|.|^2), every energy
-            wbs = plan.propagate_sources([[c[0][0], c[1][0]] for c in sc], [[c[0][1], c[1][1]] for c in sc], du, amp=amp,
-                                         mats=mem, want_wave=[True, False], inten_out=[[None, t] for t in tmp])
+            wbs = plan.propagate_sources(t["aA"], t["gA"], t["du"], amp=t["amp"], mats=_rebased(mem_b, t["mem"]),
+                                         want_wave=[True, False], inten_out=[[None, x] for x in tmp])
             self.waveSampleBeforeSample = wbs[-1][0]
             # EXP:355-361: plate attenuation, sum over the bin's energies and the image sums for the mean energy
             ops.accumulate_many(accR, tmp, sums, Es, mats=plate_att, add=False)
             # EXP:344 + EXP:348: through the sample, on to the detector
-            plan.propagate_sources([[c[2][0]] for c in sc], [[c[2][1]] for c in sc], du, wave_in=[w[0] for w in wbs], mats=smp,
-                                   want_wave=[False], inten_out=[[t] for t in tmp])
+            plan.propagate_sources(t["aB"], t["gB"], t["du"], wave_in=[w[0] for w in wbs], mats=_rebased(smp_b, t["smp"]),
+                                   want_wave=[False], inten_out=[[x] for x in tmp])
             ops.accumulate_many(accS, tmp, None, [0.0] * ne, mats=plate_att, add=False)
             if pointNum == 0:                                                              # EXP:363-375
-                smp0 = [ops.MaterialStack.concat(aw, sm) for aw, sm in zip(air_w, smp)]
-                plan.propagate_sources([[c[2][0]] for c in sc], [[c[2][1]] for c in sc], du, amp=amp, mats=smp0,
-                                       want_wave=[False], inten_out=[[t] for t in tmp])
+                plan.propagate_sources(t["aB"], t["gB"], t["du"], amp=t["amp"], mats=_rebased(smp0_b, t["smp0"]),
+                                       want_wave=[False], inten_out=[[x] for x in tmp])
                 ops.accumulate_many(accP, tmp, None, [0.0] * ne, mats=plate_att, add=False)
                 for k, E in enumerate(Es):
                     air_rt = air.stack_rt(E, phase=False) if air is not None else None
-                    self._white(white, I0[k], air_rt, plate_att[k] if plate_att is not None else None, k == 0)
+                    self._white(white, t["I0"][k], air_rt, plate.stack_rt(E, phase=False) if plate is not None else None, k == 0)
             self._detect_bin(ibin, pointNum, stacks, accs)                                 # EXP:378-401
         if leftover:
             # energies above the last threshold: the reference still propagates them (the field it leaves behind is theirs)
@@ -404,7 +458,7 @@ class Experiment:
             a1, g1, du = self._fresnel_scalars(dMO, E, (dSM + dMO) / dSM)
             self.waveSampleBeforeSample = plan.propagate([a1], [g1], du, amp=float(np.sqrt(I0)),
                                                          mats=ops.MaterialStack.concat(air_w, self.myMembrane.stack_wave(E)))[0]
-        return len(bins)
+        return len(tables)
 
     def computeSampleAndReferenceImages_Fresnel(self, pointNum):
         """Experiment.py:279-405.  Returns (SampleImage, ReferenceImage, PropagImage, detectedWhite), each
@@ -476,45 +530,44 @@ class Experiment:
         ed = self.exp_dict
         accS, accR, accP, white = accs
         dMO, dOD = ed['distMembraneToObject'], ed['distObjectToDetector']
-        bins, leftover = self._bins_of_spectrum()
-        nmax = max([len(b) for b in bins] + [1])
+        tables, _ = self._bin_tables("RayT", plate, air)
+        nmax = max([len(t["Es"]) for t in tables] + [1])
         if self._etmp is None or self._etmp.shape[0] < 2 * nmax or tuple(self._etmp.shape[1:]) != N:
             self._etmp = torch.empty((2 * nmax,) + N, dtype=torch.float32, device=accS.device)
-        for ibin, energies in enumerate(bins):
-            ne = len(energies)
-            Es = [E for _, E, _ in energies]
-            I0 = [self._incident(flux, E, ie) for ie, E, flux in energies]
-            air_rt = [air.stack_rt(E, phase=False) if air is not None else None for E in Es]
-            plate_att = [plate.stack_rt(E, phase=False) for E in Es] if plate is not None else None
-            mem = [self.myMembrane.stack_rt(E) for E in Es]
-            smp = [self.mySampleofInterest.stack_rt(E) for E in Es]
-            mem_phase = [m.with_coeffs(catt=[0.0] * m.n) for m in mem]
+        # this position's maps under the cached coefficient rows (any energy serves: only the maps are taken)
+        E0 = self.mySource.mySpectrum[0][0]
+        air_b = air.stack_rt(E0, phase=False) if air is not None else None
+        mem_b, smp_b = self.myMembrane.stack_rt(E0), self.mySampleofInterest.stack_rt(E0)
+        mem_air_b, both_b = ops.MaterialStack.concat(air_b, mem_b), ops.MaterialStack.concat(mem_b, smp_b)
+        air_smp_b = ops.MaterialStack.concat(air_b, smp_b)
+        plate_b = plate.stack_rt(E0, phase=False) if plate is not None else None
+        for ibin, t in enumerate(tables):
+            Es, ne, I0 = t["Es"], len(t["Es"]), t["I0"]
+            plate_att = _rebased(plate_b, t["plate"]) if plate is not None else None
             Ibs = [self._etmp[k] for k in range(ne)]
             tmp = [self._etmp[nmax + k] for k in range(ne)]
             # EXP:463 + 466: membrane transmission fused into the first refraction, every energy
-            ops.refract_batch(N, [ops.MaterialStack.concat(a, m) for a, m in zip(air_rt, mem)],
-                              [self._dscale(dMO, E) for E in Es], clamp, I0=I0, outs=Ibs)
+            ops.refract_batch(N, _rebased(mem_air_b, t["mem_air"]), t["dsMO"], clamp, I0=I0, outs=Ibs)
             self.IntensitySampleBeforeSample = Ibs[-1]
             # EXP:474 reference images: refracted again with the membrane phase only; EXP:480-486 their attenuated sum
-            ops.refract_batch(N, mem_phase, [self._dscale(dOD, E) for E in Es], clamp, I_in=Ibs, outs=tmp)
+            ops.refract_batch(N, _rebased(mem_b, t["mem_phase"]), t["dsOD"], clamp, I_in=Ibs, outs=tmp)
             ops.accumulate_many(accR, tmp, sums, Es, mats=plate_att, add=False)
             # EXP:469 + 473 sample images: sample attenuation and membrane+sample phase fused into the refraction
-            ops.refract_batch(N, [ops.MaterialStack.concat(mp, sm) for mp, sm in zip(mem_phase, smp)],
-                              [self._dscale(dOD, E) for E in Es], clamp, I_in=Ibs, outs=tmp)
+            ops.refract_batch(N, _rebased(both_b, t["both"]), t["dsOD"], clamp, I_in=Ibs, outs=tmp)
             ops.accumulate_many(accS, tmp, None, [0.0] * ne, mats=plate_att, add=False)
             if pointNum == 0:                                                             # EXP:488-498
                 if ne > 1:
-                    ops.refract_batch(N, [ops.MaterialStack.concat(a, sm) for a, sm in zip(air_rt[:-1], smp[:-1])],
-                                      [self._dscale(dOD, E) for E in Es[:-1]], clamp, I0=I0[:-1], outs=tmp[:-1])
+                    head = (t["air_smp"][0][:-1], t["air_smp"][1][:-1])
+                    ops.refract_batch(N, _rebased(air_smp_b, head), t["dsOD"][:-1], clamp, I0=I0[:-1], outs=tmp[:-1])
                 # the last energy of the bin leaves the displacement maps behind (EXP:492), like the per-energy loop
-                _, self.Dxreal, self.Dyreal = ops.refract(N, ops.MaterialStack.concat(air_rt[-1], smp[-1]),
-                                                          self._dscale(dOD, Es[-1]), clamp, I0=I0[-1], out=tmp[ne - 1],
-                                                          want_D=True)
+                last = air_smp_b.with_coeffs(cphase=t["air_smp"][0][-1], catt=t["air_smp"][1][-1])
+                _, self.Dxreal, self.Dyreal = ops.refract(N, last, t["dsOD"][-1], clamp, I0=I0[-1], out=tmp[ne - 1], want_D=True)
                 ops.accumulate_many(accP, tmp, None, [0.0] * ne, mats=plate_att, add=False)
-                for k in range(ne):
-                    self._white(white, I0[k], air_rt[k], plate_att[k] if plate_att is not None else None, k == 0)
+                for k, E in enumerate(Es):
+                    self._white(white, I0[k], air.stack_rt(E, phase=False) if air is not None else None,
+                                plate.stack_rt(E, phase=False) if plate is not None else None, k == 0)
             self._detect_bin(ibin, pointNum, stacks, accs)                                # EXP:501-521
-        return len(bins)
+        return len(tables)
 
     def computeSampleAndReferenceImages_RT(self, pointNum):
         """Experiment.py:407-526.  Returns (SampleImage, ReferenceImage, PropagImage, detectedWhite, Dxreal, Dyreal,

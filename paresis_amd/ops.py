@@ -108,6 +108,43 @@ def _mats(m):
     return m
 
 
+class MaterialBatch:
+    """The materials of a batch of sources over the same maps (the energies of a detector bin): `base` carries the maps,
+    cphase[s][i] / catt[s][i] the coefficients of source s.  What a list of per-source MaterialStack objects says, without
+    building them (and re-checking their maps) for every membrane position: the coefficients depend on the energy only."""
+
+    def __init__(self, base, cphase, catt):
+        self.base = _mats(base)
+        self.cphase = [[float(v) for v in r] for r in cphase]
+        self.catt = [[float(v) for v in r] for r in catt]
+        if any(len(r) != self.base.n for r in self.cphase) or any(len(r) != self.base.n for r in self.catt):
+            raise PsxError("MaterialBatch: one coefficient per material and source")
+        self.n = self.base.n
+
+    def rebase(self, base):
+        """The same coefficients over another position's maps."""
+        out = MaterialBatch.__new__(MaterialBatch)
+        out.base, out.cphase, out.catt, out.n = _mats(base), self.cphase, self.catt, self.n
+        if out.base.n != self.n:
+            raise PsxError("MaterialBatch.rebase: %d maps for %d coefficients" % (out.base.n, self.n))
+        return out
+
+
+def _batch_mats(mats, ns, shape, what):
+    """(T** host array, nmat, cphase[ns][nmat], catt[ns][nmat]) from a MaterialBatch or from one MaterialStack per source."""
+    if isinstance(mats, MaterialBatch):
+        if len(mats.cphase) != ns:
+            raise PsxError("%s: %d coefficient rows for %d sources" % (what, len(mats.cphase), ns))
+        return mats.base.cargs(shape)[0], mats.n, mats.cphase, mats.catt
+    mats = [_mats(None)] * ns if mats is None else [_mats(m) for m in mats]
+    nm = mats[0].n
+    T = mats[0].cargs(shape)[0]
+    for m in mats[1:]:
+        if m.n != nm or any(m.map(i).data_ptr() != mats[0].map(i).data_ptr() for i in range(nm)):
+            raise PsxError("%s: every source must use the same thickness maps" % what)
+    return T, nm, [m.cphase for m in mats], [m.catt for m in mats]
+
+
 _workspaces = {}
 _status_words = {}
 
@@ -228,7 +265,6 @@ def accumulate_many(acc, imgs, sums, weights, scales=None, mats=None, add=True):
     as one accumulate_sum call per image would: acc (+)= sum_e scales[e] * imgs[e] * att_e, sums += (sum, sum of
     weights[e] * term).  mats[e]: MaterialStack of image e (same maps, own attenuation coefficients) or None."""
     ne = len(imgs)
-    mats = [_mats(None)] * ne if mats is None else [_mats(m) for m in mats]
     scales = [1.0] * ne if scales is None else [float(v) for v in scales]
     shape = tuple(imgs[0].shape)
     for i, t in enumerate(imgs):
@@ -237,17 +273,13 @@ def accumulate_many(acc, imgs, sums, weights, scales=None, mats=None, add=True):
         _need(acc, torch.float32, "acc", shape)
     if sums is not None:
         _need(sums, torch.float64, "sums", (_lib.PSX_SUM_SLOTS, _lib.PSX_SUM_STRIDE))
-    nm = mats[0].n
-    T = mats[0].cargs(shape)[0]
-    for m in mats[1:]:
-        if m.n != nm or any(m.map(i).data_ptr() != mats[0].map(i).data_ptr() for i in range(nm)):
-            raise PsxError("accumulate_many: every image must use the same thickness maps")
+    T, nm, _, cat = _batch_mats(mats, ne, shape, "accumulate_many")
     for e0 in range(0, ne, _lib.PSX_MAX_SRC):
         el = range(e0, min(ne, e0 + _lib.PSX_MAX_SRC))
         n = len(el)
         check(lib().psx_accumulate_many_f32(
             _ptr(acc), (c_void_p * n)(*[imgs[e].data_ptr() for e in el]), (c_float * n)(*[scales[e] for e in el]), n, T,
-            (c_double * max(1, n * nm))(*[c for e in el for c in mats[e].catt]), nm, 1 if (add or e0 > 0) else 0,
+            (c_double * max(1, n * nm))(*[c for e in el for c in cat[e]]), nm, 1 if (add or e0 > 0) else 0,
             imgs[0].numel(), _ptr(sums), (c_double * n)(*[float(weights[e]) for e in el]), _stream()),
             "psx_accumulate_many_f32")
     return acc
@@ -288,15 +320,10 @@ def refract_batch(shape, mats, dscales, clamp, margin=15, I_in=None, I0=None, ou
     """Several refractions over the SAME thickness maps in one launch per kernel (the energies of a detector bin,
     EXP:448-486): mats[e] (same maps, own coefficients), dscales[e], I_in[e] (all or None) or the uniform I0[e], outs[e].
     Every image is what refract() gives for that refraction.  Returns the list of output images."""
-    ne = len(mats)
-    mats = [_mats(m) for m in mats]
+    ne = len(dscales)
     Nx, Ny = int(shape[0]), int(shape[1])
-    dev = mats[0].map(0).device
-    nm = mats[0].n
-    T = mats[0].cargs((Nx, Ny))[0]
-    for m in mats[1:]:
-        if m.n != nm or any(m.map(i).data_ptr() != mats[0].map(i).data_ptr() for i in range(nm)):
-            raise PsxError("refract_batch: every refraction must use the same thickness maps")
+    T, nm, cph, cat = _batch_mats(mats, ne, (Nx, Ny), "refract_batch")
+    dev = (mats.base if isinstance(mats, MaterialBatch) else _mats(mats[0])).map(0).device
     if I_in is not None:
         for e, t in enumerate(I_in):
             _need(t, torch.float32, "I_in[%d]" % e, (Nx, Ny))
@@ -314,8 +341,8 @@ def refract_batch(shape, mats, dscales, clamp, margin=15, I_in=None, I0=None, ou
         check(lib().psx_refract_batch_f32(
             n, (c_void_p * n)(*[I_in[e].data_ptr() for e in el]) if I_in is not None else None,
             (c_float * n)(*[I0[e] for e in el]), T,
-            (c_double * (n * nm))(*[c for e in el for c in mats[e].cphase]),
-            (c_double * (n * nm))(*[c for e in el for c in mats[e].catt]), nm,
+            (c_double * (n * nm))(*[c for e in el for c in cph[e]]),
+            (c_double * (n * nm))(*[c for e in el for c in cat[e]]), nm,
             (c_void_p * n)(*[outs[e].data_ptr() for e in el]), c_float(out_scale), 1 if add else 0, Nx, Ny, int(margin),
             (c_double * n)(*[float(dscales[e]) for e in el]), c_double(clamp[0]), c_double(clamp[1]),
             _ptr(status_word(dev)), _ptr(ws), _stream()), "psx_refract_batch_f32")
@@ -453,16 +480,11 @@ class FresnelPlan:
         PSX_MAX_SRC sources are taken in chunks."""
         ns, nd = len(a), len(a[0])
         shape = (self.Nx, self.Ny)
-        mats = [_mats(None)] * ns if mats is None else [_mats(m) for m in mats]
+        T, nm, cph, cat = _batch_mats(mats, ns, shape, "propagate_sources")
         amp = [1.0] * ns if amp is None else [float(v) for v in amp]
         want_wave = [True] * nd if want_wave is None else list(want_wave)
         inten_out = [[None] * nd for _ in range(ns)] if inten_out is None else [list(r) for r in inten_out]
         inten_scale = [[1.0] * nd for _ in range(ns)] if inten_scale is None else [[float(v) for v in r] for r in inten_scale]
-        nm = mats[0].n
-        T = mats[0].cargs(shape)[0]
-        for m in mats[1:]:
-            if m.n != nm or any(m.map(i).data_ptr() != mats[0].map(i).data_ptr() for i in range(nm)):
-                raise PsxError("propagate_sources: every source must use the same thickness maps")
         waves = [[torch.empty(shape, dtype=torch.complex64, device=self.device) if w else None for w in want_wave]
                  for _ in range(ns)]
         for s0 in range(0, ns, _lib.PSX_MAX_SRC):
@@ -479,8 +501,8 @@ class FresnelPlan:
             io = (c_void_p * (n * nd))(*[(inten_out[s][d].data_ptr() if inten_out[s][d] is not None else None) for s in sl for d in range(nd)])
             check(lib().psx_fresnel_propagate_sources(
                 self._h, n, nd, wi, (c_float * n)(*[amp[s] for s in sl]), T,
-                (c_double * max(1, n * nm))(*[c for s in sl for c in mats[s].cphase]),
-                (c_double * max(1, n * nm))(*[c for s in sl for c in mats[s].catt]), nm,
+                (c_double * max(1, n * nm))(*[c for s in sl for c in cph[s]]),
+                (c_double * max(1, n * nm))(*[c for s in sl for c in cat[s]]), nm,
                 (c_double * (n * nd))(*[float(a[s][d]) for s in sl for d in range(nd)]),
                 (c_double * (n * nd))(*[float(gphase[s][d]) for s in sl for d in range(nd)]), c_double(du[0]), c_double(du[1]),
                 wo, io, (c_float * (n * nd))(*[inten_scale[s][d] for s in sl for d in range(nd)]), _stream()),
