@@ -357,3 +357,34 @@ def test_bench_starts_its_own_ranks_and_rejects_a_world_mismatch(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "WORLD_SIZE=2" in str(e.value.code)
+
+
+def test_energy_bins_of_the_batched_chains_follow_the_reference_loop():
+    """Experiment._bins_of_spectrum (the batched energy chains take a detector bin at a time) against the bin bookkeeping of
+    the reference's energy loop (Experiment.py:296-301, 378-401): a bin closes at the first energy above its threshold minus
+    half a sampling step, one bin per energy at most, the last energy closes the last bin."""
+    import types
+    from paresis_amd.Experiment import Experiment
+
+    def reference_bins(spectrum, thresholds, sampling):
+        thr = list(thresholds) + [spectrum[-1][0]]                     # EXP:301
+        bins, cur, ibin = [], [], 0
+        for ie, (E, flux) in enumerate(spectrum):                      # EXP:317
+            cur.append(ie)
+            if E > thr[ibin] - sampling / 2:                           # EXP:378
+                bins.append(cur)
+                cur, ibin = [], ibin + 1
+        return bins, cur
+
+    rng = np.random.default_rng(3)
+    for n, nthr, sampling in ((1, 0, 1.0), (5, 1, 2.0), (25, 2, 2.0), (12, 3, 1.5), (7, 6, 1.0)):
+        E = 20.0 + sampling * np.arange(n)
+        spectrum = [(float(e), float(w)) for e, w in zip(E, rng.uniform(0.1, 1, n))]
+        thresholds = sorted(float(v) for v in rng.choice(E[:-1], size=min(nthr, max(0, n - 1)), replace=False)) if nthr and n > 1 else []
+        exp = Experiment.__new__(Experiment)
+        exp.mySource = types.SimpleNamespace(mySpectrum=spectrum, source_dict={"myEnergySampling": sampling})
+        exp.myDetector = types.SimpleNamespace(det_param={"myBinsThersholds": list(thresholds) + [spectrum[-1][0]]})
+        bins, leftover = exp._bins_of_spectrum()
+        ref, ref_left = reference_bins(spectrum, thresholds, sampling)
+        assert [[ie for ie, _, _ in b] for b in bins] == ref and [ie for ie, _, _ in leftover] == ref_left
+        assert ref_left == [] and sum(len(b) for b in ref) == n        # the appended last energy closes the last bin
