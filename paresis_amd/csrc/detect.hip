@@ -35,6 +35,7 @@ struct BandOp {
 // rows [x, y) of the input image that the axis-0 operator reads for them.
 struct BandPair {
     bool ok = false;
+    bool cheap = false;         // the tiles' halos re-read less than 30 % of the input rows (else two passes move fewer bytes)
     int RT = 0, n_rtiles = 0, mid_rows = 0, span_ld = 0;
     int2 *r_tile = nullptr;     // [n_rtiles] device
     size_t lds = 0;
@@ -776,6 +777,7 @@ int psx_detector_plan_create(int Nx, int Ny, int ov, int nx, int ny, int margin,
         for (int RT : {16, 8, 4}) {
             std::vector<int2> tiles;
             int mid = 1;
+            long long rows_read = 0;
             for (int r0 = 0; r0 < R.n_out; r0 += RT) {
                 int lo = R.n_in, hi = 0;
                 for (int r = r0; r < std::min(R.n_out, r0 + RT); ++r) {
@@ -784,12 +786,14 @@ int psx_detector_plan_create(int Nx, int Ny, int ov, int nx, int ny, int margin,
                 }
                 tiles.push_back(make_int2(lo, hi));
                 mid = std::max(mid, hi - lo);
+                rows_read += hi - lo;
             }
             const size_t lds = sizeof(float) * (8 * (size_t)pr.span_ld + (size_t)mid * 256 + (size_t)RT * R.W + RT);
             if ((lds > 40 * 1024 || RT * R.W > 256) && RT > 4) continue;
             if (RT * R.W > 256) return 0;
             if (lds > 64 * 1024) return 0;
             pr.RT = RT; pr.n_rtiles = (int)tiles.size(); pr.mid_rows = mid; pr.lds = lds;
+            pr.cheap = (double)rows_read <= 1.3 * (double)R.n_in;
             if (int e = up((void **)&pr.r_tile, tiles.data(), sizeof(int2) * tiles.size())) return e;
             pr.ok = true;
             return 0;
@@ -799,7 +803,7 @@ int psx_detector_plan_create(int Nx, int Ny, int ov, int nx, int ny, int margin,
     if (!rc) rc = pair(p->front, p->fy, p->fx);
     if (!rc && psf) rc = pair(p->back, p->by, p->bx);
     p->pitch2 = (p->fy.n_out + 3) / 4 * 4;
-    if (!rc && psf && p->front.ok && p->back.ok) rc = scratch(&p->t2p, (size_t)p->fx.n_out * (size_t)p->pitch2);
+    if (!rc && psf && p->back.ok) rc = scratch(&p->t2p, (size_t)p->fx.n_out * (size_t)p->pitch2);
     if (rc) {
         psx_detector_plan_destroy(p);
         return rc;
@@ -939,17 +943,25 @@ int psx_detect_f32(psx_detector_plan *p, const float *img, float *out, void *str
     PSX_REQUIRE(p && img && out, "psx_detect_f32: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const bool psf = p->bx.n_out != 0;
-    // two fused passes (k_band_pair) when the rows of the image are 16-byte aligned and the bands fit its tiles
-    if (p->front.ok && (!psf || (p->back.ok && p->t2p)) && p->Ny % 4 == 0 && (uintptr_t)img % 16 == 0 && !four_pass_forced()) {
-        if (!psf) return band_pair(p->front, p->fy, p->fx, img, p->Ny, out, p->fy.n_out, st);
-        if (int rc = band_pair(p->front, p->fy, p->fx, img, p->Ny, p->t2p, p->pitch2, st)) return rc;
-        return band_pair(p->back, p->by, p->bx, p->t2p, p->pitch2, out, p->ny, st);
+    // Each stage as ONE fused pass (k_band_pair) where that moves fewer bytes: the front stage when the image rows are 16-byte
+    // aligned, the bands fit its tiles and the tiles' halos are small (a wide source blur makes an 8-row tile re-read half
+    // its rows: two passes are cheaper then); the PSF stage whenever its bands fit -- it reads the front stage's result at a
+    // 16-byte row pitch, which the two-pass front can only write when the row length is a multiple of 4 anyway.
+    const bool allowed = !four_pass_forced();
+    const bool front_f = allowed && p->front.ok && p->front.cheap && p->Ny % 4 == 0 && (uintptr_t)img % 16 == 0;
+    const bool back_f = allowed && psf && p->back.ok && p->t2p && (front_f || p->pitch2 == p->fy.n_out);
+    float *mid_img = back_f ? p->t2p : p->t2;
+    const int mid_pitch = back_f ? p->pitch2 : p->fy.n_out;
+    if (front_f) {
+        if (int rc = band_pair(p->front, p->fy, p->fx, img, p->Ny, psf ? mid_img : out, psf ? mid_pitch : p->fy.n_out, st)) return rc;
+    } else {
+        // contiguous axis first (the only pass over the full-resolution image), then axis 0
+        if (int rc = band_cols(p->fy, img, p->t1, p->Nx, st)) return rc;
+        if (int rc = band_rows(p->fx, p->t1, psf ? mid_img : out, p->fy.n_out, st)) return rc;
     }
-    // front operator: contiguous axis first (the only pass over the full-resolution image), then axis 0
-    if (int rc = band_cols(p->fy, img, p->t1, p->Nx, st)) return rc;
-    if (int rc = band_rows(p->fx, p->t1, psf ? p->t2 : out, p->fy.n_out, st)) return rc;
     if (!psf) return 0;
     // back operator (PSF + crop) at detector resolution
+    if (back_f) return band_pair(p->back, p->by, p->bx, mid_img, mid_pitch, out, p->ny, st);
     if (int rc = band_cols(p->by, p->t2, p->t3, p->fx.n_out, st)) return rc;
     return band_rows(p->bx, p->t3, out, p->ny, st);
 }
