@@ -87,6 +87,11 @@ struct LineArgs {
     int B, Lh, S, NB;
     float2 *part[MAX_LINE];
     const float2 *w2;       // PAIR: w_2M^{k0} of each 16-point slab, k0 = q1 + 24 q2  (576 entries)
+    // DIF (see k_fresnel_lines): one 4M-point convolution per line in two PAIR rounds
+    const float2 *w4;       // exp(+2 pi i n0 / 4M), n0 < 2*S1 = 768: the thread-dependent factor of the radix-2 twiddle w_4M^{-n}
+    float2 *wgpart;         // [workgroups][2M]: the even half-spectrum's result of a line, private to the workgroup, between its two rounds
+    int wg_groups;          // line buffers in wgpart (host-side check against the grid)
+    int dsh, thr;           // D = 2M - P: L[n + D] = e[n + 2M] (the extension is P-periodic); thr = N + P - 1 - 2M: positions that have one
     unsigned *queue;        // work queues of the one-transform passes (null: static shares): the counter of workgroup w at [16 w], workgroups done at [16 * 256]
     unsigned long long *stamps;   // optional diagnostics: 32 phase timestamps per workgroup (psx_debug_stamps)
 };
@@ -135,8 +140,20 @@ __device__ __forceinline__ void lds_barrier() {
 // for the other.
 // That is the only way of sharing the forward transform between distances that fits LDS: 4.3 stage-units of work per two
 // (line, distance) results instead of 5.3, and half the samples to fetch and spread per round.
-template <int R3, bool CONTIG, bool PART = false, bool PAIR = false, bool DUAL = false, bool QUEUE = false>
+// DIF (lines of 9202 <= N <= 18402 samples, the 16384^2 grid of BASELINE config 5): the whole line is ONE circular
+// convolution of 4M = 36864 >= N + P - 1 points, split by a decimation-in-frequency radix-2 step over TWO PAIR rounds:
+//     round E:  ye = IDFT_2M( FFT_2M( x[n] + x[n + 2M] )          * H4[2k]   )
+//     round O:  yo = IDFT_2M( FFT_2M((x[n] - x[n + 2M]) w_4M^n )  * H4[2k+1] )        y[m] = (ye[m'] + w_4M^-m yo[m']) / 2,  m' = m mod 2M
+// (the block x segment partition needs 2 x 2 such rounds at N = 16384, each re-reading a 16398-sample window).  The
+// extension e of the line is P-periodic, so x[n + 2M] = e[n + 2M - P]: the loaders write ONE copy L[n] = e[n], n < 2M, and
+// forward stage A forms L[n] +- L[n + D] itself from LDS (one more workgroup barrier: everybody reads before anybody writes
+// in place); the twiddle w_4M^n = (thread factor) x (compile-time 48th root per butterfly leg) rides on stage A's input and
+// output multiplies.  Round E leaves ye in a line buffer private to the workgroup (it is read back 20 us later by the same
+// CU: L2 / MALL traffic), round O combines and stores the N wanted samples, whose index wraps once along the 24 outputs of a
+// butterfly.  Per line: 2 rounds and 2 x 18432 loads instead of 4 and 4 x 16398; no partial sums in the output image.
+template <int R3, bool CONTIG, bool PART = false, bool PAIR = false, bool DUAL = false, bool QUEUE = false, bool DIF = false>
 __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
+    static_assert(!DIF || (PART && PAIR), "DIF rounds are PAIR rounds of the partitioned engine");
     // PAIR: the second LDS line starts 16 points further, so that a point of line 0 and the same point of line 1 sit 32 banks
     // apart: stage A then gives adjacent lanes the even and the odd sample of a pair without a bank conflict
     constexpr int M = 576 * R3, LINES = TOT / M, S1 = M / RAD, MP = M + M / 32 + (PAIR ? 16 : 0);
@@ -298,8 +315,9 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 // PART sources are the blocked intermediate or contiguous lines (in_si == 1): 32-bit element offsets from the line's base
                 const float2 *srcl = a.src[d] + (a.in_blocked ? ((int64_t)(lc / IB) * N) * IB + lc % IB : (int64_t)lc * a.in_sl);
                 const int istep = a.in_blocked ? IB : 1;
-                const int a0 = pb * a.B + P - (ps + 1) * a.Lh;
-                const unsigned tlim = l < a.nlines ? (unsigned)Lw : 0u;
+                // DIF: the window is the first 2M points of the extension, every position holds a sample
+                const int a0 = DIF ? 0 : pb * a.B + P - (ps + 1) * a.Lh;
+                const unsigned tlim = l < a.nlines ? (unsigned)(DIF ? 2 * M : Lw) : 0u;
                 int tb = PAIR ? 2 * i0 + line : i0;          // window position of this thread's first sample; opaque, so that the
                 asm volatile("" : "+v"(tb));                 // 72 positions are formed here and not kept across the rounds
                 vm0 = 0u;
@@ -336,6 +354,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             lds_barrier();                                   // (0)
             for (int j = 0; j < nj; ++j) {
                 const bool more = j + 1 < nj;
+                if constexpr (DIF) lds_barrier();            // (1a) engine: stage A has read its inputs and their partners
                 lds_barrier();                               // (1)
                 if (more) fetch_half(j + 1, 0);
                 lds_barrier();                               // (2)
@@ -566,7 +585,48 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         PSX_STAMP(2);
 
         // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}  (DUAL: LDS line 0 only = engine waves 0..5)
-        if (!DUAL || tid < TC / 2) {
+        if constexpr (DIF) {
+            // leg q of this thread's butterfly is position n = n0 + 768 q of the 2M-point sequence, n0 = 2 nA + lineA = tid; its
+            // partner x[n + 2M] = L[n + D] exists for n < thr.  Round E transforms L[n] + L[n + D], round O (L[n] - L[n + D]) w_4M^n
+            // with w_4M^n = conj(w4[n0]) x exp(-2 pi i q / 48), the second factor a compile-time constant.
+            v2f v[RAD];
+            int to = tid;
+            asm volatile("" : "+v"(to));
+            const int np = to + a.dsh;
+            const v2f *pp = reinterpret_cast<const v2f *>(lds) + (np & 1) * MP + phys(np >> 1);
+            const int qb = (a.thr - to + 2 * S1 - 1) / (2 * S1);          // legs q < qb have a partner
+            const float sg = ps == 0 ? 1.f : -1.f;                       // wave-uniform
+#pragma unroll
+            for (int q = 0; q < RAD; ++q) v[q] = baseA[idxA(nA, q)];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                v2f b[RAD / 2];
+#pragma unroll
+                for (int q = 0; q < RAD / 2; ++q) b[q] = lds_read(pp + (h * (RAD / 2) + q) * (S1 + S1 / 32));
+#pragma unroll
+                for (int q = 0; q < RAD / 2; ++q) {
+                    // a leg without partner reads whatever lies there (possibly past the line buffers) and drops it
+                    const v2f bm = (h * (RAD / 2) + q) < qb ? b[q] : (v2f){0.f, 0.f};
+                    v[h * (RAD / 2) + q] = pk_fma_k(bm, sg, v[h * (RAD / 2) + q]);
+                }
+            }
+            lds_barrier();                           // (1a) every input and partner has been read: the in-place writes may start
+            if (ps != 0) {
+                // both factors on the inputs: the thread factor would otherwise stay live through the butterfly
+                const float2 wf = a.w4[to];
+                const v2f wb = (v2f){wf.x, wf.y};
+                pk_static_for<0, RAD>([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int q = decltype(qc)::value;
+                    v[q] = pk_cmulc(v[q], pk_twiddle<2 * RAD, q, true>(wb));      // x conj(w4[n0] exp(+2 pi i q / 48)) = w_4M^n
+                });
+            }
+            DftPk<RAD, false>::run(v);
+            __builtin_amdgcn_sched_barrier(0);
+            twiddle_A(v, Q1{}, Q12{}, std::false_type{});
+            twiddle_A(v, Q12{}, Q24{}, std::false_type{});
+#pragma unroll
+            for (int q = 0; q < RAD; ++q) baseA[idxA(nA, q)] = v[q];
+        } else if (!DUAL || tid < TC / 2) {
             v2f v[RAD];
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = baseA[idxA(nA, q)];
@@ -841,7 +901,90 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             const float sc = a.scale[dd];
             const v2f gp = (v2f){a.gph[dd].x, a.gph[dd].y};
             static_assert(S1 % IB == 0 && IB == 8, "blocked output stride; the block index below is i >> 3");
-            if constexpr (S1 % 64 == 0) {
+            if constexpr (DIF) {
+                // leg q holds point n' = n0 + 768 q of this round's 2M-point result (n0 = tid).  Round E parks it in the
+                // workgroup's own line buffer; round O fetches it back, forms y[m] = ye[n'] + w_4M^-m yo[n'] (the 1/2 sits in the
+                // kernel-spectrum table) and stores output sample i = m - (P - 1), m = n' + 2M for the legs below qw (sign -:
+                // w_4M^-2M = -1) and m = n' from leg qw on (the index wraps once along the butterfly).  Legs whose sample lies
+                // outside [0, N) fall outside the descriptor's range and are dropped by the hardware, as everywhere.
+                int to = tid;
+                asm volatile("" : "+v"(to));
+                constexpr int QS = 2 * S1;
+                const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+                    reinterpret_cast<v2f *>(a.wgpart) + (size_t)blockIdx.x * 2 * M, 0, 2 * M * 8, 0x00020000);
+                // (two independent `if`s in this order, not if / else: the else-branch is laid out BEFORE the if-branch in the
+                // structurized flow, and the 24 values the round-E stores read would then stay live -- spilled -- through the
+                // whole round-O branch)
+                if (ps != 0) {
+                    const float2 wf = a.w4[to];
+                    const v2f wb = (v2f){wf.x, wf.y}, wbn = -wb;
+                    const int qw = (a.P - 1 - to + QS - 1) / QS;              // first wrapped leg
+                    // twiddles first, in place; then ye, eight loads at a time, fenced (as the partial sums of the partition:
+                    // hoisted above the twiddles the 24 loads would not fit the register budget)
+                    pk_static_for<0, RAD>([&](auto qc) __attribute__((always_inline)) {
+                        constexpr int q = decltype(qc)::value;
+                        const v2f wsel = q >= qw ? wb : wbn;
+                        const v2f wq = pk_twiddle<2 * RAD, q, true>(wsel);            // +-exp(+2 pi i (n0 + 768 q) / 4M)
+                        v[q] = pk_cmul(v[q], wq);
+                    });
+#pragma unroll
+                    for (int q0 = 0; q0 < RAD; q0 += 8) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        v2u o[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) o[q] = __builtin_amdgcn_raw_buffer_load_b64(rp, to * 8, (q0 + q) * QS * 8, 0);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q0 + q] += __builtin_bit_cast(v2f, o[q]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int l = l0;
+                    const bool lok = l < a.nlines;
+                    const int ifirst = to + 2 * M - (a.P - 1);               // sample index of leg 0, not wrapped
+                    const unsigned e0 = a.out_blocked ? (unsigned)(((ifirst >> 3) * a.nlines + l) * IB + (ifirst & (IB - 1))) : (unsigned)ifirst;
+                    const unsigned estep = a.out_blocked ? (unsigned)((QS / IB) * a.nlines * IB) : (unsigned)QS;
+                    const unsigned ewrap = e0 - (a.out_blocked ? (unsigned)((2 * M / IB) * a.nlines * IB) : (unsigned)(2 * M));
+                    const int64_t wbase = a.out_blocked ? (int64_t)0 : (int64_t)l * a.out_ld;
+                    const unsigned welems = lok ? (a.out_blocked ? (unsigned)(((N + IB - 1) / IB) * IB) * (unsigned)a.nlines : (unsigned)N) : 0u;
+                    if (wo) {
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wo + wbase, 0, (int)(welems * 8u), 0x00020000);
+                        if (!(gp.x == 1.f && gp.y == 0.f)) {             // pass 2: the global phase exp(i k z / M)
+#pragma unroll
+                            for (int q = 0; q < RAD; ++q) v[q] = pk_cmul_s(v[q], gp);
+                        }
+#pragma unroll
+                        for (int q = 0; q < RAD; ++q) {
+                            const unsigned off = ((q >= qw ? ewrap : e0) + (unsigned)q * estep) * 8u;
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v[q]), rs, (int)off, 0, 0);
+                        }
+                    }
+                    if (io) {
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(io + wbase, 0, (int)(welems * 4u), 0x00020000);
+                        if (a.accumulate) {
+#pragma unroll
+                            for (int q = 0; q < RAD; ++q) {
+                                const unsigned off = ((q >= qw ? ewrap : e0) + (unsigned)q * estep) * 4u;
+                                const float I = sc * (v[q].x * v[q].x + v[q].y * v[q].y);
+                                const float old = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, old + I), rs, (int)off, 0, 0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < RAD; ++q) {
+                                const unsigned off = ((q >= qw ? ewrap : e0) + (unsigned)q * estep) * 4u;
+                                const float I = sc * (v[q].x * v[q].x + v[q].y * v[q].y);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, I), rs, (int)off, 0, 0);
+                            }
+                        }
+                    }
+                }
+                int pe = ps;
+                asm volatile("" : "+s"(pe));         // opaque: seen as the complement of the test above, the two are merged again
+                if (pe == 0) {
+#pragma unroll
+                    for (int q = 0; q < RAD; ++q)
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v[q]), rp, to * 8, q * QS * 8, 0);
+                }
+            } else if constexpr (S1 % 64 == 0) {
                 // A wave's 64 butterflies belong to ONE line, so its outputs go through a buffer descriptor whose range is
                 // exactly the window they may touch: the hardware drops the stores of the unwanted outputs (i < 0 wraps to
                 // a huge offset, i >= N lies past the window).  No compare, no exec-mask bookkeeping per output -- the
@@ -1110,16 +1253,24 @@ __global__ void k_kern_H(double2 *H, int P, double a, double du) {   // EXP:243-
 
 // The taps h = IDFT_P(H) come out of an unnormalised float64 inverse transform (rocFFT); segment sg of the kernel --
 // taps [off, off + len) -- is laid out zero-padded to M points (and scaled by 1/P) for the forward transform of size M.
+// DIF (part == 2; M here = the 18432 points of a coupled round): both "segments" hold ALL P taps, zero-padded to M points --
+// segment 0 as they are (its transform is the even half H[2k] of the kernel spectrum of twice the size), segment 1 times w^d,
+// w = exp(-2 pi i / 2M) (the odd half H[2k+1]): the decimation-in-frequency split of one double-size transform.
 __global__ void k_kern_pad(const double2 *__restrict__ hP, double2 *__restrict__ buf, int P, int M, int Lh, int S, int part) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M * S) return;
     const int sg = t / M, d = t - sg * M;
-    const int off = part ? sg * Lh : 0, len = part ? min(Lh, P - off) : P;
+    const int off = part == 1 ? sg * Lh : 0, len = part == 1 ? min(Lh, P - off) : P;
     double2 v = make_double2(0.0, 0.0);
     if (d < len) {
         v = hP[off + d];
         v.x /= P;
         v.y /= P;
+        if (part == 2 && sg == 1) {
+            double s, c;
+            sincospi(-(double)d / (double)M, &s, &c);
+            v = make_double2(v.x * c - v.y * s, v.x * s + v.y * c);
+        }
     }
     buf[t] = v;
 }
@@ -1136,7 +1287,7 @@ __global__ void k_kern_perm(const double2 *__restrict__ Hh, float2 *__restrict__
 }
 
 // PAIR: the spectrum of a segment has 2M points; position p of an LDS line meets the bins k(p) and k(p) + M
-__global__ void k_kern_perm_pair(const double2 *__restrict__ Hh, float4 *__restrict__ out, int M, int R3, int S) {
+__global__ void k_kern_perm_pair(const double2 *__restrict__ Hh, float4 *__restrict__ out, int M, int R3, int S, double extra) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M * S) return;
     const int sg = t / M, p = t - sg * M;
@@ -1144,7 +1295,7 @@ __global__ void k_kern_perm_pair(const double2 *__restrict__ Hh, float4 *__restr
     const int q1 = p / S1, q2 = (p % S1) / R3, q3 = p % R3;
     const int k = q1 + RAD * q2 + RAD * RAD * q3;
     const double2 v0 = Hh[(size_t)sg * 2 * M + k], v1 = Hh[(size_t)sg * 2 * M + k + M];
-    const double sc = 1.0 / (2.0 * M);
+    const double sc = extra / (2.0 * M);        // DIF: the 1/2 of the radix-2 recombination rides here
     out[t] = make_float4((float)(v0.x * sc), (float)(v0.y * sc), (float)(v1.x * sc), (float)(v1.y * sc));
 }
 
@@ -1157,6 +1308,15 @@ __global__ void k_pair_twiddles(float2 *w2, int M, int R3) {
     double s, c;
     sincospi(-(double)(q1 + RAD * q2) / (double)M, &s, &c);       // -2 pi k0 / (2M)
     w2[sl] = make_float2((float)c, (float)s);
+}
+
+// DIF: w4[n0] = exp(+2 pi i n0 / 4M), n0 < 2 S1
+__global__ void k_dif_twiddles(float2 *w4, int M) {
+    const int n0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n0 >= 2 * (M / RAD)) return;
+    double s, c;
+    sincospi((double)n0 / (2.0 * (double)M), &s, &c);
+    w4[n0] = make_float2((float)c, (float)s);
 }
 
 __global__ void k_stage_twiddles(float2 *twA, float2 *twB, int M, int R3) {
@@ -1209,6 +1369,17 @@ void part_geometry(int N, int margin, int &B, int &Lh, int &S, int &NB, int mcon
     }
 }
 
+// Does a line of N samples run as the two-round DIF convolution (k_fresnel_lines, DIF)?  It must be too long for one coupled
+// product, fit one convolution of 4 x 9216 points, and the block x segment partition must need more than two rounds.
+bool dif_geometry(int N, int margin) {
+    static const bool no_dif = getenv("PSX_NO_DIF") != nullptr;     // diagnostics: the round-2 partition
+    if (no_dif || getenv("PSX_NO_PAIR") != nullptr || pick_r3(N, margin)) return false;
+    int B, Lh, S, NB;
+    part_geometry(N, margin, B, Lh, S, NB);
+    const int P = N + 2 * margin, Mc = 2 * PART_M;
+    return S * NB > 2 && P <= Mc && N + P - 1 <= 2 * Mc && N + P - 1 >= Mc;
+}
+
 }  // namespace
 
 namespace psx {
@@ -1217,7 +1388,9 @@ struct AxisTables {
     int N = 0, R3 = 0, M = 0;
     int part = 0, B = 0, Lh = 0, S = 1, NB = 1;     // partitioned convolution (lines that do not fit one transform)
     int pair = 0, Mconv = 0;                        // part: the two LDS lines coupled into one transform of Mconv = 2M points
+    int dif = 0;                                    // pair: one 2*Mconv-point convolution per line in two rounds (radix-2 DIF split)
     float2 *w2 = nullptr;                           // pair: slab twiddles
+    float2 *w4 = nullptr;                           // dif: thread factors of w_{2 Mconv}
     float2 *twA = nullptr, *twB = nullptr;
     // float64 transforms of the kernel-spectrum build: taps = IDFT_P(chirp), spectrum = FFT_M(zero-padded taps) x S segments
     rocfft_plan planP = nullptr, planM = nullptr;
@@ -1243,6 +1416,8 @@ struct LdsEngine {
     size_t inter_elems = 0;
     float2 *pre = nullptr;       // [Ny][Nx] transmitted source wave, transposed (pass 0)
     float2 *part = nullptr;      // [max_dist][Nx][Ny] partial sums of pass 2 of the partitioned convolution when only |.|^2 is wanted
+    float2 *wgpart = nullptr;    // [CUs][Mconv]: DIF rounds park the even half's result of a line here (one buffer per workgroup)
+    int wgpart_groups = 0;
     unsigned *queue = nullptr;   // [2][QUEUE_WORDS]: work queues of pass 1 and pass 2 (zero between launches: the kernels re-arm them)
     bool use_queue = false;      // psx_fresnel_plan_work_queue
     float2 *pre_b = nullptr;     // [PSX_MAX_SRC][Ny][Nx], [MAX_LINE][inter_elems]: the same two for a batch of source waves,
@@ -1266,6 +1441,12 @@ bool lds_engine_supported(int Nx, int Ny, int margin) {
     // block of it (B/8 sample-blocks x Ny lines) for a partitioned one; a row of the result in pass 2.
     if (!(margin >= 0 && margin <= Nx - 1 && margin <= Ny - 1 && margin <= 2048 && (int64_t)Nx * Ny < (1ll << 31))) return false;
     int64_t span = (int64_t)cdiv(Nx, IB) * IB;                       // samples of a pass-1 line inside one window
+    if (dif_geometry(Nx, margin)) {
+        // the window is the whole blocked intermediate and its byte offsets are unsigned: the furthest leg of a butterfly
+        // (dropped by the range check) must still be below 2^32
+        const int64_t imax = 2 * (2 * PART_M) - (Nx + 2 * margin - 1) + 2 * (PART_M / RAD);
+        return cdiv(imax, IB) * IB * (int64_t)Ny * (int64_t)sizeof(float2) < (1ll << 32);
+    }
     if (!pick_r3(Nx, margin)) {
         int B, Lh, S, NB;
         part_geometry(Nx, margin, B, Lh, S, NB);      // the coupled-line partition (B is largest there)
@@ -1283,6 +1464,15 @@ static int make_axis(AxisTables &t, int N, int margin, size_t &bytes) {
         t.part = 1;
         t.pair = no_pair ? 0 : 1;
         part_geometry(N, margin, t.B, t.Lh, t.S, t.NB, t.pair ? 2 * PART_M : PART_M);
+        // Lines that fit ONE convolution of 4 x 9216 points take it in two coupled rounds (k_fresnel_lines, DIF) whenever the
+        // block x segment partition needs more; the extension must have a partner for some positions and none beyond 2M
+        if (t.pair && dif_geometry(N, margin)) {
+            t.dif = 1;
+            t.S = 2;
+            t.NB = 1;
+            t.B = (N + 7) / 8 * 8;
+            t.Lh = N + 2 * margin;
+        }
     }
     t.M = 576 * t.R3;
     t.Mconv = t.pair ? 2 * t.M : t.M;
@@ -1299,6 +1489,12 @@ static int make_axis(AxisTables &t, int N, int margin, size_t &bytes) {
         bytes += sizeof(float2) * (t.M / t.R3);
         k_pair_twiddles<<<(int)cdiv(t.M / t.R3, 256), 256>>>(t.w2, t.M, t.R3);
         if (int rc = launch_check("k_pair_twiddles")) return rc;
+    }
+    if (t.dif) {
+        PSX_HIP(hipMalloc((void **)&t.w4, sizeof(float2) * 2 * S1));
+        bytes += sizeof(float2) * 2 * S1;
+        k_dif_twiddles<<<(int)cdiv(2 * S1, 256), 256>>>(t.w4, t.M);
+        if (int rc = launch_check("k_dif_twiddles")) return rc;
     }
     const size_t P = (size_t)(N + 2 * margin), M = (size_t)t.Mconv;
     PSX_ROCFFT(rocfft_plan_create(&t.planP, rocfft_placement_inplace, rocfft_transform_type_complex_inverse,
@@ -1340,7 +1536,12 @@ int lds_engine_create(psx_fresnel_plan *p) {
     p->bytes += sizeof(float2) * npix;
     PSX_HIP(hipMalloc((void **)&e->queue, sizeof(unsigned) * 2 * QUEUE_WORDS));
     PSX_HIP(hipMemset(e->queue, 0, sizeof(unsigned) * 2 * QUEUE_WORDS));
-    if (e->ax[1].part && e->ax[1].S > 1) {      // complex partial sums of pass 2 when only |.|^2 leaves the pass
+    if (e->ax[0].dif || e->ax[1].dif) {
+        e->wgpart_groups = current_cu_count();
+        PSX_HIP(hipMalloc((void **)&e->wgpart, sizeof(float2) * 2 * PART_M * (size_t)e->wgpart_groups));
+        p->bytes += sizeof(float2) * 2 * PART_M * (size_t)e->wgpart_groups;
+    }
+    if (e->ax[1].part && e->ax[1].S > 1 && !e->ax[1].dif) {      // complex partial sums of pass 2 when only |.|^2 leaves the pass
         PSX_HIP(hipMalloc((void **)&e->part, sizeof(float2) * npix * p->max_dist));
         p->bytes += sizeof(float2) * npix * p->max_dist;
     }
@@ -1355,6 +1556,7 @@ void lds_engine_destroy(psx_fresnel_plan *p) {
         (void)hipFree(t.twA);
         (void)hipFree(t.twB);
         (void)hipFree(t.w2);
+        (void)hipFree(t.w4);
         if (t.planP) rocfft_plan_destroy(t.planP);
         if (t.planM) rocfft_plan_destroy(t.planM);
         if (t.infoP) rocfft_execution_info_destroy(t.infoP);
@@ -1368,6 +1570,7 @@ void lds_engine_destroy(psx_fresnel_plan *p) {
     (void)hipFree(e->inter);
     (void)hipFree(e->pre);
     (void)hipFree(e->part);
+    (void)hipFree(e->wgpart);
     (void)hipFree(e->pre_b);
     (void)hipFree(e->inter_b);
     (void)hipFree(e->queue);
@@ -1421,14 +1624,14 @@ static int kernel_spectrum(psx_fresnel_plan *p, AxisTables &t, double a, double 
         void *buf = t.bufP;
         PSX_ROCFFT(rocfft_execute(t.planP, &buf, nullptr, t.infoP));
     }
-    PSX_TIMED("k_kern_pad", st, k_kern_pad<<<(int)cdiv((int64_t)t.Mconv * t.S, 256), 256, 0, st>>>(t.bufP, t.bufM, P, t.Mconv, t.Lh, t.S, t.part));
+    PSX_TIMED("k_kern_pad", st, k_kern_pad<<<(int)cdiv((int64_t)t.Mconv * t.S, 256), 256, 0, st>>>(t.bufP, t.bufM, P, t.Mconv, t.Lh, t.S, t.dif ? 2 : t.part));
     {
         ProfScope ps("kern_fft_M", st);
         void *buf = t.bufM;
         PSX_ROCFFT(rocfft_execute(t.planM, &buf, nullptr, t.infoM));
     }
     if (t.pair)
-        PSX_TIMED("k_kern_perm", st, k_kern_perm_pair<<<(int)cdiv((int64_t)t.M * t.S, 256), 256, 0, st>>>(t.bufM, reinterpret_cast<float4 *>(k.H), t.M, t.R3, t.S));
+        PSX_TIMED("k_kern_perm", st, k_kern_perm_pair<<<(int)cdiv((int64_t)t.M * t.S, 256), 256, 0, st>>>(t.bufM, reinterpret_cast<float4 *>(k.H), t.M, t.R3, t.S, t.dif ? 0.5 : 1.0));
     else
         PSX_TIMED("k_kern_perm", st, k_kern_perm<<<(int)cdiv((int64_t)t.M * t.S, 256), 256, 0, st>>>(t.bufM, k.H, t.M, t.R3, t.S));
     if (int rc = launch_check("kernel spectrum")) {
@@ -1441,7 +1644,7 @@ static int kernel_spectrum(psx_fresnel_plan *p, AxisTables &t, double a, double 
     return 0;
 }
 
-template <int R3, bool CONTIG, bool PART = false, bool PAIR = false, bool DUAL = false, bool QUEUE = false>
+template <int R3, bool CONTIG, bool PART = false, bool PAIR = false, bool DUAL = false, bool QUEUE = false, bool DIF = false>
 static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
     if constexpr (!PART && !QUEUE) {
         if (la.queue) return launch_lines<R3, CONTIG, PART, PAIR, DUAL, true>(la, st, name);
@@ -1450,19 +1653,25 @@ static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
     constexpr size_t lds_bytes = sizeof(float2) * ((size_t)(TOT / M) * (M + M / 32 + (PAIR ? 16 : 0)) + (2 * R3 + RAD) * (RAD + 1)) + 16;   // lines + the three twiddle tables + the unit ring
     static std::atomic<unsigned long long> attr_mask{0};
     if (first_on_device(attr_mask))
-        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG, PART, PAIR, DUAL, QUEUE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG, PART, PAIR, DUAL, QUEUE, DIF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_bytes));
     // persistent workgroups: one per CU (the LDS footprint allows no more), a multiple of the 8 XCDs
     const int n_cu = current_cu_count();
     const int nwork = ((la.nlines + LINES - 1) / LINES) * (PART ? la.n_dist * la.NB : (la.dist_inner ? 1 : la.n_dist));
     int nslot = n_cu / 8;
     if (nslot > (nwork + 7) / 8) nslot = (nwork + 7) / 8;
-    PSX_TIMED(name, st, k_fresnel_lines<R3, CONTIG, PART, PAIR, DUAL, QUEUE><<<8 * nslot, T, lds_bytes, st>>>(la));
+    if constexpr (DIF) {
+        if (!la.wgpart || !la.w4 || 8 * nslot > la.wg_groups)
+            return fail(PSX_E_STATE, "LDS engine: %d workgroups for %d private line buffers", 8 * nslot, la.wg_groups);
+    }
+    PSX_TIMED(name, st, k_fresnel_lines<R3, CONTIG, PART, PAIR, DUAL, QUEUE, DIF><<<8 * nslot, T, lds_bytes, st>>>(la));
     return launch_check(name);
 }
 
 template <bool CONTIG>
-static int launch_lines_r3(int R3, const LineArgs &la, hipStream_t st, const char *name, bool part = false, bool pair = false) {
+static int launch_lines_r3(int R3, const LineArgs &la, hipStream_t st, const char *name, bool part = false, bool pair = false,
+                           bool dif = false) {
+    if (part && pair && dif) return launch_lines<16, CONTIG, true, true, false, false, true>(la, st, name);
     if (part && pair) return launch_lines<16, CONTIG, true, true>(la, st, name);
     if (part) return launch_lines<16, CONTIG, true>(la, st, name);
     switch (R3) {
@@ -1539,6 +1748,8 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
             la.gph[i] = make_float2(1.f, 0.f);
         }
         la.w2 = e->ax[0].w2;
+        la.w4 = e->ax[0].w4; la.wgpart = e->wgpart; la.wg_groups = e->wgpart_groups;
+        la.dsh = 2 * PART_M - p->Px; la.thr = p->Nx + p->Px - 1 - 2 * PART_M;
         static const bool no_dual = getenv("PSX_NO_DUAL") != nullptr;        // diagnostics: A/B of the shared forward transform
         if (!no_dual && la.dist_inner && nnz >= 2 && !e->ax[0].part) {
             // one line x two distances per round: the forward transform of a line is shared by the pair
@@ -1553,7 +1764,7 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
                 default: rc = launch_lines<16, true, false, false, true>(la, st, "k_fresnel_cols"); break;
             }
             if (rc) return rc;
-        } else if (int rc = launch_lines_r3<true>(e->ax[0].R3, la, st, "k_fresnel_cols", e->ax[0].part, e->ax[0].pair)) return rc;
+        } else if (int rc = launch_lines_r3<true>(e->ax[0].R3, la, st, "k_fresnel_cols", e->ax[0].part, e->ax[0].pair, e->ax[0].dif)) return rc;
     }
 
     // ---- pass 2: lines along axis 1 of the image = columns of the intermediate (strided reads: the second transpose);
@@ -1584,7 +1795,9 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
             lb.gph[i] = make_float2((float)std::cos(g), (float)std::sin(g));   // exact reduction of ~1e11 rad (EXP:250)
         }
         lb.w2 = e->ax[1].w2;
-        if (int rc2 = launch_lines_r3<false>(e->ax[1].R3, lb, st, "k_fresnel_rows", e->ax[1].part, e->ax[1].pair)) return rc2;
+        lb.w4 = e->ax[1].w4; lb.wgpart = e->wgpart; lb.wg_groups = e->wgpart_groups;
+        lb.dsh = 2 * PART_M - p->Py; lb.thr = p->Ny + p->Py - 1 - 2 * PART_M;
+        if (int rc2 = launch_lines_r3<false>(e->ax[1].R3, lb, st, "k_fresnel_rows", e->ax[1].part, e->ax[1].pair, e->ax[1].dif)) return rc2;
     }
     return 0;
 }
@@ -1667,12 +1880,14 @@ int lds_engine_propagate_sources(psx_fresnel_plan *p, const SourcesArgs &a) {
     la.twA = e->ax[0].twA; la.twB = e->ax[0].twB;
     la.accumulate = 0; la.stamps = nullptr; la.n_dist = V; la.dist_inner = 0; la.queue = e->use_queue ? e->queue : nullptr;
     la.B = e->ax[0].B; la.Lh = e->ax[0].Lh; la.S = e->ax[0].S; la.NB = e->ax[0].NB; la.w2 = e->ax[0].w2;
+    la.w4 = nullptr; la.wgpart = nullptr; la.wg_groups = 0; la.dsh = 0; la.thr = 0;
     LineArgs lb;
     lb.N = p->Ny; lb.nlines = p->Nx; lb.margin = p->margin; lb.P = p->Py; lb.L = p->Ny + p->Py - 1;
     lb.in_si = 0; lb.in_sl = 0; lb.in_blocked = 1; lb.out_ld = p->Ny; lb.out_blocked = 0;
     lb.twA = e->ax[1].twA; lb.twB = e->ax[1].twB;
     lb.accumulate = 0; lb.stamps = nullptr; lb.n_dist = V; lb.dist_inner = 0; lb.queue = e->use_queue ? e->queue + QUEUE_WORDS : nullptr;
     lb.B = e->ax[1].B; lb.Lh = e->ax[1].Lh; lb.S = e->ax[1].S; lb.NB = e->ax[1].NB; lb.w2 = e->ax[1].w2;
+    lb.w4 = nullptr; lb.wgpart = nullptr; lb.wg_groups = 0; lb.dsh = 0; lb.thr = 0;
     for (int i = 0; i < MAX_LINE; ++i) {
         const int v = i < V ? i : 0;
         la.src[i] = e->pre_b + (size_t)(v / a.n_dist) * npix;
