@@ -39,6 +39,7 @@
 using namespace psx;
 
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -56,6 +57,9 @@ constexpr int RAD = 24;       // radix of the two big stages
 // still writes whole 128-byte lines (2 image rows x 8 samples), and the 16-byte pieces a pass-2 workgroup reads (two
 // adjacent pass-2 lines) sit 64 bytes apart instead of a whole image row: half the cache lines per wave load.
 constexpr int IB = 8;
+#ifndef PSX_DIF_NHA
+#define PSX_DIF_NHA 52        // DIF rounds: window positions (of 72 per loader thread) that travel during the transform
+#endif
 
 __host__ __device__ constexpr int phys(int p) { return p + (p >> 5); }   // one pad slot per 32: conflict-free slabs
 
@@ -94,12 +98,14 @@ struct LineArgs {
     int dsh, thr;           // D = 2M - P: L[n + D] = e[n + 2M] (the extension is P-periodic); thr = N + P - 1 - 2M: positions that have one
     unsigned *queue;        // work queues of the one-transform passes (null: static shares): the counter of workgroup w at [16 w], workgroups done at [16 * 256]
     unsigned long long *stamps;   // optional diagnostics: 32 phase timestamps per workgroup (psx_debug_stamps)
+    int stamp_j;                  // ... of this round of every workgroup (PSX_STAMP_ROUND, default 1: a steady-state round)
 };
 
 // phase timestamp of wave 0 for the SECOND line group of each workgroup, a steady-state round (diagnostic runs only)
 #define PSX_STAMP(k)                                                             \
     do {                                                                         \
-        if (a.stamps && tid == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + (k)] = wall_clock64(); \
+        if (a.stamps && (DIF ? (j == a.stamp_j && ftid() == 0) : (tid == 0 && j == a.stamp_j)))                       \
+            a.stamps[(size_t)blockIdx.x * 32 + (k)] = wall_clock64();                                                \
     } while (0)
 
 // orders the LDS traffic of ONE wave (cross-lane exchange through LDS without a workgroup barrier): no instruction is
@@ -171,6 +177,22 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
     const int N = a.N, mg = a.margin;
+    // A fresh copy of the thread index for values that are re-derived inside the round loop instead of being kept across it
+    // (the engine waves have no register to spare).  DIF: not even the index itself stays in a VGPR -- the wave's base sits in
+    // an SGPR and the lane number comes from v_mbcnt (it was the one value the DIF instance spilled: reloaded once a round
+    // from scratch memory, behind a full memory wait).
+    const int wave_base = DIF ? __builtin_amdgcn_readfirstlane(tid & ~63) : 0;
+    auto ftid = [&]() __attribute__((always_inline)) {
+        int t;
+        if constexpr (DIF) {
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(t));
+            t += wave_base;
+        } else {
+            t = tid;
+            asm volatile("" : "+v"(t));
+        }
+        return t;
+    };
 
     // ---- line groups of this workgroup: XCD x = blockIdx % 8 owns a contiguous chunk of groups (its 32 CUs then read
     // neighbouring columns at the same time: the 128-byte lines of the strided source are shared in that XCD's L2)
@@ -301,10 +323,46 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             const int lt = tid - TC;
             constexpr int STEP = TL / LINES, NH = M / STEP / 2, PSTEP = STEP + STEP / 32;
             static_assert(STEP % 32 == 0 && (M / STEP) % 2 == 0, "affine LDS addressing of the loader halves");
-            const int line = CONTIG ? lt / STEP : lt % LINES, i0 = CONTIG ? lt % STEP : lt / LINES;
+            // (DIF: adjacent lanes take adjacent samples whatever the source layout -- 512 contiguous bytes per wave load in pass 1)
+            const int line = (CONTIG && !DIF) ? lt / STEP : lt % LINES, i0 = (CONTIG && !DIF) ? lt % STEP : lt / LINES;
             float2 *base = lds + line * MP + phys(i0);
             const int P = a.P, Lw = a.B + a.Lh - 1, Etot = N + P - 1;
-            float2 xs[NH];
+            // DIF: every one of the 2M window positions holds a sample (no validity masks), position t is sample
+            // reflect(((t + 1 + mg) mod P) - mg) of the line: five vector instructions and a buffer load whose descriptor is the
+            // line.  The 72 positions of a thread then move as NHA + NHB instead of 36 + 36: the more of them travel during the
+            // transform, the shorter the fetch that is exposed between barriers (3) and (4).
+            constexpr int NHA = DIF ? PSX_DIF_NHA : NH, NHB = 2 * NH - NHA;
+            float2 xs[NHA];
+            auto fetch_dif = [&](int j, auto k0_tag, auto cnt_tag) __attribute__((always_inline)) {
+                constexpr int K0 = decltype(k0_tag)::value, CNT = decltype(cnt_tag)::value;
+                int d, g;
+                item(j, d, g);
+                const int lc = min(g, a.nlines - 1);
+                const float2 *srcl = a.src[d] + (a.in_blocked ? ((int64_t)(lc / IB) * N) * IB + lc % IB : (int64_t)lc * a.in_sl);
+                const int sh = a.in_blocked ? 6 : 3;                           // byte stride of a sample: 64 (blocked) or 8
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float2 *>(srcl), 0, g < a.nlines ? (int)((unsigned)N << sh) : 0, 0x00020000);   // a line past the image reads zeros
+                int jb = 2 * i0 + line + mg + 1;
+                asm volatile("" : "+v"(jb));
+#pragma unroll
+                for (int k = 0; k < CNT; ++k) {
+                    const unsigned j0 = (unsigned)(jb + 2 * STEP * (K0 + k));
+                    const unsigned jp = min(j0, j0 - (unsigned)P);                   // mod P (j0 < 2P)
+                    unsigned i1, i2;       // |a - b| in one instruction (the compiler expands __sad into sub, neg, max)
+                    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(i1) : "v"(jp), "s"(mg));           // np.pad 'reflect' (EXP:237) on the left ...
+                    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(i2) : "v"(i1), "s"(N - 1));
+                    const unsigned i = (unsigned)(N - 1) - i2;                                 // ... and on the right
+                    xs[k] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(i << sh), 0, 0));
+                }
+            };
+            auto spread_dif = [&](auto k0_tag, auto cnt_tag) __attribute__((always_inline)) {
+                constexpr int K0 = decltype(k0_tag)::value, CNT = decltype(cnt_tag)::value;
+#pragma unroll
+                for (int k = 0; k < CNT; ++k) base[(K0 + k) * PSTEP] = xs[k];
+            };
+            using KA0 = std::integral_constant<int, 0>;
+            using KAN = std::integral_constant<int, NHA>;
+            using KBN = std::integral_constant<int, NHB>;
             unsigned vm0 = 0u, vm1 = 0u;                    // which of the NH positions hold a sample (the rest are zeros)
             static_assert(NH <= 64, "validity mask");
             auto fetch_half = [&](int j, int h) __attribute__((always_inline)) {
@@ -346,27 +404,47 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 }
             };
             if (nj > 0) {
-                fetch_half(0, 0);
-                spread_half(0);
-                fetch_half(0, 1);
-                spread_half(1);
+                if constexpr (DIF) {
+                    fetch_dif(0, KA0{}, KAN{});
+                    spread_dif(KA0{}, KAN{});
+                    fetch_dif(0, KAN{}, KBN{});
+                    spread_dif(KAN{}, KBN{});
+                } else {
+                    fetch_half(0, 0);
+                    spread_half(0);
+                    fetch_half(0, 1);
+                    spread_half(1);
+                }
             }
             lds_barrier();                                   // (0)
             for (int j = 0; j < nj; ++j) {
                 const bool more = j + 1 < nj;
                 if constexpr (DIF) lds_barrier();            // (1a) engine: stage A has read its inputs and their partners
                 lds_barrier();                               // (1)
-                if (more) fetch_half(j + 1, 0);
+                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 16] = wall_clock64();
+                if (more) {
+                    if constexpr (DIF) fetch_dif(j + 1, KA0{}, KAN{});
+                    else fetch_half(j + 1, 0);
+                }
+                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 17] = wall_clock64();
                 lds_barrier();                               // (2)
                 lds_barrier();                               // (3)
+                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 18] = wall_clock64();
                 __builtin_amdgcn_s_setprio(3);
                 if (more) {
-                    spread_half(0);
-                    fetch_half(j + 1, 1);
-                    spread_half(1);
+                    if constexpr (DIF) spread_dif(KA0{}, KAN{});
+                    else spread_half(0);
+                    if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 21] = wall_clock64();
+                    if constexpr (DIF) fetch_dif(j + 1, KAN{}, KBN{});
+                    else fetch_half(j + 1, 1);
+                    if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 22] = wall_clock64();
+                    if constexpr (DIF) spread_dif(KAN{}, KBN{});
+                    else spread_half(1);
                 }
                 __builtin_amdgcn_s_setprio(0);
+                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 19] = wall_clock64();
                 lds_barrier();                               // (4)
+                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 20] = wall_clock64();
             }
             return;
         }
@@ -463,7 +541,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             if constexpr (DUAL) lds_barrier();           // (1b) engine: forward stage B done (six waves), before the middle stage
             // Issued after barrier (1), not before: issuing strided loads stalls for ~5 us (the texture path hands out one
             // 128-byte line per lane pair) and forward stage A lasts only 3 us -- the engine would wait for the loaders.
-            if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 16] = wall_clock64();
+            if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 16] = wall_clock64();
             // the unit after next: claimed during the first round of a unit, by loader wave 0.  The atomic on the workgroup's own
             // queue goes out AHEAD of the round's loads and nobody waits for it here (memory returns in order: behind the loads
             // it would come back last and hold up the spread; consumed at once it would hold up the loads by a round trip); its
@@ -474,10 +552,10 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             unsigned mine = 0xffffffffu;
             if (claiming && !own_dry && lt == 0) mine = atomicAdd(qcount(slot), 1u);
             if (more) fetch(j + 1);
-            if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 17] = wall_clock64();
+            if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 17] = wall_clock64();
             lds_barrier();                               // (2) engine: wave-private stages done
             lds_barrier();                               // (3) engine: inverse stage A holds all of LDS in registers
-            if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 18] = wall_clock64();
+            if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 18] = wall_clock64();
             // the spread sits between two barriers the engine waits at: it goes first on its SIMD (a loader wave would
             // otherwise get every fourth issue slot).  The fetch keeps normal priority: hurrying the strided loads only
             // queues the engine's twiddle loads behind them.
@@ -500,9 +578,9 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             } else {
                 ++usub;
             }
-            if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 19] = wall_clock64();
+            if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 19] = wall_clock64();
             lds_barrier();                               // (4) next group is in LDS
-            if (a.stamps && lt == 0 && j == 1) a.stamps[(size_t)blockIdx.x * 32 + 20] = wall_clock64();
+            if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 20] = wall_clock64();
         }
         if (DYN && lt < 64) {
             // the last workgroup to leave re-arms the queues for the next launch (every claim of this launch has been made)
@@ -536,8 +614,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         bB = baseA;
         pB = p0B;
         if (paired) {
-            int to = tid;
-            asm volatile("" : "+v"(to));
+            int to = ftid();
             // a half-wave (32 butterflies = 768 points) takes the wave's range of the first LH lines (lanes 0-31) or of the
             // second LH lines (lanes 32-63); blocks are counted through the concatenated half
             const int gb = (to >> 6) * (32 / R3) + (to & 31) / R3;          // block inside the half: 24 blocks per line
@@ -590,8 +667,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             // partner x[n + 2M] = L[n + D] exists for n < thr.  Round E transforms L[n] + L[n + D], round O (L[n] - L[n + D]) w_4M^n
             // with w_4M^n = conj(w4[n0]) x exp(-2 pi i q / 48), the second factor a compile-time constant.
             v2f v[RAD];
-            int to = tid;
-            asm volatile("" : "+v"(to));
+            int to = ftid();
             const int np = to + a.dsh;
             const v2f *pp = reinterpret_cast<const v2f *>(lds) + (np & 1) * MP + phys(np >> 1);
             const int qb = (a.thr - to + 2 * S1 - 1) / (2 * S1);          // legs q < qb have a partner
@@ -643,8 +719,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         // PAIR: lane u < 48 of wave w couples slab 48 w + u of line 0 with the same slab of line 1; its table is the interleaved
         // pair (H[k], H[k + M]) per point: 4 points = 4 float4 per chunk; the first chunk travels here, the others under the
         // arithmetic of the chunk before (a slab pair already holds 64 registers of data)
-        int tp = tid;
-        if constexpr (PAIR || DUAL) asm volatile("" : "+v"(tp));
+        const int tp = (PAIR || DUAL) ? ftid() : tid;
         const int pslab = 48 * (tp >> 6) + (tp & 63);                         // slab index inside a line (PAIR)
         const bool pact = (tp & 63) < 48;
         const float4 *hp4 = reinterpret_cast<const float4 *>(a.H[d] + (size_t)(PART ? ps : 0) * 2 * M) + (size_t)(pact ? pslab : 0) * SLAB;
@@ -662,8 +737,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         } else {
             int sl = slab0;
             if constexpr (R3 < 16) {                 // re-derived here (as above): the hoisted 64-bit offset was spilled
-                int to = tid;
-                asm volatile("" : "+v"(to));
+                int to = ftid();
                 sl = (to >> 6) * WSLABS + ((to & 63) & 32) + ((to & 31) < 16 ? 2 * (to & 31) : 2 * ((to & 31) - 16) + 1);
             }
             const float4 *h4 = reinterpret_cast<const float4 *>(a.H[d] + (PART ? ps * M : 0) + (unsigned)((sl % (M / SLAB)) * SLAB));
@@ -873,6 +947,16 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             v2f v[RAD];
 #pragma unroll
             for (int q = 0; q < RAD; ++q) v[q] = baseA[idxA(nA, q)];
+            // DIF, round O: the thread factor of the recombination twiddle is requested here, ahead of the loaders' second
+            // fetch (the CU's loads return in order: behind that fetch it would come back microseconds later)
+            v2f wdif = (v2f){1.f, 0.f};
+            if constexpr (DIF) {
+                if (ps != 0) {
+                    int tw = ftid();
+                    const float2 wf = a.w4[tw];
+                    wdif = (v2f){wf.x, wf.y};
+                }
+            }
             lds_barrier();                           // (3)
             PSX_STAMP(11);
             twiddle_A(v, Q1{}, Q12{}, std::true_type{});
@@ -887,8 +971,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             // comes back from scratch memory once a round, behind a full memory wait)
             int nAo = nA, lineAo = lineA;
             if constexpr (R3 < 16 && !PAIR) {
-                int to = tid;
-                asm volatile("" : "+v"(to));
+                int to = ftid();
                 nAo = to % S1;
                 lineAo = to / S1;
             }
@@ -903,12 +986,13 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             static_assert(S1 % IB == 0 && IB == 8, "blocked output stride; the block index below is i >> 3");
             if constexpr (DIF) {
                 // leg q holds point n' = n0 + 768 q of this round's 2M-point result (n0 = tid).  Round E parks it in the
-                // workgroup's own line buffer; round O fetches it back, forms y[m] = ye[n'] + w_4M^-m yo[n'] (the 1/2 sits in the
+                // workgroup's own line buffer (legs 2k and 2k+1 of a thread side by side: the thread that writes is the thread
+                // that reads, so the layout is free -- twelve 16-byte accesses per thread instead of 24 of 8; the window between
+                // barriers (3) and (4) is bound by the CU's memory pipeline); round O fetches it back, forms y[m] = ye[n'] + w_4M^-m yo[n'] (the 1/2 sits in the
                 // kernel-spectrum table) and stores output sample i = m - (P - 1), m = n' + 2M for the legs below qw (sign -:
                 // w_4M^-2M = -1) and m = n' from leg qw on (the index wraps once along the butterfly).  Legs whose sample lies
                 // outside [0, N) fall outside the descriptor's range and are dropped by the hardware, as everywhere.
-                int to = tid;
-                asm volatile("" : "+v"(to));
+                int to = ftid();
                 constexpr int QS = 2 * S1;
                 const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
                     reinterpret_cast<v2f *>(a.wgpart) + (size_t)blockIdx.x * 2 * M, 0, 2 * M * 8, 0x00020000);
@@ -916,27 +1000,33 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 // structurized flow, and the 24 values the round-E stores read would then stay live -- spilled -- through the
                 // whole round-O branch)
                 if (ps != 0) {
-                    const float2 wf = a.w4[to];
-                    const v2f wb = (v2f){wf.x, wf.y}, wbn = -wb;
+                    PSX_STAMP(23);
+                    const v2f wb = wdif, wbn = -wb;
                     const int qw = (a.P - 1 - to + QS - 1) / QS;              // first wrapped leg
                     // twiddles first, in place; then ye, eight loads at a time, fenced (as the partial sums of the partition:
                     // hoisted above the twiddles the 24 loads would not fit the register budget)
+                    // ye is requested behind the butterfly (above it the 24 loads would not fit the register budget) and travels
+                    // under the twiddle pass
+                    __builtin_amdgcn_sched_barrier(0);
+                    v4u o[RAD / 2];
+#pragma unroll
+                    for (int q = 0; q < RAD / 2; ++q) o[q] = __builtin_amdgcn_raw_buffer_load_b128(rp, to * 16, q * TC * 16, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                     pk_static_for<0, RAD>([&](auto qc) __attribute__((always_inline)) {
                         constexpr int q = decltype(qc)::value;
                         const v2f wsel = q >= qw ? wb : wbn;
                         const v2f wq = pk_twiddle<2 * RAD, q, true>(wsel);            // +-exp(+2 pi i (n0 + 768 q) / 4M)
                         v[q] = pk_cmul(v[q], wq);
                     });
+                    __builtin_amdgcn_sched_barrier(0);
+                    PSX_STAMP(14);
 #pragma unroll
-                    for (int q0 = 0; q0 < RAD; q0 += 8) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        v2u o[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) o[q] = __builtin_amdgcn_raw_buffer_load_b64(rp, to * 8, (q0 + q) * QS * 8, 0);
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q0 + q] += __builtin_bit_cast(v2f, o[q]);
+                    for (int q = 0; q < RAD / 2; ++q) {
+                        v[2 * q] += __builtin_bit_cast(v2f, (v2u){o[q].x, o[q].y});
+                        v[2 * q + 1] += __builtin_bit_cast(v2f, (v2u){o[q].z, o[q].w});
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    PSX_STAMP(15);
                     const int l = l0;
                     const bool lok = l < a.nlines;
                     const int ifirst = to + 2 * M - (a.P - 1);               // sample index of leg 0, not wrapped
@@ -981,8 +1071,10 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 asm volatile("" : "+s"(pe));         // opaque: seen as the complement of the test above, the two are merged again
                 if (pe == 0) {
 #pragma unroll
-                    for (int q = 0; q < RAD; ++q)
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v[q]), rp, to * 8, q * QS * 8, 0);
+                    for (int q = 0; q < RAD / 2; ++q) {
+                        const v2u lo = __builtin_bit_cast(v2u, v[2 * q]), hi = __builtin_bit_cast(v2u, v[2 * q + 1]);
+                        __builtin_amdgcn_raw_buffer_store_b128((v4u){lo.x, lo.y, hi.x, hi.y}, rp, to * 16, q * TC * 16, 0);
+                    }
                 }
             } else if constexpr (S1 % 64 == 0) {
                 // A wave's 64 butterflies belong to ONE line, so its outputs go through a buffer descriptor whose range is
@@ -1716,12 +1808,13 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
     // group)): one prologue and one tail instead of n_dist.  The in-place middle stage consumes the forward spectrum, so the
     // forward stages are repeated per distance (keeping it in registers needs 64 VGPRs the engine waves do not have).
     static const bool stamp_pass1 = getenv("PSX_STAMP_PASS1") != nullptr;   // diagnostics only
+    static const int stamp_round = getenv("PSX_STAMP_ROUND") ? atoi(getenv("PSX_STAMP_ROUND")) : 1;
     {
         LineArgs la;
         la.N = p->Nx; la.nlines = p->Ny; la.margin = p->margin; la.P = p->Px; la.L = p->Nx + p->Px - 1;
         la.in_si = 1; la.in_sl = p->Nx; la.in_blocked = 0; la.out_ld = 0; la.out_blocked = 1;
         la.twA = e->ax[0].twA; la.twB = e->ax[0].twB;
-        la.accumulate = 0; la.stamps = stamp_pass1 ? g_stamps : nullptr;
+        la.accumulate = 0; la.stamps = stamp_pass1 ? g_stamps : nullptr; la.stamp_j = stamp_round;
         la.queue = e->use_queue ? e->queue : nullptr;
         la.n_dist = nnz;
         static const bool no_inner = getenv("PSX_NO_DIST_INNER") != nullptr;   // diagnostics: A/B of the work order
@@ -1774,7 +1867,7 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         lb.N = p->Ny; lb.nlines = p->Nx; lb.margin = p->margin; lb.P = p->Py; lb.L = p->Ny + p->Py - 1;
         lb.in_si = 0; lb.in_sl = 0; lb.in_blocked = 1; lb.out_ld = p->Ny; lb.out_blocked = 0;
         lb.twA = e->ax[1].twA; lb.twB = e->ax[1].twB;
-        lb.accumulate = a.accumulate; lb.stamps = stamp_pass1 ? nullptr : g_stamps;
+        lb.accumulate = a.accumulate; lb.stamps = stamp_pass1 ? nullptr : g_stamps; lb.stamp_j = stamp_round;
         lb.queue = e->use_queue ? e->queue + QUEUE_WORDS : nullptr;
         lb.n_dist = nnz;
         lb.dist_inner = 0;
@@ -1878,14 +1971,14 @@ int lds_engine_propagate_sources(psx_fresnel_plan *p, const SourcesArgs &a) {
     la.N = p->Nx; la.nlines = p->Ny; la.margin = p->margin; la.P = p->Px; la.L = p->Nx + p->Px - 1;
     la.in_si = 1; la.in_sl = p->Nx; la.in_blocked = 0; la.out_ld = 0; la.out_blocked = 1;
     la.twA = e->ax[0].twA; la.twB = e->ax[0].twB;
-    la.accumulate = 0; la.stamps = nullptr; la.n_dist = V; la.dist_inner = 0; la.queue = e->use_queue ? e->queue : nullptr;
+    la.accumulate = 0; la.stamps = nullptr; la.stamp_j = 1; la.n_dist = V; la.dist_inner = 0; la.queue = e->use_queue ? e->queue : nullptr;
     la.B = e->ax[0].B; la.Lh = e->ax[0].Lh; la.S = e->ax[0].S; la.NB = e->ax[0].NB; la.w2 = e->ax[0].w2;
     la.w4 = nullptr; la.wgpart = nullptr; la.wg_groups = 0; la.dsh = 0; la.thr = 0;
     LineArgs lb;
     lb.N = p->Ny; lb.nlines = p->Nx; lb.margin = p->margin; lb.P = p->Py; lb.L = p->Ny + p->Py - 1;
     lb.in_si = 0; lb.in_sl = 0; lb.in_blocked = 1; lb.out_ld = p->Ny; lb.out_blocked = 0;
     lb.twA = e->ax[1].twA; lb.twB = e->ax[1].twB;
-    lb.accumulate = 0; lb.stamps = nullptr; lb.n_dist = V; lb.dist_inner = 0; lb.queue = e->use_queue ? e->queue + QUEUE_WORDS : nullptr;
+    lb.accumulate = 0; lb.stamps = nullptr; lb.stamp_j = 1; lb.n_dist = V; lb.dist_inner = 0; lb.queue = e->use_queue ? e->queue + QUEUE_WORDS : nullptr;
     lb.B = e->ax[1].B; lb.Lh = e->ax[1].Lh; lb.S = e->ax[1].S; lb.NB = e->ax[1].NB; lb.w2 = e->ax[1].w2;
     lb.w4 = nullptr; lb.wgpart = nullptr; lb.wg_groups = 0; lb.dsh = 0; lb.thr = 0;
     for (int i = 0; i < MAX_LINE; ++i) {

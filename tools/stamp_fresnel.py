@@ -41,4 +41,10 @@ base = s[:, 4:5]      # engine passed barrier 1
 print("loader wave 12 (relative to the engine leaving barrier 1):")
 for n, c in zip(["fetch start", "fetch issued", "spread start (barrier 3 passed)", "spread done", "barrier 4 passed"], range(5)):
     print("  %-34s %7.2f us" % (n, ((ld[:, c:c+1] - base) * 10.0).mean() / 1e3))
+if np.any(s[:, 21] > 0):       # partitioned / DIF loaders: the window moves in two halves between barriers (3) and (4)
+    print("  first half spread %.2f, second half fetched (issued) %.2f us after barrier 3" %
+          tuple(((s[:, c:c+1] - ld[:, 2:3]) * 10.0).mean() / 1e3 for c in (21, 22)))
+if np.any(s[:, 23] > 0):       # DIF, round O: inside "twiddle, butterfly, stores"
+    print("  round O after barrier 3: butterfly done %.2f, recombination twiddles done %.2f, ye added %.2f, stores issued %.2f us" %
+          tuple(((s[:, c:c+1] - s[:, 11:12]) * 10.0).mean() / 1e3 for c in (23, 14, 15, 12)))
 print("engine: barrier 2 passed %.2f, barrier 3 passed %.2f, stores issued %.2f, barrier 4 passed %.2f us" % tuple(((s[:, c:c+1] - base) * 10.0).mean() / 1e3 for c in (10, 11, 12, 13)))
