@@ -62,8 +62,13 @@ def parse():
     ap.add_argument("--positions", type=int, default=64,
                     help="membrane positions of the config-4 batch measured after the timed steps (0 = skip)")
     ap.add_argument("--positions-size", type=int, default=0, help="study grid of the batch (default: --size, at most 4096)")
+    ap.add_argument("--no-warm-batch", action="store_true", help="positions batch: skip the second, warm-start measurement")
     ap.add_argument("--positions-trace", action="store_true",
                     help="record a HIP event after every position of the batch and report the per-position times of rank 0")
+    ap.add_argument("--spinup-ms", type=float, default=80.0,
+                    help="GPU load before the W warm-up steps so that the clocks have ramped (0 = none; reported as `spinup`)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (BASELINE configs 1, 2 and 5)")
+    ap.add_argument("--configs", default="512,2048,16384", help="study grids of the `configs` object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -73,6 +78,11 @@ def spawn_ranks(a):
     """`--gpus N` outside torchrun: start N ranks as a child torch.distributed.run and leave with its exit code.  Runs before
     torch.cuda / HIP is touched in this process (never exec or fork a process that has initialised the GPU)."""
     import socket
+    if any(k.startswith("ROCPROFILER_") or k.startswith("ROCPROF_") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        # the profiler's preloaded library has initialised the GPU in THIS process already: starting the ranks from it is the
+        # fork/exec of a GPU process the pool forbids.  Profile one rank: python3 bench.py (no --gpus).
+        raise SystemExit("bench.py: --gpus %d under rocprofv3 would start the ranks from a process that has initialised the GPU; "
+                         "profile a single rank instead" % a.gpus)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -97,12 +107,17 @@ def main():
     from paresis_amd import _lib, ops, synth
     from paresis_amd.getk import getk, k_refraction, k_sample
 
+    from paresis_amd import dist as pdist
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-    if world > 1:
-        td.init_process_group(backend=a.backend, rank=rank, world_size=world)
+    # one GPU per rank under nccl (= RCCL): more ranks than GPUs is refused HERE, before any collective (RCCL itself would
+    # only say "Duplicate GPU detected" from the first barrier, or hang); gloo may rehearse several ranks on one GPU
+    torch.cuda.set_device(pdist.local_device(a.backend if world > 1 else "gloo", rank, world))
     dev = torch.device("cuda", torch.cuda.current_device())
+    if world > 1:
+        import datetime
+        kw = {"device_id": dev} if a.backend == "nccl" else {}      # RCCL otherwise guesses the device from the global rank
+        td.init_process_group(backend=a.backend, rank=rank, world_size=world,
+                              timeout=datetime.timedelta(seconds=pdist.timeout_s()), **kw)
     lib = _lib.lib()
     assert lib.psx_device_ok() == 1, lib.psx_last_error()
     _lib.check(lib.psx_refract_set_halo(a.halo), "psx_refract_set_halo")
@@ -158,6 +173,19 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
+    # Clock spin-up, disclosed in the line (`spinup`): a process needs ~40 ms of continuous load before its steps reach their
+    # steady time (tools/step_ramp.py: steps 2-10 of a fresh process take 1.36-1.62 ms, steps 30+ 1.25 ms), and W = 5 warm-up
+    # steps are 6 ms.  The same step is therefore run for >= --spinup-ms of GPU time first (host-timed, coarse), THEN come the
+    # W warm-up steps and the K timed steps of the contract, back to back: no real run of this path is 30 ms long.
+    spin = {"ms": 0.0, "steps": 0}
+    if a.spinup_ms > 0:
+        ts = time.perf_counter()
+        while (time.perf_counter() - ts) * 1e3 < a.spinup_ms or spin["steps"] < 2:
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+            spin["steps"] += 4
+        spin["ms"] = round((time.perf_counter() - ts) * 1e3, 1)
     for _ in range(a.warmup):
         step()
     barrier()
@@ -227,6 +255,8 @@ def main():
                       "streams": 1 if side is None else 2,
                       "parallelism": "positions sharded, 1 per GPU" if world > 1 else "single GPU"},
            "ranks_seen": ranks_seen,
+           "spinup": {"ms": spin["ms"], "steps": spin["steps"],
+                      "note": "the same step run untimed BEFORE the W warm-up steps until the clocks have ramped (--spinup-ms)"},
            "steady": {"ms_per_step": round(dt_steady / a.steps * 1e3, 4),
                       "value": round(units * N * N * world / (dt_steady / a.steps) / 1e6, 1),
                       "note": "the same K un-instrumented steps timed a second time, after the per-kernel event pass: the device "
@@ -241,11 +271,28 @@ def main():
             for sim in ("Fresnel", "RayT"):
                 try:
                     out["positions_batch"][sim] = positions_batch(a, sim, pn, rank, world, dev)
-                except Exception as exc:              # the step's line above is measured already: keep it, report the batch as failed
+                except Exception as exc:
                     import traceback
                     traceback.print_exc()
+                    if world > 1:
+                        # the ranks may be out of step: no further collective can be trusted on this communicator, and a rank
+                        # waiting in one would hang until the timeout.  Leave now, non-zero (torchrun then ends the others).
+                        sys.stderr.write("bench.py: rank %d: positions batch failed (%s: %s) -- leaving\n" % (rank, type(exc).__name__, exc))
+                        sys.stderr.flush()
+                        os._exit(6 if isinstance(exc, pdist.DistError) else 5)
+                    # one rank: the step's line above is measured already: keep it, report the batch as failed
                     out["positions_batch"][sim] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
+    # ---- BASELINE.json configs 1, 2 and 5 on the same line (rank 0 of a one-rank run only: they are single-GPU configurations)
+    if rank == 0 and world == 1 and not a.no_configs and N == 4096:
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):
+            try:
+                out["configs"] = run_configs(a, dev)
+            except Exception as exc:
+                import traceback
+                traceback.print_exc()
+                out["configs"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if rank == 0:
         P = N + 30
         nmat = 2
@@ -274,8 +321,13 @@ def main():
             prof = pmc_profile(N)
             ach = alg[dom] / (per[dom] * 1e-3) / 1e9
             traffic = pmc_value(prof, dom, "hbm_bytes_per_launch")
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            out["roofline"] = {"bound": "valu-issue", "priced_against": "hbm",
+                               "bound_note": "frac = ALGORITHMIC bytes (price list below) / launch time / HBM peak, as the contract asks; "
+                                             "the kernel itself moves about a third of those bytes (hbm_frac_measured) and is limited "
+                                             "by vector-instruction issue (roofline_valu)",
+                               "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "traffic_from": prof.get("_file") if prof else None,
                                "ms_per_launch": round(per[dom], 4), "algorithmic_bytes_per_launch": alg[dom],
                                "pricing": "64 B per padded pixel and propagation (BASELINE.md section 4): 32*P^2 per distance "
                                           "and line kernel; (12+4*nmat)*P^2 per refraction"}
@@ -334,6 +386,9 @@ def main():
             out["cpu_baseline"], out["parity"] = cpu_baseline(N, geo, delta, beta, E, M, pix, I0, fres, refr)
             if not out["parity"]["ok"]:
                 rc = 3
+        for e in (out.get("configs") or {}).values():
+            if isinstance(e, dict) and e.get("parity", {}).get("ok") is False:
+                rc = 3
         pb = out.get("positions_batch", {})
         for sim, e in pb.items():
             if e.get("check", {}).get("ok") is False:
@@ -356,7 +411,13 @@ def positions_batch(a, sim, N, rank, world, dev):
     """BASELINE.json config 4: `--positions` membrane positions strided over the ranks, the full loop of main.py:63-110 per
     position (membrane synthesis with seed(pointNum), chain, detection, shot noise) and the RCCL gather of every position's
     Sample/Reference stacks onto rank 0 -- round by round behind the computation (--gather overlap, default) or once at the
-    end (--gather final) -- all inside the timed region (barrier + synchronize on both sides, MAX over ranks)."""
+    end (--gather final) -- all inside the timed region, MAX over ranks.  Measured twice: `cold` (barrier + synchronize on
+    both sides, host clock: the GPU is idle when the clock starts, so the first positions run at ramping clocks -- at 8 ranks a
+    rank's whole share is ~10 ms) and `warm` (the GPU kept under load up to the start: untimed positions, an on-stream
+    all-reduce instead of a host barrier, HIP events around the region).
+
+    Every decision that changes WHICH collectives follow is taken by all ranks together (dist.agree_on_overlap); an exception
+    once collectives are in flight ends the process (exit 5 / 6) instead of being retried on the same communicator."""
     import torch
     import torch.distributed as td
     from paresis_amd import dist, ops, synth
@@ -382,17 +443,24 @@ def positions_batch(a, sim, N, rank, world, dev):
     dims = exp.myDetector.det_param["myDimensions"]
     stack_shape = (nbins, int(dims[0]), int(dims[1]))
     overlap = world > 1 and a.gather == "overlap"
+    gat = None
+    if overlap:
+        # buffers of every round on every rank first (rank 0 alone holds the ~2 GiB of receive buckets: the likeliest failure
+        # is one-sided), then ONE collective decision
+        gat = dist.PositionGatherer(P, rank, world, to_host=False, shape=stack_shape)
+        inject = os.environ.get("PSX_BENCH_INJECT", "") == "prepare:%d" % rank
+        overlap = dist.agree_on_overlap(gat, inject_failure=inject)
+        if not overlap:
+            gat = None
     if overlap and sim == "Fresnel":
         exp._plan().work_queue(True)      # the transfer's copy kernels share the GPU with the line kernels from here on
-
-    mode = {"overlap": overlap}
 
     def gather_all(positions_fn):
         """Computes this rank's positions and brings every position's stacks to rank 0: round by round behind the computation
         (dist.PositionGatherer) or in one gather at the end.  Returns (gathered, seconds of computation issued + finished)."""
         t1 = time.perf_counter()
-        if mode["overlap"]:
-            gat = dist.PositionGatherer(P, rank, world, to_host=False, shape=stack_shape)
+        if gat is not None:
+            gat.reset()
             for p in mine:
                 gat.add(p, positions_fn(p))
             ev = torch.cuda.Event()
@@ -406,19 +474,12 @@ def positions_batch(a, sim, N, rank, world, dev):
         return dist.gather_positions(results, P, rank, world, to_host=False), tc
 
     if world > 1:
-        # the whole gather path once at its full size, untimed: communicator and peer connections, the packing kernels, and
-        # the caching allocator's blocks for the staging buffers (a first-time hipMalloc of ~2 GiB on rank 0 would land in
-        # the timed region)
+        # the whole gather path once at its full size, untimed: communicator and peer connections, the packing kernels, the
+        # caching allocator's blocks.  Collectives are in flight from here on: no fallback, a failure ends the process.
         warm = position(P + 1 + rank)
-        try:
-            gather_all(lambda p: warm)
-        except Exception:                  # the overlapped form failed where every rank fails alike (an API it lacks): one gather at the end
-            if not mode["overlap"]:
-                raise
-            import traceback
-            traceback.print_exc()
-            mode["overlap"] = False
-            gather_all(lambda p: warm)
+        if os.environ.get("PSX_BENCH_INJECT", "") == "warmup:%d" % rank:
+            raise dist.DistError("injected failure in the gather warm-up (test)")
+        gather_all(lambda p: warm)
         del warm
     # The interpreter's cyclic garbage collector would otherwise run a full collection somewhere in the first positions
     # (hundreds of thousands of objects allocated by the set-up above: ~40-60 ms of host time with the GPU idle -- the
@@ -426,11 +487,7 @@ def positions_batch(a, sim, N, rank, world, dev):
     import gc
     gc.collect()
     gc.freeze()
-    barrier()
-    t0 = time.perf_counter()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(mine) + 1)] if a.positions_trace else None
-    if marks:
-        marks[0].record()
     done = [0]
 
     def timed_position(p):
@@ -440,12 +497,44 @@ def positions_batch(a, sim, N, rank, world, dev):
             marks[done[0]].record()
         return out
 
+    # ---- cold: the contract's bracket (barrier + synchronize, host clock)
+    barrier()
+    t0 = time.perf_counter()
+    if marks:
+        marks[0].record()
     gathered, t_comp = gather_all(timed_position)
     barrier()
     dt = time.perf_counter() - t0
     exp.resolve_mean_energy()
     ops.check_status(dev, "positions batch")
-    times = torch.tensor([dt, t_comp, dt - t_comp], dtype=torch.float64, device=cpu_dev)
+    per_pos_ms = [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(len(mine))] if marks else None
+    marks = None
+    # ---- warm: same work, the GPU loaded up to the first timed kernel.  ~60 ms of untimed positions are queued (the host runs
+    # ahead of the GPU), then an all-reduce ON THE STREAM lines the ranks up without idling the GPUs (td.barrier() would
+    # synchronise the host and the device), then the start event; the end event follows the last unpack kernel and one more
+    # on-stream all-reduce, so that every rank's interval covers the slowest rank's work.
+    warm_ms = None
+    if not a.no_warm_batch:
+        tick = torch.zeros(1, dtype=torch.float32, device=cpu_dev)
+        n_pre = max(4, int(60.0 / max(0.3, dt * 1e3 / max(1, len(mine)))))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        for i in range(n_pre):
+            position(P + 1 + rank)
+        if world > 1:
+            td.all_reduce(tick)
+        e0.record()
+        g2, _ = gather_all(position)
+        if world > 1:
+            td.all_reduce(tick)
+        e1.record()
+        barrier()
+        warm_ms = e0.elapsed_time(e1)
+        del g2
+        exp.resolve_mean_energy()
+        ops.check_status(dev, "positions batch (warm)")
+    gc.unfreeze()
+    times = torch.tensor([dt, t_comp, dt - t_comp, (warm_ms or 0.0) * 1e-3], dtype=torch.float64, device=cpu_dev)
     per_rank = [times]
     if world > 1:
         per_rank = [torch.empty_like(times) for _ in range(world)]
@@ -459,6 +548,7 @@ def positions_batch(a, sim, N, rank, world, dev):
     res = {"positions": P, "n_gpus": world, "ranks_seen": len(per_rank), "study_grid": N, "detector": n_det,
            "ms_total": round(dt_max * 1e3, 3), "ms_per_position": round(dt_max * 1e3 / P, 4),
            "positions_per_s": round(P / dt_max, 1), "Mpixel_per_s": round(P * N * N / dt_max / 1e6, 1),
+           "clock": "cold: barrier + synchronize on both sides, host clock, GPU idle at the start",
            "per_rank_compute_ms": [round(float(t[1]) * 1e3, 3) for t in per_rank],
            "gather_ms": round(max(float(t[2]) for t in per_rank) * 1e3, 3),
            "gathered_bytes": int(sum(v[0].numel() + v[1].numel() for v in gathered.values()) * 4),
@@ -466,8 +556,14 @@ def positions_batch(a, sim, N, rank, world, dev):
            "gather_overlapped": bool(dist.last_gather.get("overlapped")),
            "timed_region": "synthesis + chain + detection + shot noise of every position + the gather onto rank 0 (images stay "
                            "in rank 0's HBM)", "backend": a.backend if world > 1 else None}
-    if marks:
-        res["per_position_ms_rank0"] = [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(len(mine))]
+    if warm_ms is not None:
+        wmax = max(float(t[3]) for t in per_rank)
+        res["warm"] = {"ms_total": round(wmax * 1e3, 3), "ms_per_position": round(wmax * 1e3 / P, 4),
+                       "positions_per_s": round(P / wmax, 1), "Mpixel_per_s": round(P * N * N / wmax / 1e6, 1),
+                       "clock": "the same batch once more with the GPU under load up to the start (untimed positions, on-stream "
+                                "all-reduce, no host synchronisation), HIP events around the region, MAX over ranks"}
+    if per_pos_ms:
+        res["per_position_ms_rank0"] = per_pos_ms
     # rank 0 re-computes positions it did not own (every position when it is alone) and compares with what arrived
     others = [p for p in range(P) if p % world != 0] if world > 1 else list(range(P))
     sample = sorted(set(others[:2] + others[-1:])) if others else []
@@ -486,6 +582,133 @@ def positions_batch(a, sim, N, rank, world, dev):
     if world > 1:
         td.barrier()
     return res
+
+
+def run_configs(a, dev):
+    """The other single-GPU configurations of BASELINE.json on the driver's line (`configs`), same process, after the headline:
+    config 1's grid (512^2 = detector 256 x oversampling 2, 1 distance, with Detector.detection), config 2 (2048^2, 1 distance)
+    and config 5 (16384^2 = detector 4096 x oversampling 4, 4 distances, with Detector.detection -- pad, source blur, bin-sum,
+    PSF 1.2 px, DET:79-119 -- of all 8 images INSIDE the timed step).  Each entry: ms per step, Mpixel/s (units x N^2 / t),
+    step_frac under the price list of `roofline` (+ the detector's bytes) and the fp32 error against the float64
+    restatement -- whole images where that takes seconds, a 64-column strip at 16384^2 (a separable operator acts on axis 0
+    alone when nothing varies along axis 1)."""
+    import types
+
+    import torch
+    from oracle import cpu_baseline as cb
+    from oracle import paresis_oracle as orc
+    from paresis_amd import ops, synth
+    from paresis_amd.Samples.getMembraneFromFile import getMembraneSegmentedFromFile
+    from paresis_amd.getk import getk, k_refraction, k_sample
+
+    E, I0 = 52.0, 7500.0
+    db = [synth.DELTA_BETA_52KEV[m] for m in ("CuSn", "PMMA")]
+    delta, beta = [d for d, _ in db], [b for _, b in db]
+    k, kk = k_sample(E), getk(E * 1000)
+    smp = types.SimpleNamespace(myMeanSphereRadius=15.0, myNbOfLayers=2)
+    out = {}
+    for N in [int(v) for v in a.configs.split(",") if v]:
+        ov = 4 if N >= 8192 else 2
+        zs = (3.6,) if N <= 2048 else DISTANCES
+        detect = N != 2048
+        M = 145.2 / 141.6
+        pix = 6.0 / ov / M
+        h = pix * 1e-6
+        geom, _ = getMembraneSegmentedFromFile(smp, N, N, pix * 140.0 / 141.6, 0, 6000.0, stacked=True)
+        T = geom[2]
+        wave_mats = ops.MaterialStack(T, cphase=[-k * d for d in delta], catt=[-k * b for b in beta])
+        rt_mats = ops.MaterialStack(T, cphase=[-k * d for d in delta], catt=[-2 * k * b for b in beta])
+        plan = ops.FresnelPlan(N, N, max_dist=len(zs))
+        aa = [z / (2 * kk * M) for z in zs]
+        gp = [kk * z / M for z in zs]
+        du = (2 * np.pi / (N * h),) * 2
+        dsc = [z / k_refraction(E) / (h * M) / h for z in zs]
+        fres = [torch.empty((N, N), dtype=torch.float32, device=dev) for _ in zs]
+        refr = [torch.empty((N, N), dtype=torch.float32, device=dev) for _ in zs]
+        n = N // ov
+        sig_src, sig_psf = 10.0 * 3.6 / 141.6 / 6.0 * ov / 2.355, 1.2
+        det = ops.DetectorPlan(N, N, ov, n, n, sig_src, sig_psf) if detect else None
+        dets = [torch.empty((n, n), dtype=torch.float32, device=dev) for _ in range(2 * len(zs))] if detect else []
+        amp = float(np.sqrt(I0))
+
+        def step():
+            plan.propagate(aa, gp, du, amp=amp, mats=wave_mats, want_wave=[False] * len(zs), inten_out=fres)
+            ops.refract_multi((N, N), rt_mats, dsc, (N, N), I0=I0, outs=refr)
+            if det is not None:
+                for i, img in enumerate(fres + refr):
+                    det.detect(img, out=dets[i])
+
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        one = time.perf_counter() - t0
+        K = int(min(200, max(3, 0.15 / one)))
+        for _ in range(int(min(K, max(1, 0.05 / one)))):     # clocks
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / K
+        ops.check_status(dev, "configs %d" % N)
+        P = N + 30
+        nmat = 2
+        step_bytes = len(zs) * (64 + 12 + 4 * nmat) * P * P
+        if detect:
+            step_bytes += 2 * len(zs) * int(4 * (N + 30 * ov) ** 2 * (1 + 1.0 / ov ** 2))
+        e = {"workload": "%dx%d fp32 study grid (detector %d x oversampling %d), %d distance(s)%s" %
+                         (N, N, n, ov, len(zs), ", Detector.detection of all %d images in the step" % (2 * len(zs)) if detect else ""),
+             "steps": K, "ms": round(dt * 1e3, 4), "Mpixel_per_s": round(len(zs) * N * N / dt / 1e6, 1),
+             "step_bytes": step_bytes, "step_frac": round(step_bytes / dt / 1e9 / HBM_PEAK_GBS, 4),
+             "fresnel_engine": {1: "rocfft", 2: "lds"}[plan.engine]}
+        # ---- parity against the float64 restatement (the checker; after the timed region)
+        nt = max(1, min(32, (os.cpu_count() or 1) // 2))
+        par = {}
+        if N <= 2048:
+            g64 = T.cpu().numpy()
+            ref_f = cb.fresnel_intensity(g64, delta, beta, amp, zs[0], E, M, pix, nt)
+            ref_r = cb.refraction_intensity(g64, delta, beta, I0, zs[0], E, M, pix, nt)
+            par["fresnel"] = float(np.max(np.abs(fres[0].cpu().numpy() - ref_f)) / np.max(np.abs(ref_f)))
+            par["refraction"] = float(np.max(np.abs(refr[0].cpu().numpy() - ref_r)) / np.max(np.abs(ref_r)))
+            if detect:
+                ref_d = orc.detection(ref_f, sig_src * 2.355, ov, (n, n), sig_psf)
+                par["detector"] = float(np.max(np.abs(dets[0].cpu().numpy() - ref_d)) / np.max(np.abs(ref_d)))
+            par["what"] = "whole images, distance %.1f m" % zs[0]
+        else:
+            W = 64
+            strip = np.repeat(T[:, :, :1].cpu().numpy(), W, axis=2).copy()
+            Ts = torch.from_numpy(strip).to(dev)
+            ws = ops.MaterialStack(Ts, cphase=[-k * d for d in delta], catt=[-k * b for b in beta])
+            rs = ops.MaterialStack(Ts, cphase=[-k * d for d in delta], catt=[-2 * k * b for b in beta])
+            sp = ops.FresnelPlan(N, W, max_dist=1)
+            so = [torch.empty((N, W), dtype=torch.float32, device=dev)]
+            sp.propagate(aa[-1:], gp[-1:], (du[0], 2 * np.pi / (W * h)), amp=amp, mats=ws, want_wave=[False], inten_out=so)
+            ref_f = cb.fresnel_intensity(strip, delta, beta, amp, zs[-1], E, M, pix, nt)
+            par["fresnel"] = float(np.max(np.abs(so[0].cpu().numpy() - ref_f)) / np.max(np.abs(ref_f)))
+            sr, _, _ = ops.refract((N, W), rs, dsc[-1], (N, W), I0=I0)
+            ref_r = cb.refraction_intensity(strip, delta, beta, I0, zs[-1], E, M, pix, nt)
+            par["refraction"] = float(np.max(np.abs(sr.cpu().numpy() - ref_r)) / np.max(np.abs(ref_r)))
+            sd = ops.DetectorPlan(N, W, ov, n, W // ov, sig_src, sig_psf)
+            dd = sd.detect(so[0])
+            ref_d = orc.detection(ref_f, sig_src * 2.355, ov, (n, W // ov), sig_psf)
+            par["detector"] = float(np.max(np.abs(dd.cpu().numpy() - ref_d)) / np.max(np.abs(ref_d)))
+            par["what"] = "%d-column strip of the same membrane (constant along axis 1), distance %.1f m" % (W, zs[-1])
+            sp.close()
+            sd.close()
+            del Ts, ws, rs, so, sr, dd
+        par["tolerance"] = PARITY_TOL
+        par["ok"] = bool(max(v for kx, v in par.items() if kx in ("fresnel", "refraction", "detector")) <= PARITY_TOL)
+        e["parity"] = par
+        out[str(N)] = e
+        plan.close()
+        if det is not None:
+            det.close()
+        del T, geom, fres, refr, dets, wave_mats, rt_mats
+        torch.cuda.empty_cache()
+    return out
 
 
 def pmc_profile(N):

@@ -4,10 +4,39 @@ One process per GPU (torchrun).  Positions are independent given seed(pointNum),
 r, r+G, r+2G, ... with no data-path collective; the only exchange is the final gather of the detector images onto
 rank 0 with torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for the tests).
 """
+import datetime
 import os
+import time
 
 import torch
 import torch.distributed as td
+
+
+class DistError(RuntimeError):
+    """A condition under which the ranks can no longer be trusted to issue the same collectives: the caller must leave the
+    process with a non-zero code (os._exit) instead of trying another collective on the same communicator."""
+
+
+def timeout_s():
+    """Upper bound for any single wait on the other ranks (PSX_DIST_TIMEOUT_S, default 300 s): the process-group timeout
+    and the bounded wait of PositionGatherer.finish()."""
+    return float(os.environ.get("PSX_DIST_TIMEOUT_S", "300"))
+
+
+def local_device(backend, rank, world, n_devices=None):
+    """The GPU of this rank under `nccl` (= RCCL): LOCAL_RANK, one rank per GPU.  More ranks than GPUs is refused here,
+    before any collective -- RCCL would only report `ncclInvalidUsage: Duplicate GPU detected` from the first barrier (or
+    hang).  Under `gloo` several ranks may share a GPU (rehearsals): LOCAL_RANK modulo the device count."""
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    if n_devices is None:
+        n_devices = torch.cuda.device_count()
+    if backend == "nccl":
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        if local_world > n_devices or local >= n_devices:
+            raise SystemExit("paresis_amd.dist: %d ranks on this node but %d GPU(s) visible: the nccl backend needs one GPU per "
+                             "rank (use --backend gloo to rehearse several ranks on one GPU)" % (local_world, n_devices))
+        return local
+    return local % max(1, n_devices)
 
 
 def init(backend=None):
@@ -18,10 +47,42 @@ def init(backend=None):
     if not td.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
         if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % max(1, torch.cuda.device_count()))
-        td.init_process_group(backend=backend, rank=rank, world_size=world)
+            dev = local_device(backend, rank, world)
+            torch.cuda.set_device(dev)
+            kw["device_id"] = torch.device("cuda", dev)       # RCCL otherwise guesses the device from the global rank
+        elif torch.cuda.is_available():
+            torch.cuda.set_device(local_device(backend, rank, world))
+        td.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s()), **kw)
     return rank, world
+
+
+def any_rank_failed(failed):
+    """Collective decision: True on EVERY rank when `failed` is true on any.  To be called at a point every rank reaches
+    whatever happened to it (e.g. after a try/except around a phase WITHOUT collectives), so that all ranks then take the
+    same branch; a rank deciding on its own would issue different collectives from the others and hang them."""
+    if not (td.is_available() and td.is_initialized()):
+        return bool(failed)
+    flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=_dev())
+    td.all_reduce(flag, op=td.ReduceOp.MAX)
+    return bool(int(flag.item()))
+
+
+def agree_on_overlap(gatherer, inject_failure=False):
+    """The ranks decide TOGETHER whether the round-by-round gather can be used: every rank allocates its buffers
+    (PositionGatherer.prepare: no collective inside), the outcomes meet in one all_reduce(MAX), and either all ranks return
+    True or all return False (one gather at the end instead).  inject_failure: test hook, this rank pretends its allocation
+    failed."""
+    failed = False
+    try:
+        if inject_failure:
+            raise MemoryError("injected allocation failure (test)")
+        gatherer.prepare()
+    except (RuntimeError, MemoryError) as exc:
+        print("rank %d: no buffers for the overlapped gather (%s: %s)" % (gatherer.rank, type(exc).__name__, exc))
+        failed = True
+    return not any_rank_failed(failed)
 
 
 def barrier():
@@ -202,11 +263,37 @@ class PositionGatherer:
         self.shape = tuple(int(v) for v in shape) if shape is not None else None
         self.flag = None
         self.next_round = 0
+        self.pool = None               # (wires, buckets) of every round, allocated by prepare()
+        self.issued = 0                # collectives issued so far: an exception after the first one is not recoverable
+
+    def prepare(self):
+        """Allocates the wire buffer of every round and, on dst, the `world` receive buckets per round (~2 GiB for 64
+        positions of 2048^2 on 8 ranks) WITHOUT issuing a collective.  This is the step most likely to fail on one rank
+        only (dst alone holds the buckets): wrap it in try/except and put the outcome through any_rank_failed() -- every rank
+        can then fall back to the one-gather form together.  Without prepare() the buffers are allocated round by round."""
+        if self.local or self.pool is not None:
+            return
+        if self.shape is None:
+            raise ValueError("PositionGatherer.prepare: needs the stack shape (constructor argument)")
+        dev = _dev()
+        per_img = self.shape[0] * self.shape[1] * self.shape[2]
+        wires = [_CountsWire(2 * per_img, dev) for _ in range(self.rounds)]
+        buckets = [[torch.empty_like(w.bytes) for _ in range(self.world)] if self.rank == self.dst else None for w in wires]
+        self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.pool = (wires, buckets)
+
+    def reset(self):
+        """Ready for another run over the same positions with the buffers of prepare() (the bench: an untimed run first)."""
+        self.results, self.work, self.wires, self.buckets = {}, [], [], []
+        self.next_round = 0
+        self.issued = 0
+        if self.flag is not None:
+            self.flag.zero_()
 
     def _issue(self, t):
         dev = _dev()
         per_img = self.shape[0] * self.shape[1] * self.shape[2]
-        wire = _CountsWire(2 * per_img, dev)
+        wire = self.pool[0][t] if self.pool is not None else _CountsWire(2 * per_img, dev)
         wire.head.zero_()
         p = t * self.world + self.rank
         if p in self.results:
@@ -214,8 +301,15 @@ class PositionGatherer:
             wire.pack(self.results[p][1], per_img, self.flag)
         else:
             wire.counts.zero_()
-        bucket = [torch.empty_like(wire.bytes) for _ in range(self.world)] if self.rank == self.dst else None
-        self.work.append(td.gather(wire.bytes, bucket, dst=self.dst, async_op=True))
+        if self.pool is not None:
+            bucket = self.pool[1][t]
+        else:
+            bucket = [torch.empty_like(wire.bytes) for _ in range(self.world)] if self.rank == self.dst else None
+        self.issued += 1
+        try:
+            self.work.append(td.gather(wire.bytes, bucket, dst=self.dst, async_op=True))
+        except RuntimeError as exc:           # a peer is gone (gloo: connection reset; RCCL: communicator aborted)
+            raise DistError("PositionGatherer: gather of round %d could not be issued on rank %d: %s" % (t, self.rank, exc)) from exc
         self.wires.append(wire)
         self.buckets.append(bucket)
 
@@ -234,8 +328,11 @@ class PositionGatherer:
             self._issue(self.next_round)
             self.next_round += 1
 
-    def finish(self):
-        """Waits for the rounds in flight; returns on dst {position: images} (every position), {} elsewhere."""
+    def finish(self, timeout=None):
+        """Waits for the rounds in flight -- at most `timeout` seconds each (default: timeout_s()), then DistError: a rank
+        that died or left the sequence of collectives must not hang the others until the process-group timeout -- and returns
+        on dst {position: images} (every position), {} elsewhere."""
+        timeout = timeout_s() if timeout is None else float(timeout)
         host = lambda tup: tuple(t.detach().cpu() if isinstance(t, torch.Tensor) and self.to_host else t for t in tup)
         last_gather.clear()
         if self.local:
@@ -247,9 +344,22 @@ class PositionGatherer:
         while self.next_round < self.rounds:                            # rounds this rank has no position in
             self._issue(self.next_round)
             self.next_round += 1
-        for w in self.work:
-            w.wait()
-        td.all_reduce(self.flag, op=td.ReduceOp.MAX)
+        deadline = time.monotonic() + timeout
+        try:
+            for t, w in enumerate(self.work):
+                # polled, not wait(): gloo's wait() blocks the host without bound and nccl's only orders the streams (the
+                # host would then hang in the first .item() below instead)
+                while not w.is_completed():
+                    if time.monotonic() > deadline:
+                        raise DistError("PositionGatherer.finish: the gather of round %d did not complete within %.0f s on rank "
+                                        "%d (a rank failed or left the sequence of collectives)" % (t, timeout, self.rank))
+                    time.sleep(0.00005)
+                w.wait()
+            td.all_reduce(self.flag, op=td.ReduceOp.MAX)
+        except RuntimeError as exc:           # includes DistError; a peer that died surfaces here as a transport error
+            if isinstance(exc, DistError):
+                raise
+            raise DistError("PositionGatherer.finish: rank %d lost a peer: %s" % (self.rank, exc)) from exc
         if int(self.flag.item()):                                       # something was not photon counts: float32, all together
             return gather_positions(self.results, self.P, self.rank, self.world, dst=self.dst, to_host=self.to_host, pack=False,
                                     force_collectives=self.force)

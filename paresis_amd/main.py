@@ -44,22 +44,49 @@ def run(exp_dict, save=True, saving_format=".tif", backend=None):
     # the detector stacks go to rank 0 round by round while the next positions are computed (dist.PositionGatherer); the
     # Fresnel plan then hands out its line groups through a queue, so that the transfer's copy kernels cost it a few per cent
     dims = experiment.myDetector.det_param["myDimensions"]
-    gatherer = dist.PositionGatherer(exp_dict['nbExpPoints'], rank, world, to_host=True,
-                                     shape=(experiment._close_bins(), int(dims[0]), int(dims[1])))
-    if world > 1 and sim == "Fresnel":
+    # Without shot noise the images are not photon counts: the packed 16-bit rounds would all be flagged and the gather
+    # repeated in float32 at the end -- one float32 gather at the end from the start, then.  The overlapped form also needs
+    # its buffers on every rank: rank 0 alone holds the receive buckets, so whether they could be allocated is decided
+    # TOGETHER (a rank that fell back on its own would issue different collectives from the others and hang them).
+    overlapped = world > 1 and bool(exp_dict.get('noise', True))
+    gatherer = None
+    if overlapped:
+        gatherer = dist.PositionGatherer(exp_dict['nbExpPoints'], rank, world, to_host=True,
+                                         shape=(experiment._close_bins(), int(dims[0]), int(dims[1])))
+        if not dist.agree_on_overlap(gatherer):
+            overlapped, gatherer = False, None
+    if overlapped and sim == "Fresnel":
         experiment._plan().work_queue(True)
+    results = {}
     for pointNum in dist.my_positions(exp_dict['nbExpPoints'], rank, world):
         experiment.myMembrane.myGeometry = []
         experiment.myMembrane.getMyGeometry(experiment.exp_dict['studyDimensions'], experiment.myMembrane.membranePixelSize,
                                             experiment.exp_dict['overSampling'], pointNum, exp_dict['nbExpPoints'])   # main.py:64-65
         print("\nCalculations point", pointNum)
         out = experiment.computeSampleAndReferenceImages(pointNum)
-        gatherer.add(pointNum, out)
+        if gatherer is not None:
+            gatherer.add(pointNum, out)
+        else:
+            results[pointNum] = out
         if save and exp_dict.get('saveMembrane', True):
             # main.py:98: every rank writes the membrane maps of its own positions (one node, one file system: no gather)
             save_image(experiment.myMembrane.myGeometry[0], root + 'membraneThickness/' + exp_dict['experimentName'] +
                        '_sampling' + str(exp_dict['overSampling']) + '_' + str(pointNum) + saving_format)
-    gathered = gatherer.finish()
+    try:
+        if gatherer is not None:
+            gathered = gatherer.finish()
+        else:
+            gathered = dist.gather_positions(results, exp_dict['nbExpPoints'], rank, world, to_host=True,
+                                             pack=bool(exp_dict.get('noise', True)))
+    except dist.DistError as exc:             # the ranks are out of step: no further collective can be trusted
+        import sys
+        import traceback
+        traceback.print_exc()
+        sys.stderr.write("paresis_amd.main: %s -- leaving\n" % exc)
+        sys.stderr.flush()
+        os._exit(6)
+    finally:
+        gc.unfreeze()                         # run() is also an API: leave the collector as it was found
     experiment.resolve_mean_energy()
     if rank == 0 and save:
         os.makedirs(root, exist_ok=True)

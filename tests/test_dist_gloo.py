@@ -176,3 +176,89 @@ def test_main_run_world2_matches_world1(tmp_path):
     for p in range(3):
         for a, b in zip(runs[1][p], runs[2][p]):
             assert np.array_equal(a, b), p
+
+
+# ---- round 3: the first contact with 8 GPUs must not hang -----------------------------
+def test_more_ranks_than_gpus_is_refused_before_any_collective(monkeypatch):
+    """`nccl` needs one GPU per rank: world 2 on a 1-GPU lease used to reach td.barrier() and die there with
+    `ncclInvalidUsage: Duplicate GPU detected`; now the rank-to-device mapping refuses up front.  gloo may share a GPU."""
+    from paresis_amd import dist
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        dist.local_device("nccl", 1, 2, n_devices=1)
+    assert "one GPU per rank" in str(e.value)
+    assert dist.local_device("gloo", 1, 2, n_devices=1) == 0
+    assert dist.local_device("nccl", 1, 2, n_devices=8) == 1
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert dist.local_device("nccl", 3, 8, n_devices=8) == 3
+
+
+def _fallback_worker(rank, world, port, q, mode):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), PSX_DIST_TIMEOUT_S="20")
+    import time
+    from paresis_amd import dist
+    r, w = dist.init(backend="gloo")
+    P = 4
+    img = lambda p: (torch.full((1, 3, 4), float(p + 1)), torch.full((1, 3, 4), float(10 * p + 1)))
+    gat = dist.PositionGatherer(P, r, w, to_host=True, shape=(1, 3, 4))
+    if mode == "prepare":
+        # rank 1 cannot allocate its buffers: BOTH ranks must fall back to the one-gather form, in the same collective order
+        overlapped = dist.agree_on_overlap(gat, inject_failure=(r == 1))
+        assert overlapped is False
+        out = dist.gather_positions({p: img(p) for p in dist.my_positions(P, r, w)}, P, r, w)
+        if r == 0:
+            q.put(sorted(out) == list(range(P)) and all(torch.equal(out[p][0], img(p)[0]) for p in range(P)))
+        else:
+            q.put(out == {})
+        dist.finish()
+        torch.distributed.destroy_process_group()
+        return
+    # modes "warmup" / "silent": both agreed on the overlapped form; rank 1 then dies (or goes quiet) BEFORE issuing its
+    # gathers.  Rank 0 must notice -- a transport error, or the bounded wait -- and leave non-zero, not hang until a
+    # process-group timeout.
+    assert dist.agree_on_overlap(gat) is True
+    if r == 1:
+        if mode == "silent":          # alive, but never issues its gathers: only rank 0's bounded wait can end this
+            time.sleep(8.0)
+        os._exit(5)
+    t0 = time.monotonic()
+    try:
+        for p in dist.my_positions(P, r, w):
+            gat.add(p, img(p))
+        gat.finish(timeout=3.0)
+    except dist.DistError:
+        q.put(time.monotonic() - t0)
+        q.close()
+        q.join_thread()               # os._exit does not flush the queue's feeder thread
+        os._exit(6)
+    q.put(-1.0)
+
+
+@pytest.mark.parametrize("mode", ["prepare", "warmup", "silent"])
+def test_gather_fallback_is_a_collective_decision_and_a_dead_rank_does_not_hang(mode):
+    import time
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    t0 = time.monotonic()
+    for p in procs:
+        p.start()
+    if mode == "prepare":
+        res = [q.get(timeout=120) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert all(r is True for r in res)
+        return
+    waited = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+    assert [p.exitcode for p in procs] == [6, 5]          # both ranks left non-zero ...
+    assert waited < 10.0                                   # ... rank 0 within seconds, not after a process-group timeout
+    if mode == "silent":
+        assert waited > 2.5                                # (here it was the bounded wait of finish(timeout=3) that ended it)
+    assert time.monotonic() - t0 < 60
