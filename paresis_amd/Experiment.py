@@ -207,8 +207,10 @@ class Experiment:
         if type(darkField) == int or type(darkField) == float:
             return fastRefraction(intensityRefracted, phi, propagationDistance, Energy, magnification,
                                   self.exp_dict["studyPixelSize"])
+        known = self.mySampleofInterest.dark_field_max(darkField) if hasattr(self.mySampleofInterest, "dark_field_max") else None
         return fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magnification,
-                                self.exp_dict["studyPixelSize"], darkField)
+                                self.exp_dict["studyPixelSize"], darkField, darkFieldMax=known,
+                                check=not self.exp_dict.get('deferStatus'))
 
     def computeSampleAndReferenceImages(self, pointNum):
         """Dispatcher on exp_dict['simulation_type'] (main.py:68-73)."""
@@ -578,10 +580,12 @@ class Experiment:
         plate, air = self.myPlate, (None if ed['inVacuum'] else self.myAirVolume)
         Ibs, tmp = self._tmp[1], self._tmp[0]
         scattering = self.mySampleofInterest.has_dark_field()
-        if scattering and pointNum == 0:
-            self.darkFieldPropag = torch.zeros(N, dtype=torch.float32, device=dev)
-        elif not isinstance(self.darkFieldPropag, torch.Tensor) or tuple(self.darkFieldPropag.shape) != N:
+        # EXP:444 re-zeros the dark-field map on EVERY call (it only builds up while position 0 is computed, EXP:491): a
+        # scattering sample therefore returns zeros for pointNum > 0, whatever positions this object computed before
+        if not isinstance(self.darkFieldPropag, torch.Tensor) or tuple(self.darkFieldPropag.shape) != N:
             self.darkFieldPropag = torch.zeros(N, dtype=torch.float32, device=dev)        # scalar dark field: stays zero
+        elif scattering:
+            ops.fill(self.darkFieldPropag, 0.0)
         dMO, dOD = ed['distMembraneToObject'], ed['distObjectToDetector']
         clamp = (N[0], N[1])                                                              # RF2:61-64
         if not scattering and self._batch_energies(N, None):

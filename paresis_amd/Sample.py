@@ -192,6 +192,9 @@ class AnalyticalSample(Sample):
     def dark_field(self, energy):
         """newDf of setWaveRT (Sample.py:322-344): 2 delta sqrt(N_s) sqrt(ln(2/delta)+1) of the LAST scattering
         material (the reference overwrites, it does not accumulate); int 0 when nothing scatters."""
+        cached = getattr(self, "_df_cache", {}).get((energy, id(self.myGeometry)))
+        if cached is not None:
+            return cached[0]
         d = self._coeff(self.delta, energy)
         newDf = 0
         for imat in range(len(self.myMaterials)):
@@ -202,7 +205,20 @@ class AnalyticalSample(Sample):
             NsphereVol = fraction * 3 / 4 / np.pi / (radius ** 3)
             geom = self.geometry_dev()[imat].to(torch.float64) * 1e6
             newDf = (2 * d[imat] * np.sqrt(np.log(2 / d[imat]) + 1)) * torch.sqrt(NsphereVol ** (1 / 3) * geom)
+        if isinstance(newDf, torch.Tensor):
+            # the map depends on the (static) thickness maps and the energy only: kept, with its maximum -- fastRefractionDF
+            # sizes the displacement maps it returns by it (RF2:117) and would otherwise read it back on every call
+            if not hasattr(self, "_df_cache"):
+                self._df_cache = {}
+            self._df_cache[(energy, id(self.myGeometry))] = (newDf, float(newDf.max().item()))
         return newDf
+
+    def dark_field_max(self, darkField):
+        """The exact maximum (rad) of a map dark_field() returned, or None for any other array."""
+        for t, mx in getattr(self, "_df_cache", {}).values():
+            if t is darkField:
+                return mx
+        return None
 
     # ------------------------------------------------------------------------------------- reference API
     def setWave(self, incidentWave, energy):

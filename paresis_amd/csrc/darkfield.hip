@@ -5,6 +5,8 @@
 // interpreted double loop.  The scatter becomes a gather: each output pixel sums the patches of the sources within
 // R = max patch half-size that reach it.  The per-source normalisation is separable, (sum_d exp(-d^2/2sigma^2))^2, and is
 // precomputed once per source together with the patch half-size.
+#include <algorithm>
+
 #include "common.hpp"
 
 using namespace psx;
@@ -70,8 +72,8 @@ __global__ __launch_bounds__(256) void k_df_gather(const float *__restrict__ I2D
 // The same gather from LDS: a workgroup owns a 32x32 tile of outputs and stages the sources of tile + halo R (weight
 // I2DF * inv, exponent coefficient -1/(2 sigma^2), patch half-size) once; the neighbourhood loop then runs on LDS, and only
 // as far as the widest patch actually present in the staged window (most tiles of an image lie outside the scattering
-// sample: half-size 0, one term).  Same terms in the same order as k_df_gather (the exponent is formed as d^2 * (-1/2 sigma^2)
-// instead of -d^2 / (2 sigma^2): one rounding apart).
+// sample: half-size 0, one term).  Same terms in the same order as k_df_gather (the exponent is formed as d^2 * (-log2(e)/2 sigma^2)
+// and goes through v_exp_f32, 1 ulp, instead of expf(-d^2 / (2 sigma^2)): 0.50 -> 0.39 ms at 4096^2).
 constexpr int DT = 32;
 __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict__ I2DF, const float *__restrict__ DF,
                                                          const float2 *__restrict__ prep, const float *__restrict__ I2,
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict
                 w = I2DF[q] * pr.y;
                 if (h > 0) {
                     const float sigma = 0.5f * DF[q];
-                    c = -1.f / (2.f * sigma * sigma);
+                    c = -1.4426950408889634f / (2.f * sigma * sigma);        // x log2(e): the gather uses the hardware's 2^x
                 }
             }
         }
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict
                 const int h = sh[row + dj];
                 if (h < 0 || abs(di) > h || abs(dj) > h) continue;
                 const float2 wc = swc[row + dj];
-                acc += h == 0 ? wc.x : wc.x * expf((float)(di * di + dj * dj) * wc.y);
+                acc += h == 0 ? wc.x : wc.x * __builtin_amdgcn_exp2f((float)(di * di + dj * dj) * wc.y);
             }
         }
         const int64_t p = (int64_t)i * Ny + j;
@@ -130,9 +132,126 @@ __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict
     }
 }
 
+// ---- the front of fastRefractionDF as ONE pass (RF2:114-150): width map in radians -> pixels (float64), its maximum (the
+// margin of the returned displacement maps is ceil(6 max), RF2:117), the DF > Nx/4 -> 0 rule (RF2:135), the split of the
+// intensity by DF != 0 (RF2:147-150), and -- the width map being all the patch normalisation depends on -- the per-source
+// patch half-size and 1/normalisation that k_df_prepare would compute after the refraction.
+// words[0] / words[1]: bit patterns of the largest width before / after the rule (non-negative doubles order like integers).
+__global__ __launch_bounds__(256) void k_df_split(const float *__restrict__ I, const double *__restrict__ DFrad, double scale,
+                                                  double limit, float *__restrict__ I_nodf, float *__restrict__ I_df,
+                                                  float *__restrict__ DFpx, float2 *__restrict__ prep,
+                                                  unsigned long long *__restrict__ words, int64_t n) {
+    double m0 = 0.0, m1 = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        double d = DFrad[p] * scale;
+        m0 = fmax(m0, d);
+        if (d > limit) d = 0.0;
+        m1 = fmax(m1, d);
+        const float df = (float)d, v = I[p];
+        DFpx[p] = df;
+        I_nodf[p] = df != 0.f ? 0.f : v;
+        I_df[p] = df != 0.f ? v : 0.f;
+        float half = 0.f, inv = 1.f;                  // DF == 0: plain deposit (RF2:183-184)
+        if (df != 0.f) {                              // RF2:171-178
+            const float sigma = 0.5f * df;
+            const int h = patch_half(sigma);
+            // sum_{|k| <= h} exp(-k^2 a) with ONE exponential: the terms obey t_k = t_{k-1} q_k, q_k = q_{k-1} e^{-2a}, q_1 = e^{-a}
+            // (float64 throughout: 1e-15 per step; the direct sum of 2h+1 float64 exponentials was 0.6 ms of this pass at 4096^2)
+            const double e1 = exp(-1.0 / 2.0 / ((double)sigma * sigma)), r = e1 * e1;
+            double t = 1.0, q = e1, sum = 1.0;
+            for (int k = 1; k <= h; ++k) {
+                t *= q;
+                q *= r;
+                sum += 2.0 * t;
+            }
+            half = (float)h;
+            inv = (float)(1.0 / (sum * sum));
+        }
+        prep[p] = make_float2(half, inv);
+    }
+    // one atomic pair per WORKGROUP of a grid of at most 1024 (atomics on one word retire at ~90 per microsecond: one pair
+    // per wave of a 16384-block grid was 0.6 ms of a pass that streams in 0.1)
+    __shared__ double sm[2][4];
+    for (int o = 32; o > 0; o >>= 1) {
+        m0 = fmax(m0, __shfl_xor(m0, o));
+        m1 = fmax(m1, __shfl_xor(m1, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sm[0][threadIdx.x >> 6] = m0;
+        sm[1][threadIdx.x >> 6] = m1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m0 = fmax(fmax(sm[0][0], sm[0][1]), fmax(sm[0][2], sm[0][3]));
+        m1 = fmax(fmax(sm[1][0], sm[1][1]), fmax(sm[1][2], sm[1][3]));
+        if (m0 > 0.0) atomicMax(&words[0], (unsigned long long)__double_as_longlong(m0));
+        if (m1 > 0.0) atomicMax(&words[1], (unsigned long long)__double_as_longlong(m1));
+    }
+}
+
+// I = a + b (the two halves of the split have disjoint supports; the refractions zeroed the clamped rays in them, RF2:128-129)
+__global__ __launch_bounds__(256) void k_df_merge(float *__restrict__ I, const float *__restrict__ a, const float *__restrict__ b,
+                                                  int64_t n) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) I[p] = a[p] + b[p];
+}
+
+// dst[Nx + 2 md][Ny + 2 md] = centre [Nx][Ny] of src[Nx + 2 ms][Ny + 2 ms], zero frame
+__global__ __launch_bounds__(256) void k_repad(const float *__restrict__ src, int ms, float *__restrict__ dst, int md, int Nx,
+                                               int Ny) {
+    const int Wd = Ny + 2 * md, Ws = Ny + 2 * ms;
+    const int64_t n = (int64_t)(Nx + 2 * md) * Wd;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(p / Wd) - md, j = (int)(p % Wd) - md;
+        dst[p] = (i >= 0 && i < Nx && j >= 0 && j < Ny) ? src[(int64_t)(i + ms) * Ws + j + ms] : 0.f;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int psx_darkfield_split_f32(const float *I, const double *DF_rad, double scale, double limit, float *I_nodf, float *I_df,
+                            float *DF_px, void *prep, unsigned long long *words, int Nx, int Ny, void *stream) {
+    PSX_REQUIRE(I && DF_rad && I_nodf && I_df && DF_px && prep && words && Nx > 0 && Ny > 0, "psx_darkfield_split_f32: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)Nx * Ny;
+    PSX_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned long long), st));
+    const int grid = (int)std::min<int64_t>(1024, cdiv(n, 256));
+    PSX_TIMED("k_df_split", st, k_df_split<<<grid, 256, 0, st>>>(I, DF_rad, scale, limit, I_nodf, I_df, DF_px,
+                                                                            (float2 *)prep, words, n));
+    return launch_check("k_df_split");
+}
+
+int psx_darkfield_merge_f32(float *I, const float *a, const float *b, int64_t n, void *stream) {
+    PSX_REQUIRE(I && a && b && n > 0, "psx_darkfield_merge_f32: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    PSX_TIMED("k_df_merge", st, k_df_merge<<<ew_grid(n, 256), 256, 0, st>>>(I, a, b, n));
+    return launch_check("k_df_merge");
+}
+
+int psx_repad_f32(const float *src, int margin_src, float *dst, int margin_dst, int Nx, int Ny, void *stream) {
+    PSX_REQUIRE(src && dst && Nx > 0 && Ny > 0 && margin_src >= 0 && margin_dst >= 0, "psx_repad_f32: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)(Nx + 2 * margin_dst) * (Ny + 2 * margin_dst);
+    PSX_TIMED("k_repad", st, k_repad<<<ew_grid(n, 256), 256, 0, st>>>(src, margin_src, dst, margin_dst, Nx, Ny));
+    return launch_check("k_repad");
+}
+
+int psx_darkfield_blur_prepared_f32(const float *I2DF, const float *DF, const void *prep, const float *I2, float *out, int Nx,
+                                    int Ny, int R, void *stream) {
+    PSX_REQUIRE(I2DF && DF && out && prep && Nx > 0 && Ny > 0 && R >= 0, "psx_darkfield_blur_prepared_f32: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)Nx * Ny;
+    const size_t lds = (size_t)(DT + 2 * R) * (DT + 2 * R) * (sizeof(float2) + sizeof(int));
+    if (lds <= 60 * 1024) {
+        const int tiles_x = (int)cdiv(Nx, DT), tiles_y = (int)cdiv(Ny, DT);
+        PSX_TIMED("k_df_gather", st, k_df_gather_tiled<<<tiles_x * tiles_y, 256, lds, st>>>(I2DF, DF, (const float2 *)prep, I2, out,
+                                                                                            Nx, Ny, R, tiles_y));
+        return launch_check("k_df_gather");
+    }
+    PSX_TIMED("k_df_gather", st, k_df_gather<<<ew_grid(n, 256), 256, 0, st>>>(I2DF, DF, (const float2 *)prep, I2, out, Nx, Ny, R));
+    return launch_check("k_df_gather");
+}
 
 size_t psx_darkfield_workspace_bytes(int Nx, int Ny) { return sizeof(float2) * (size_t)(Nx > 0 ? Nx : 0) * (size_t)(Ny > 0 ? Ny : 0); }
 

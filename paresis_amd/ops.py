@@ -396,6 +396,55 @@ def darkfield_blur(I2DF, DF, I2, R):
     return out
 
 
+def darkfield_split(I, DF_rad, scale, limit):
+    """The front of fastRefractionDF in one pass (psx_darkfield_split_f32).  Returns (I_nodf, I_df, DF_px float32, prep,
+    words): words = two device uint64 holding the float64 bit patterns of max(DF_px) before / after the DF > limit -> 0 rule
+    -- read them with darkfield_maxima() only when the caller does not know the maximum (one host synchronisation)."""
+    _need(I, torch.float32, "I")
+    _need(DF_rad, torch.float64, "darkField", I.shape)
+    Nx, Ny = I.shape
+    dev = I.device
+    I_nodf, I_df, DF_px = (torch.empty((Nx, Ny), dtype=torch.float32, device=dev) for _ in range(3))
+    prep = torch.empty(lib().psx_darkfield_workspace_bytes(Nx, Ny), dtype=torch.uint8, device=dev)
+    words = torch.empty(2, dtype=torch.int64, device=dev)
+    check(lib().psx_darkfield_split_f32(_ptr(I), _ptr(DF_rad), c_double(scale), c_double(limit), _ptr(I_nodf), _ptr(I_df),
+                                        _ptr(DF_px), _ptr(prep), _ptr(words), Nx, Ny, _stream()), "psx_darkfield_split_f32")
+    return I_nodf, I_df, DF_px, prep, words
+
+
+def darkfield_maxima(words):
+    """(max DF_px, max DF_px after the DF > limit rule) from the device words of darkfield_split: ONE device-to-host copy."""
+    import numpy as np
+    w = words.cpu().numpy().view(np.float64)
+    return float(w[0]), float(w[1])
+
+
+def darkfield_blur_prepared(I2DF, DF, prep, I2, R):
+    """darkfield_blur() on the patch table darkfield_split() made from the width map."""
+    _need(I2DF, torch.float32, "I2DF")
+    _need(DF, torch.float32, "DF", I2DF.shape)
+    out = torch.empty_like(I2DF)
+    Nx, Ny = I2DF.shape
+    check(lib().psx_darkfield_blur_prepared_f32(_ptr(I2DF), _ptr(DF), _ptr(prep), _ptr(I2), _ptr(out), Nx, Ny, int(R), _stream()),
+          "psx_darkfield_blur_prepared_f32")
+    return out
+
+
+def darkfield_merge(I, a, b):
+    """I[:] = a + b through the library (no PyTorch kernel in the dark-field path)."""
+    check(lib().psx_darkfield_merge_f32(_ptr(I), _ptr(a), _ptr(b), I.numel(), _stream()), "psx_darkfield_merge_f32")
+    return I
+
+
+def repad(src, margin_src, margin_dst, shape):
+    """The centre `shape` of a map padded by margin_src, re-padded with zeros to margin_dst (psx_repad_f32)."""
+    Nx, Ny = int(shape[0]), int(shape[1])
+    _need(src, torch.float32, "src", (Nx + 2 * margin_src, Ny + 2 * margin_src))
+    dst = torch.empty((Nx + 2 * margin_dst, Ny + 2 * margin_dst), dtype=torch.float32, device=src.device)
+    check(lib().psx_repad_f32(_ptr(src), int(margin_src), _ptr(dst), int(margin_dst), Nx, Ny, _stream()), "psx_repad_f32")
+    return dst
+
+
 def set_deterministic(on=True):
     """Deterministic-order debug mode of the scatter paths that use float atomics (far rays, fastloop): order-independent
     fixed-point deposits, bitwise reproducible results, slower.  Per host thread; off by default."""

@@ -47,53 +47,55 @@ def fastRefraction(intensityRefracted, phi, propagationDistance, Energy, magnifi
                             MARGIN, None)
 
 
-def fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magnification, studyPixelSize, darkField):
+def fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magnification, studyPixelSize, darkField,
+                     darkFieldMax=None, check=True):
     """RF2:88-196: refraction with a dark-field (small-angle scattering) width map `darkField` in radians.
 
     The intensity is split where the dark field is / is not zero (RF2:147-150), both parts are refracted with the same
     kernels as fastRefraction, and the dark-field part is spread by a per-pixel Gaussian of sigma = DF/2 pixels
-    (csrc/darkfield.hip).  Returns (intensity [Nx,Ny], Dx, Dy) with Dx, Dy padded by ceil(6*max DF) like the reference;
-    the maximum is read back from the GPU (the returned shapes depend on it).  The matplotlib pop-ups of RF2:152-167 are
-    not reproduced."""
+    (csrc/darkfield.hip).  Returns (intensity [Nx,Ny], Dx, Dy) with Dx, Dy padded by ceil(6*max DF) like the reference.
+    The shapes of Dx, Dy depend on the largest width: `darkFieldMax` (extension: the exact maximum of `darkField`, in
+    radians -- Experiment knows it per sample and energy) makes the call fully asynchronous; without it the maximum is read
+    back from the GPU (one synchronisation).  Every array operation is a kernel of the library: the conversion to pixels,
+    the DF > Nx/4 rule, the split and the patch table in one pass (psx_darkfield_split_f32), two refractions, the re-splat.
+    The matplotlib pop-ups of RF2:152-167 are not reproduced."""
     I = to_dev(intensityRefracted, torch.float32)
     mutate_host = intensityRefracted if isinstance(intensityRefracted, np.ndarray) else None
     Nx, Ny = I.shape
     k = k_refraction(Energy)
     h = studyPixelSize * 1e-6
     dscale = propagationDistance / k / (h * magnification) / h
-    DF = to_dev(darkField, torch.float64) * (propagationDistance / (h * magnification))     # RF2:114 rad -> pixels
-    maxDF = float(DF.max().item())
-    margin2 = int(np.ceil(maxDF * 6))                                                      # RF2:117
-    DF = torch.where(DF > Nx / 4, torch.zeros_like(DF), DF).to(torch.float32).contiguous()  # RF2:135
-    has_df = DF != 0
-    I_nodf = torch.where(has_df, torch.zeros_like(I), I).contiguous()                      # RF2:147-150
-    I_df = torch.where(has_df, I, torch.zeros_like(I)).contiguous()
-    phi64 = to_dev(phi, torch.float64)
-    if margin2 >= 1:
-        # the tile kernels need a margin >= their gather halo; a wider margin only changes deposits that the crop removes
-        m = max(margin2, 8)
-        I2, Dxp, Dyp = ops.refract((Nx, Ny), None, dscale, (Nx, Ny), margin=m, I_in=I_nodf, phi_in=phi64, want_D=True,
-                                   I_mut=I_nodf)
-        I2DF, _, _ = ops.refract((Nx, Ny), None, dscale, (Nx, Ny), margin=m, I_in=I_df, phi_in=phi64, I_mut=I_df)
-        Dx = torch.nn.functional.pad(Dxp[m:m + Nx, m:m + Ny], (margin2,) * 4)
-        Dy = torch.nn.functional.pad(Dyp[m:m + Nx, m:m + Ny], (margin2,) * 4)
+    scale = propagationDistance / (h * magnification)                                      # RF2:114 rad -> pixels
+    limit = Nx / 4                                                                         # RF2:135
+    I_nodf, I_df, DF, prep, words = ops.darkfield_split(I, to_dev(darkField, torch.float64), scale, limit)
+    if darkFieldMax is not None and float(darkFieldMax) * scale <= limit:
+        maxDF = maxDFc = float(darkFieldMax) * scale        # the rule removes nothing: both maxima are the known one
     else:
+        maxDF, maxDFc = ops.darkfield_maxima(words)
+    margin2 = int(np.ceil(maxDF * 6))                                                      # RF2:117
+    phi64 = to_dev(phi, torch.float64)
+    # the tile kernels need a margin >= their gather halo; a wider margin only changes deposits that the crop removes
+    m = max(margin2, 8)
+    I2, Dxp, Dyp = ops.refract((Nx, Ny), None, dscale, (Nx, Ny), margin=m, I_in=I_nodf, phi_in=phi64, want_D=True,
+                               I_mut=I_nodf)
+    I2DF, _, _ = ops.refract((Nx, Ny), None, dscale, (Nx, Ny), margin=m, I_in=I_df, phi_in=phi64, I_mut=I_df)
+    if margin2 == m:
+        Dx, Dy = Dxp, Dyp
+    else:
+        Dx, Dy = ops.repad(Dxp, m, margin2, (Nx, Ny)), ops.repad(Dyp, m, margin2, (Nx, Ny))
+    if margin2 < 1:
         # margin 0 (dark field identically zero): the scatter's border rules act on the image edge itself, so the literal
         # loop is used on the un-padded arrays (RF2:235-262)
-        _, Dxp, Dyp = ops.refract((Nx, Ny), None, dscale, (Nx, Ny), margin=8, I_in=I_nodf, phi_in=phi64, want_D=True,
-                                  I_mut=I_nodf)
-        ops.refract((Nx, Ny), None, dscale, (Nx, Ny), margin=8, I_in=I_df, phi_in=phi64, I_mut=I_df)
-        Dx = Dxp[8:8 + Nx, 8:8 + Ny].contiguous()
-        Dy = Dyp[8:8 + Nx, 8:8 + Ny].contiguous()
-        I2 = ops.fastloop(I_nodf, Dx, Dy, torch.zeros_like(I))
-        I2DF = ops.fastloop(I_df, Dx, Dy, torch.zeros_like(I))
-    I.copy_(I_nodf + I_df)                               # clamped rays zeroed in the caller's array (RF2:128-129)
+        I2 = ops.fastloop(I_nodf, Dx, Dy, ops.fill(torch.empty_like(I), 0.0))
+        I2DF = ops.fastloop(I_df, Dx, Dy, ops.fill(torch.empty_like(I), 0.0))
+    ops.darkfield_merge(I, I_nodf, I_df)                 # clamped rays zeroed in the caller's array (RF2:128-129)
     if mutate_host is not None:
         mutate_host[...] = I.cpu().numpy()
-    R = int(round(1.5 * float(DF.max().item()))) + 1
-    out = ops.darkfield_blur(I2DF, DF, I2, R)
+    R = int(round(1.5 * maxDFc)) + 1
+    out = ops.darkfield_blur_prepared(I2DF, DF, prep, I2, R)
     ops.status_scan(out)
-    ops.check_status(out.device, "fastRefractionDF")     # RF2:190-193
+    if check:                                            # (a chain that defers the check reads the status word once, at its end)
+        ops.check_status(out.device, "fastRefractionDF")     # RF2:190-193
     return out, Dx, Dy
 
 

@@ -3,7 +3,7 @@
 import os, sys, time, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from paresis_amd import _lib, synth
+from paresis_amd import _lib, ops, synth
 from paresis_amd import refractionFileNumba2 as RF2
 lib = _lib.lib()
 N = 4096
@@ -13,7 +13,11 @@ k = 2 * np.pi * 52e3 * 1.6e-19 / (6.626e-34 * 2.998e8)
 phi = torch.from_numpy(-k * 6.2e-7 * geo["membrane"][0].astype(np.float64)).cuda()
 I = torch.full((N, N), 7500.0, dtype=torch.float32, device="cuda")
 df = torch.from_numpy(np.where(geo["sample"][0] > 0, 2.0e-6, 0.0)).cuda()
-f = lambda: RF2.fastRefractionDF(I.clone(), phi, 3.6, 52.0, M, pix, df)
+dfmax = float(df.max().item())
+Iw = I.clone()
+def f():
+    Iw.copy_(I)                       # (the call zeroes clamped rays in its input; a device copy, outside the library)
+    return RF2.fastRefractionDF(Iw, phi, 3.6, 52.0, M, pix, df, darkFieldMax=dfmax, check=False)
 f(); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(3): f()
