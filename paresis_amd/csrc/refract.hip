@@ -38,7 +38,14 @@ struct Geo {
     // accumulator: the tile plus a one-pixel guard ring (a ray whose base pixel lies in [-1, TH-1] x [-1, TW-1] deposits
     // its four shares at base + {0, 1, AW, AW+1} with no per-share test; the ring is never written out), then a trash
     // area for rays that miss altogether
-    static constexpr int AW = TW + 2, ACC = (TH + 2) * AW, TRASH = 2 * 64 + AW + 2;
+    // Row pitch AW = 64 entries (not TW + 2): 128 dwords, a multiple of the 64 banks.  Two lanes of a ds_add_u64 then share a
+    // bank only when they hit the SAME column in different rows -- neighbouring lanes whose displacements differ in both
+    // floor(dx) and floor(dy) -- where the pitch TW + 2 = 58 (116 dwords = 52 mod 64) made every pair of lanes 6 or 26 apart
+    // collide as soon as their floor(dx) differed (SQ_LDS_BANK_CONFLICT 35 % of the LDS-active cycles, profiles/r02).
+    // A ray that misses the tile adds its shares to the bottom guard row (never read) at its lane's column; the shares at
+    // +AW land in one more row behind it: TRASH = that row.
+    static constexpr int AW = 64, ACC = (TH + 2) * AW, TRASH = AW + 2;
+    static_assert(AW >= TW + 2, "accumulator pitch");
     static constexpr size_t LDS = sizeof(double) * SR * SC + sizeof(float) * GR * GC + sizeof(long long) * (ACC + TRASH) + 16;
 };
 using GeoSmall = Geo<56, 56, 4, 1024>;   // 80 KiB of LDS: two workgroups per CU; 1.31 source evaluations per pixel
@@ -141,7 +148,9 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     const bool window_inside = r0 - H - 1 >= 0 && r0 + TH + H + 1 <= a.Nx && c0 - H - 1 >= 0 && c0 + TW + H + 1 <= a.Ny;
     // staged pixels per thread whose loads are issued together: ALL of them (9 x nmat loads in flight, registers are
     // plentiful at 4 waves per SIMD) -- one memory latency per tile instead of one per batch of four
-    constexpr int U = SITERS;
+    // (more than four maps: in two batches -- 5 x 8 thickness values + intensities + phases do not fit the 64 VGPRs of a
+    // kernel that keeps two 16-wave workgroups on a CU, and the nmat = 8 instances spilled 7-21 registers)
+    constexpr int U = NM > 4 ? (SITERS + 1) / 2 : SITERS;
     auto stage = [&](auto inside_tag) __attribute__((always_inline)) {
         constexpr bool IN = decltype(inside_tag)::value;
         for (int it0 = 0; it0 < SITERS; it0 += U) {
@@ -186,7 +195,7 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     };
     // Interior tiles, sources first: the GR x GC block of pixels that deposit is (GR*GC / NTHREADS) whole passes with
     // shift/mask indexing and no membership test; the one-pixel stencil ring around it only needs the phase.
-    constexpr bool SPLIT = (GC & (GC - 1)) == 0 && (GR * GC) % NTHREADS == 0 && 2 * (SR + SC) <= NTHREADS;
+    constexpr bool SPLIT = NM <= 4 && (GC & (GC - 1)) == 0 && (GR * GC) % NTHREADS == 0 && 2 * (SR + SC) <= NTHREADS;
     auto stage_interior = [&]() __attribute__((always_inline)) {
         constexpr int NP = GR * GC / NTHREADS;
         float t[NP + 1][NM > 0 ? NM : 1], Iin[NP + 1];
@@ -345,7 +354,7 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
             // a miss adds its shares to the trash area; 24-bit multiply + select, not a divergent branch
             int aidx = (int)__umul24((unsigned)ti, (unsigned)AW) + tj;
             asm volatile("" : "+v"(aidx));               // computed for every lane, then selected
-            long long *acc = sacc + (hit ? aidx : ACC + 2 * lane);
+            long long *acc = sacc + (hit ? aidx : (TH + 1) * AW + lane);
             // float -> fixed point with one native conversion: the unit is 2^-30 of (the power of two above) the
             // largest staged intensity, so |v|*2^s <= 2^30 fits int32; the 64-bit sum has 2^33 of headroom
             auto dep = [&](int off, float v) __attribute__((always_inline)) {

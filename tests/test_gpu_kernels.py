@@ -186,6 +186,37 @@ def test_refraction_from_thickness_maps(ops):
         assert relmax(acc.cpu().numpy(), 3.0 + 0.5 * ref) < TOL
 
 
+@pytest.mark.parametrize("nmat", [5, 8])
+def test_refraction_more_than_four_maps(ops, nmat):
+    """The nmat = 8 instantiations (5..8 maps; staged in two batches, free of scratch memory since round 3): the membrane map
+    split into `nmat` slices with their own coefficients against the oracle on the equivalent (I, phi), on a grid with
+    interior AND border tiles, one distance and a distance batch."""
+    g = load("refraction.npz")
+    z, E, M, pix = g["0/params"]
+    T0 = g["0/T"]
+    reps = (int(np.ceil(200 / T0.shape[0])), int(np.ceil(200 / T0.shape[1])))
+    T = np.tile(T0, reps)[:200, :200].astype(np.float32)
+    Nx, Ny = T.shape
+    kk = orc.k_sample(E)
+    rng = np.random.default_rng(nmat)
+    frac = rng.uniform(0.5, 1.5, nmat)
+    geom = np.stack([(T * f).astype(np.float32) for f in frac])
+    delta = list(rng.uniform(1e-7, 6e-7, nmat))
+    beta = list(rng.uniform(1e-10, 4e-9, nmat))
+    I_ref, phi_ref, _ = orc.set_wave_rt(np.full((Nx, Ny), 7500.0), geom.astype(np.float64), delta, beta, E, 0)
+    m = ops.MaterialStack(dev(geom, torch.float32), cphase=[-kk * d for d in delta], catt=[-2 * kk * b for b in beta])
+    h = pix * 1e-6
+    zs = (z, 0.5 * z)
+    dsc = [zz / orc.k_refraction(E) / (h * M) / h for zz in zs]
+    outs = ops.refract_multi((Nx, Ny), m, dsc, (Nx, Ny), I0=7500.0)
+    for zz, ds, o in zip(zs, dsc, outs):
+        ref, _, _ = orc.fast_refraction(I_ref.copy(), phi_ref, zz, E, M, pix)
+        single, _, _ = ops.refract((Nx, Ny), m, ds, (Nx, Ny), I0=7500.0)
+        assert relmax(single.cpu().numpy(), ref) < TOL, (nmat, zz)
+        assert relmax(o.cpu().numpy(), ref) < TOL, (nmat, zz)
+    ops.check_status(outs[0].device)
+
+
 def test_refraction_known_answers(ops):
     rng = np.random.default_rng(3)
     Nx, Ny = 70, 131

@@ -388,3 +388,18 @@ def test_energy_bins_of_the_batched_chains_follow_the_reference_loop():
         ref, ref_left = reference_bins(spectrum, thresholds, sampling)
         assert [[ie for ie, _, _ in b] for b in bins] == ref and [ie for ie, _, _ in leftover] == ref_left
         assert ref_left == [] and sum(len(b) for b in ref) == n        # the appended last energy closes the last bin
+
+
+def test_no_shipped_kernel_spills_registers():
+    """Code-object notes of libparesis_hip.so (no GPU needed): every kernel of the library is free of scratch memory -- the
+    line kernels sit at the 128-VGPR cap of 4 waves per SIMD, the refraction kernels at the 64 of two 16-wave workgroups per
+    CU, and a spilled register comes back behind a full memory wait in kernels that are bound by instruction issue."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    ks = kernel_resources.kernels()
+    assert len(ks) > 100                                    # the library's instantiations were found
+    bad = [(k["symbol"], k["vgpr_spill_count"], k["private_segment_fixed_size"]) for k in ks
+           if k["vgpr_spill_count"] or k["private_segment_fixed_size"]]
+    assert not bad, bad
+    assert any("k_fresnel_lines" in k["symbol"] for k in ks) and any("k_refract_near" in k["symbol"] for k in ks)
