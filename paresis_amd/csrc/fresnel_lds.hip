@@ -57,6 +57,7 @@ constexpr int RAD = 24;       // radix of the two big stages
 // still writes whole 128-byte lines (2 image rows x 8 samples), and the 16-byte pieces a pass-2 workgroup reads (two
 // adjacent pass-2 lines) sit 64 bytes apart instead of a whole image row: half the cache lines per wave load.
 constexpr int IB = 8;
+constexpr int QUEUE_WORDS = 16 * 257;     // work queues: a counter per workgroup (<= 256, 64 bytes apart) + the count of workgroups done
 #ifndef PSX_DIF_NHA
 #define PSX_DIF_NHA 52        // DIF rounds: window positions (of 72 per loader thread) that travel during the transform
 #endif
@@ -1500,8 +1501,6 @@ struct KernEntry {
 // cache key of a kernel spectrum: it depends on these scalars only
 typedef std::tuple<double, double, int, int> KernKey;   // (a, du, N, M)
 
-constexpr int QUEUE_WORDS = 16 * 257;     // a counter per workgroup (<= 256, 64 bytes apart) + the count of workgroups done
-
 struct LdsEngine {
     AxisTables ax[2];            // [0]: lines along axis 0 (length Nx), [1]: along axis 1 (length Ny)
     float2 *inter = nullptr;     // [max_dist][Nx/IB][Ny][IB] intermediates (pass-1 line y, sample x)
@@ -1752,12 +1751,24 @@ static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
     const int nwork = ((la.nlines + LINES - 1) / LINES) * (PART ? la.n_dist * la.NB : (la.dist_inner ? 1 : la.n_dist));
     int nslot = n_cu / 8;
     if (nslot > (nwork + 7) / 8) nslot = (nwork + 7) / 8;
+    if constexpr (QUEUE) {
+        // the queue buffer holds a counter per workgroup of at most 256 (QUEUE_WORDS) and a thief looks at the queues of its
+        // XCD with one lane each, 32 at most: a device with more than 256 CUs runs the queued passes on 256 workgroups
+        static_assert(QUEUE_WORDS == 16 * 257, "queue layout: 256 counters 64 bytes apart + the count of workgroups done");
+        if (nslot > 32) nslot = 32;
+    }
     if constexpr (DIF) {
         if (!la.wgpart || !la.w4 || 8 * nslot > la.wg_groups)
             return fail(PSX_E_STATE, "LDS engine: %d workgroups for %d private line buffers", 8 * nslot, la.wg_groups);
     }
     PSX_TIMED(name, st, k_fresnel_lines<R3, CONTIG, PART, PAIR, DUAL, QUEUE, DIF><<<8 * nslot, T, lds_bytes, st>>>(la));
-    return launch_check(name);
+    const int rc = launch_check(name);
+    if constexpr (QUEUE) {
+        // a launch that did not start leaves nobody to re-arm the counters: zero them here, or every later launch would
+        // silently skip the units they already count
+        if (rc) (void)hipMemsetAsync(la.queue, 0, sizeof(unsigned) * QUEUE_WORDS, st);
+    }
+    return rc;
 }
 
 template <bool CONTIG>

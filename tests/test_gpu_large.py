@@ -232,8 +232,9 @@ def test_16384_partitioned_engine_and_detector():
 # Round 2: the places where a regression could hide at the BASELINE sizes ("weak" item 1)
 def test_bench_fresnel_call_4096_four_distances():
     """bench.py's exact Fresnel call -- 4096^2, ONE call to 4 distances, transmission fused, |.|^2 outputs (the only user of
-    pass 1's distance-inner rounds with 4 distances) -- every one of the 4 images against the rocFFT engine (<= 3e-6) and
-    against the CPU restatement on a 64-wide strip (EXP:219-252)."""
+    pass 1's distance-inner rounds with 4 distances) -- every one of the 4 images against the rocFFT engine (<= 3e-6), the
+    image of the longest distance WHOLE against the float64 CPU restatement, and all four against it on a 64-wide strip
+    (EXP:219-252)."""
     from oracle import cpu_baseline as cb
     from paresis_amd import ops, synth
     from paresis_amd.getk import getk
@@ -258,9 +259,15 @@ def test_bench_fresnel_call_4096_four_distances():
     for d in range(4):
         err = float((res[0][d] - res[1][d]).abs().max() / res[1][d].abs().max())
         assert err < 3e-6, (d, err)
+    # one WHOLE image (the longest distance) against the float64 restatement, not only the strip below
+    import os
+    d_b = [synth.DELTA_BETA_52KEV[m] for m in ("CuSn", "PMMA")]
+    nt = max(1, min(32, (os.cpu_count() or 1) // 2))
+    full = cb.fresnel_intensity(g["membrane"], [x[0] for x in d_b], [x[1] for x in d_b], amp, zs[3], E, g["M"], g["pix_um"], nt)
+    assert relmax(res[0][3].cpu().numpy(), full) < 1e-5
+    del full
     # strip: a wave that does not vary along axis 1 -- the separable operator then acts on axis 0 alone; 64 columns of the
     # membrane's first column, all 4 distances in one call on the LDS engine, against the float64 restatement
-    d_b = [synth.DELTA_BETA_52KEV[m] for m in ("CuSn", "PMMA")]
     strip = np.repeat(g["membrane"][:, :, :1], 64, axis=2).copy()
     Ts = torch.from_numpy(strip).cuda()
     ws, _ = _stacks(ops, Ts)

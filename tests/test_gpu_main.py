@@ -15,12 +15,24 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("sim,name,ov", [("RayT", "Fil_Nylon_ID17", 2), ("Fresnel", "Fil_Nylon_ID17", 2),
-                                         ("Fresnel", "Sphere_PMMA_plate", 1), ("RayT", "Sphere_PMMA_plate", 2)])
+                                         ("Fresnel", "Sphere_PMMA_plate", 1), ("RayT", "Sphere_PMMA_plate", 2),
+                                         ("RayT", "Config1_512", 2), ("Fresnel", "Config1_512", 2)])
 def test_xml_experiment_matches_oracle(sim, name, ov):
+    """The XML-built chains against the oracle.  The oracle is fed the configuration the package derived from the XML
+    (cfg_from_experiment), so an XML plumbing error that changes both sides alike would be invisible here: the derived
+    scalars are therefore held, first, to the reference's own arithmetic (tests/golden/xml_scalars.npz, where the
+    experiment is listed; Config1_512 = BASELINE.json config 1 at its stated 512^2 = detector 256 x oversampling 2)."""
     from paresis_amd.Experiment import Experiment
+    from tests._golden import load
     ed = {"experimentName": name, "filepath": "/tmp/", "overSampling": ov, "nbExpPoints": 2, "simulation_type": sim,
           "noise": False}
     exp = Experiment(ed)
+    g = load("xml_scalars.npz")
+    if name in [str(n) for n in g["names"]] and int(g[name + "/overSampling"]) == ov:
+        assert ed["magnification"] == float(g[name + "/magnification"])
+        assert [int(v) for v in ed["studyDimensions"]] == [int(v) for v in g[name + "/studyDimensions"]]
+        assert ed["studyPixelSize"] == float(g[name + "/studyPixelSize"])
+        assert exp.myMembrane.membranePixelSize == float(g[name + "/membranePixelSize"])
     for point in (0, 1):
         exp.myMembrane.myGeometry = []
         exp.myMembrane.getMyGeometry(ed["studyDimensions"], exp.myMembrane.membranePixelSize, ov, point, 2)   # main.py:64-65

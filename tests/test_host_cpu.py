@@ -114,6 +114,25 @@ def test_xml_experiment_loads_like_the_reference(monkeypatch):
         Experiment({"experimentName": "nope", "overSampling": 2, "nbExpPoints": 1, "simulation_type": "RayT"})
 
 
+def test_xml_derived_scalars_match_the_reference_arithmetic():
+    """Every shipped experiment: magnification, study grid, study and membrane pixel sizes as the XML loader derives them,
+    against tests/golden/xml_scalars.npz -- the reference's own getStudyDimensions (EXP:204-216) run on the same numbers,
+    EXP:81 / EXP:96 by the same expressions (tests/golden/make_golden_xml.py).  Bit-equal: it is the same float64
+    arithmetic in the same order.  Guards what the XML-vs-oracle GPU test cannot see (both of its sides take these scalars
+    from the package)."""
+    from paresis_amd.Experiment import Experiment
+    g = load("xml_scalars.npz")
+    for name in [str(n) for n in g["names"]]:
+        ov = int(g[name + "/overSampling"])
+        ed = {"experimentName": name, "filepath": "/tmp/", "overSampling": ov, "nbExpPoints": 1, "simulation_type": "RayT"}
+        exp = Experiment(ed)
+        assert ed["magnification"] == float(g[name + "/magnification"]), name
+        assert [int(v) for v in ed["studyDimensions"]] == [int(v) for v in g[name + "/studyDimensions"]], name
+        assert ed["studyPixelSize"] == float(g[name + "/studyPixelSize"]), name
+        assert exp.myMembrane.membranePixelSize == float(g[name + "/membranePixelSize"]), name
+    assert [int(v) for v in g["Config1_512/studyDimensions"]] == [512, 512]      # BASELINE.json config 1's grid
+
+
 def test_xml_plate_and_psf_experiment():
     from paresis_amd.Experiment import Experiment
     ed = {"experimentName": "Sphere_PMMA_plate", "filepath": "/tmp/", "overSampling": 1, "nbExpPoints": 1,

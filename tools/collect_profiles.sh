@@ -10,6 +10,11 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 SFX=${1:-}
 shift || true
+for arg in "$@"; do
+    case "$arg" in
+        --gpus|--gpus=*) echo "collect_profiles.sh: profile ONE rank (bench.py --gpus N would start its ranks from a process the profiler's library has already initialised the GPU in)" >&2; exit 2;;
+    esac
+done
 CMD="python3 $ROOT/bench.py --no-cpu-baseline --positions 0 $*"      # the bench run (timed steps + the per-kernel event pass), minus the CPU leg and the positions batch
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/fin_stats$SFX $OUT/fin_fetch$SFX $OUT/fin_write$SFX $OUT/fin_sq$SFX
