@@ -42,8 +42,8 @@ struct Geo {
     // bank only when they hit the SAME column in different rows -- neighbouring lanes whose displacements differ in both
     // floor(dx) and floor(dy) -- where the pitch TW + 2 = 58 (116 dwords = 52 mod 64) made every pair of lanes 6 or 26 apart
     // collide as soon as their floor(dx) differed (SQ_LDS_BANK_CONFLICT 35 % of the LDS-active cycles, profiles/r02).
-    // A ray that misses the tile adds its shares to the bottom guard row (never read) at its lane's column; the shares at
-    // +AW land in one more row behind it: TRASH = that row.
+    // A ray that misses the tile adds its shares to the bottom guard row (never read), at the column of its would-be target
+    // modulo the pitch; the shares at +AW land in one more row behind it: TRASH = that row.
     static constexpr int AW = 64, ACC = (TH + 2) * AW, TRASH = AW + 2;
     static_assert(AW >= TW + 2, "accumulator pitch");
     static constexpr size_t LDS = sizeof(double) * SR * SC + sizeof(float) * GR * GC + sizeof(long long) * (ACC + TRASH) + 16;
@@ -354,7 +354,10 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
             // a miss adds its shares to the trash area; 24-bit multiply + select, not a divergent branch
             int aidx = (int)__umul24((unsigned)ti, (unsigned)AW) + tj;
             asm volatile("" : "+v"(aidx));               // computed for every lane, then selected
-            long long *acc = sacc + (hit ? aidx : (TH + 1) * AW + lane);
+            // a miss goes to the column its target WOULD have had: the lanes of a wave then keep their distinct banks whether
+            // they hit or miss (at column = lane, the eight halo-column lanes of every row collided with hits three or four
+            // lanes away -- a two-way conflict in nearly every deposit instruction)
+            long long *acc = sacc + (hit ? aidx : (TH + 1) * AW + (tj & (AW - 1)));
             // float -> fixed point with one native conversion: the unit is 2^-30 of (the power of two above) the
             // largest staged intensity, so |v|*2^s <= 2^30 fits int32; the 64-bit sum has 2^33 of headroom
             auto dep = [&](int off, float v) __attribute__((always_inline)) {

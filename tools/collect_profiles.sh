@@ -15,7 +15,7 @@ for arg in "$@"; do
         --gpus|--gpus=*) echo "collect_profiles.sh: profile ONE rank (bench.py --gpus N would start its ranks from a process the profiler's library has already initialised the GPU in)" >&2; exit 2;;
     esac
 done
-CMD="python3 $ROOT/bench.py --no-cpu-baseline --positions 0 $*"      # the bench run (timed steps + the per-kernel event pass), minus the CPU leg and the positions batch
+CMD="python3 $ROOT/bench.py --no-cpu-baseline --positions 0 --no-configs $*"      # the bench run (timed steps + the per-kernel event pass), minus the CPU leg and the positions batch
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/fin_stats$SFX $OUT/fin_fetch$SFX $OUT/fin_write$SFX $OUT/fin_sq$SFX
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fin_stats$SFX -o runc -- $CMD > $OUT/fin_stats$SFX.log 2>&1
