@@ -597,7 +597,7 @@ def run_configs(a, dev):
     import torch
     from oracle import cpu_baseline as cb
     from oracle import paresis_oracle as orc
-    from paresis_amd import ops, synth
+    from paresis_amd import _lib, ops, synth
     from paresis_amd.Samples.getMembraneFromFile import getMembraneSegmentedFromFile
     from paresis_amd.getk import getk, k_refraction, k_sample
 
@@ -627,6 +627,11 @@ def run_configs(a, dev):
         refr = [torch.empty((N, N), dtype=torch.float32, device=dev) for _ in zs]
         n = N // ov
         sig_src, sig_psf = 10.0 * 3.6 / 141.6 / 6.0 * ov / 2.355, 1.2
+        # gather halo of the refraction tiles (a speed knob, the images do not depend on it): at oversampling 4 the
+        # displacements are four times as many pixels as at oversampling 2 and the 8-pixel halo pays (16384^2: tile kernel
+        # 4.3 -> 5.5 ms, far-ray replay 5.7 -> 3.0 ms); the headline's 4-pixel halo elsewhere
+        halo = 8 if ov >= 4 else a.halo
+        _lib.check(_lib.lib().psx_refract_set_halo(halo), "psx_refract_set_halo")
         det = ops.DetectorPlan(N, N, ov, n, n, sig_src, sig_psf) if detect else None
         dets = [torch.empty((n, n), dtype=torch.float32, device=dev) for _ in range(2 * len(zs))] if detect else []
         amp = float(np.sqrt(I0))
@@ -654,6 +659,19 @@ def run_configs(a, dev):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / K
         ops.check_status(dev, "configs %d" % N)
+        # one more step with the library's event pairs: where the step's time goes
+        import ctypes
+        lib = _lib.lib()
+        lib.psx_profile_enable(1)
+        step()
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 16)
+        _lib.check(lib.psx_profile_summary(buf, len(buf)), "psx_profile_summary")
+        lib.psx_profile_enable(0)
+        kern = {}
+        for line in buf.value.decode().splitlines():
+            nm, cnt, tot = line.split()
+            kern[nm] = round(float(tot), 4)
         P = N + 30
         nmat = 2
         step_bytes = len(zs) * (64 + 12 + 4 * nmat) * P * P
@@ -663,7 +681,8 @@ def run_configs(a, dev):
                          (N, N, n, ov, len(zs), ", Detector.detection of all %d images in the step" % (2 * len(zs)) if detect else ""),
              "steps": K, "ms": round(dt * 1e3, 4), "Mpixel_per_s": round(len(zs) * N * N / dt / 1e6, 1),
              "step_bytes": step_bytes, "step_frac": round(step_bytes / dt / 1e9 / HBM_PEAK_GBS, 4),
-             "fresnel_engine": {1: "rocfft", 2: "lds"}[plan.engine]}
+             "fresnel_engine": {1: "rocfft", 2: "lds"}[plan.engine], "refraction_halo": halo,
+             "kernel_ms_per_step": dict(sorted(kern.items(), key=lambda kv: -kv[1]))}
         # ---- parity against the float64 restatement (the checker; after the timed region)
         nt = max(1, min(32, (os.cpu_count() or 1) // 2))
         par = {}
@@ -708,6 +727,7 @@ def run_configs(a, dev):
             det.close()
         del T, geom, fres, refr, dets, wave_mats, rt_mats
         torch.cuda.empty_cache()
+    _lib.check(_lib.lib().psx_refract_set_halo(a.halo), "psx_refract_set_halo")
     return out
 
 
