@@ -645,3 +645,44 @@ def test_work_queue_gives_the_same_images(ops, case):
         r = plan.propagate_sources(aa, gg, du, amp=[1.0] * 5, mats=ms)
         assert all(torch.equal(q[s][d], r[s][d]) for s in range(5) for d in range(nd))
     plan.close()
+
+
+def test_darkfield_front_kernels_against_numpy(ops):
+    """psx_darkfield_split_f32 / merge / repad (round 3: the array glue of fastRefractionDF, RF2:114-150,128-129,139-140, as
+    kernels) against the same operations in numpy, including the DF > Nx/4 rule, both maxima and a grid that is not a
+    multiple of anything."""
+    rng = np.random.default_rng(11)
+    Nx, Ny = 93, 70
+    I = rng.uniform(1.0, 9.0, (Nx, Ny)).astype(np.float32)
+    DFrad = np.where(rng.uniform(size=(Nx, Ny)) < 0.4, 0.0, rng.uniform(1e-7, 3e-6, (Nx, Ny)))
+    DFrad[5, 7] = 1.0e-4                       # becomes > Nx/4 pixels: zeroed by the rule, but counts for the margin
+    scale = 3.6 / (2.9e-6 * 1.02)
+    a, b, dfpx, prep, words = ops.darkfield_split(dev(I, torch.float32), dev(DFrad, torch.float64), scale, Nx / 4)
+    px = DFrad * scale
+    mx0 = px.max()
+    pxc = np.where(px > Nx / 4, 0.0, px)
+    m0, m1 = ops.darkfield_maxima(words)
+    assert m0 == mx0 and m1 == pxc.max()                       # float64, bit for bit
+    df32 = pxc.astype(np.float32)
+    assert np.array_equal(dfpx.cpu().numpy(), df32)
+    assert np.array_equal(a.cpu().numpy(), np.where(df32 != 0, 0.0, I).astype(np.float32))
+    assert np.array_equal(b.cpu().numpy(), np.where(df32 != 0, I, 0.0).astype(np.float32))
+    # patch table: (half-size, 1/normalisation) of gaussian_shape(DF/2) (RF2:14-23: side round(3 sigma)*2+1, banker's rounding)
+    tab = prep.view(torch.float32).view(Nx, Ny, 2).cpu().numpy()
+    for (i, j) in [(0, 0), (5, 7), (40, 33), (92, 69), (17, 2)]:
+        s = 0.5 * float(df32[i, j])
+        if s == 0:
+            assert tab[i, j, 0] == 0 and tab[i, j, 1] == 1
+            continue
+        g = orc.create_gaussian_shape(s)
+        h = (g.shape[0] - 1) // 2
+        raw = np.exp(-(np.arange(-h, h + 1) ** 2) / 2.0 / s ** 2)
+        assert tab[i, j, 0] == h
+        assert abs(tab[i, j, 1] * raw.sum() ** 2 - 1) < 1e-6
+    out = torch.empty((Nx, Ny), dtype=torch.float32, device="cuda")
+    ops.darkfield_merge(out, a, b)
+    assert np.array_equal(out.cpu().numpy(), I)
+    src = rng.uniform(-1, 1, (Nx + 16, Ny + 16)).astype(np.float32)
+    for md in (0, 3, 11):
+        got = ops.repad(dev(src, torch.float32), 8, md, (Nx, Ny)).cpu().numpy()
+        assert np.array_equal(got, np.pad(src[8:8 + Nx, 8:8 + Ny], md))
