@@ -15,14 +15,17 @@ I = torch.full((N, N), 7500.0, dtype=torch.float32, device="cuda")
 df = torch.from_numpy(np.where(geo["sample"][0] > 0, 2.0e-6, 0.0)).cuda()
 dfmax = float(df.max().item())
 Iw = I.clone()
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 def f():
-    Iw.copy_(I)                       # (the call zeroes clamped rays in its input; a device copy, outside the library)
+    # (the call zeroes CLAMPED rays in its input, |D| > N: there are none here, so the same array serves every repetition and
+    # nothing but the call runs between the clocks -- under `rocprofv3 --kernel-trace --stats` every kernel that appears REPS
+    # times or more belongs to the call: all of them are the library's)
     return RF2.fastRefractionDF(Iw, phi, 3.6, 52.0, M, pix, df, darkFieldMax=dfmax, check=False)
 f(); torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(3): f()
+for _ in range(REPS): f()
 torch.cuda.synchronize()
-wall = (time.perf_counter() - t0) / 3 * 1e3
+wall = (time.perf_counter() - t0) / REPS * 1e3
 lib.psx_profile_enable(1); f(); torch.cuda.synchronize()
 buf = ctypes.create_string_buffer(1 << 16); lib.psx_profile_summary(buf, len(buf)); lib.psx_profile_enable(0)
-print("fastRefractionDF %dx%d: %.1f ms wall; library kernels: %s" % (N, N, wall, buf.value.decode().replace("\n", "; ")))
+print("fastRefractionDF %dx%d: %.2f ms wall; library kernels: %s" % (N, N, wall, buf.value.decode().replace("\n", "; ")))
