@@ -51,8 +51,14 @@ def _worker(rank, world, port, n_positions, q, kind="counts", overlapped=False):
     if r == 0:
         ok = sorted(out) == list(range(n_positions)) and packed == (kind == "counts")
         per_round = 2 * 70 * 2 + 8 + 8 * 64
-        ok = ok and dist.last_gather["wire_bytes"] == ((2 * per_round if overlapped else 3 * 2 * 70 * 2 + 8 + 8 * 64) if packed
-                                                       else 3 * 2 * 70 * 4)
+        rounds = (n_positions + world - 1) // world
+        if world == 2 and n_positions == 5:        # the byte counts of the original two-rank case, spelled out
+            ok = ok and dist.last_gather["wire_bytes"] == ((2 * per_round if overlapped else 3 * 2 * 70 * 2 + 8 + 8 * 64) if packed
+                                                           else 3 * 2 * 70 * 4)
+        elif packed and overlapped:                # every position that is not rank 0's crosses once, as one packed round
+            ok = ok and dist.last_gather["wire_bytes"] == (n_positions - len(mine)) * per_round
+        elif not packed:
+            ok = ok and dist.last_gather["wire_bytes"] == (world - 1) * rounds * 2 * 70 * 4
         for p in range(n_positions):
             S, R = images(p)
             ok = ok and torch.equal(out[p][0], S) and torch.equal(out[p][1], R) and out[p][0].dtype == torch.float32
@@ -76,6 +82,25 @@ def test_gather_positions_world2(kind, overlapped):
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res)
+
+
+@pytest.mark.parametrize("world,n_positions,overlapped,kind", [(3, 7, True, "counts"), (3, 7, False, "one_rank_fractions"),
+                                                                (4, 6, True, "counts"), (4, 3, True, "counts")])
+def test_gather_positions_more_ranks_and_ragged_rounds(world, n_positions, overlapped, kind):
+    """The gather with 3 and 4 ranks, a position count that does not divide (the last round is partly empty) and fewer
+    positions than ranks (a rank that owns none): what 8 ranks with 64 positions never exercise, and the indexing an 8-rank
+    run relies on."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_positions, q, kind, overlapped)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
