@@ -82,13 +82,14 @@ def test_both_engines_agree_4096():
 
 
 @pytest.mark.parametrize("shape", [(5000, 5000), (4704, 1500), (1200, 6008), (4594, 4594), (9800, 320), (320, 12000),
-                                   (12400, 320), (320, 16384), (16384, 200), (13001, 200), (18402, 136)])
+                                   (12400, 320), (320, 16384), (16384, 200), (13001, 200), (18402, 136), (12279, 72), (72, 12278)])
 def test_partitioned_lds_engine_matches_rocfft_and_oracle(shape):
     """Lines longer than one LDS transform (N > 4593) run as a partitioned convolution -- output blocks x kernel segments,
     partial sums in HBM, the two LDS lines coupled into one 18432-point transform -- on one or both axes: one product per
     line (5000, 4704, 6008, 4594), one segment x two blocks (9800, 12000); lines of 12280..18402 samples as ONE convolution
     of 36864 points split by a radix-2 decimation-in-frequency step over two coupled rounds (12400, 16384 on either axis,
-    13001: odd period, the partner of a sample sits in the other LDS line; 18402: the longest such line, period = 18432);
+    13001: odd period, the partner of a sample sits in the other LDS line; 18402: the longest such line, period = 18432;
+    12279: the shortest, next to 12278, the longest line the two-segment partition still takes in two rounds);
     checked against the rocFFT engine (complex wave and accumulated
     intensity, 2 distances in one call) and, on a 300-pixel-wide cut, against the oracle's FFT of the same lines."""
     from paresis_amd import ops
