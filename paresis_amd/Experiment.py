@@ -582,10 +582,10 @@ class Experiment:
         scattering = self.mySampleofInterest.has_dark_field()
         # EXP:444 re-zeros the dark-field map on EVERY call (it only builds up while position 0 is computed, EXP:491): a
         # scattering sample therefore returns zeros for pointNum > 0, whatever positions this object computed before
-        if not isinstance(self.darkFieldPropag, torch.Tensor) or tuple(self.darkFieldPropag.shape) != N:
-            self.darkFieldPropag = torch.zeros(N, dtype=torch.float32, device=dev)        # scalar dark field: stays zero
-        elif scattering:
-            ops.fill(self.darkFieldPropag, 0.0)
+        # (EXP:444 allocates a NEW array: the map returned for an earlier position stays what it was, so a scattering sample
+        # gets a fresh tensor per call -- filling the old one in place would clear what the caller still holds)
+        if scattering or not isinstance(self.darkFieldPropag, torch.Tensor) or tuple(self.darkFieldPropag.shape) != N:
+            self.darkFieldPropag = ops.fill(torch.empty(N, dtype=torch.float32, device=dev), 0.0)   # scalar dark field: stays zero
         dMO, dOD = ed['distMembraneToObject'], ed['distObjectToDetector']
         clamp = (N[0], N[1])                                                              # RF2:61-64
         if not scattering and self._batch_energies(N, None):

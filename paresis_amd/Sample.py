@@ -189,13 +189,19 @@ class AnalyticalSample(Sample):
         return ops.MaterialStack(self.geometry_dev(), cphase=(-k * d * frac if phase else 0 * d),
                                  catt=(-2 * k * b * frac if att else 0 * b))
 
+    DF_CACHE_ENTRIES = 32      # width maps kept per sample (one per energy of a spectrum; a 50 kVp tube has ~25)
+
     def dark_field(self, energy):
         """newDf of setWaveRT (Sample.py:322-344): 2 delta sqrt(N_s) sqrt(ln(2/delta)+1) of the LAST scattering
         material (the reference overwrites, it does not accumulate); int 0 when nothing scatters."""
-        cached = getattr(self, "_df_cache", {}).get((energy, id(self.myGeometry)))
-        if cached is not None:
-            return cached[0]
+        # cache entry = (geometry object, what the map was computed from, map, exact maximum); validated by IDENTITY of the
+        # geometry (an id() alone can be reused by a new object) and by value of everything else that enters the formula
         d = self._coeff(self.delta, energy)
+        sig = (tuple(self.myMaterials), self.myName, self.myType, tuple(float(v) for v in d))
+        cache = self.__dict__.setdefault("_df_cache", {})
+        hit = cache.get(energy)
+        if hit is not None and hit[0] is self.myGeometry and hit[1] == sig:
+            return hit[2]
         newDf = 0
         for imat in range(len(self.myMaterials)):
             model = self._df_model(imat)
@@ -207,15 +213,17 @@ class AnalyticalSample(Sample):
             newDf = (2 * d[imat] * np.sqrt(np.log(2 / d[imat]) + 1)) * torch.sqrt(NsphereVol ** (1 / 3) * geom)
         if isinstance(newDf, torch.Tensor):
             # the map depends on the (static) thickness maps and the energy only: kept, with its maximum -- fastRefractionDF
-            # sizes the displacement maps it returns by it (RF2:117) and would otherwise read it back on every call
-            if not hasattr(self, "_df_cache"):
-                self._df_cache = {}
-            self._df_cache[(energy, id(self.myGeometry))] = (newDf, float(newDf.max().item()))
+            # sizes the displacement maps it returns by it (RF2:117) and would otherwise read it back on every call.
+            # Bounded: one float64 [Nx][Ny] map per energy adds up (25 energies at 4096^2 = 3.4 GB); the oldest entries go.
+            cache.pop(energy, None)
+            while len(cache) >= self.DF_CACHE_ENTRIES:
+                cache.pop(next(iter(cache)))
+            cache[energy] = (self.myGeometry, sig, newDf, float(newDf.max().item()))
         return newDf
 
     def dark_field_max(self, darkField):
         """The exact maximum (rad) of a map dark_field() returned, or None for any other array."""
-        for t, mx in getattr(self, "_df_cache", {}).values():
+        for _, _, t, mx in getattr(self, "_df_cache", {}).values():
             if t is darkField:
                 return mx
         return None

@@ -236,8 +236,9 @@ def gather_positions(results, n_positions, rank, world, dst=0, to_host=True, pac
                 q = t * world + r
                 if q < n_positions:
                     out[q] = (bucket[r][t, 0], bucket[r][t, 1])
-    if rank == dst and 0 in results:                     # Propag / White / Dx,Dy exist for position 0 only (owner(0) == 0)
-        out[0] = host(results[0])
+    extras = move_extras(results, rank, world, dst, to_host) if n_positions > 0 else None   # Propag / White / Dx,Dy: position 0 only
+    if extras is not None:
+        out[0] = extras
     return out if rank == dst else {}
 
 
@@ -328,6 +329,13 @@ class PositionGatherer:
             self._issue(self.next_round)
             self.next_round += 1
 
+    def _move_extras(self, host):
+        if 0 not in self.results and self.rank == owner(0, self.world) and self.dst != self.rank:
+            raise DistError("PositionGatherer: rank %d owns position 0 but never added it" % self.rank)
+        if self.P <= 0:
+            return None
+        return move_extras(self.results, self.rank, self.world, self.dst, self.to_host)
+
     def finish(self, timeout=None):
         """Waits for the rounds in flight -- at most `timeout` seconds each (default: timeout_s()), then DistError: a rank
         that died or left the sequence of collectives must not hang the others until the process-group timeout -- and returns
@@ -344,17 +352,22 @@ class PositionGatherer:
         while self.next_round < self.rounds:                            # rounds this rank has no position in
             self._issue(self.next_round)
             self.next_round += 1
-        deadline = time.monotonic() + timeout
         try:
             for t, w in enumerate(self.work):
                 # polled, not wait(): gloo's wait() blocks the host without bound and nccl's only orders the streams (the
-                # host would then hang in the first .item() below instead)
+                # host would then hang in the first .item() below instead).  The bound is per round -- a long healthy run
+                # with many rounds in flight is not declared dead by the sum of its transfers -- and the poll backs off
+                # from 50 us to 1 ms, so a waiting rank does not keep a host core from the packing / launch thread.
+                deadline = time.monotonic() + timeout
+                nap = 0.00005
                 while not w.is_completed():
                     if time.monotonic() > deadline:
                         raise DistError("PositionGatherer.finish: the gather of round %d did not complete within %.0f s on rank "
                                         "%d (a rank failed or left the sequence of collectives)" % (t, timeout, self.rank))
-                    time.sleep(0.00005)
+                    time.sleep(nap)
+                    nap = min(0.001, nap * 1.5)
                 w.wait()
+            extras = self._move_extras(host)
             td.all_reduce(self.flag, op=td.ReduceOp.MAX)
         except RuntimeError as exc:           # includes DistError; a peer that died surfaces here as a transport error
             if isinstance(exc, DistError):
@@ -378,10 +391,61 @@ class PositionGatherer:
                         b = b.cpu()
                     img = _CountsWire(2 * per_img, b.device, like=b).unpack().view((2,) + self.shape)
                     out[q] = (img[0], img[1])
-            if 0 in self.results:                                        # Propag / White / Dx,Dy exist for position 0 only
-                out[0] = host(self.results[0])
+            if extras is not None:                                       # Propag / White / Dx,Dy exist for position 0 only
+                out[0] = extras
         last_gather.update(packed=True, wire_bytes=wire_bytes, overlapped=True)
         return out if self.rank == self.dst else {}
+
+
+def move_extras(results, rank, world, dst, to_host):
+    """Position 0's full tuple (Sample, Reference, Propag, White[, Dx, Dy, DF]) on `dst`, None elsewhere.  Propag / White and
+    the displacement maps exist for position 0 only (EXP:363-375, 488-498) and live on its owner, rank 0.  With dst == 0
+    nothing moves.  With another sink (the straggler that computes the extras and the rank that receives everybody's images
+    are then two different GPUs) they cross in ONE point-to-point transfer per tensor: a small int64 header (count, ndim and
+    shape of each) first -- the sink cannot know the shapes of the RT chain's padded maps -- then float32 payloads.
+    Every rank calls this at the same point of its sequence; ranks other than 0 and dst do nothing."""
+    host = lambda tup: tuple(t.detach().cpu() if isinstance(t, torch.Tensor) and to_host else t for t in tup)
+    src = owner(0, world)
+    if dst == src:
+        return host(results[0]) if (rank == dst and 0 in results) else None
+    dev = _dev()
+    HDR = 64
+    if rank == src:
+        tens = [t for t in results[0]]
+        hdr = torch.zeros(HDR, dtype=torch.int64)
+        hdr[0] = len(tens)
+        k = 1
+        for t in tens:
+            if not isinstance(t, torch.Tensor):          # e.g. a displacement map that was never computed: travels as None
+                hdr[k] = -1
+                k += 1
+                continue
+            hdr[k] = t.dim()
+            hdr[k + 1:k + 1 + t.dim()] = torch.tensor(list(t.shape), dtype=torch.int64)
+            k += 1 + t.dim()
+        td.send(hdr.to(dev), dst=dst)
+        for t in tens:
+            if isinstance(t, torch.Tensor):
+                td.send(t.detach().to(dev, torch.float32).contiguous(), dst=dst)
+        return None
+    if rank == dst:
+        hdr = torch.zeros(HDR, dtype=torch.int64, device=dev)
+        td.recv(hdr, src=src)
+        hdr = hdr.cpu().tolist()
+        out, k = [], 1
+        for _ in range(hdr[0]):
+            nd = hdr[k]
+            if nd < 0:
+                out.append(None)
+                k += 1
+                continue
+            shape = tuple(hdr[k + 1:k + 1 + nd])
+            k += 1 + nd
+            t = torch.empty(shape, dtype=torch.float32, device=dev)
+            td.recv(t, src=src)
+            out.append(t)
+        return host(tuple(out))
+    return None
 
 
 def _dev():

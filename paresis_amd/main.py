@@ -58,21 +58,23 @@ def run(exp_dict, save=True, saving_format=".tif", backend=None):
     if overlapped and sim == "Fresnel":
         experiment._plan().work_queue(True)
     results = {}
-    for pointNum in dist.my_positions(exp_dict['nbExpPoints'], rank, world):
-        experiment.myMembrane.myGeometry = []
-        experiment.myMembrane.getMyGeometry(experiment.exp_dict['studyDimensions'], experiment.myMembrane.membranePixelSize,
-                                            experiment.exp_dict['overSampling'], pointNum, exp_dict['nbExpPoints'])   # main.py:64-65
-        print("\nCalculations point", pointNum)
-        out = experiment.computeSampleAndReferenceImages(pointNum)
-        if gatherer is not None:
-            gatherer.add(pointNum, out)
-        else:
-            results[pointNum] = out
-        if save and exp_dict.get('saveMembrane', True):
-            # main.py:98: every rank writes the membrane maps of its own positions (one node, one file system: no gather)
-            save_image(experiment.myMembrane.myGeometry[0], root + 'membraneThickness/' + exp_dict['experimentName'] +
-                       '_sampling' + str(exp_dict['overSampling']) + '_' + str(pointNum) + saving_format)
+    # the loop and the final gather share ONE failure path: PositionGatherer.add() issues collectives too, and a DistError
+    # raised there must not unwind through the process group's teardown (its contract: leave with os._exit)
     try:
+        for pointNum in dist.my_positions(exp_dict['nbExpPoints'], rank, world):
+            experiment.myMembrane.myGeometry = []
+            experiment.myMembrane.getMyGeometry(experiment.exp_dict['studyDimensions'], experiment.myMembrane.membranePixelSize,
+                                                experiment.exp_dict['overSampling'], pointNum, exp_dict['nbExpPoints'])   # main.py:64-65
+            print("\nCalculations point", pointNum)
+            out = experiment.computeSampleAndReferenceImages(pointNum)
+            if gatherer is not None:
+                gatherer.add(pointNum, out)
+            else:
+                results[pointNum] = out
+            if save and exp_dict.get('saveMembrane', True):
+                # main.py:98: every rank writes the membrane maps of its own positions (one node, one file system: no gather)
+                save_image(experiment.myMembrane.myGeometry[0], root + 'membraneThickness/' + exp_dict['experimentName'] +
+                           '_sampling' + str(exp_dict['overSampling']) + '_' + str(pointNum) + saving_format)
         if gatherer is not None:
             gathered = gatherer.finish()
         else:

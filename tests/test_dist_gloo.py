@@ -14,7 +14,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_positions, q, kind="counts", overlapped=False):
+def _worker(rank, world, port, n_positions, q, kind="counts", overlapped=False, dst=0):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     from paresis_amd import dist
@@ -40,22 +40,22 @@ def _worker(rank, world, port, n_positions, q, kind="counts", overlapped=False):
         S, R = images(p)
         results[p] = (S, R, torch.full((2, 5, 7), 3.5), torch.full((2, 5, 7), 4.0)) if p == 0 else (S, R)
     if overlapped:                    # round by round, each gather issued as soon as the rank's position of the round exists
-        gat = dist.PositionGatherer(n_positions, r, w, to_host=True, shape=(2, 5, 7))
+        gat = dist.PositionGatherer(n_positions, r, w, dst=dst, to_host=True, shape=(2, 5, 7))
         for p in mine:
             gat.add(p, results[p])
         out = gat.finish()
     else:
-        out = dist.gather_positions(results, n_positions, r, w)
+        out = dist.gather_positions(results, n_positions, r, w, dst=dst)
     packed = dist.last_gather.get("packed")
     dist.finish()
-    if r == 0:
+    if r == dst:
         ok = sorted(out) == list(range(n_positions)) and packed == (kind == "counts")
         per_round = 2 * 70 * 2 + 8 + 8 * 64
         rounds = (n_positions + world - 1) // world
         if world == 2 and n_positions == 5:        # the byte counts of the original two-rank case, spelled out
             ok = ok and dist.last_gather["wire_bytes"] == ((2 * per_round if overlapped else 3 * 2 * 70 * 2 + 8 + 8 * 64) if packed
                                                            else 3 * 2 * 70 * 4)
-        elif packed and overlapped:                # every position that is not rank 0's crosses once, as one packed round
+        elif packed and overlapped:                # every position that is not the sink's crosses once, as one packed round
             ok = ok and dist.last_gather["wire_bytes"] == (n_positions - len(mine)) * per_round
         elif not packed:
             ok = ok and dist.last_gather["wire_bytes"] == (world - 1) * rounds * 2 * 70 * 4
@@ -105,6 +105,37 @@ def test_gather_positions_more_ranks_and_ragged_rounds(world, n_positions, overl
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(res)
+
+
+def _run_ranks(world, n_positions, kind, overlapped, dst, timeout=240):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_positions, q, kind, overlapped, dst)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res)
+
+
+def test_gather_world8_64_positions_like_the_scale_run():
+    """The exact indexing of the driver's 8-GPU run (BASELINE config 4: 64 positions over 8 ranks, 8 full rounds, round by
+    round through PositionGatherer with the packed wire format), on gloo with small images."""
+    _run_ranks(8, 64, "counts", True, 0)
+
+
+@pytest.mark.parametrize("world,n_positions,overlapped,dst", [(8, 64, True, 7), (4, 6, True, 2), (3, 7, False, 1), (2, 1, True, 1)])
+def test_gather_sink_is_not_the_owner_of_position_zero(world, n_positions, overlapped, dst):
+    """dst != 0: rank 0 computes position 0 with its extras (Propag / White: the straggler), another rank receives every
+    position (the sink).  The extras reach the sink by one point-to-point transfer; everything else is indexed as before."""
+    _run_ranks(world, n_positions, "counts", overlapped, dst)
+
+
+def test_gather_sink_elsewhere_float_fallback():
+    _run_ranks(3, 5, "one_rank_fractions", True, 2)
 
 
 def test_single_process_is_world_one(monkeypatch):

@@ -204,6 +204,7 @@ def test_darkfield_chain():
     g = load("darkfield.npz")
     cfg = experiment_cfg(g, "chain", orc.Obj)
     exp = build_experiment(cfg, "RT", sample_materials=("Lung",), sample_name="lungs")
+    DF0 = None
     for point in (0, 1):
         exp.myMembrane.myGeometry = g["chain/p%d/membrane" % point]
         exp.exp_dict["meanEnergy"] = 0
@@ -216,6 +217,13 @@ def test_darkfield_chain():
             assert tuple(Dx.shape) == g[t + "Dx"].shape
             assert relmax(Dx.cpu().numpy(), g[t + "Dx"]) < 1e-6
             assert relmax(DF.cpu().numpy(), g[t + "DF"]) < 1e-6
+            DF0 = DF
+        else:
+            # EXP:444 allocates a new map per call: position 1 returns zeros AND leaves position 0's map as it was
+            # (main.run keeps results[0] until the gather at the end of the run)
+            assert float(DF.abs().max()) == 0.0
+            assert DF.data_ptr() != DF0.data_ptr()
+            assert relmax(DF0.cpu().numpy(), g["chain/p0/DF"]) < 1e-6
 
 
 @pytest.mark.parametrize("sim", ["RT", "Fresnel"])
