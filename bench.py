@@ -37,6 +37,7 @@ DISTANCES = (1.6, 3.6, 5.2, 7.2)
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_GINST = 1228.8     # wave64 vector instructions per second, x1e9: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles (same guide)
 PARITY_TOL = 1e-5            # BASELINE.json north_star: max|out-ref|/max|ref|
+METRIC = "Mpixels/s, 4096^2 Fresnel+refraction step"
 
 
 def parse():
@@ -91,7 +92,19 @@ def spawn_ranks(a):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    sys.exit(subprocess.call(cmd, env=env))
+    # Process count of `python bench.py --gpus N`: this parent (never touches the GPU) + the launcher's agent + N ranks = N + 2
+    # (N + 1 when the driver starts torch.distributed.run itself); each rank uses exactly one GPU.
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        # the ranks are gone and rank 0 may never have printed its line: say so in a form the driver can parse.  A negative
+        # code is the signal that killed the launcher (e.g. -9: the box's process / memory guard, which leaves no message).
+        print(json.dumps({"error": "bench.py --gpus %d: the rank launcher exited with code %d before a result line was complete "
+                                   "(rank tracebacks, if any, are on stderr; exit 5 = a rank failed inside the positions batch, "
+                                   "6 = a peer was lost / bounded wait expired, 3 / 4 = parity or gather check failed, negative = "
+                                   "killed by that signal)" % (a.gpus, rc),
+                          "rc": rc, "n_gpus": a.gpus, "metric": METRIC, "value": None, "unit": "Mpixel/s",
+                          "processes_started": a.gpus + 2}), flush=True)
+    sys.exit(rc if rc >= 0 else 128 - rc)
 
 
 def main():
@@ -244,7 +257,7 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     value = units * N * N * world / (dt / a.steps) / 1e6
 
-    out = {"metric": "Mpixels/s, 4096^2 Fresnel+refraction step", "value": round(value, 1), "unit": "Mpixel/s",
+    out = {"metric": METRIC, "value": round(value, 1), "unit": "Mpixel/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "%dx%d fp32 study grid, 1 membrane position per GPU per step, 4 propagation distances "

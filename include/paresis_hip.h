@@ -102,7 +102,8 @@ int psx_accumulate_many_f32(float *acc, const float *const *imgs, const float *s
  * I_mut             optional: the reference zeroes clamped entries of its INPUT intensity in place (RF2:61-62);
  *                   pass I_in here to reproduce that, NULL otherwise.
  * status            optional device word; PSX_STATUS_NONFINITE is OR-ed in when the output holds NaN/inf.
- * workspace         device scratch of psx_refract_workspace_bytes(Nx,Ny) bytes (far-ray list), caller-owned.
+ * workspace         device scratch of psx_refract_workspace_bytes(Nx,Ny) bytes (far-ray lists; with psx_set_deterministic on,
+ *                   also the scratch words of the order-independent replay), caller-owned, no initial state needed.
  */
 size_t psx_refract_workspace_bytes(int Nx, int Ny);
 /* Gather halo of the tile kernel: 4, 6 or 8 pixels (default 4); a setting of the CALLING HOST THREAD (one thread per GPU).  A tile gathers every ray of its window (tile + halo)
@@ -137,11 +138,16 @@ int psx_refract_batch_f32(int n, const float *const *I_in, const float *I0, cons
                           int margin, const double *dscale, double clamp_x, double clamp_y, unsigned *status, void *workspace,
                           void *stream);
 
-/* Deterministic-order debug mode (the reference's scatter is a single-threaded raster loop, RF2:217-263;
- * here far rays and psx_fastloop_f32 deposit with global float atomics in arbitrary order).  With on != 0 those deposits go
- * as 64-bit fixed-point integers into a scratch accumulator image (order-independent sums) and reach the float image with
- * one add per pixel: two runs of the same call are then bitwise equal.  Costs a hipMalloc, a stream synchronisation and two
- * extra passes per call -- a debugging aid, off by default.  A setting of the calling host thread. */
+/* Order-independent scatter (the reference's scatter is a single-threaded raster loop, RF2:217-263; the
+ * tile gathers are fixed point and reproducible as they are, but far rays and psx_fastloop_f32 deposit with global float
+ * atomics in arrival order, and a last-bit difference can flip a Poisson draw downstream).  With on != 0 the far-ray replay of
+ * psx_refract_f32 / _multi_f32 / _batch_f32 runs as three passes over the same lists -- clear the touched 64-bit scratch
+ * words and max-reduce the listed intensities; add the shares as fixed-point integers; exchange every touched word with 0
+ * and add its sum ONCE to the float image -- so that two runs of the same call are bitwise equal, whatever the GPU count.
+ * Allocates nothing and synchronises nothing: the scratch ([ndist][Nx*Ny] words) is part of the caller's workspace, needs
+ * no initial state, and psx_refract_*_workspace_bytes() includes it WHILE THE MODE IS ON (set the mode, then size the
+ * workspace).  psx_fastloop_f32, which has no workspace argument, keeps the allocating form (hipMalloc + a stream
+ * synchronisation per call).  A setting of the calling host thread; off by default (measured cost: DESIGN.md section 4.3). */
 int psx_set_deterministic(int on);
 
 /* The raw scatter loop on explicit displacement fields: fastloopNumba (refractionFileNumba2.py:198-263).
@@ -290,6 +296,13 @@ int psx_profile_summary(char *buf, size_t cap);
  * kernels of the LDS Fresnel engine, 16 x uint64 per workgroup from the refraction kernel (tools/stamp_*.py).
  * NULL (default) switches it off.  Never enabled in timed runs. */
 int psx_debug_stamps(void *buf);
+
+/* Diagnostic A/B switches, process-wide, all off by default; the library reads NOTHING from the environment.  Names:
+ *   "no_dif", "no_pair" (read when a Fresnel plan is created), "no_dual", "no_dist_inner", "stamp_pass1", "stamp_round"
+ *   (default 1), "detect_4pass".  tools/ and tests/ set them; timed product runs never do.  psx_debug_switches_active writes
+ *   "name=value ..." of every switch that is not at its default (empty string: none) -- bench.py echoes it in its JSON line. */
+int psx_debug_switch(const char *name, int value);
+int psx_debug_switches_active(char *buf, size_t cap);
 
 /* ---- status word ------------------------------------------------------------------------------------------------ */
 /* OR PSX_STATUS_NONFINITE into *status when img holds NaN or |v| > 1e50 (float32: inf) */

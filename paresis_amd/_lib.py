@@ -17,7 +17,7 @@ PSX_MAX_SRC = 16
 PSX_SUM_SLOTS, PSX_SUM_STRIDE = 32, 16
 ENGINE_AUTO, ENGINE_ROCFFT, ENGINE_LDS = 0, 1, 2
 STATUS_NONFINITE = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class PsxError(RuntimeError):
@@ -84,6 +84,8 @@ PROTOTYPES = {
     "psx_membrane_layers_f32": (c_int, [_vp, c_int, POINTER(c_int), POINTER(c_int), c_int, c_int, c_int, c_int, c_double, c_int,
                                         _vp, _vp, c_float, _vp]),
     "psx_debug_stamps": (c_int, [_vp]),
+    "psx_debug_switch": (c_int, [c_char_p, c_int]),
+    "psx_debug_switches_active": (c_int, [ctypes.c_char_p, c_size_t]),
     "psx_profile_enable": (c_int, [c_int]),
     "psx_profile_summary": (c_int, [ctypes.c_char_p, c_size_t]),
 }

@@ -90,6 +90,20 @@ inline int mats_variant(int n) { return n <= 4 ? n : 8; }
 // diagnostic phase-timestamp buffer (psx_debug_stamps); null in every timed run
 extern unsigned long long *g_stamps;
 
+// Diagnostic A/B switches (psx_debug_switch): process-wide, all 0 by default (stamp_round: 1), never read from the
+// environment -- a stray variable must not change what a product run computes.  The host code reads them per call.
+enum DebugSwitch {
+    DBG_NO_DIF = 0,        // 16384^2-class lines through the block x segment partition instead of the two-round DIF convolution
+    DBG_NO_PAIR,           // partitioned engine with M-point products (round-1 form)
+    DBG_NO_DUAL,           // pass 1 without the forward transform shared by two distances
+    DBG_NO_DIST_INNER,     // pass 1: every (distance, line group) pair its own work item
+    DBG_STAMP_PASS1,       // psx_debug_stamps records pass 1 instead of pass 2
+    DBG_STAMP_ROUND,       // which round of a unit the stamps are taken in
+    DBG_DETECT_4PASS,      // detector stages as four passes instead of fused pairs
+    DBG_COUNT
+};
+int debug_switch(DebugSwitch s);
+
 // ---- optional per-kernel timing with HIP events on the launch stream (psx_profile_*) ---------------------------------
 // Off by default: a ProfScope then costs one branch.  When on, every kernel launch of the library is bracketed by two
 // events recorded on the stream it is launched on; psx_profile_summary() resolves them after the work has drained.

@@ -1,4 +1,5 @@
 // core.hip -- error reporting, argument packing, device probe.
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -64,6 +65,15 @@ hipEvent_t take_event() {
 
 unsigned long long *g_stamps = nullptr;
 
+namespace {
+const char *const g_dbg_names[DBG_COUNT] = {"no_dif", "no_pair", "no_dual", "no_dist_inner", "stamp_pass1", "stamp_round",
+                                            "detect_4pass"};
+const int g_dbg_default[DBG_COUNT] = {0, 0, 0, 0, 0, 1, 0};
+std::atomic<int> g_dbg[DBG_COUNT] = {{0}, {0}, {0}, {0}, {0}, {1}, {0}};
+}  // namespace
+
+int debug_switch(DebugSwitch s) { return g_dbg[s].load(std::memory_order_relaxed); }
+
 bool prof_enabled() { return g_prof_on; }
 
 int prof_begin(const char *name, hipStream_t st) {
@@ -88,7 +98,7 @@ __global__ void psx_probe_kernel(int *out) { *out = 950; }
 
 extern "C" {
 
-int psx_abi_version(void) { return 2; }   // 2: psx_accumulate_sum_f32, psx_poisson_multi_f32, psx_set_deterministic; batch vs one-distance refraction wording
+int psx_abi_version(void) { return 3; }   // 3: psx_debug_switch(es_active), psx_refract_workspace_init, psx_set_deterministic(1) allocation-free
 
 const char *psx_last_error(void) { return psx::err_buf(); }
 
@@ -113,6 +123,30 @@ int psx_device_ok(void) {
 
 int psx_debug_stamps(void *buf) {
     psx::g_stamps = (unsigned long long *)buf;
+    return 0;
+}
+
+int psx_debug_switch(const char *name, int value) {
+    if (!name) return psx::fail(PSX_E_ARG, "psx_debug_switch: null name");
+    for (int i = 0; i < psx::DBG_COUNT; ++i)
+        if (!strcmp(name, psx::g_dbg_names[i])) {
+            psx::g_dbg[i].store(value, std::memory_order_relaxed);
+            return 0;
+        }
+    return psx::fail(PSX_E_ARG, "psx_debug_switch: unknown switch '%s'", name);
+}
+
+int psx_debug_switches_active(char *buf, size_t cap) {
+    if (!buf || cap == 0) return psx::fail(PSX_E_ARG, "psx_debug_switches_active: null buffer");
+    size_t off = 0;
+    buf[0] = 0;
+    for (int i = 0; i < psx::DBG_COUNT; ++i) {
+        const int v = psx::g_dbg[i].load(std::memory_order_relaxed);
+        if (v == psx::g_dbg_default[i]) continue;
+        int n = snprintf(buf + off, cap - off, "%s%s=%d", off ? " " : "", psx::g_dbg_names[i], v);
+        if (n < 0 || (size_t)n >= cap - off) return psx::fail(PSX_E_ARG, "psx_debug_switches_active: buffer too small");
+        off += (size_t)n;
+    }
     return 0;
 }
 

@@ -932,10 +932,7 @@ int band_pair(const BandPair &pr, const BandOp &C, const BandOp &R, const float 
     return launch_check("k_band_pair");
 }
 
-bool four_pass_forced() {
-    static const bool v = [] { const char *e = getenv("PSX_DETECT_4PASS"); return e && *e && *e != '0'; }();
-    return v;
-}
+bool four_pass_forced() { return debug_switch(DBG_DETECT_4PASS) != 0; }   // diagnostics (psx_debug_switch "detect_4pass")
 
 }  // namespace
 

@@ -1465,8 +1465,8 @@ void part_geometry(int N, int margin, int &B, int &Lh, int &S, int &NB, int mcon
 // Does a line of N samples run as the two-round DIF convolution (k_fresnel_lines, DIF)?  It must be too long for one coupled
 // product, fit one convolution of 4 x 9216 points, and the block x segment partition must need more than two rounds.
 bool dif_geometry(int N, int margin) {
-    static const bool no_dif = getenv("PSX_NO_DIF") != nullptr;     // diagnostics: the round-2 partition
-    if (no_dif || getenv("PSX_NO_PAIR") != nullptr || pick_r3(N, margin)) return false;
+    // diagnostics (psx_debug_switch "no_dif" / "no_pair"): the round-2 / round-1 partition, read when a plan is created
+    if (debug_switch(DBG_NO_DIF) || debug_switch(DBG_NO_PAIR) || pick_r3(N, margin)) return false;
     int B, Lh, S, NB;
     part_geometry(N, margin, B, Lh, S, NB);
     const int P = N + 2 * margin, Mc = 2 * PART_M;
@@ -1549,7 +1549,7 @@ bool lds_engine_supported(int Nx, int Ny, int margin) {
 static int make_axis(AxisTables &t, int N, int margin, size_t &bytes) {
     t.N = N;
     t.R3 = pick_r3(N, margin);
-    static const bool no_pair = getenv("PSX_NO_PAIR") != nullptr;     // diagnostics: the round-1 partition (M-point products)
+    const bool no_pair = debug_switch(DBG_NO_PAIR) != 0;     // diagnostics: the round-1 partition (M-point products)
     if (!t.R3) {
         t.R3 = 16;
         t.part = 1;
@@ -1818,8 +1818,8 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
     // y of the blocked intermediate of each distance.  ONE launch covers all distances (work item = (distance, line
     // group)): one prologue and one tail instead of n_dist.  The in-place middle stage consumes the forward spectrum, so the
     // forward stages are repeated per distance (keeping it in registers needs 64 VGPRs the engine waves do not have).
-    static const bool stamp_pass1 = getenv("PSX_STAMP_PASS1") != nullptr;   // diagnostics only
-    static const int stamp_round = getenv("PSX_STAMP_ROUND") ? atoi(getenv("PSX_STAMP_ROUND")) : 1;
+    const bool stamp_pass1 = debug_switch(DBG_STAMP_PASS1) != 0;   // diagnostics only (psx_debug_switch)
+    const int stamp_round = debug_switch(DBG_STAMP_ROUND);
     {
         LineArgs la;
         la.N = p->Nx; la.nlines = p->Ny; la.margin = p->margin; la.P = p->Px; la.L = p->Nx + p->Px - 1;
@@ -1828,7 +1828,7 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         la.accumulate = 0; la.stamps = stamp_pass1 ? g_stamps : nullptr; la.stamp_j = stamp_round;
         la.queue = e->use_queue ? e->queue : nullptr;
         la.n_dist = nnz;
-        static const bool no_inner = getenv("PSX_NO_DIST_INNER") != nullptr;   // diagnostics: A/B of the work order
+        const bool no_inner = debug_switch(DBG_NO_DIST_INNER) != 0;   // diagnostics: A/B of the work order
         // one source for all distances: a workgroup takes the distances of a line group in consecutive rounds and fetches the
         // group once -- but only when there are enough line groups to occupy every CU that way (small grids: 32 groups of 16
         // lines at 512^2 would leave 224 CUs idle; there every (distance, group) pair is its own work item)
@@ -1854,7 +1854,7 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         la.w2 = e->ax[0].w2;
         la.w4 = e->ax[0].w4; la.wgpart = e->wgpart; la.wg_groups = e->wgpart_groups;
         la.dsh = 2 * PART_M - p->Px; la.thr = p->Nx + p->Px - 1 - 2 * PART_M;
-        static const bool no_dual = getenv("PSX_NO_DUAL") != nullptr;        // diagnostics: A/B of the shared forward transform
+        const bool no_dual = debug_switch(DBG_NO_DUAL) != 0;        // diagnostics: A/B of the shared forward transform
         if (!no_dual && la.dist_inner && nnz >= 2 && !e->ax[0].part) {
             // one line x two distances per round: the forward transform of a line is shared by the pair
             if (nnz & 1) {

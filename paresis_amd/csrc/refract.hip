@@ -80,6 +80,7 @@ struct RefractArgs {
     FarRay *far_list;        // then [ndist][ntiles][TH*TW] records (a tile can never overflow its slot)
     int tiles_x, tiles_y, tile_cap;
     unsigned long long *stamps;   // diagnostics (psx_debug_stamps): 16 phase timestamps per workgroup
+    unsigned *det_mx;             // order-independent replay (psx_set_deterministic): max word, cleared by the tile kernel
 };
 
 #define PSX_RSTAMP(k)                                                                     \
@@ -140,6 +141,9 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     if (tid == 0) {
         *sfar = 0u;
         *smax = 0u;
+        // order-independent replay: the word its first pass max-reduces into starts from zero (every reader of the previous
+        // call's value finished before this kernel started: same stream)
+        if (a.det_mx && blockIdx.x == 0) *a.det_mx = 0u;
     }
     __syncthreads();
     // Tiles whose staged window (tile + halo + stencil ring) lies inside the image -- all but the outermost ring of
@@ -459,7 +463,7 @@ __device__ __forceinline__ RefractArgs one_distance_block(const RefractTab &t, i
     a.Dx_out = nullptr; a.Dy_out = nullptr; a.I_mut = nullptr;
     a.Nx = s.Nx; a.Ny = s.Ny; a.margin = s.margin; a.clamp_xf = s.clamp_xf; a.clamp_yf = s.clamp_yf;
     a.status = s.status; a.far_count = s.far_count; a.far_list = s.far_list;
-    a.tiles_x = s.tiles_x; a.tiles_y = s.tiles_y; a.tile_cap = s.tile_cap; a.stamps = nullptr;
+    a.tiles_x = s.tiles_x; a.tiles_y = s.tiles_y; a.tile_cap = s.tile_cap; a.stamps = nullptr; a.det_mx = s.det_mx;
     return a;
 }
 
@@ -473,33 +477,31 @@ __global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // Replay of the far rays with the reference's literal border rules (RF2:235-262) in padded coordinates.
 // One WAVE per list (list = distance * ntiles + tile): a list holds a few dozen records and the kernel is a chain of
 // dependent latencies (count -> records -> atomics), so it wants as many lists in flight per CU as there are wave slots.
-// Deterministic-order debug mode (psx_set_deterministic; SURVEY.md section 5, "race detection"): the reference deposits in
-// raster order, float atomics deposit in whatever order the waves arrive.  In this mode every far-ray deposit goes, as a
-// 64-bit fixed-point integer, into an accumulator image of its own -- integer sums do not depend on the order -- and one add
-// per pixel brings the total into the float image afterwards: two runs are bitwise equal.  The unit is 2^-38 of the power of
-// two above the largest |intensity| on the lists (a max-reduction, itself order-independent).
+//
+// Order-independent form (psx_set_deterministic; SURVEY.md section 5, "race detection"): the reference
+// deposits in raster order, float atomics deposit in whatever order the waves arrive, and a far ray's last bit can flip a
+// Poisson draw downstream.  With the mode on the replay runs as THREE passes over the same lists, none of which allocates,
+// synchronises or relies on anything a previous call left behind:
+//   FAR_PREP  every share the plain replay would deposit stores 0 into a 64-bit scratch word of its target pixel (scratch
+//             = [ndist][Nx*Ny] words at the end of the caller's workspace; only touched words are ever looked at, so the
+//             region needs no initial state) and the lists' largest |intensity| is max-reduced into one word (cleared by
+//             the tile kernel; a max does not depend on the order);
+//   FAR_ADD   the shares go into those words as fixed-point integers (unit 2^-30 of the power of two above that maximum,
+//             one native float->int conversion; integer sums do not depend on the order; 2^33 of headroom);
+//   FAR_FOLD  every share exchanges its word with 0: exactly one thread per pixel receives the complete sum and adds it,
+//             ONCE, to the float image the tile kernel wrote.
+// float(tile sum) + float(far sum) is then a function of the inputs alone: two runs are bitwise equal, on any number of GPUs.
 struct DetAcc {
-    long long *acc;          // [ndist][Nx*Ny], zeroed
-    const unsigned *mx;      // float bits of the largest |out_scale * I| among the far rays
+    long long *acc;          // [ndist][Nx*Ny] scratch words (no initial state needed)
+    unsigned *mx;            // float bits of the largest |I| on the far lists of the call
 };
+enum { FAR_FLOAT = 0, FAR_PREP = 1, FAR_ADD = 2, FAR_FOLD = 3 };
 
+// psx_fastloop_f32's deterministic mode (no workspace there: scratch image + max word allocated per call)
 __device__ __forceinline__ double det_scale(const unsigned *mx) {
     int ex;
     frexpf(__uint_as_float(*mx), &ex);
     return ldexp(1.0, 38 - ex);
-}
-
-template <class G>
-__global__ __launch_bounds__(FAR_THREADS) void k_far_max(RefractArgs a, unsigned *mx) {
-    constexpr int TH = G::TH, TW = G::TW;
-    const unsigned nlists = (unsigned)(a.tiles_x * a.tiles_y) * (unsigned)a.ndist;
-    const unsigned lst = blockIdx.x * (FAR_THREADS / 64) + (threadIdx.x >> 6);
-    if (lst >= nlists) return;
-    const unsigned n = a.far_count[lst];
-    const FarRay *list = a.far_list + (size_t)lst * (TH * TW);
-    float m = 0.f;
-    for (unsigned e = threadIdx.x & 63; e < n; e += 64) m = fmaxf(m, fabsf(a.out_scale * list[e].I));
-    if (m > 0.f && m <= 3.0e38f) atomicMax(mx, __float_as_uint(m));     // non-negative floats order like their bits
 }
 
 __global__ __launch_bounds__(256) void k_det_apply(float *out, const long long *acc, const unsigned *mx, int64_t n) {
@@ -510,8 +512,10 @@ __global__ __launch_bounds__(256) void k_det_apply(float *out, const long long *
     }
 }
 
-template <class G, bool DET = false, bool ONE = false>      // ONE: a single distance (its index is then a constant)
-__device__ __forceinline__ void refract_far_body(const RefractArgs &a, const DetAcc &det) {
+template <class G, int MODE = FAR_FLOAT, bool ONE = false>      // ONE: a single distance (its index is then a constant)
+__device__ __forceinline__ void refract_far_body(const RefractArgs &a) {
+    // scratch of the order-independent passes: the max word in its own 16 bytes, the words of distance 0 behind it
+    const DetAcc det{reinterpret_cast<long long *>(a.det_mx + 4), a.det_mx};
     constexpr int TH = G::TH, TW = G::TW, H = G::H;
     const unsigned nlists = (unsigned)(a.tiles_x * a.tiles_y) * (unsigned)a.ndist;
     const unsigned lst = blockIdx.x * (FAR_THREADS / 64) + (threadIdx.x >> 6);
@@ -521,13 +525,27 @@ __device__ __forceinline__ void refract_far_body(const RefractArgs &a, const Det
     const FarRay *list = a.far_list + (size_t)lst * (TH * TW);
     const unsigned dist = ONE ? 0u : lst / (unsigned)(a.tiles_x * a.tiles_y);
     float *const I_out = a.I_out[ONE ? 0 : dist];
-    const double dscale_fix = DET ? det_scale(det.mx) : 0.0;
-    (void)dist; (void)dscale_fix;
+    (void)dist;
+    // fixed-point unit of the order-independent passes: 2^-30 of the power of two above the largest listed |I|
+    float fscale = 0.f;
+    double finv = 0.0;
+    if constexpr (MODE == FAR_ADD || MODE == FAR_FOLD) {
+        const unsigned mb = *det.mx;
+        const int sexp = min(120, max(-120, 30 - (mb ? ilogbf(__uint_as_float(mb)) + 1 : 0)));
+        fscale = ldexpf(1.f, sexp);
+        finv = ldexp(1.0, -sexp);
+    }
+    long long *const acc = MODE == FAR_FLOAT ? nullptr : det.acc + (size_t)dist * a.Nx * a.Ny;
+    float lmax = 0.f;
     const int Px = a.Nx + 2 * a.margin, Py = a.Ny + 2 * a.margin;
     for (unsigned e = threadIdx.x & 63; e < n; e += 64) {
         const FarRay fr = list[e];
         const int i = fr.src / a.Ny, j = fr.src - i * a.Ny;
         const float I = fr.I;
+        if constexpr (MODE == FAR_PREP) {
+            const float ai = fabsf(I);
+            if (ai <= 3.0e38f) lmax = fmaxf(lmax, ai);
+        }
         int bi, ni, bj, nj;
         float wbi, wni, wbj, wnj;
         axis_split_ref(fr.dx, i + a.margin, bi, ni, wbi, wni);
@@ -539,14 +557,28 @@ __device__ __forceinline__ void refract_far_body(const RefractArgs &a, const Det
                 // already deposited by the gather of the target's tile iff the source lies in that tile's window
                 const int r0 = (ui / TH) * TH, c0 = (uj / TW) * TW;
                 if (i >= r0 - H && i < r0 + TH + H && j >= c0 - H && j < c0 + TW + H) return;
-                const float add = a.out_scale * v;
-                if (a.status && !(fabsf(add) <= 3.0e38f)) atomicOr(a.status, PSX_STATUS_NONFINITE);
-                if constexpr (DET) {
-                    if (fabsf(add) <= 3.0e38f)
-                        atomicAdd(reinterpret_cast<unsigned long long *>(det.acc + (size_t)dist * a.Nx * a.Ny + (int64_t)ui * a.Ny + uj),
-                                  (unsigned long long)llrint((double)add * dscale_fix));
+                const int64_t p = (int64_t)ui * a.Ny + uj;
+                if constexpr (MODE == FAR_FLOAT) {
+                    const float add = a.out_scale * v;
+                    if (a.status && !(fabsf(add) <= 3.0e38f)) atomicOr(a.status, PSX_STATUS_NONFINITE);
+                    atomicAdd(&I_out[p], add);
+                } else if constexpr (MODE == FAR_PREP) {
+                    acc[p] = 0ll;
+                } else if constexpr (MODE == FAR_ADD) {
+                    if (!(fabsf(v) <= 3.0e38f)) {                      // NaN / inf: flagged, not summed (the caller raises, RF2:81-82)
+                        if (a.status) atomicOr(a.status, PSX_STATUS_NONFINITE);
+                        return;
+                    }
+                    int qi;
+                    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(qi) : "v"(v * fscale));   // |v| <= max |I| <= 2^-sexp * 2^30
+                    atomicAdd(reinterpret_cast<unsigned long long *>(acc + p), (unsigned long long)(long long)qi);
                 } else {
-                    atomicAdd(&I_out[(int64_t)ui * a.Ny + uj], add);
+                    const long long q = (long long)atomicExch(reinterpret_cast<unsigned long long *>(acc + p), 0ull);
+                    if (q != 0) {
+                        const float add = a.out_scale * (float)((double)q * finv);
+                        if (a.status && !(fabsf(add) <= 3.0e38f)) atomicOr(a.status, PSX_STATUS_NONFINITE);
+                        I_out[p] += add;                               // the only thread that received this pixel's sum
+                    }
                 }
             }
         };
@@ -556,17 +588,22 @@ __device__ __forceinline__ void refract_far_body(const RefractArgs &a, const Det
         deposit(ni, nj, I * wni * wnj);
         deposit(bi, nj, I * wbi * wnj);
     }
+    if constexpr (MODE == FAR_PREP) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+        if ((threadIdx.x & 63) == 0 && lmax > 0.f) atomicMax(det.mx, __float_as_uint(lmax));   // non-negative floats order like their bits
+    }
 }
 
-template <class G, bool DET = false>
-__global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a, DetAcc det) {
-    refract_far_body<G, DET>(a, det);
+template <class G, int MODE = FAR_FLOAT>
+__global__ __launch_bounds__(FAR_THREADS) void k_refract_far(RefractArgs a) {
+    refract_far_body<G, MODE>(a);
 }
 
-template <class G>
+template <class G, int MODE = FAR_FLOAT>
 __global__ __launch_bounds__(FAR_THREADS) void k_refract_far_batch(RefractTab t) {
     const RefractArgs a = one_distance_block<0>(t, blockIdx.y);
-    refract_far_body<G, false, true>(a, DetAcc{nullptr, nullptr});
+    refract_far_body<G, MODE, true>(a);
 }
 
 
@@ -623,8 +660,9 @@ __global__ __launch_bounds__(256) void k_fastloop(const float *__restrict__ I, c
 thread_local int g_refract_geometry = 0;   // 0: GeoSmall (H=4), 1: GeoWide (H=8), 2: GeoMid (H=6)
 thread_local int g_deterministic = 0;      // psx_set_deterministic
 
-// scratch of the deterministic mode: accumulators + the max word, owned for the duration of one call (debug mode: a plain
-// hipMalloc / synchronise / hipFree per call is acceptable there)
+// scratch of psx_fastloop_f32's deterministic mode (that entry point has no workspace argument): accumulators + the max
+// word, owned for the duration of one call -- a plain hipMalloc / synchronise / hipFree per call, a debugging aid.  The
+// refraction entry points take theirs from the caller's workspace and allocate nothing (refract_far_body).
 struct DetScratch {
     long long *acc = nullptr;
     unsigned *mx = nullptr;
@@ -642,10 +680,17 @@ struct DetScratch {
     }
 };
 
+// far-ray counters and lists of a call: [ndist][ntiles] counts, then [ndist][ntiles][TH*TW] records
 template <class G>
-size_t workspace_for(int Nx, int Ny, int ndist) {
+size_t lists_bytes(int Nx, int Ny, int ndist) {
     const size_t nt = (size_t)cdiv(Nx, G::TH) * (size_t)cdiv(Ny, G::TW) * (size_t)ndist;
     return 16 * ((sizeof(unsigned) * nt + 15) / 16) + sizeof(FarRay) * nt * G::TH * G::TW;
+}
+// + (order-independent replay) one max word in its own 16 bytes and [ndist][Nx*Ny] 64-bit scratch words behind the lists
+inline size_t det_bytes(int Nx, int Ny, int ndist) { return (size_t)ndist * (16 + sizeof(long long) * (size_t)Nx * (size_t)Ny); }
+template <class G>
+size_t workspace_for(int Nx, int Ny, int ndist) {
+    return lists_bytes<G>(Nx, Ny, ndist) + (g_deterministic ? det_bytes(Nx, Ny, ndist) : 0);
 }
 
 template <class G>
@@ -655,6 +700,7 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
     a.tile_cap = G::TH * G::TW;
     a.far_count = (unsigned *)workspace;
     a.far_list = (FarRay *)((char *)workspace + 16 * ((sizeof(unsigned) * (size_t)a.tiles_x * a.tiles_y * a.ndist + 15) / 16));
+    a.det_mx = g_deterministic ? (unsigned *)((char *)workspace + lists_bytes<G>(a.Nx, a.Ny, a.ndist)) : nullptr;
     int rc_launch = 0;
     auto launch = [&](auto nm, auto hi, auto hp) -> int {
         constexpr int NM = decltype(nm)::value;
@@ -668,20 +714,13 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
         if (int rc = launch_check("k_refract_near")) return rc;
         const int nlists = a.tiles_x * a.tiles_y * a.ndist;
         const int fgrid = (nlists + FAR_THREADS / 64 - 1) / (FAR_THREADS / 64);
-        if (g_deterministic) {
-            const size_t npix = (size_t)a.Nx * a.Ny;
-            DetScratch ds;
-            if (int rc = ds.alloc(npix * a.ndist, st)) return rc;
-            const DetAcc det{ds.acc, ds.mx};
-            PSX_TIMED("k_far_max", st, k_far_max<G><<<fgrid, FAR_THREADS, 0, st>>>(a, ds.mx));
-            PSX_TIMED("k_refract_far", st, k_refract_far<G, true><<<fgrid, FAR_THREADS, 0, st>>>(a, det));
-            for (int d = 0; d < a.ndist; ++d)
-                PSX_TIMED("k_det_apply", st, k_det_apply<<<ew_grid((int64_t)npix, 256), 256, 0, st>>>(a.I_out[d], ds.acc + npix * d, ds.mx, (int64_t)npix));
-            const int rc_det = launch_check("deterministic far replay");
-            const int rc_rel = ds.release(st);            // the scratch goes back also when a launch failed
-            return rc_det ? rc_det : rc_rel;
+        if (a.det_mx) {      // order-independent replay: three passes over the lists, scratch from the workspace (see DetAcc)
+            PSX_TIMED("k_refract_far_prep", st, k_refract_far<G, FAR_PREP><<<fgrid, FAR_THREADS, 0, st>>>(a));
+            PSX_TIMED("k_refract_far_add", st, k_refract_far<G, FAR_ADD><<<fgrid, FAR_THREADS, 0, st>>>(a));
+            PSX_TIMED("k_refract_far_fold", st, k_refract_far<G, FAR_FOLD><<<fgrid, FAR_THREADS, 0, st>>>(a));
+            return 0;
         }
-        PSX_TIMED("k_refract_far", st, k_refract_far<G><<<fgrid, FAR_THREADS, 0, st>>>(a, DetAcc{nullptr, nullptr}));
+        PSX_TIMED("k_refract_far", st, k_refract_far<G><<<fgrid, FAR_THREADS, 0, st>>>(a));
         return 0;
     };
     PSX_DISPATCH_NMAT(nmat, {
@@ -705,6 +744,10 @@ int launch_refract_batch(RefractTab &t, int n, bool has_I, int nmat, void *works
         const int k = e < n ? e : 0;
         a.far_count = (unsigned *)workspace + (size_t)k * nt;
         a.far_list = (FarRay *)((char *)workspace + 16 * ((sizeof(unsigned) * nt * REFRACT_TAB + 15) / 16)) + (size_t)k * nt * a.tile_cap;
+        // order-independent replay: every refraction of the chunk its own max word + scratch words behind the chunk's lists
+        a.det_mx = g_deterministic ? (unsigned *)((char *)workspace + lists_bytes<G>(a.Nx, a.Ny, REFRACT_TAB) +
+                                                  (size_t)k * det_bytes(a.Nx, a.Ny, 1))
+                                   : nullptr;
     }
     int rc_launch = 0;
     auto launch = [&](auto nm, auto hi) -> int {
@@ -717,7 +760,14 @@ int launch_refract_batch(RefractTab &t, int n, bool has_I, int nmat, void *works
         PSX_TIMED("k_refract_near", st, k_refract_near_batch<G, NM, HI><<<dim3((unsigned)nt, (unsigned)n), G::NT, G::LDS, st>>>(t));
         if (int rc = launch_check("k_refract_near")) return rc;
         const int fgrid = ((int)nt + FAR_THREADS / 64 - 1) / (FAR_THREADS / 64);
-        PSX_TIMED("k_refract_far", st, k_refract_far_batch<G><<<dim3((unsigned)fgrid, (unsigned)n), FAR_THREADS, 0, st>>>(t));
+        const dim3 fg((unsigned)fgrid, (unsigned)n);
+        if (t.e[0].det_mx) {
+            PSX_TIMED("k_refract_far_prep", st, k_refract_far_batch<G, FAR_PREP><<<fg, FAR_THREADS, 0, st>>>(t));
+            PSX_TIMED("k_refract_far_add", st, k_refract_far_batch<G, FAR_ADD><<<fg, FAR_THREADS, 0, st>>>(t));
+            PSX_TIMED("k_refract_far_fold", st, k_refract_far_batch<G, FAR_FOLD><<<fg, FAR_THREADS, 0, st>>>(t));
+        } else {
+            PSX_TIMED("k_refract_far", st, k_refract_far_batch<G><<<fg, FAR_THREADS, 0, st>>>(t));
+        }
         return launch_check("k_refract_far");
     };
     PSX_DISPATCH_NMAT(nmat, {
@@ -837,16 +887,6 @@ int psx_refract_batch_f32(int n, const float *const *I_in, const float *I0, cons
         for (int f = 0; f < e; ++f) PSX_REQUIRE(I_out[f] != I_out[e], "psx_refract_batch_f32: refractions %d and %d share an output image", f, e);
     }
     hipStream_t st = (hipStream_t)stream;
-    if (g_deterministic) {                    // debug mode: one refraction at a time through the scratch accumulators
-        const size_t one = psx_refract_workspace_bytes(Nx, Ny);
-        (void)one;
-        for (int e = 0; e < n; ++e)
-            if (int rc = psx_refract_f32(has_I ? I_in[e] : nullptr, I0 ? I0[e] : 1.f, T, cphase ? cphase + (size_t)e * nmat : nullptr,
-                                         catt ? catt + (size_t)e * nmat : nullptr, nmat, nullptr, I_out[e], out_scale, accumulate,
-                                         nullptr, nullptr, nullptr, Nx, Ny, margin, dscale[e], clamp_x, clamp_y, status, workspace, stream))
-                return rc;
-        return 0;
-    }
     PSX_REQUIRE(Nx >= 3 && Ny >= 3, "psx_refract_batch_f32: grid %dx%d too small for the edge_order=2 gradient", Nx, Ny);
     PSX_REQUIRE((int64_t)Nx * Ny < (1ll << 31), "psx_refract_batch_f32: grid %dx%d exceeds int32 pixel indices", Nx, Ny);
     PSX_REQUIRE(margin >= 8 && margin <= 4096, "psx_refract_batch_f32: margin %d must be >= 8 (the widest gather halo)", margin);

@@ -451,6 +451,19 @@ def set_deterministic(on=True):
     check(lib().psx_set_deterministic(1 if on else 0), "psx_set_deterministic")
 
 
+def debug_switch(name, value=1):
+    """A diagnostic A/B switch of the library (psx_debug_switch; include/paresis_hip.h lists the names).  Process-wide, off by
+    default; for tools and tests -- the library never reads the environment."""
+    check(lib().psx_debug_switch(str(name).encode(), int(value)), "psx_debug_switch")
+
+
+def debug_switches_active():
+    """'name=value ...' of every diagnostic switch that is not at its default ('' = a clean product run)."""
+    buf = ctypes.create_string_buffer(512)
+    check(lib().psx_debug_switches_active(buf, len(buf)), "psx_debug_switches_active")
+    return buf.value.decode()
+
+
 def fastloop(I, Dx, Dy, I2):
     """fastloopNumba (refractionFileNumba2.py:198-263) on explicit float32 displacement maps; accumulates into I2."""
     _need(I, torch.float32, "I")

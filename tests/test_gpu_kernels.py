@@ -471,6 +471,67 @@ def test_deterministic_order_mode(ops):
     assert float((I2 - outs[0]).abs().max() / outs[0].abs().max()) < 2e-6
 
 
+def test_order_independent_far_replay_needs_no_workspace_state(ops):
+    """the allocation-free order-independent replay (three passes over the far lists, scratch words inside
+    the caller's workspace).  The scratch has NO initial state: the workspace is filled with garbage before every call and
+    shared between calls of different shapes (one distance, a distance batch, an energy batch, accumulate mode); every image is
+    bitwise reproducible, equal to the one-distance call's, and within float rounding of the float-atomic replay."""
+    import paresis_amd.ops as O
+    rng = np.random.default_rng(5)
+    Nx, Ny = 333, 290
+    T = dev(np.stack([np.cumsum(rng.uniform(0, 2e-5, (Nx, Ny)), axis=0), rng.uniform(0, 3e-4, (Nx, Ny))]), torch.float32)
+    k = 2.6e11
+    mats = ops.MaterialStack(T, cphase=[-k * 6.2e-7, -k * 9.9e-8], catt=[-2 * k * 4e-9, -2 * k * 4.5e-11])
+    ds = [1.0, 2.2, 3.1, 4.5]            # displacement scale: rad/pixel of phase gradient -> pixels
+    plain = ops.refract_multi((Nx, Ny), mats, ds, (Nx, Ny), I0=100.0)
+    torch.cuda.synchronize()
+
+    def trash():
+        for buf in O._workspaces.values():
+            buf.random_(0, 255)
+
+    try:
+        ops.set_deterministic(True)
+        runs = []
+        for _ in range(2):
+            trash()
+            runs.append([t.clone() for t in ops.refract_multi((Nx, Ny), mats, ds, (Nx, Ny), I0=100.0)])
+        for d in range(4):
+            assert torch.equal(runs[0][d], runs[1][d]), d
+            err = float((runs[0][d] - plain[d]).abs().max() / plain[d].abs().max())
+            assert err < 2e-6, (d, err)
+            trash()
+            one = ops.refract((Nx, Ny), mats, ds[d], (Nx, Ny), I0=100.0)[0]
+            assert torch.equal(one, runs[0][d]), d                # the batch is the one-distance call, bit for bit
+        # accumulate mode (the energy sum of the chain): out += refraction, twice -> deterministic as well
+        acc = []
+        for _ in range(2):
+            o = torch.full((Nx, Ny), 3.0, dtype=torch.float32, device="cuda")
+            trash()
+            ops.refract((Nx, Ny), mats, ds[3], (Nx, Ny), I0=100.0, out=o, add=True)
+            acc.append(o)
+        assert torch.equal(acc[0], acc[1])
+        assert float((acc[0] - 3.0 - runs[0][3]).abs().max() / runs[0][3].abs().max()) < 1e-6
+        # energy batch (psx_refract_batch_f32): 3 coefficient sets over the same maps, one launch per pass
+        stacks = [mats.with_coeffs(cphase=[c * f for c in mats.cphase], catt=mats.catt) for f in (1.0, 0.8, 1.3)]
+        eb = []
+        for _ in range(2):
+            trash()
+            eb.append([t.clone() for t in ops.refract_batch((Nx, Ny), stacks, [ds[2]] * 3, (Nx, Ny), I0=[100.0, 90.0, 80.0])])
+        for e in range(3):
+            assert torch.equal(eb[0][e], eb[1][e]), e
+            trash()
+            one = ops.refract((Nx, Ny), stacks[e], ds[2], (Nx, Ny), I0=[100.0, 90.0, 80.0][e])[0]
+            assert torch.equal(one, eb[0][e]), e
+    finally:
+        ops.set_deterministic(False)
+    ops.check_status(T.device)
+    # the case must have far rays at all: the float-atomic replay differs from the fixed-point one somewhere, or at least the
+    # far lists are not empty (displacements beyond the 4-pixel halo)
+    gx = np.abs(np.gradient(T[0].cpu().numpy().astype(np.float64) * mats.cphase[0] + T[1].cpu().numpy().astype(np.float64) * mats.cphase[1], axis=0))
+    assert (gx * ds[3]).max() > 6
+
+
 def test_pack_counts_roundtrip_and_overflow(ops):
     """psx_pack_counts_u16 / psx_unpack_counts_u16 (the gather of the per-position stacks moves photon counts as 16-bit
     integers): exact round trip for every count 0..65534 and, through the exception table, for larger counts up to 2^24;

@@ -347,9 +347,12 @@ def test_edf_reader_accepts_foreign_headers(tmp_path):
     assert np.allclose(openImage(f), img.astype(np.float64))
 
 
-def test_bench_starts_its_own_ranks_and_rejects_a_world_mismatch(monkeypatch):
+def test_bench_starts_its_own_ranks_and_rejects_a_world_mismatch(monkeypatch, capsys):
     """`bench.py --gpus N` outside torchrun launches N ranks through torch.distributed.run (before touching the GPU) and leaves
-    with the child's exit code; under torchrun a --gpus that disagrees with WORLD_SIZE is refused."""
+    with the child's exit code -- after ONE JSON line on stdout that says the ranks died, when they did (the driver parses
+    stdout; a launcher that exits non-zero used to leave nothing there); under torchrun a --gpus that disagrees with
+    WORLD_SIZE is refused."""
+    import json
     import subprocess
     import sys
     import bench
@@ -366,6 +369,8 @@ def test_bench_starts_its_own_ranks_and_rejects_a_world_mismatch(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 7
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["rc"] == 7 and line["n_gpus"] == 4 and line["value"] is None and "error" in line and line["processes_started"] == 6
     cmd = seen["cmd"]
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]

@@ -2,6 +2,8 @@ import os, sys, ctypes, time
 sys.path.insert(0, "/root/repo")
 import torch
 from paresis_amd import ops, _lib
+import _switches                      # PSX_SWITCHES="no_dif=1 ..." -> psx_debug_switch (the library reads no environment)
+_switches.apply()
 lib = _lib.lib()
 N = 16384
 plan = ops.FresnelPlan(N, N, max_dist=1)

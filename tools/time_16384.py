@@ -4,6 +4,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from paresis_amd import ops
+import _switches                      # PSX_SWITCHES="no_dif=1 ..." -> psx_debug_switch (the library reads no environment)
+_switches.apply()
 N, ov, n = 16384, 4, 4096
 def wall(f, n=3):
     f(); torch.cuda.synchronize()

@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from paresis_amd import ops
+import _switches                      # PSX_SWITCHES="no_dif=1 ..." -> psx_debug_switch (the library reads no environment)
+_switches.apply()
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 ov = int(sys.argv[2]) if len(sys.argv) > 2 else 2

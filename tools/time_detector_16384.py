@@ -2,6 +2,8 @@ import ctypes, os, sys, time, types
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 from paresis_amd import _lib, ops
+import _switches                      # PSX_SWITCHES="no_dif=1 ..." -> psx_debug_switch (the library reads no environment)
+_switches.apply()
 lib = _lib.lib()
 N, ov = 16384, 4
 n = N // ov
