@@ -37,15 +37,25 @@ struct Geo {
     static constexpr int GR = TH + 2 * H, GC = TW + 2 * H;           // source pixels gathered by one tile
     // accumulator: the tile plus a one-pixel guard ring (a ray whose base pixel lies in [-1, TH-1] x [-1, TW-1] deposits
     // its four shares at base + {0, 1, AW, AW+1} with no per-share test; the ring is never written out), then a trash
-    // area for rays that miss altogether
-    // Row pitch AW = 64 entries (not TW + 2): 128 dwords, a multiple of the 64 banks.  Two lanes of a ds_add_u64 then share a
-    // bank only when they hit the SAME column in different rows -- neighbouring lanes whose displacements differ in both
-    // floor(dx) and floor(dy) -- where the pitch TW + 2 = 58 (116 dwords = 52 mod 64) made every pair of lanes 6 or 26 apart
-    // collide as soon as their floor(dx) differed (SQ_LDS_BANK_CONFLICT 35 % of the LDS-active cycles, profiles/r02).
-    // A ray that misses the tile adds its shares to the bottom guard row (never read), at the column of its would-be target
-    // modulo the pitch; the shares at +AW land in one more row behind it: TRASH = that row.
-    static constexpr int AW = 64, ACC = (TH + 2) * AW, TRASH = AW + 2;
+    // area for rays that miss altogether.
+    // Two layout choices, kept as build-time switches for the A/B of VERDICT r3 item 3 (tools/ab_refract.sh):
+    //   PSX_ACC_PITCH  row pitch AW in entries: 58 -> TW + 2 (116 dwords = 52 mod 64 banks: lanes 6 or 26 apart share a bank as
+    //                  soon as their floor(dx) differ), 64 -> 128 dwords (lanes collide only in the same column of different rows)
+    //   PSX_MISS       where a ray that misses the tile adds its shares: 0 -> a slot of its own behind the accumulator
+    //                  (ACC + 2*lane; pitch 58 only: with pitch 64 the area no longer fits two workgroups per CU), 1 -> the
+    //                  bottom guard row (never read) at its lane's column, 2 -> the guard row at the column of its would-be
+    //                  target modulo the pitch (pitch 64 only)
+#ifndef PSX_ACC_PITCH
+#define PSX_ACC_PITCH 64
+#endif
+#ifndef PSX_MISS
+#define PSX_MISS 2
+#endif
+    static constexpr int AW = PSX_ACC_PITCH == 64 ? 64 : TW + 2, ACC = (TH + 2) * AW;
+    static constexpr int MISS = PSX_MISS;
+    static constexpr int TRASH = MISS == 0 ? 2 * 64 + AW + 2 : 64 + 2;
     static_assert(AW >= TW + 2, "accumulator pitch");
+    static_assert(MISS != 2 || (AW & (AW - 1)) == 0, "target-column misses need a power-of-two pitch");
     static constexpr size_t LDS = sizeof(double) * SR * SC + sizeof(float) * GR * GC + sizeof(long long) * (ACC + TRASH) + 16;
 };
 using GeoSmall = Geo<56, 56, 4, 1024>;   // 80 KiB of LDS: two workgroups per CU; 1.31 source evaluations per pixel
@@ -361,7 +371,10 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
             // a miss goes to the column its target WOULD have had: the lanes of a wave then keep their distinct banks whether
             // they hit or miss (at column = lane, the eight halo-column lanes of every row collided with hits three or four
             // lanes away -- a two-way conflict in nearly every deposit instruction)
-            long long *acc = sacc + (hit ? aidx : (TH + 1) * AW + (tj & (AW - 1)));
+            long long *acc = sacc + (hit ? aidx
+                                         : G::MISS == 0 ? ACC + 2 * lane
+                                         : G::MISS == 1 ? (TH + 1) * AW + lane
+                                                        : (TH + 1) * AW + (tj & (AW - 1)));
             // float -> fixed point with one native conversion: the unit is 2^-30 of (the power of two above) the
             // largest staged intensity, so |v|*2^s <= 2^30 fits int32; the 64-bit sum has 2^33 of headroom
             auto dep = [&](int off, float v) __attribute__((always_inline)) {

@@ -127,6 +127,16 @@ def test_partitioned_lds_engine_matches_rocfft_and_oracle(shape):
     plan.close()
     ref = orc.wave_propagation(col.cpu().numpy().astype(np.complex128), zs[0], 52.0, 1.01, (Nx, 64), h * 1e6)
     assert relmax(out.cpu().numpy(), ref) < 1e-5
+    # ... and on axis 1 alone when it does not vary along axis 0: long lines ALONG AXIS 1 are pass 2 of the engine (strided
+    # reads of the blocked intermediate; for 12 280 <= Ny <= 18 402 the <16, false, PART, PAIR, ., ., DIF> instance, config 5's
+    # dominant kernel), which the axis-0 strip never reaches
+    if Ny > 4593:
+        row = w[:1, :].expand(64, Ny).contiguous()
+        plan = ops.FresnelPlan(64, Ny, engine=2)
+        out = plan.propagate(a[:1], gp[:1], (2 * np.pi / (64 * h), du[1]), wave_in=row)[0]
+        plan.close()
+        ref = orc.wave_propagation(row.cpu().numpy().astype(np.complex128), zs[0], 52.0, 1.01, (64, Ny), h * 1e6)
+        assert relmax(out.cpu().numpy(), ref) < 1e-5, ("axis 1", shape)
 
 
 @pytest.mark.parametrize("N", [1024])

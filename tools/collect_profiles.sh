@@ -2,6 +2,7 @@
 # Collects the rocprofv3 evidence for profiles/ on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 900 -- 'bash tools/collect_profiles.sh'                      # the default bench run (4096^2)
 #   gpurun --timeout 900 -- 'bash tools/collect_profiles.sh _16384 --size 16384 --steps 3 --warmup 1'
+#   gpurun --timeout 900 -- 'bash tools/collect_profiles.sh _cfg5 --only-configs --configs 16384'   # config 5 as on the driver's line
 # then, back in the container:  python tools/summarise_profiles.py r02 [_16384]
 # Kernel statistics and every PMC group are separate runs (counters are never combined with a trace), the profiled
 # program is `python3 bench.py ...` itself (nothing between `--` and it).
@@ -16,6 +17,9 @@ for arg in "$@"; do
     esac
 done
 CMD="python3 $ROOT/bench.py --no-cpu-baseline --positions 0 --no-configs $*"      # the bench run (timed steps + the per-kernel event pass), minus the CPU leg and the positions batch
+case " $* " in
+    *" --only-configs "*) CMD="python3 $ROOT/bench.py $*";;     # a `configs` entry alone, as the driver's line runs it (GPU membrane, halo 8, detector)
+esac
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/fin_stats$SFX $OUT/fin_fetch$SFX $OUT/fin_write$SFX $OUT/fin_sq$SFX
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fin_stats$SFX -o runc -- $CMD > $OUT/fin_stats$SFX.log 2>&1
