@@ -142,8 +142,9 @@ int psx_refract_batch_f32(int n, const float *const *I_in, const float *I0, cons
  * tile gathers are fixed point and reproducible as they are, but far rays and psx_fastloop_f32 deposit with global float
  * atomics in arrival order, and a last-bit difference can flip a Poisson draw downstream).  With on != 0 the far-ray replay of
  * psx_refract_f32 / _multi_f32 / _batch_f32 runs as three passes over the same lists -- clear the touched 64-bit scratch
- * words and max-reduce the listed intensities; add the shares as fixed-point integers; exchange every touched word with 0
- * and add its sum ONCE to the float image -- so that two runs of the same call are bitwise equal, whatever the GPU count.
+ * words; add every share as a fixed-point integer in the unit of its target's tile with a returning atomic (the thread that
+ * reads back zero was first at that pixel); let the first depositor of each pixel add the complete sum ONCE to the float
+ * image -- so that two runs of the same call are bitwise equal, whatever the GPU count.  One atomic per share, as before.
  * Allocates nothing and synchronises nothing: the scratch ([ndist][Nx*Ny] words) is part of the caller's workspace, needs
  * no initial state, and psx_refract_*_workspace_bytes() includes it WHILE THE MODE IS ON (set the mode, then size the
  * workspace).  psx_fastloop_f32, which has no workspace argument, keeps the allocating form (hipMalloc + a stream

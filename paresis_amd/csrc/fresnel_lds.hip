@@ -56,7 +56,12 @@ constexpr int RAD = 24;       // radix of the two big stages
 // The intermediate between the two passes is stored in blocks of IB samples of a pass-1 line: [Nx/IB][Ny][IB].  Pass 1
 // still writes whole 128-byte lines (2 image rows x 8 samples), and the 16-byte pieces a pass-2 workgroup reads (two
 // adjacent pass-2 lines) sit 64 bytes apart instead of a whole image row: half the cache lines per wave load.
-constexpr int IB = 8;
+#ifndef PSX_IB
+#define PSX_IB 8              // build-time A/B of the block shape (tools/ab_ib.sh): 4, 8, 16
+#endif
+constexpr int IB = PSX_IB;
+constexpr int IBS = IB == 4 ? 2 : (IB == 8 ? 3 : 4);      // log2(IB)
+static_assert((1 << IBS) == IB, "intermediate block size");
 constexpr int QUEUE_WORDS = 16 * 257;     // work queues: a counter per workgroup (<= 256, 64 bytes apart) + the count of workgroups done
 #ifndef PSX_DIF_NHA
 #define PSX_DIF_NHA 52        // DIF rounds: window positions (of 72 per loader thread) that travel during the transform
@@ -984,7 +989,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             float *io = a.inten_out[dd];
             const float sc = a.scale[dd];
             const v2f gp = (v2f){a.gph[dd].x, a.gph[dd].y};
-            static_assert(S1 % IB == 0 && IB == 8, "blocked output stride; the block index below is i >> 3");
+            static_assert(S1 % IB == 0, "blocked output stride; the block index below is i >> IBS");
             if constexpr (DIF) {
                 // leg q holds point n' = n0 + 768 q of this round's 2M-point result (n0 = tid).  Round E parks it in the
                 // workgroup's own line buffer (legs 2k and 2k+1 of a thread side by side: the thread that writes is the thread
@@ -1031,7 +1036,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                     const int l = l0;
                     const bool lok = l < a.nlines;
                     const int ifirst = to + 2 * M - (a.P - 1);               // sample index of leg 0, not wrapped
-                    const unsigned e0 = a.out_blocked ? (unsigned)(((ifirst >> 3) * a.nlines + l) * IB + (ifirst & (IB - 1))) : (unsigned)ifirst;
+                    const unsigned e0 = a.out_blocked ? (unsigned)(((ifirst >> IBS) * a.nlines + l) * IB + (ifirst & (IB - 1))) : (unsigned)ifirst;
                     const unsigned estep = a.out_blocked ? (unsigned)((QS / IB) * a.nlines * IB) : (unsigned)QS;
                     const unsigned ewrap = e0 - (a.out_blocked ? (unsigned)((2 * M / IB) * a.nlines * IB) : (unsigned)(2 * M));
                     const int64_t wbase = a.out_blocked ? (int64_t)0 : (int64_t)l * a.out_ld;
@@ -1086,7 +1091,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 const int l = l0 + (PAIR ? 0 : __builtin_amdgcn_readfirstlane(DUAL ? lineAo % LH : lineAo));
                 const bool lok = l < a.nlines;
                 // element index of output i inside the window: plain rows: i (window = row l); blocked: ((i>>3)*nlines+l)*8 + i%8
-                const int e0 = a.out_blocked ? ((ifirst >> 3) * a.nlines + l) * IB + (ifirst & (IB - 1)) : ifirst;
+                const int e0 = a.out_blocked ? ((ifirst >> IBS) * a.nlines + l) * IB + (ifirst & (IB - 1)) : ifirst;
                 constexpr int QS = PAIR ? 2 * S1 : S1;                    // output samples between two outputs of a butterfly
                 const int estep = a.out_blocked ? (QS / IB) * a.nlines * IB : QS;
                 // PART: the window is the output block only -- samples [b*B, b*B + Bv) of the line; in the blocked layout
@@ -1168,7 +1173,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             } else if (l0 + (DUAL ? lineAo % LH : lineAo) < a.nlines) {
                 // short lines (R3 <= 4): a wave straddles lines, per-lane pointers and masks
                 const int lsh = l0 + (DUAL ? lineAo % LH : lineAo);
-                const int64_t ob = a.out_blocked ? ((int64_t)(ifirst >> 3) * a.nlines + lsh) * IB + (ifirst & (IB - 1))
+                const int64_t ob = a.out_blocked ? ((int64_t)(ifirst >> IBS) * a.nlines + lsh) * IB + (ifirst & (IB - 1))
                                                  : (int64_t)lsh * a.out_ld + ifirst;
                 const int64_t oq = a.out_blocked ? (int64_t)(S1 / IB) * a.nlines * IB : (int64_t)S1;
                 if (wo) wo += ob;
@@ -1444,20 +1449,21 @@ int pick_r3(int N, int margin) {
 // Lines longer than that: partition outputs (blocks of B, a multiple of 8) and kernel taps (segments of Lh) so that one
 // block x segment product is an M-point convolution, B + Lh - 1 <= M; fewest products, then fewest segments.
 constexpr int PART_M = 576 * 16;
+constexpr int BR = IB > 8 ? IB : 8;      // output blocks start on a block boundary of the intermediate
 // mconv: points of one product -- PART_M, or 2 * PART_M when the two LDS lines are coupled into one transform (PAIR)
 void part_geometry(int N, int margin, int &B, int &Lh, int &S, int &NB, int mconv = 2 * PART_M) {
     const int P = N + 2 * margin;
     long best = -1;
     for (int s = 1; s <= 64; ++s) {
         const int lh = (P + s - 1) / s;
-        const int bmax = (mconv - lh + 1) / 8 * 8;
-        if (bmax < 8) continue;
+        const int bmax = (mconv - lh + 1) / BR * BR;
+        if (bmax < BR) continue;
         const int nb = (N + bmax - 1) / bmax;
         const long cost = (long)s * nb;
         if (best < 0 || cost < best) {
             best = cost;
             S = s; Lh = lh; NB = nb;
-            B = ((N + nb - 1) / nb + 7) / 8 * 8;
+            B = ((N + nb - 1) / nb + BR - 1) / BR * BR;
         }
     }
 }
@@ -1561,7 +1567,7 @@ static int make_axis(AxisTables &t, int N, int margin, size_t &bytes) {
             t.dif = 1;
             t.S = 2;
             t.NB = 1;
-            t.B = (N + 7) / 8 * 8;
+            t.B = (N + BR - 1) / BR * BR;
             t.Lh = N + 2 * margin;
         }
     }

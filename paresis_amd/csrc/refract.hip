@@ -45,11 +45,14 @@ struct Geo {
     //                  (ACC + 2*lane; pitch 58 only: with pitch 64 the area no longer fits two workgroups per CU), 1 -> the
     //                  bottom guard row (never read) at its lane's column, 2 -> the guard row at the column of its would-be
     //                  target modulo the pitch (pitch 64 only)
+    // Measured (round 4, gpurun_out/r4s1; k_refract_near per 4-distance launch at 4096^2 / 16384^2): 58/0 267.5 us / 3.92 ms
+    // (round 2's layout), 58/1 266.7 / 3.91, 64/1 268.6 / 3.89, 64/2 275.3 / 4.00 (round 3's: the regression): the default
+    // is 58/1.  (Measured conflict ratios hardly differ: what is counted are same-address collisions of the scatter.)
 #ifndef PSX_ACC_PITCH
-#define PSX_ACC_PITCH 64
+#define PSX_ACC_PITCH 58
 #endif
 #ifndef PSX_MISS
-#define PSX_MISS 2
+#define PSX_MISS 1
 #endif
     static constexpr int AW = PSX_ACC_PITCH == 64 ? 64 : TW + 2, ACC = (TH + 2) * AW;
     static constexpr int MISS = PSX_MISS;
@@ -64,6 +67,7 @@ using GeoSmall = Geo<56, 56, 4, 1024>;   // 80 KiB of LDS: two workgroups per CU
 using GeoMid = Geo<52, 52, 6, 1024>;     // 76 KiB; 1.51 evaluations
 using GeoWide = Geo<48, 48, 8, 1024>;    // 73 KiB: two workgroups per CU (one stages while the other deposits); 1.78 evaluations
 constexpr int FAR_THREADS = 256;
+constexpr int DET_NO_UNIT = -(1 << 30);     // det_sexp entry of a tile without a fixed-point unit (all-zero or non-finite window)
 
 // a far ray, already evaluated by the tile that owns its source pixel
 struct FarRay {
@@ -90,7 +94,10 @@ struct RefractArgs {
     FarRay *far_list;        // then [ndist][ntiles][TH*TW] records (a tile can never overflow its slot)
     int tiles_x, tiles_y, tile_cap;
     unsigned long long *stamps;   // diagnostics (psx_debug_stamps): 16 phase timestamps per workgroup
-    unsigned *det_mx;             // order-independent replay (psx_set_deterministic): max word, cleared by the tile kernel
+    // order-independent far-ray replay (psx_set_deterministic; null otherwise), all inside the caller's workspace:
+    int *det_sexp;                // [ntiles] fixed-point exponent of each tile (written by the tile kernel: no initial state)
+    unsigned char *det_marks;     // [ndist][ntiles][TH*TW] which shares of a far ray were the first to reach their pixel
+    long long *det_acc;           // [ndist][Nx*Ny] scratch words (only touched words are ever looked at: no initial state)
 };
 
 #define PSX_RSTAMP(k)                                                                     \
@@ -151,9 +158,6 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     if (tid == 0) {
         *sfar = 0u;
         *smax = 0u;
-        // order-independent replay: the word its first pass max-reduces into starts from zero (every reader of the previous
-        // call's value finished before this kernel started: same stream)
-        if (a.det_mx && blockIdx.x == 0) *a.det_mx = 0u;
     }
     __syncthreads();
     // Tiles whose staged window (tile + halo + stencil ring) lies inside the image -- all but the outermost ring of
@@ -270,6 +274,9 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     const int sexp = min(120, max(-120, 30 - (mbits ? ilogbf(__uint_as_float(mbits)) + 1 : 0)));
     const float fscale_f = finite_in ? ldexpf(1.f, sexp) : 0.f;     // power of two: scaling a float by it is exact
     const double finv = finite_in ? ldexp(1.0, -sexp) : 0.0;
+    // order-independent far-ray replay: far shares that land in this tile are summed in THIS tile's fixed-point unit (every
+    // tile writes its entry on every call; DET_NO_UNIT: the tile has no finite non-zero intensity to take a unit from)
+    if (a.det_sexp && tid == 0) a.det_sexp[tile] = (finite_in && mbits) ? sexp : DET_NO_UNIT;
 
 
     // ---- every source pixel of tile+halo deposits what lands inside this tile.
@@ -476,7 +483,8 @@ __device__ __forceinline__ RefractArgs one_distance_block(const RefractTab &t, i
     a.Dx_out = nullptr; a.Dy_out = nullptr; a.I_mut = nullptr;
     a.Nx = s.Nx; a.Ny = s.Ny; a.margin = s.margin; a.clamp_xf = s.clamp_xf; a.clamp_yf = s.clamp_yf;
     a.status = s.status; a.far_count = s.far_count; a.far_list = s.far_list;
-    a.tiles_x = s.tiles_x; a.tiles_y = s.tiles_y; a.tile_cap = s.tile_cap; a.stamps = nullptr; a.det_mx = s.det_mx;
+    a.tiles_x = s.tiles_x; a.tiles_y = s.tiles_y; a.tile_cap = s.tile_cap; a.stamps = nullptr;
+    a.det_sexp = s.det_sexp; a.det_marks = s.det_marks; a.det_acc = s.det_acc;
     return a;
 }
 
@@ -495,20 +503,26 @@ __global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // deposits in raster order, float atomics deposit in whatever order the waves arrive, and a far ray's last bit can flip a
 // Poisson draw downstream.  With the mode on the replay runs as THREE passes over the same lists, none of which allocates,
 // synchronises or relies on anything a previous call left behind:
-//   FAR_PREP  every share the plain replay would deposit stores 0 into a 64-bit scratch word of its target pixel (scratch
-//             = [ndist][Nx*Ny] words at the end of the caller's workspace; only touched words are ever looked at, so the
-//             region needs no initial state) and the lists' largest |intensity| is max-reduced into one word (cleared by
-//             the tile kernel; a max does not depend on the order);
-//   FAR_ADD   the shares go into those words as fixed-point integers (unit 2^-30 of the power of two above that maximum,
-//             one native float->int conversion; integer sums do not depend on the order; 2^33 of headroom);
-//   FAR_FOLD  every share exchanges its word with 0: exactly one thread per pixel receives the complete sum and adds it,
-//             ONCE, to the float image the tile kernel wrote.
+//   FAR_PREP  every share the plain replay would deposit stores 0 into the 64-bit scratch word of its target pixel (scratch
+//             = [ndist][Nx*Ny] words inside the caller's workspace; only touched words are ever looked at, so the region
+//             needs no initial state);
+//   FAR_ADD   the share goes into that word as a fixed-point integer in the unit of the TARGET's tile (2^-30 of the power
+//             of two above the largest intensity that tile staged: the tile kernel leaves it in det_sexp[tile] on every call)
+//             with a RETURNING atomic add.  The word is [12-bit deposit counter | 52-bit two's-complement sum]: every deposit
+//             also adds 1 << 52, so the word is zero only before the first deposit -- whatever the signs of the shares --
+//             and the thread that reads back 0 knows it was first; it notes that in the ray's mark byte;
+//   FAR_FOLD  the first depositor of a pixel reads the complete sum (plain load: the kernel boundary ordered every add
+//             before it) and adds it, ONCE, to the float image the tile kernel wrote.
 // float(tile sum) + float(far sum) is then a function of the inputs alone: two runs are bitwise equal, on any number of GPUs.
+// One atomic per share, as in the float form; the other two passes are plain stores / loads.  Shares that have no unit (the
+// target tile staged nothing but zeros, or something non-finite) or exceed 2^20 times the tile's largest intensity keep the
+// float atomic: a black tile next to a bright one, not a case the order of the sums can matter in beyond that tile.
 struct DetAcc {
-    long long *acc;          // [ndist][Nx*Ny] scratch words (no initial state needed)
-    unsigned *mx;            // float bits of the largest |I| on the far lists of the call
+    long long *acc;          // psx_fastloop_f32's deterministic mode (see below)
+    const unsigned *mx;
 };
 enum { FAR_FLOAT = 0, FAR_PREP = 1, FAR_ADD = 2, FAR_FOLD = 3 };
+constexpr unsigned long long DET_ONE = 1ull << 52, DET_MASK = DET_ONE - 1ull;
 
 // psx_fastloop_f32's deterministic mode (no workspace there: scratch image + max word allocated per call)
 __device__ __forceinline__ double det_scale(const unsigned *mx) {
@@ -527,8 +541,6 @@ __global__ __launch_bounds__(256) void k_det_apply(float *out, const long long *
 
 template <class G, int MODE = FAR_FLOAT, bool ONE = false>      // ONE: a single distance (its index is then a constant)
 __device__ __forceinline__ void refract_far_body(const RefractArgs &a) {
-    // scratch of the order-independent passes: the max word in its own 16 bytes, the words of distance 0 behind it
-    const DetAcc det{reinterpret_cast<long long *>(a.det_mx + 4), a.det_mx};
     constexpr int TH = G::TH, TW = G::TW, H = G::H;
     const unsigned nlists = (unsigned)(a.tiles_x * a.tiles_y) * (unsigned)a.ndist;
     const unsigned lst = blockIdx.x * (FAR_THREADS / 64) + (threadIdx.x >> 6);
@@ -539,72 +551,65 @@ __device__ __forceinline__ void refract_far_body(const RefractArgs &a) {
     const unsigned dist = ONE ? 0u : lst / (unsigned)(a.tiles_x * a.tiles_y);
     float *const I_out = a.I_out[ONE ? 0 : dist];
     (void)dist;
-    // fixed-point unit of the order-independent passes: 2^-30 of the power of two above the largest listed |I|
-    float fscale = 0.f;
-    double finv = 0.0;
-    if constexpr (MODE == FAR_ADD || MODE == FAR_FOLD) {
-        const unsigned mb = *det.mx;
-        const int sexp = min(120, max(-120, 30 - (mb ? ilogbf(__uint_as_float(mb)) + 1 : 0)));
-        fscale = ldexpf(1.f, sexp);
-        finv = ldexp(1.0, -sexp);
-    }
-    long long *const acc = MODE == FAR_FLOAT ? nullptr : det.acc + (size_t)dist * a.Nx * a.Ny;
-    float lmax = 0.f;
+    long long *const acc = MODE == FAR_FLOAT ? nullptr : a.det_acc + (size_t)dist * a.Nx * a.Ny;
+    unsigned char *const marks = MODE == FAR_FLOAT ? nullptr : a.det_marks + (size_t)lst * (TH * TW);
     const int Px = a.Nx + 2 * a.margin, Py = a.Ny + 2 * a.margin;
     for (unsigned e = threadIdx.x & 63; e < n; e += 64) {
         const FarRay fr = list[e];
         const int i = fr.src / a.Ny, j = fr.src - i * a.Ny;
         const float I = fr.I;
-        if constexpr (MODE == FAR_PREP) {
-            const float ai = fabsf(I);
-            if (ai <= 3.0e38f) lmax = fmaxf(lmax, ai);
-        }
         int bi, ni, bj, nj;
         float wbi, wni, wbj, wnj;
         axis_split_ref(fr.dx, i + a.margin, bi, ni, wbi, wni);
         axis_split_ref(fr.dy, j + a.margin, bj, nj, wbj, wnj);
-        if (bi < 0 || bi >= Px || bj < 0 || bj >= Py) continue;       // RF2:235-236
-        auto deposit = [&](int pi, int pj, float v) {
-            const int ui = pi - a.margin, uj = pj - a.margin;           // crop (RF2:78)
-            if (ui >= 0 && ui < a.Nx && uj >= 0 && uj < a.Ny && v != 0.f) {
-                // already deposited by the gather of the target's tile iff the source lies in that tile's window
-                const int r0 = (ui / TH) * TH, c0 = (uj / TW) * TW;
-                if (i >= r0 - H && i < r0 + TH + H && j >= c0 - H && j < c0 + TW + H) return;
-                const int64_t p = (int64_t)ui * a.Ny + uj;
-                if constexpr (MODE == FAR_FLOAT) {
-                    const float add = a.out_scale * v;
-                    if (a.status && !(fabsf(add) <= 3.0e38f)) atomicOr(a.status, PSX_STATUS_NONFINITE);
-                    atomicAdd(&I_out[p], add);
-                } else if constexpr (MODE == FAR_PREP) {
-                    acc[p] = 0ll;
-                } else if constexpr (MODE == FAR_ADD) {
-                    if (!(fabsf(v) <= 3.0e38f)) {                      // NaN / inf: flagged, not summed (the caller raises, RF2:81-82)
-                        if (a.status) atomicOr(a.status, PSX_STATUS_NONFINITE);
-                        return;
-                    }
-                    int qi;
-                    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(qi) : "v"(v * fscale));   // |v| <= max |I| <= 2^-sexp * 2^30
-                    atomicAdd(reinterpret_cast<unsigned long long *>(acc + p), (unsigned long long)(long long)qi);
-                } else {
-                    const long long q = (long long)atomicExch(reinterpret_cast<unsigned long long *>(acc + p), 0ull);
-                    if (q != 0) {
-                        const float add = a.out_scale * (float)((double)q * finv);
+        unsigned mark = MODE == FAR_FOLD ? (unsigned)marks[e] : 0u;      // bit k: share k was the first deposit of its pixel
+        if (bi >= 0 && bi < Px && bj >= 0 && bj < Py) {                  // RF2:235-236
+            auto deposit = [&](int k, int pi, int pj, float v) {
+                const int ui = pi - a.margin, uj = pj - a.margin;           // crop (RF2:78)
+                if (ui >= 0 && ui < a.Nx && uj >= 0 && uj < a.Ny && v != 0.f) {
+                    // already deposited by the gather of the target's tile iff the source lies in that tile's window
+                    const int tr = ui / TH, tc = uj / TW, r0 = tr * TH, c0 = tc * TW;
+                    if (i >= r0 - H && i < r0 + TH + H && j >= c0 - H && j < c0 + TW + H) return;
+                    const int64_t p = (int64_t)ui * a.Ny + uj;
+                    if constexpr (MODE == FAR_FLOAT) {
+                        const float add = a.out_scale * v;
                         if (a.status && !(fabsf(add) <= 3.0e38f)) atomicOr(a.status, PSX_STATUS_NONFINITE);
-                        I_out[p] += add;                               // the only thread that received this pixel's sum
+                        atomicAdd(&I_out[p], add);
+                    } else if constexpr (MODE == FAR_PREP) {
+                        acc[p] = 0ll;
+                    } else if constexpr (MODE == FAR_ADD) {
+                        const int sx = a.det_sexp[tr * a.tiles_y + tc];
+                        const float x = v * ldexpf(1.f, max(sx, -120));         // exact scaling (or overflow to inf)
+                        if (sx == DET_NO_UNIT || !(fabsf(x) < 1.1258999e15f)) { // no unit / beyond 2^50 units / NaN: float atomic
+                            const float add = a.out_scale * v;
+                            if (a.status && !(fabsf(add) <= 3.0e38f)) atomicOr(a.status, PSX_STATUS_NONFINITE);
+                            atomicAdd(&I_out[p], add);
+                            return;
+                        }
+                        const long long q = llrintf(x);
+                        if (q == 0) return;                                     // below the unit: contributes nothing
+                        const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(acc + p),
+                                                                 DET_ONE + ((unsigned long long)q & DET_MASK));
+                        if (old == 0ull) mark |= 1u << k;
+                    } else {
+                        if (!(mark & (1u << k))) return;
+                        const int sx = a.det_sexp[tr * a.tiles_y + tc];
+                        const long long w = acc[p];
+                        const long long sum = (long long)((unsigned long long)w << 12) >> 12;      // sign-extend the 52-bit sum
+                        const float add = a.out_scale * (float)((double)sum * ldexp(1.0, -sx));
+                        if (a.status && !(fabsf(add) <= 3.0e38f)) atomicOr(a.status, PSX_STATUS_NONFINITE);
+                        I_out[p] += add;                                       // the only thread that owns this pixel's sum
                     }
                 }
+            };
+            deposit(0, bi, bj, I * wbi * wbj);
+            if (ni >= 0 && ni < Px && nj >= 0 && nj < Py) {                  // RF2:238-262: all three or none
+                deposit(1, ni, bj, I * wni * wbj);
+                deposit(2, ni, nj, I * wni * wnj);
+                deposit(3, bi, nj, I * wbi * wnj);
             }
-        };
-        deposit(bi, bj, I * wbi * wbj);
-        if (ni < 0 || ni >= Px || nj < 0 || nj >= Py) continue;       // RF2:238-262: all three or none
-        deposit(ni, bj, I * wni * wbj);
-        deposit(ni, nj, I * wni * wnj);
-        deposit(bi, nj, I * wbi * wnj);
-    }
-    if constexpr (MODE == FAR_PREP) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-        if ((threadIdx.x & 63) == 0 && lmax > 0.f) atomicMax(det.mx, __float_as_uint(lmax));   // non-negative floats order like their bits
+        }
+        if constexpr (MODE == FAR_ADD) marks[e] = (unsigned char)mark;
     }
 }
 
@@ -699,11 +704,32 @@ size_t lists_bytes(int Nx, int Ny, int ndist) {
     const size_t nt = (size_t)cdiv(Nx, G::TH) * (size_t)cdiv(Ny, G::TW) * (size_t)ndist;
     return 16 * ((sizeof(unsigned) * nt + 15) / 16) + sizeof(FarRay) * nt * G::TH * G::TW;
 }
-// + (order-independent replay) one max word in its own 16 bytes and [ndist][Nx*Ny] 64-bit scratch words behind the lists
-inline size_t det_bytes(int Nx, int Ny, int ndist) { return (size_t)ndist * (16 + sizeof(long long) * (size_t)Nx * (size_t)Ny); }
+// + (order-independent replay) behind the lists: the tiles' exponents, a mark byte per list entry, [ndist][Nx*Ny] scratch words
+inline size_t pad16(size_t b) { return (b + 15) / 16 * 16; }
+template <class G>
+size_t det_bytes(int Nx, int Ny, int ndist) {
+    const size_t nt = (size_t)cdiv(Nx, G::TH) * (size_t)cdiv(Ny, G::TW);
+    return pad16(sizeof(int) * nt) + pad16(nt * ndist * G::TH * G::TW) + sizeof(long long) * (size_t)Nx * (size_t)Ny * (size_t)ndist;
+}
+template <class G>
+void det_pointers(RefractArgs &a, char *base, int ndist) {
+    const size_t nt = (size_t)a.tiles_x * a.tiles_y;
+    a.det_sexp = (int *)base;
+    a.det_marks = (unsigned char *)(base + pad16(sizeof(int) * nt));
+    a.det_acc = (long long *)(base + pad16(sizeof(int) * nt) + pad16(nt * ndist * G::TH * G::TW));
+}
 template <class G>
 size_t workspace_for(int Nx, int Ny, int ndist) {
-    return lists_bytes<G>(Nx, Ny, ndist) + (g_deterministic ? det_bytes(Nx, Ny, ndist) : 0);
+    return lists_bytes<G>(Nx, Ny, ndist) + (g_deterministic ? det_bytes<G>(Nx, Ny, ndist) : 0);
+}
+
+// one chunk of a batch: the lists of REFRACT_TAB refractions, then (order-independent replay) REFRACT_TAB one-distance regions
+template <class G>
+size_t batch_chunk_bytes(int Nx, int Ny) {
+    return lists_bytes<G>(Nx, Ny, REFRACT_TAB) + (g_deterministic ? (size_t)REFRACT_TAB * det_bytes<G>(Nx, Ny, 1) : 0);
+}
+static size_t batch_chunk_max(int Nx, int Ny) {
+    return std::max(batch_chunk_bytes<GeoSmall>(Nx, Ny), std::max(batch_chunk_bytes<GeoWide>(Nx, Ny), batch_chunk_bytes<GeoMid>(Nx, Ny)));
 }
 
 template <class G>
@@ -713,7 +739,8 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
     a.tile_cap = G::TH * G::TW;
     a.far_count = (unsigned *)workspace;
     a.far_list = (FarRay *)((char *)workspace + 16 * ((sizeof(unsigned) * (size_t)a.tiles_x * a.tiles_y * a.ndist + 15) / 16));
-    a.det_mx = g_deterministic ? (unsigned *)((char *)workspace + lists_bytes<G>(a.Nx, a.Ny, a.ndist)) : nullptr;
+    a.det_sexp = nullptr; a.det_marks = nullptr; a.det_acc = nullptr;
+    if (g_deterministic) det_pointers<G>(a, (char *)workspace + lists_bytes<G>(a.Nx, a.Ny, a.ndist), a.ndist);
     int rc_launch = 0;
     auto launch = [&](auto nm, auto hi, auto hp) -> int {
         constexpr int NM = decltype(nm)::value;
@@ -727,7 +754,7 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
         if (int rc = launch_check("k_refract_near")) return rc;
         const int nlists = a.tiles_x * a.tiles_y * a.ndist;
         const int fgrid = (nlists + FAR_THREADS / 64 - 1) / (FAR_THREADS / 64);
-        if (a.det_mx) {      // order-independent replay: three passes over the lists, scratch from the workspace (see DetAcc)
+        if (a.det_acc) {      // order-independent replay: three passes over the lists, scratch from the workspace
             PSX_TIMED("k_refract_far_prep", st, k_refract_far<G, FAR_PREP><<<fgrid, FAR_THREADS, 0, st>>>(a));
             PSX_TIMED("k_refract_far_add", st, k_refract_far<G, FAR_ADD><<<fgrid, FAR_THREADS, 0, st>>>(a));
             PSX_TIMED("k_refract_far_fold", st, k_refract_far<G, FAR_FOLD><<<fgrid, FAR_THREADS, 0, st>>>(a));
@@ -757,10 +784,10 @@ int launch_refract_batch(RefractTab &t, int n, bool has_I, int nmat, void *works
         const int k = e < n ? e : 0;
         a.far_count = (unsigned *)workspace + (size_t)k * nt;
         a.far_list = (FarRay *)((char *)workspace + 16 * ((sizeof(unsigned) * nt * REFRACT_TAB + 15) / 16)) + (size_t)k * nt * a.tile_cap;
-        // order-independent replay: every refraction of the chunk its own max word + scratch words behind the chunk's lists
-        a.det_mx = g_deterministic ? (unsigned *)((char *)workspace + lists_bytes<G>(a.Nx, a.Ny, REFRACT_TAB) +
-                                                  (size_t)k * det_bytes(a.Nx, a.Ny, 1))
-                                   : nullptr;
+        // order-independent replay: every refraction of the chunk its own exponents, marks and scratch words behind the chunk's lists
+        a.det_sexp = nullptr; a.det_marks = nullptr; a.det_acc = nullptr;
+        if (g_deterministic)
+            det_pointers<G>(a, (char *)workspace + lists_bytes<G>(a.Nx, a.Ny, REFRACT_TAB) + (size_t)k * det_bytes<G>(a.Nx, a.Ny, 1), 1);
     }
     int rc_launch = 0;
     auto launch = [&](auto nm, auto hi) -> int {
@@ -774,7 +801,7 @@ int launch_refract_batch(RefractTab &t, int n, bool has_I, int nmat, void *works
         if (int rc = launch_check("k_refract_near")) return rc;
         const int fgrid = ((int)nt + FAR_THREADS / 64 - 1) / (FAR_THREADS / 64);
         const dim3 fg((unsigned)fgrid, (unsigned)n);
-        if (t.e[0].det_mx) {
+        if (t.e[0].det_acc) {
             PSX_TIMED("k_refract_far_prep", st, k_refract_far_batch<G, FAR_PREP><<<fg, FAR_THREADS, 0, st>>>(t));
             PSX_TIMED("k_refract_far_add", st, k_refract_far_batch<G, FAR_ADD><<<fg, FAR_THREADS, 0, st>>>(t));
             PSX_TIMED("k_refract_far_fold", st, k_refract_far_batch<G, FAR_FOLD><<<fg, FAR_THREADS, 0, st>>>(t));
@@ -881,8 +908,9 @@ int psx_set_deterministic(int on) {
 }
 
 size_t psx_refract_batch_workspace_bytes(int Nx, int Ny, int n) {
+    if (Nx <= 0 || Ny <= 0) return 16;
     const int chunks = (std::max(n, 1) + REFRACT_TAB - 1) / REFRACT_TAB;
-    return (size_t)chunks * psx_refract_multi_workspace_bytes(Nx, Ny, REFRACT_TAB);
+    return (size_t)chunks * batch_chunk_max(Nx, Ny);
 }
 
 int psx_refract_batch_f32(int n, const float *const *I_in, const float *I0, const float *const *T, const double *cphase,
@@ -903,7 +931,7 @@ int psx_refract_batch_f32(int n, const float *const *I_in, const float *I0, cons
     PSX_REQUIRE(Nx >= 3 && Ny >= 3, "psx_refract_batch_f32: grid %dx%d too small for the edge_order=2 gradient", Nx, Ny);
     PSX_REQUIRE((int64_t)Nx * Ny < (1ll << 31), "psx_refract_batch_f32: grid %dx%d exceeds int32 pixel indices", Nx, Ny);
     PSX_REQUIRE(margin >= 8 && margin <= 4096, "psx_refract_batch_f32: margin %d must be >= 8 (the widest gather halo)", margin);
-    const size_t chunk_ws = psx_refract_multi_workspace_bytes(Nx, Ny, REFRACT_TAB);
+    const size_t chunk_ws = batch_chunk_max(Nx, Ny);
     for (int e0 = 0; e0 < n; e0 += REFRACT_TAB) {           // REFRACT_TAB argument blocks fit one launch
         const int m = std::min(REFRACT_TAB, n - e0);
         RefractTab t = {};
