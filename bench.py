@@ -72,9 +72,8 @@ def parse():
                     help="diagnostic A/B switch of the library (psx_debug_switch; repeatable); echoed in the line as `debug_switches`")
     ap.add_argument("--work-queue", action="store_true",
                     help="A/B: the line kernels' work queue on the headline step itself (default: static shares)")
-    ap.add_argument("--float-atomics", action="store_true",
-                    help="positions batch: far rays replayed with float atomics (faster by a few per cent, not reproducible run to "
-                         "run) instead of the order-independent replay")
+    ap.add_argument("--no-reproducible-batch", action="store_true",
+                    help="positions batch: skip the third measurement (ray tracing with the order-independent far-ray replay)")
     ap.add_argument("--deterministic-step", action="store_true",
                     help="A/B: the headline step's refraction with the order-independent far-ray replay")
     ap.add_argument("--sink", type=int, default=0,
@@ -328,9 +327,15 @@ def main():
         pn = a.positions_size or min(N, 4096)
         with contextlib.redirect_stdout(sys.stderr):     # the mirrors print like the reference; stdout carries the JSON line only
             out["positions_batch"] = {}
-            for sim in ("Fresnel", "RayT"):
+            # ray tracing twice: far rays replayed with float atomics (the faster form: last bits depend on the arrival order, a
+            # Poisson draw may flip) and with the order-independent replay (bit-reproducible on any number of GPUs, main.run's
+            # `reproducible` switch; measured cost in DESIGN.md section 4.3)
+            for key in ("Fresnel", "RayT", "RayT_reproducible"):
+                sim = key.split("_")[0]
+                if key == "RayT_reproducible" and a.no_reproducible_batch:
+                    continue
                 try:
-                    out["positions_batch"][sim] = positions_batch(a, sim, pn, rank, world, dev)
+                    out["positions_batch"][key] = positions_batch(a, sim, pn, rank, world, dev, reproducible=key.endswith("_reproducible"))
                 except Exception as exc:
                     import traceback
                     traceback.print_exc()
@@ -341,7 +346,7 @@ def main():
                         sys.stderr.flush()
                         os._exit(6 if isinstance(exc, pdist.DistError) else 5)
                     # one rank: the step's line above is measured already: keep it, report the batch as failed
-                    out["positions_batch"][sim] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                    out["positions_batch"][key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     # ---- BASELINE.json configs 1, 2 and 5 on the same line (rank 0 of a one-rank run only: they are single-GPU configurations)
     if rank == 0 and world == 1 and not a.no_configs and N == 4096:
@@ -489,7 +494,7 @@ def main():
     sys.exit(rc)
 
 
-def positions_batch(a, sim, N, rank, world, dev):
+def positions_batch(a, sim, N, rank, world, dev, reproducible=False):
     """BASELINE.json config 4: `--positions` membrane positions strided over the ranks, the full loop of main.py:63-110 per
     position (membrane synthesis with seed(pointNum), chain, detection, shot noise) and the RCCL gather of every position's
     Sample/Reference stacks onto rank 0 -- round by round behind the computation (--gather overlap, default) or once at the
@@ -510,7 +515,7 @@ def positions_batch(a, sim, N, rank, world, dev):
     sink = a.sink if 0 <= a.sink < world else 0
     # ray tracing: far rays through the order-independent replay, so that a position's images are the same bits on 1 GPU and on
     # 8 (float atomics let a last bit flip a Poisson draw); the Fresnel chain has no float atomics anywhere
-    det_mode = sim == "RayT" and not a.float_atomics
+    det_mode = sim == "RayT" and reproducible
     ops.set_deterministic(det_mode)
     cpu_dev = dev if (world == 1 or a.backend == "nccl") else torch.device("cpu")
 

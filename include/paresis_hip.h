@@ -256,7 +256,7 @@ int psx_darkfield_blur_f32(const float *I2DF, const float *DF, const float *I2, 
 int psx_darkfield_split_f32(const float *I, const double *DF_rad, double scale, double limit, float *I_nodf, float *I_df,
                             float *DF_px, void *prep, unsigned long long *words, int Nx, int Ny, void *stream);
 int psx_darkfield_blur_prepared_f32(const float *I2DF, const float *DF, const void *prep, const float *I2, float *out, int Nx,
-                                    int Ny, int R, void *stream);
+                                    int Ny, int R, unsigned *status, void *stream);   /* status: optional word, PSX_STATUS_NONFINITE (RF2:190-193) */
 int psx_darkfield_merge_f32(float *I, const float *a, const float *b, int64_t n, void *stream);
 int psx_repad_f32(const float *src, int margin_src, float *dst, int margin_dst, int Nx, int Ny, void *stream);
 

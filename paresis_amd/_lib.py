@@ -74,7 +74,7 @@ PROTOTYPES = {
     "psx_darkfield_workspace_bytes": (c_size_t, [c_int, c_int]),
     "psx_darkfield_blur_f32": (c_int, [_vp, _vp, _vp, _vp, c_int, c_int, c_int, _vp, _vp]),
     "psx_darkfield_split_f32": (c_int, [_vp, _vp, c_double, c_double, _vp, _vp, _vp, _vp, _vp, c_int, c_int, _vp]),
-    "psx_darkfield_blur_prepared_f32": (c_int, [_vp, _vp, _vp, _vp, _vp, c_int, c_int, c_int, _vp]),
+    "psx_darkfield_blur_prepared_f32": (c_int, [_vp, _vp, _vp, _vp, _vp, c_int, c_int, c_int, _vp, _vp]),
     "psx_darkfield_merge_f32": (c_int, [_vp, _vp, _vp, c_int64, _vp]),
     "psx_repad_f32": (c_int, [_vp, c_int, _vp, c_int, c_int, c_int, _vp]),
     "psx_membrane_f32": (c_int, [_dp, _dp, _dp, c_int64, c_int, c_int, c_int, c_int, c_double, c_int, _vp, _vp]),

@@ -75,13 +75,19 @@ __global__ __launch_bounds__(256) void k_df_gather(const float *__restrict__ I2D
 // sample: half-size 0, one term).  Same terms in the same order as k_df_gather (the exponent is formed as d^2 * (-log2(e)/2 sigma^2)
 // and goes through v_exp_f32, 1 ulp, instead of expf(-d^2 / (2 sigma^2)): 0.50 -> 0.39 ms at 4096^2).
 constexpr int DT = 32;
+// Round 4: one 16-byte LDS entry per staged source -- (weight, exponent coefficient, patch half-size, unused) read with ONE
+// ds_read_b128 -- and a branch-free inner loop: the term of a source is formed for every (di, dj) of the window's widest
+// patch and selected by `half-size >= max(|di|, |dj|)` (a scalar per loop trip), where the first version tested three
+// conditions per term with the exec-mask bookkeeping of a divergent `continue` and read two LDS arrays.  Inside a scattering
+// sample nearly every source has the window's widest patch, so almost nothing that is computed is thrown away.  The status
+// scan of the result (RF2:190-193) rides on the store.
 __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict__ I2DF, const float *__restrict__ DF,
                                                          const float2 *__restrict__ prep, const float *__restrict__ I2,
-                                                         float *__restrict__ out, int Nx, int Ny, int R, int tiles_y) {
+                                                         float *__restrict__ out, int Nx, int Ny, int R, int tiles_y,
+                                                         unsigned *status) {
     extern __shared__ __attribute__((aligned(16))) char sdf[];
     const int W = DT + 2 * R;
-    float2 *swc = reinterpret_cast<float2 *>(sdf);                 // [W][W] (weight, coefficient)
-    int *sh = reinterpret_cast<int *>(swc + W * W);                // [W][W] half-size (-1: no contribution)
+    float4 *swc = reinterpret_cast<float4 *>(sdf);                 // [W][W] (weight, coefficient, half-size, -)
     __shared__ int hmax;
     const int t0 = (blockIdx.x / tiles_y) * DT, c0 = (blockIdx.x % tiles_y) * DT;
     if (threadIdx.x == 0) hmax = 0;
@@ -104,8 +110,7 @@ __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict
                 }
             }
         }
-        swc[e] = make_float2(w, c);
-        sh[e] = h;
+        swc[e] = make_float4(w, c, (float)h, 0.f);
         hm = max(hm, h);
     }
     for (int o = 32; o > 0; o >>= 1) hm = max(hm, __shfl_xor(hm, o));
@@ -113,23 +118,34 @@ __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict
     __syncthreads();
     const int Re = min(R, hmax);
     const int tj = threadIdx.x & 31, ti0 = threadIdx.x >> 5;
+    bool bad = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int ti = ti0 + 8 * k, i = t0 + ti, j = c0 + tj;
         if (i >= Nx || j >= Ny) continue;
         float acc = 0.f;
-        for (int di = -Re; di <= Re; ++di) {
-            const int row = (ti + di + R) * W + tj + R;
-            for (int dj = -Re; dj <= Re; ++dj) {
-                const int h = sh[row + dj];
-                if (h < 0 || abs(di) > h || abs(dj) > h) continue;
-                const float2 wc = swc[row + dj];
-                acc += h == 0 ? wc.x : wc.x * __builtin_amdgcn_exp2f((float)(di * di + dj * dj) * wc.y);
+        if (Re == 0) {                                   // no patch reaches this tile: every source deposits on itself
+            const float4 e = swc[(ti + R) * W + tj + R];
+            acc = e.z >= 0.f ? e.x : 0.f;
+        } else {
+            for (int di = -Re; di <= Re; ++di) {
+                const float4 *row = swc + (ti + di + R) * W + tj + R;
+                const float di2 = (float)(di * di);
+                for (int dj = -Re; dj <= Re; ++dj) {
+                    const float4 e = row[dj];
+                    const float need = (float)max(abs(di), abs(dj));          // scalar: di, dj are uniform
+                    // h == 0: coefficient 0, exp2(0) = 1, selected only at di = dj = 0 (same value as the plain deposit)
+                    const float t = e.x * __builtin_amdgcn_exp2f((di2 + (float)(dj * dj)) * e.y);
+                    acc += e.z >= need ? t : 0.f;
+                }
             }
         }
         const int64_t p = (int64_t)i * Ny + j;
-        out[p] = acc + (I2 ? I2[p] : 0.f);
+        const float v = acc + (I2 ? I2[p] : 0.f);
+        bad |= !(fabsf(v) <= 3.0e38f);
+        out[p] = v;
     }
+    if (status && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, PSX_STATUS_NONFINITE);
 }
 
 // ---- the front of fastRefractionDF as ONE pass (RF2:114-150): width map in radians -> pixels (float64), its maximum (the
@@ -238,19 +254,20 @@ int psx_repad_f32(const float *src, int margin_src, float *dst, int margin_dst, 
 }
 
 int psx_darkfield_blur_prepared_f32(const float *I2DF, const float *DF, const void *prep, const float *I2, float *out, int Nx,
-                                    int Ny, int R, void *stream) {
+                                    int Ny, int R, unsigned *status, void *stream) {
     PSX_REQUIRE(I2DF && DF && out && prep && Nx > 0 && Ny > 0 && R >= 0, "psx_darkfield_blur_prepared_f32: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)Nx * Ny;
-    const size_t lds = (size_t)(DT + 2 * R) * (DT + 2 * R) * (sizeof(float2) + sizeof(int));
+    const size_t lds = (size_t)(DT + 2 * R) * (DT + 2 * R) * sizeof(float4);
     if (lds <= 60 * 1024) {
         const int tiles_x = (int)cdiv(Nx, DT), tiles_y = (int)cdiv(Ny, DT);
         PSX_TIMED("k_df_gather", st, k_df_gather_tiled<<<tiles_x * tiles_y, 256, lds, st>>>(I2DF, DF, (const float2 *)prep, I2, out,
-                                                                                            Nx, Ny, R, tiles_y));
+                                                                                            Nx, Ny, R, tiles_y, status));
         return launch_check("k_df_gather");
     }
     PSX_TIMED("k_df_gather", st, k_df_gather<<<ew_grid(n, 256), 256, 0, st>>>(I2DF, DF, (const float2 *)prep, I2, out, Nx, Ny, R));
-    return launch_check("k_df_gather");
+    if (int rc = launch_check("k_df_gather")) return rc;
+    return status ? psx_status_scan_f32(out, n, status, stream) : 0;
 }
 
 size_t psx_darkfield_workspace_bytes(int Nx, int Ny) { return sizeof(float2) * (size_t)(Nx > 0 ? Nx : 0) * (size_t)(Ny > 0 ? Ny : 0); }
@@ -261,11 +278,11 @@ int psx_darkfield_blur_f32(const float *I2DF, const float *DF, const float *I2, 
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)Nx * Ny;
     PSX_TIMED("k_df_prepare", st, k_df_prepare<<<ew_grid(n, 256), 256, 0, st>>>(I2DF, DF, (float2 *)workspace, n));
-    const size_t lds = (size_t)(DT + 2 * R) * (DT + 2 * R) * (sizeof(float2) + sizeof(int));
-    if (lds <= 60 * 1024) {          // patches of up to 2 R + 1 = 51 pixels; wider ones take the plain gather
+    const size_t lds = (size_t)(DT + 2 * R) * (DT + 2 * R) * sizeof(float4);
+    if (lds <= 60 * 1024) {          // patches of up to 2 R + 1 = 29 pixels; wider ones take the plain gather
         const int tiles_x = (int)cdiv(Nx, DT), tiles_y = (int)cdiv(Ny, DT);
         PSX_TIMED("k_df_gather", st, k_df_gather_tiled<<<tiles_x * tiles_y, 256, lds, st>>>(I2DF, DF, (const float2 *)workspace, I2,
-                                                                                            out, Nx, Ny, R, tiles_y));
+                                                                                            out, Nx, Ny, R, tiles_y, nullptr));
         return launch_check("k_df_gather");
     }
     PSX_TIMED("k_df_gather", st, k_df_gather<<<ew_grid(n, 256), 256, 0, st>>>(I2DF, DF, (const float2 *)workspace, I2, out,

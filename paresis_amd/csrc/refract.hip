@@ -277,6 +277,23 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     // order-independent far-ray replay: far shares that land in this tile are summed in THIS tile's fixed-point unit (every
     // tile writes its entry on every call; DET_NO_UNIT: the tile has no finite non-zero intensity to take a unit from)
     if (a.det_sexp && tid == 0) a.det_sexp[tile] = (finite_in && mbits) ? sexp : DET_NO_UNIT;
+    // A window that holds no intensity at all deposits nothing, lists nothing and leaves zeros: skip the deposit loops (the
+    // halves of the dark-field split, RF2:147-150, are zero over most of the image; so is any masked input).  Not when the
+    // displacement maps are wanted (they do not depend on the intensity), nor when a foreign array is to be zeroed.
+    if (mbits == 0u && !a.Dx_out && (a.I_mut == nullptr || a.I_mut == a.I_in)) {     // uniform: one LDS word
+        for (int d = 0; d < a.ndist; ++d) {
+            if (!a.accumulate) {
+                float *const I_out = a.I_out[d];
+                for (int idx = tid; idx < TH * TW; idx += NTHREADS) {
+                    const int tr = idx / TW, tc = idx - tr * TW;
+                    const int i = r0 + tr, j = c0 + tc;
+                    if (i < a.Nx && j < a.Ny) I_out[(int64_t)i * a.Ny + j] = 0.f;    // out_scale * 0 (a NaN scale aside)
+                }
+            }
+            if (tid == 0) a.far_count[(size_t)d * nt + tile] = 0u;
+        }
+        return;
+    }
 
 
     // ---- every source pixel of tile+halo deposits what lands inside this tile.

@@ -419,13 +419,15 @@ def darkfield_maxima(words):
     return float(w[0]), float(w[1])
 
 
-def darkfield_blur_prepared(I2DF, DF, prep, I2, R):
-    """darkfield_blur() on the patch table darkfield_split() made from the width map."""
+def darkfield_blur_prepared(I2DF, DF, prep, I2, R, scan=True):
+    """darkfield_blur() on the patch table darkfield_split() made from the width map; scan: NaN / inf in the result raise
+    the device status word (RF2:190-193), checked by the kernel that stores it."""
     _need(I2DF, torch.float32, "I2DF")
     _need(DF, torch.float32, "DF", I2DF.shape)
     out = torch.empty_like(I2DF)
     Nx, Ny = I2DF.shape
-    check(lib().psx_darkfield_blur_prepared_f32(_ptr(I2DF), _ptr(DF), _ptr(prep), _ptr(I2), _ptr(out), Nx, Ny, int(R), _stream()),
+    check(lib().psx_darkfield_blur_prepared_f32(_ptr(I2DF), _ptr(DF), _ptr(prep), _ptr(I2), _ptr(out), Nx, Ny, int(R),
+                                                _ptr(status_word(I2DF.device)) if scan else None, _stream()),
           "psx_darkfield_blur_prepared_f32")
     return out
 

@@ -92,8 +92,7 @@ def fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magni
     if mutate_host is not None:
         mutate_host[...] = I.cpu().numpy()
     R = int(round(1.5 * maxDFc)) + 1
-    out = ops.darkfield_blur_prepared(I2DF, DF, prep, I2, R)
-    ops.status_scan(out)
+    out = ops.darkfield_blur_prepared(I2DF, DF, prep, I2, R)        # the NaN / inf scan of RF2:190-193 rides on its stores
     if check:                                            # (a chain that defers the check reads the status word once, at its end)
         ops.check_status(out.device, "fastRefractionDF")     # RF2:190-193
     return out, Dx, Dy
