@@ -734,8 +734,8 @@ def run_configs(a, dev):
         # gather halo of the refraction tiles (a speed knob, the images do not depend on it): at oversampling 4 the
         # displacements are four times as many pixels as at oversampling 2 and the 8-pixel halo pays (16384^2: tile kernel
         # 4.3 -> 5.5 ms, far-ray replay 5.7 -> 3.0 ms); the headline's 4-pixel halo elsewhere
-        halo = 8 if ov >= 4 else a.halo
-        _lib.check(_lib.lib().psx_refract_set_halo(halo), "psx_refract_set_halo")
+        # (round 4: picked by measurement -- ops.tune_refract_halo times the step's own refraction call with each halo)
+        halo, halo_ms = ops.tune_refract_halo(lambda: ops.refract_multi((N, N), rt_mats, dsc, (N, N), I0=I0, outs=refr))
         det = ops.DetectorPlan(N, N, ov, n, n, sig_src, sig_psf) if detect else None
         dets = [torch.empty((n, n), dtype=torch.float32, device=dev) for _ in range(2 * len(zs))] if detect else []
         amp = float(np.sqrt(I0))
@@ -793,6 +793,7 @@ def run_configs(a, dev):
              "step_bytes": step_bytes, "step_frac": round(step_bytes / dt / 1e9 / HBM_PEAK_GBS, 4),
              "step_frac_per_propagation": round(step_bytes_pp / dt / 1e9 / HBM_PEAK_GBS, 4),
              "fresnel_engine": {1: "rocfft", 2: "lds"}[plan.engine], "refraction_halo": halo,
+             "refraction_halo_tuning_ms": {str(h): round(v, 4) for h, v in halo_ms.items()},
              "kernel_ms_per_step": dict(sorted(kern.items(), key=lambda kv: -kv[1]))}
         if kshort:
             e["kernel_ms_short_launches"] = dict(sorted(kshort.items(), key=lambda kv: -kv[1]),

@@ -115,6 +115,7 @@ class Experiment:
         self._pending_means = []
         self._sums_pool, self._sums_next = None, 0
         self.darkFieldPropag = None
+        self._halo = None             # refraction gather halo of this experiment (exp_dict['refractionHalo']: 4 | 6 | 8 | 'auto')
 
     @classmethod
     def from_objects(cls, exp_dict, source, detector, membrane, sample, air=None, plate=None):
@@ -201,8 +202,9 @@ class Experiment:
         a, g, du = self._fresnel_scalars(propagationDistance, Energy, magnification)
         return self._plan().propagate([a], [g], du, wave_in=to_dev(waveToPropagate, torch.complex64))[0]
 
-    def refraction(self, intensityRefracted, phi, propagationDistance, Energy, magnification, darkField=0):
-        """Experiment.py:255-277."""
+    def refraction(self, intensityRefracted, phi, propagationDistance, Energy, magnification, darkField=0, _mutate=True):
+        """Experiment.py:255-277.  (_mutate=False: the chain's own calls, whose input is a temporary, skip the in-place zeroing
+        of clamped rays in the dark-field variant.)"""
         from .refractionFileNumba2 import fastRefraction, fastRefractionDF
         if type(darkField) == int or type(darkField) == float:
             return fastRefraction(intensityRefracted, phi, propagationDistance, Energy, magnification,
@@ -210,7 +212,7 @@ class Experiment:
         known = self.mySampleofInterest.dark_field_max(darkField) if hasattr(self.mySampleofInterest, "dark_field_max") else None
         return fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magnification,
                                 self.exp_dict["studyPixelSize"], darkField, darkFieldMax=known,
-                                check=not self.exp_dict.get('deferStatus'))
+                                check=not self.exp_dict.get('deferStatus'), mutate=_mutate)
 
     def computeSampleAndReferenceImages(self, pointNum):
         """Dispatcher on exp_dict['simulation_type'] (main.py:68-73)."""
@@ -526,6 +528,26 @@ class Experiment:
         h = self.exp_dict['studyPixelSize'] * 1e-6
         return z / k_refraction(Energy) / (h * self.exp_dict['magnification']) / h
 
+    def _set_halo(self, N, clamp, air):
+        """exp_dict['refractionHalo']: 4 (default), 6, 8 or 'auto' -- the gather halo of the refraction tiles is a speed knob whose
+        best value depends on how far the rays of THIS experiment travel in study pixels (oversampling, distances, membrane).
+        'auto' times the experiment's own longest hop with each halo once, on the first call (ops.tune_refract_halo: three host
+        synchronisations), and keeps the winner for the life of the object."""
+        if self._halo is None:
+            want = self.exp_dict.get('refractionHalo', 4)
+            if want == 'auto':
+                ed = self.exp_dict
+                E = self.mySource.mySpectrum[-1][0]
+                z = max(ed['distMembraneToObject'], ed['distObjectToDetector'])
+                stack = ops.MaterialStack.concat(air.stack_rt(E, phase=False) if air is not None else None, self.myMembrane.stack_rt(E))
+                out = self._tmp[0]
+                self._halo, self._halo_times = ops.tune_refract_halo(
+                    lambda: ops.refract(N, stack, self._dscale(z, E), clamp, I0=1.0, out=out))
+                ops.check_status(out.device, "refraction halo tuning")
+            else:
+                self._halo = int(want)
+        ops.set_refract_halo(self._halo)
+
     def _rt_bins_batched(self, pointNum, stacks, accs, plate, air, N, sums, clamp):
         """The ray-tracing chain of one position (EXP:448-521) with the energies of each bin taken together
         (psx_refract_batch_f32: one launch per kernel for up to 8 energies); samples without dark field only."""
@@ -588,6 +610,7 @@ class Experiment:
             self.darkFieldPropag = ops.fill(torch.empty(N, dtype=torch.float32, device=dev), 0.0)   # scalar dark field: stays zero
         dMO, dOD = ed['distMembraneToObject'], ed['distObjectToDetector']
         clamp = (N[0], N[1])                                                              # RF2:61-64
+        self._set_halo(N, clamp, air)
         if not scattering and self._batch_energies(N, None):
             nvisited = self._rt_bins_batched(pointNum, stacks, accs, plate, air, N, sums, clamp)
             self._zero_unvisited_bins(stacks, nvisited, pointNum)
@@ -618,7 +641,7 @@ class Experiment:
             if scattering:                                       # Lung / cylinder_beeds: fastRefractionDF (EXP:272-275)
                 DF = self.mySampleofInterest.dark_field(currentEnergy)
                 Ias, phis = ops.transmit_rt(Ibs, 1.0, both)
-                img, _, _ = self.refraction(Ias, phis, dOD, currentEnergy, ed['magnification'], DF)
+                img, _, _ = self.refraction(Ias, phis, dOD, currentEnergy, ed['magnification'], DF, _mutate=False)
                 self._add_intensity(accS, img, plate_att, add=not first)
             elif plate_att is None:
                 ops.refract(N, both, self._dscale(dOD, currentEnergy), clamp, I_in=Ibs, out=accS, add=not first)
@@ -629,7 +652,8 @@ class Experiment:
                 if scattering:
                     Ip, phip = ops.transmit_rt(None, I0, ops.MaterialStack.concat(air_rt, smp))
                     self.darkFieldPropag += (DF * flux).to(torch.float32)                 # EXP:491
-                    img, self.Dxreal, self.Dyreal = self.refraction(Ip, phip, dOD, currentEnergy, ed['magnification'], DF)
+                    img, self.Dxreal, self.Dyreal = self.refraction(Ip, phip, dOD, currentEnergy, ed['magnification'], DF,
+                                                                    _mutate=False)
                     self._add_intensity(accP, img, plate_att, add=not first)
                 else:
                     _, self.Dxreal, self.Dyreal = ops.refract(N, ops.MaterialStack.concat(air_rt, smp),

@@ -381,6 +381,33 @@ def refract_multi(shape, mats, dscales, clamp, margin=15, I_in=None, I0=1.0, phi
     return outs
 
 
+def set_refract_halo(halo):
+    """Gather halo of the refraction tile kernel: 4, 6 or 8 pixels (psx_refract_set_halo; a pure speed knob)."""
+    check(lib().psx_refract_set_halo(int(halo)), "psx_refract_set_halo")
+
+
+def tune_refract_halo(call, halos=(4, 6, 8), reps=2):
+    """Picks the gather halo by MEASUREMENT: `call()` (a refraction with the caller's real arguments) is timed with each halo --
+    one untimed run, then `reps` runs between two events -- and the fastest stays set.  Which halo wins depends on how many
+    rays travel further than it (the far-ray replay costs ~15 global atomics per ns): 4 pixels at oversampling 2, 8 at
+    oversampling 4 with the bench's membranes.  The images do not depend on the choice (float-atomic order of far rays apart).
+    One host synchronisation per candidate: meant for the set-up of a run, not for its loop.  Returns (halo, {halo: ms})."""
+    times = {}
+    for h in halos:
+        set_refract_halo(h)
+        call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        e1.synchronize()
+        times[h] = e0.elapsed_time(e1) / reps
+    best = min(times, key=times.get)
+    set_refract_halo(best)
+    return best, times
+
+
 def darkfield_blur(I2DF, DF, I2, R):
     """Variable-width Gaussian re-splat of fastRefractionDF (refractionFileNumba2.py:168-186): returns
     I2 + sum_s I2DF[s] * gaussian_shape(DF[s]/2) centred on s.  DF in pixels at the target pixels; R = max half-size."""

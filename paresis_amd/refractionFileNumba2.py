@@ -48,7 +48,7 @@ def fastRefraction(intensityRefracted, phi, propagationDistance, Energy, magnifi
 
 
 def fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magnification, studyPixelSize, darkField,
-                     darkFieldMax=None, check=True):
+                     darkFieldMax=None, check=True, mutate=True):
     """RF2:88-196: refraction with a dark-field (small-angle scattering) width map `darkField` in radians.
 
     The intensity is split where the dark field is / is not zero (RF2:147-150), both parts are refracted with the same
@@ -58,7 +58,8 @@ def fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magni
     radians -- Experiment knows it per sample and energy) makes the call fully asynchronous; without it the maximum is read
     back from the GPU (one synchronisation).  Every array operation is a kernel of the library: the conversion to pixels,
     the DF > Nx/4 rule, the split and the patch table in one pass (psx_darkfield_split_f32), two refractions, the re-splat.
-    The matplotlib pop-ups of RF2:152-167 are not reproduced."""
+    The matplotlib pop-ups of RF2:152-167 are not reproduced.  mutate=False (extension; the chain's caller passes a temporary it
+    never reads again): the clamped rays are not zeroed in `intensityRefracted` (RF2:128-129), which saves one pass."""
     I = to_dev(intensityRefracted, torch.float32)
     mutate_host = intensityRefracted if isinstance(intensityRefracted, np.ndarray) else None
     Nx, Ny = I.shape
@@ -88,9 +89,10 @@ def fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magni
         # loop is used on the un-padded arrays (RF2:235-262)
         I2 = ops.fastloop(I_nodf, Dx, Dy, ops.fill(torch.empty_like(I), 0.0))
         I2DF = ops.fastloop(I_df, Dx, Dy, ops.fill(torch.empty_like(I), 0.0))
-    ops.darkfield_merge(I, I_nodf, I_df)                 # clamped rays zeroed in the caller's array (RF2:128-129)
-    if mutate_host is not None:
-        mutate_host[...] = I.cpu().numpy()
+    if mutate:
+        ops.darkfield_merge(I, I_nodf, I_df)             # clamped rays zeroed in the caller's array (RF2:128-129)
+        if mutate_host is not None:
+            mutate_host[...] = I.cpu().numpy()
     R = int(round(1.5 * maxDFc)) + 1
     out = ops.darkfield_blur_prepared(I2DF, DF, prep, I2, R)        # the NaN / inf scan of RF2:190-193 rides on its stores
     if check:                                            # (a chain that defers the check reads the status word once, at its end)

@@ -33,6 +33,25 @@ def test_chain_rt(tag):
     assert list(g[tag + "/RT/bins_after"]) == exp.myDetector.det_param["myBinsThersholds"]
 
 
+def test_chain_rt_with_measured_halo():
+    """exp_dict['refractionHalo'] = 'auto': the gather halo is picked by timing the experiment's own longest hop with 4, 6
+    and 8 pixels on the first call; the images are those of the golden run whatever wins."""
+    from paresis_amd import ops
+    g = load("experiment.npz")
+    cfg = experiment_cfg(g, "mono/RT", orc.Obj)
+    exp = build_experiment(cfg, "RT")
+    exp.exp_dict["refractionHalo"] = "auto"
+    try:
+        exp.myMembrane.myGeometry = g["mono/RT/p0/membrane"]
+        exp.exp_dict["meanEnergy"] = 0
+        S, R, Pg, W, Dx, Dy, DF = exp.computeSampleAndReferenceImages_RT(0)
+        assert exp._halo in (4, 6, 8) and sorted(exp._halo_times) == [4, 6, 8]
+        for nm, a in (("Sample", S), ("Reference", R), ("Propag", Pg), ("White", W)):
+            assert relmax(a.cpu().numpy(), g["mono/RT/p0/" + nm]) < TOL, nm
+    finally:
+        ops.set_refract_halo(4)
+
+
 @pytest.mark.parametrize("engine", [1, 0])
 @pytest.mark.parametrize("tag", ["mono", "poly"])
 def test_chain_fresnel(tag, engine):

@@ -28,6 +28,14 @@ lib.psx_debug_stamps(ctypes.c_void_p(buf.data_ptr()))
 run()
 torch.cuda.synchronize()
 lib.psx_debug_stamps(None)
+lib.psx_profile_enable(1)
+for _ in range(20):
+    run()
+torch.cuda.synchronize()
+pbuf = ctypes.create_string_buffer(1 << 14)
+lib.psx_profile_summary(pbuf, len(pbuf))
+lib.psx_profile_enable(0)
+print("event pairs, 20 un-stamped calls (name launches total_ms):", pbuf.value.decode().replace("\n", "; "))
 s = buf.cpu().numpy().astype(np.float64)
 s = s[s[:, 13] > 0]
 names = ["prologue: first fetch + spread (once per launch)", "-> round 2 start (round 1 not stamped)", "fwd A", "barrier 1", "fwd B", "wave sync",
@@ -36,6 +44,13 @@ names = ["prologue: first fetch + spread (once per launch)", "-> round 2 start (
 d = np.diff(s[:, :14], axis=1) * 10.0   # 100 MHz ticks -> ns
 rnd = d[:, 2:].sum(1).mean()
 print("workgroups:", len(s), " steady-state round %.2f us" % (rnd / 1e3))
+# the launch as the chip sees it (the 100 MHz counter is global): first workgroup's first stamp (after its twiddle tables are
+# in LDS) -> last workgroup's last stamp of the stamped round; against the launch's event-pair time this separates dispatch +
+# table fill + drain from the rounds themselves (where do the ~40 us of a 2-round launch go?)
+print("  stamped span: first stamp of any workgroup -> last stamp of the stamped round, all workgroups: %.2f us; per workgroup "
+      "stamp 0 -> 13: mean %.2f, max %.2f us; start skew (stamp 0, max - min) %.2f us; end skew (stamp 13) %.2f us"
+      % ((s[:, 13].max() - s[:, 0].min()) / 100.0, (s[:, 13] - s[:, 0]).mean() / 100.0, (s[:, 13] - s[:, 0]).max() / 100.0,
+         (s[:, 0].max() - s[:, 0].min()) / 100.0, (s[:, 13].max() - s[:, 13].min()) / 100.0))
 for n, v in zip(names, d.mean(0)):
     print("  %-52s %7.2f us  %5.1f %%" % (n, v / 1e3, 100 * v / rnd))
 ld = s[:, 16:21]

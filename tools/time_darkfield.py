@@ -16,11 +16,12 @@ df = torch.from_numpy(np.where(geo["sample"][0] > 0, 2.0e-6, 0.0)).cuda()
 dfmax = float(df.max().item())
 Iw = I.clone()
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+MUTATE = not (len(sys.argv) > 2 and sys.argv[2] == "chain")      # "chain": as Experiment calls it (input is a temporary)
 def f():
     # (the call zeroes CLAMPED rays in its input, |D| > N: there are none here, so the same array serves every repetition and
     # nothing but the call runs between the clocks -- under `rocprofv3 --kernel-trace --stats` every kernel that appears REPS
     # times or more belongs to the call: all of them are the library's)
-    return RF2.fastRefractionDF(Iw, phi, 3.6, 52.0, M, pix, df, darkFieldMax=dfmax, check=False)
+    return RF2.fastRefractionDF(Iw, phi, 3.6, 52.0, M, pix, df, darkFieldMax=dfmax, check=False, mutate=MUTATE)
 f(); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(REPS): f()
@@ -28,4 +29,4 @@ torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / REPS * 1e3
 lib.psx_profile_enable(1); f(); torch.cuda.synchronize()
 buf = ctypes.create_string_buffer(1 << 16); lib.psx_profile_summary(buf, len(buf)); lib.psx_profile_enable(0)
-print("fastRefractionDF %dx%d: %.2f ms wall; library kernels: %s" % (N, N, wall, buf.value.decode().replace("\n", "; ")))
+print("fastRefractionDF %dx%d (mutate=%s): %.2f ms wall; library kernels: %s" % (N, N, MUTATE, wall, buf.value.decode().replace("\n", "; ")))
