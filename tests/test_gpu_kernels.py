@@ -747,3 +747,38 @@ def test_darkfield_front_kernels_against_numpy(ops):
     for md in (0, 3, 11):
         got = ops.repad(dev(src, torch.float32), 8, md, (Nx, Ny)).cpu().numpy()
         assert np.array_equal(got, np.pad(src[8:8 + Nx, 8:8 + Ny], md))
+
+
+@pytest.mark.parametrize("max_df", [1.1, 2.4, 6.6, 7.9, 9.6])
+def test_darkfield_resplat_all_tile_shapes(ops, max_df):
+    """The variable-width Gaussian re-splat (RF2:168-186) through psx_darkfield_split_f32 + psx_darkfield_blur_prepared_f32
+    against the reference's literal per-source patch loop in float64, for widths that take the 32 x 16 tiles with separable
+    LDS tables (R <= 10), the 16 x 16 tiles (R = 11, 12) and the plain gather (R > 12); sources with and without dark field,
+    zero sources, patches clipped by the image border, a grid that is no multiple of the tile."""
+    rng = np.random.default_rng(int(max_df * 10))
+    Nx, Ny = 75, 58
+    I2DF = np.where(rng.uniform(size=(Nx, Ny)) < 0.2, 0.0, rng.uniform(1.0, 9.0, (Nx, Ny))).astype(np.float32)
+    I2 = rng.uniform(0.0, 3.0, (Nx, Ny)).astype(np.float32)
+    DFpx = np.where(rng.uniform(size=(Nx, Ny)) < 0.3, 0.0, rng.uniform(0.3, max_df, (Nx, Ny)))
+    DFpx[10, 10] = max_df
+    # psx_darkfield_split_f32 with scale 1 turns the width map into the float32 pixels + patch table the gather uses
+    _, _, DF32, prep, words = ops.darkfield_split(dev(I2DF, torch.float32), dev(DFpx, torch.float64), 1.0, 1e9)
+    R = int(round(1.5 * max_df)) + 1
+    out = ops.darkfield_blur_prepared(dev(I2DF, torch.float32), DF32, prep, dev(I2, torch.float32), R)
+    ops.check_status(out.device)
+    df = DF32.cpu().numpy().astype(np.float64)
+    m = int(np.ceil(6 * max_df))
+    ref = np.zeros((Nx + 2 * m, Ny + 2 * m))
+    for i in range(Nx):
+        for j in range(Ny):
+            v = float(I2DF[i, j])
+            if v == 0:
+                continue
+            if df[i, j] != 0:
+                patch = orc.create_gaussian_shape(df[i, j] / 2)
+                h = patch.shape[0] // 2
+                ref[m + i - h:m + i + h + 1, m + j - h:m + j + h + 1] += patch * v
+            else:
+                ref[m + i, m + j] += v
+    ref = ref[m:m + Nx, m:m + Ny] + I2
+    assert relmax(out.cpu().numpy(), ref) < 2e-6, max_df
