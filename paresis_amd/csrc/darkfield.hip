@@ -74,34 +74,33 @@ __global__ __launch_bounds__(256) void k_df_gather(const float *__restrict__ I2D
 // as far as the widest patch actually present in the staged window (most tiles of an image lie outside the scattering
 // sample: half-size 0, one term).  Same terms in the same order as k_df_gather (the exponent is formed as d^2 * (-log2(e)/2 sigma^2)
 // and goes through v_exp_f32, 1 ulp, instead of expf(-d^2 / (2 sigma^2)): 0.50 -> 0.39 ms at 4096^2).
-// Round 4: the patch of a source is SEPARABLE -- exp(-(di^2 + dj^2) / 2 sigma_s^2) = E_s(|di|) E_s(|dj|), and so is its square
-// support (max(|di|, |dj|) <= h_s  <=>  |di| <= h_s and |dj| <= h_s).  The staging pass therefore tabulates, per staged source,
-//     A_k = w_s E_s(k) [k <= h_s],  k = 0..R      and      E_k = E_s(k) [k <= h_s],  k = 1..R
-// (R + 1 exponentials per source, planes [2R + 1][window] of floats in LDS), and a term of the gather is
-//     A_|di|[s] * E_|dj|[s]          -- two 4-byte LDS reads and one fma: no exponential, no compare, no select.
-// The first tiled version evaluated w exp2((di^2 + dj^2) c) per term behind three tests (0.39 ms at 4096^2, 81 terms per
-// output inside the sample); a branch-free form with one 16-byte LDS entry per term took 0.33 ms and was bound by the
-// quarter-rate v_exp_f32; sharing an entry between four adjacent outputs changed nothing (0.36 ms: not LDS-bound).
-// A workgroup owns DTX x DTY = 32 x 16 outputs, two per thread (rows ti and ti + 16 of one column).
-// (16 x 16 for the widest patches: the planes of R = 12 then still fit the 160 KB of a CU)
-constexpr int DTY = 16;
-inline size_t df_lds_bytes(int R, int DTX) { return sizeof(float) * (size_t)(2 * R + 1) * (DTX + 2 * R) * (DTY + 2 * R); }
-
-template <int DTX>
+constexpr int DT = 32;
+// Round 4: one 16-byte LDS entry per staged source -- (weight, exponent coefficient, patch half-size, unused) read with ONE
+// ds_read_b128 -- and a branch-free inner loop: the term of a source is formed for every (di, dj) of the window's widest
+// patch and selected by `half-size >= max(|di|, |dj|)` (a scalar per loop trip), where the first version tested three
+// conditions per term with the exec-mask bookkeeping of a divergent `continue` and read two LDS arrays.  Inside a scattering
+// sample nearly every source has the window's widest patch, so almost nothing that is computed is thrown away.  The status
+// scan of the result (RF2:190-193) rides on the store.  0.39 -> 0.33 ms at 4096^2 (2.4-pixel dark field inside a cylinder).
+// Two further forms were built on it, measured and taken out again (same tests green): four adjacent outputs per thread
+// sharing each LDS entry (a third of the reads: 0.36 ms -- not LDS-bound), and the separable form -- per staged source the
+// tables A_k = w E(k), E_k = E(k), E(k) = exp2(k^2 c) for k up to the window's widest patch, so that a term is two 4-byte LDS
+// reads and one fma with no exponential, compare or select: 0.51 ms with the tables built for every window, 0.48 with
+// tables only where a patch reaches, 0.40 with the reads of a source row issued together (compile-time reach): the planes
+// take 48 KB per 32 x 16 tile (three workgroups per CU) and every term waits on LDS latency.
 __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict__ I2DF, const float *__restrict__ DF,
                                                          const float2 *__restrict__ prep, const float *__restrict__ I2,
                                                          float *__restrict__ out, int Nx, int Ny, int R, int tiles_y,
                                                          unsigned *status) {
     extern __shared__ __attribute__((aligned(16))) char sdf[];
-    const int WX = DTX + 2 * R, WY = DTY + 2 * R, WN = WX * WY;
-    float *pl = reinterpret_cast<float *>(sdf);          // planes A_0 .. A_R, then E_1 .. E_R, each [WX][WY]
+    const int W = DT + 2 * R;
+    float4 *swc = reinterpret_cast<float4 *>(sdf);                 // [W][W] (weight, coefficient, half-size, -)
     __shared__ int hmax;
-    const int t0 = (blockIdx.x / tiles_y) * DTX, c0 = (blockIdx.x % tiles_y) * DTY;
+    const int t0 = (blockIdx.x / tiles_y) * DT, c0 = (blockIdx.x % tiles_y) * DT;
     if (threadIdx.x == 0) hmax = 0;
     __syncthreads();
     int hm = 0;
-    for (int e = threadIdx.x; e < WN; e += 256) {
-        const int a = e / WY, b = e - a * WY;
+    for (int e = threadIdx.x; e < W * W; e += 256) {
+        const int a = e / W, b = e - a * W;
         const int si = t0 - R + a, sj = c0 - R + b;
         float w = 0.f, c = 0.f;
         int h = -1;
@@ -113,39 +112,39 @@ __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict
                 w = I2DF[q] * pr.y;
                 if (h > 0) {
                     const float sigma = 0.5f * DF[q];
-                    c = -1.4426950408889634f / (2.f * sigma * sigma);        // x log2(e): the hardware's 2^x
+                    c = -1.4426950408889634f / (2.f * sigma * sigma);        // x log2(e): the gather uses the hardware's 2^x
                 }
             }
         }
-        pl[e] = h >= 0 ? w : 0.f;                                          // A_0
-        for (int k = 1; k <= R; ++k) {
-            const float E = k <= h ? __builtin_amdgcn_exp2f((float)(k * k) * c) : 0.f;
-            pl[k * WN + e] = w * E;                                          // A_k
-            pl[(R + k) * WN + e] = E;                                        // E_k
-        }
+        swc[e] = make_float4(w, c, (float)h, 0.f);
         hm = max(hm, h);
     }
     for (int o = 32; o > 0; o >>= 1) hm = max(hm, __shfl_xor(hm, o));
     if ((threadIdx.x & 63) == 0) atomicMax(&hmax, hm);
     __syncthreads();
     const int Re = min(R, hmax);
-    const int tj = threadIdx.x & (DTY - 1), ti0 = threadIdx.x / DTY;      // 16 columns x 16 rows of threads
+    const int tj = threadIdx.x & 31, ti0 = threadIdx.x >> 5;
     bool bad = false;
 #pragma unroll
-    for (int k = 0; k < DTX / 16; ++k) {
-        const int ti = ti0 + 16 * k, i = t0 + ti, j = c0 + tj;
+    for (int k = 0; k < 4; ++k) {
+        const int ti = ti0 + 8 * k, i = t0 + ti, j = c0 + tj;
         if (i >= Nx || j >= Ny) continue;
         float acc = 0.f;
-        for (int di = -Re; di <= Re; ++di) {
-            const float *A = pl + abs(di) * WN + (ti + di + R) * WY + tj + R;   // plane A_|di|, this source row, own column
-            const float *E = pl + R * WN + (ti + di + R) * WY + tj + R;           // planes E_1.. start at (R + 1) * WN
-            float r = A[0];                                                       // dj = 0
-            for (int dj = 1; dj <= Re; ++dj) {
-                const float *Ed = E + dj * WN;
-                r = fmaf(A[-dj], Ed[-dj], r);
-                r = fmaf(A[dj], Ed[dj], r);
+        if (Re == 0) {                                   // no patch reaches this tile: every source deposits on itself
+            const float4 e = swc[(ti + R) * W + tj + R];
+            acc = e.z >= 0.f ? e.x : 0.f;
+        } else {
+            for (int di = -Re; di <= Re; ++di) {
+                const float4 *row = swc + (ti + di + R) * W + tj + R;
+                const float di2 = (float)(di * di);
+                for (int dj = -Re; dj <= Re; ++dj) {
+                    const float4 e = row[dj];
+                    const float need = (float)max(abs(di), abs(dj));          // scalar: di, dj are uniform
+                    // h == 0: coefficient 0, exp2(0) = 1, selected only at di = dj = 0 (same value as the plain deposit)
+                    const float t = e.x * __builtin_amdgcn_exp2f((di2 + (float)(dj * dj)) * e.y);
+                    acc += e.z >= need ? t : 0.f;
+                }
             }
-            acc += r;
         }
         const int64_t p = (int64_t)i * Ny + j;
         const float v = acc + (I2 ? I2[p] : 0.f);
@@ -153,30 +152,6 @@ __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict
         out[p] = v;
     }
     if (status && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, PSX_STATUS_NONFINITE);
-}
-
-// tiled gather when the planes fit LDS (patches of up to 2 R + 1 = 25 pixels), else the plain one; returns <0 when not launched
-static int launch_df_gather_tiled(const float *I2DF, const float *DF, const float2 *prep, const float *I2, float *out, int Nx, int Ny,
-                                  int R, unsigned *status, hipStream_t st) {
-    constexpr size_t LDS_MAX = 160 * 1024 - 64;
-    const int tiles_y = (int)cdiv(Ny, DTY);
-    if (df_lds_bytes(R, 32) <= LDS_MAX) {
-        static std::atomic<unsigned long long> m32{0};
-        if (first_on_device(m32))
-            PSX_HIP(hipFuncSetAttribute((const void *)k_df_gather_tiled<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
-        PSX_TIMED("k_df_gather", st, k_df_gather_tiled<32><<<(int)cdiv(Nx, 32) * tiles_y, 256, df_lds_bytes(R, 32), st>>>(
-                                         I2DF, DF, prep, I2, out, Nx, Ny, R, tiles_y, status));
-        return launch_check("k_df_gather");
-    }
-    if (df_lds_bytes(R, 16) <= LDS_MAX) {
-        static std::atomic<unsigned long long> m16{0};
-        if (first_on_device(m16))
-            PSX_HIP(hipFuncSetAttribute((const void *)k_df_gather_tiled<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
-        PSX_TIMED("k_df_gather", st, k_df_gather_tiled<16><<<(int)cdiv(Nx, 16) * tiles_y, 256, df_lds_bytes(R, 16), st>>>(
-                                         I2DF, DF, prep, I2, out, Nx, Ny, R, tiles_y, status));
-        return launch_check("k_df_gather");
-    }
-    return -1000;
 }
 
 // ---- the front of fastRefractionDF as ONE pass (RF2:114-150): width map in radians -> pixels (float64), its maximum (the
@@ -289,7 +264,13 @@ int psx_darkfield_blur_prepared_f32(const float *I2DF, const float *DF, const vo
     PSX_REQUIRE(I2DF && DF && out && prep && Nx > 0 && Ny > 0 && R >= 0, "psx_darkfield_blur_prepared_f32: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)Nx * Ny;
-    if (int rc = launch_df_gather_tiled(I2DF, DF, (const float2 *)prep, I2, out, Nx, Ny, R, status, st); rc != -1000) return rc;
+    const size_t lds = (size_t)(DT + 2 * R) * (DT + 2 * R) * sizeof(float4);
+    if (lds <= 60 * 1024) {
+        const int tiles_x = (int)cdiv(Nx, DT), tiles_y = (int)cdiv(Ny, DT);
+        PSX_TIMED("k_df_gather", st, k_df_gather_tiled<<<tiles_x * tiles_y, 256, lds, st>>>(I2DF, DF, (const float2 *)prep, I2, out,
+                                                                                            Nx, Ny, R, tiles_y, status));
+        return launch_check("k_df_gather");
+    }
     PSX_TIMED("k_df_gather", st, k_df_gather<<<ew_grid(n, 256), 256, 0, st>>>(I2DF, DF, (const float2 *)prep, I2, out, Nx, Ny, R));
     if (int rc = launch_check("k_df_gather")) return rc;
     return status ? psx_status_scan_f32(out, n, status, stream) : 0;
@@ -303,7 +284,13 @@ int psx_darkfield_blur_f32(const float *I2DF, const float *DF, const float *I2, 
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)Nx * Ny;
     PSX_TIMED("k_df_prepare", st, k_df_prepare<<<ew_grid(n, 256), 256, 0, st>>>(I2DF, DF, (float2 *)workspace, n));
-    if (int rc = launch_df_gather_tiled(I2DF, DF, (const float2 *)workspace, I2, out, Nx, Ny, R, nullptr, st); rc != -1000) return rc;
+    const size_t lds = (size_t)(DT + 2 * R) * (DT + 2 * R) * sizeof(float4);
+    if (lds <= 60 * 1024) {          // patches of up to 2 R + 1 = 29 pixels; wider ones take the plain gather
+        const int tiles_x = (int)cdiv(Nx, DT), tiles_y = (int)cdiv(Ny, DT);
+        PSX_TIMED("k_df_gather", st, k_df_gather_tiled<<<tiles_x * tiles_y, 256, lds, st>>>(I2DF, DF, (const float2 *)workspace, I2,
+                                                                                            out, Nx, Ny, R, tiles_y, nullptr));
+        return launch_check("k_df_gather");
+    }
     PSX_TIMED("k_df_gather", st, k_df_gather<<<ew_grid(n, 256), 256, 0, st>>>(I2DF, DF, (const float2 *)workspace, I2, out,
                                                                               Nx, Ny, R));
     return launch_check("k_df_gather");
