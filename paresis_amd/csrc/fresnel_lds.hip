@@ -687,7 +687,12 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 for (int q = 0; q < RAD / 2; ++q) b[q] = lds_read(pp + (h * (RAD / 2) + q) * (S1 + S1 / 32));
 #pragma unroll
                 for (int q = 0; q < RAD / 2; ++q) {
-                    // a leg without partner reads whatever lies there (possibly past the line buffers) and drops it
+                    // A leg without partner (q >= qb) reads whatever lies at its would-be partner's address and drops it.  That
+                    // address can lie behind the twiddle tables, and for short DIF lines (large D = 2M - P) past the end of
+                    // the workgroup's LDS allocation: furthest byte = 8 * (MP + phys((767 + D) / 2) + 23 * 396) <= 184 KB for
+                    // P >= 12 310.  An out-of-range DS read is defined on gfx9: it returns 0 and touches nothing (the LDS
+                    // aperture check; it does set MEM_VIOL in TRAPSTS, which only matters under a trap handler).  Clamping
+                    // the 24 addresses instead costs 24 vector instructions in the stage that has none to spare.
                     const v2f bm = (h * (RAD / 2) + q) < qb ? b[q] : (v2f){0.f, 0.f};
                     v[h * (RAD / 2) + q] = pk_fma_k(bm, sg, v[h * (RAD / 2) + q]);
                 }

@@ -16,7 +16,7 @@ def agg(d):
         name = r["Kernel_Name"]
         if "anonymous" not in name:
             continue
-        short = name.split("::")[1].split("(")[0]
+        short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]     # with its template arguments
         out[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in out.items()}
 
@@ -24,7 +24,7 @@ def agg(d):
 fetch, write, sq = agg("fin_fetch"), agg("fin_write"), agg("fin_sq")
 summary = {}
 for k in sorted(set(fetch) | set(write) | set(sq)):
-    if not (k.startswith("k_fresnel") or k.startswith("k_refract") or k.startswith("k_source")):
+    if not (k.startswith("k_fresnel") or k.startswith("k_refract") or k.startswith("k_source") or k.startswith("k_band")):
         continue
     e = {}
     if k in fetch:
@@ -35,8 +35,11 @@ for k in sorted(set(fetch) | set(write) | set(sq)):
         e["hbm_bytes_per_launch"] = int((2 * fetch[k]["FETCH_SIZE"] + write[k]["WRITE_SIZE"]) * 1024)
     e.update(sq.get(k, {}))
     summary[k] = e
-json.dump({"note": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ counters each in its own run) of "
-                   "`python3 bench.py --no-cpu-baseline --positions 0%s` (warm-up + timed steps + the per-kernel event pass) on one MI355X; averages per " % (" (" + sfx.strip("_") + "^2 grid)" if sfx else "") +
+cmd = ("`python3 bench.py --only-configs --configs 16384 --no-config-parity` (config 5 as the driver's line runs it: GPU-synthesised "
+       "membrane, halo picked by ops.tune_refract_halo -- its three candidates appear as three k_refract instances --, detector "
+       "inside the step)") if sfx == "_cfg5" else (
+       "`python3 bench.py --no-cpu-baseline --positions 0%s` (warm-up + timed steps + the per-kernel event pass)" % (" (" + sfx.strip("_") + "^2 grid)" if sfx else ""))
+json.dump({"note": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ counters each in its own run) of " + cmd + " on one MI355X; averages per " +
                    "launch.  hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE reads half of a wide "
                    "coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section), WRITE_SIZE is exact.",
            "kernels": summary}, open("profiles/%s_pmc_summary%s.json" % (tag, sfx), "w"), indent=1)
