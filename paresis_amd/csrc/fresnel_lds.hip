@@ -1264,7 +1264,7 @@ __device__ __forceinline__ void source_transposed_tile(const float2 *__restrict_
                         }
                         float c, sn;
                         cis_f64(ph, c, sn);
-                        a *= expf((float)la);
+                        a *= exp_att(la);
                         ww = make_float2(wi.x * c - wi.y * sn, wi.x * sn + wi.y * c);
                     }
                     w = make_float2(a * ww.x, a * ww.y);
@@ -1278,7 +1278,7 @@ __device__ __forceinline__ void source_transposed_tile(const float2 *__restrict_
                     }
                     float c, sn;
                     cis_f64(ph, c, sn);
-                    const float av = amp * expf((float)la);
+                    const float av = amp * exp_att(la);
                     w = make_float2(av * c, av * sn);
                 }
                 tile[xr + 16 * r][yq + e] = w;

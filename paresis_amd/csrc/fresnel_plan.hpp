@@ -91,7 +91,7 @@ __device__ __forceinline__ float2 source_wave(const float2 *__restrict__ wave_in
         mats_eval<NM>(m, p, ph, la);
         float c, s;
         cis_f64(ph, c, s);
-        a *= expf((float)la);
+        a *= exp_att(la);
         w = make_float2(w.x * c - w.y * s, w.x * s + w.y * c);
     }
     return make_float2(a * w.x, a * w.y);

@@ -67,6 +67,15 @@ using GeoSmall = Geo<56, 56, 4, 1024>;   // 80 KiB of LDS: two workgroups per CU
 using GeoMid = Geo<52, 52, 6, 1024>;     // 76 KiB; 1.51 evaluations
 using GeoWide = Geo<48, 48, 8, 1024>;    // 73 KiB: two workgroups per CU (one stages while the other deposits); 1.78 evaluations
 constexpr int FAR_THREADS = 256;
+// Lanes per far-ray list: a whole wave.  Fewer lanes per list (several lists per wave, on the idea that the replay is a chain
+// of dependent latencies and most lists are short) was measured as a build-time A/B in round 4 (tools/ab_far.sh,
+// gpurun_out/r4s7) and is SLOWER the fewer lanes a list gets -- 4096^2 step, k_refract_far: 64 lanes 33.6 us, 32: 36.4,
+// 16: 46.3, 8: 69.4, 4: 107.5; config 5 (halo 8): 3.01 / 3.17 / 3.33 / 3.50 / 3.69 ms; the three passes of the
+// order-independent form scale the same way -- the records of a list are what runs in parallel.
+#ifndef PSX_FAR_SUB
+#define PSX_FAR_SUB 64
+#endif
+constexpr int FAR_SUB = PSX_FAR_SUB, FAR_LISTS = FAR_THREADS / FAR_SUB;     // lists per workgroup
 constexpr int DET_NO_UNIT = -(1 << 30);     // det_sexp entry of a tile without a fixed-point unit (all-zero or non-finite window)
 
 // a far ray, already evaluated by the tile that owns its source pixel
@@ -560,7 +569,7 @@ template <class G, int MODE = FAR_FLOAT, bool ONE = false>      // ONE: a single
 __device__ __forceinline__ void refract_far_body(const RefractArgs &a) {
     constexpr int TH = G::TH, TW = G::TW, H = G::H;
     const unsigned nlists = (unsigned)(a.tiles_x * a.tiles_y) * (unsigned)a.ndist;
-    const unsigned lst = blockIdx.x * (FAR_THREADS / 64) + (threadIdx.x >> 6);
+    const unsigned lst = blockIdx.x * FAR_LISTS + threadIdx.x / FAR_SUB;
     if (lst >= nlists) return;
     const unsigned n = a.far_count[lst];
     if (n == 0) return;
@@ -571,7 +580,7 @@ __device__ __forceinline__ void refract_far_body(const RefractArgs &a) {
     long long *const acc = MODE == FAR_FLOAT ? nullptr : a.det_acc + (size_t)dist * a.Nx * a.Ny;
     unsigned char *const marks = MODE == FAR_FLOAT ? nullptr : a.det_marks + (size_t)lst * (TH * TW);
     const int Px = a.Nx + 2 * a.margin, Py = a.Ny + 2 * a.margin;
-    for (unsigned e = threadIdx.x & 63; e < n; e += 64) {
+    for (unsigned e = threadIdx.x % FAR_SUB; e < n; e += FAR_SUB) {
         const FarRay fr = list[e];
         const int i = fr.src / a.Ny, j = fr.src - i * a.Ny;
         const float I = fr.I;
@@ -770,7 +779,7 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
                   k_refract_near<G, NM, HI, HP><<<a.tiles_x * a.tiles_y, G::NT, G::LDS, st>>>(a));
         if (int rc = launch_check("k_refract_near")) return rc;
         const int nlists = a.tiles_x * a.tiles_y * a.ndist;
-        const int fgrid = (nlists + FAR_THREADS / 64 - 1) / (FAR_THREADS / 64);
+        const int fgrid = (nlists + FAR_LISTS - 1) / FAR_LISTS;
         if (a.det_acc) {      // order-independent replay: three passes over the lists, scratch from the workspace
             PSX_TIMED("k_refract_far_prep", st, k_refract_far<G, FAR_PREP><<<fgrid, FAR_THREADS, 0, st>>>(a));
             PSX_TIMED("k_refract_far_add", st, k_refract_far<G, FAR_ADD><<<fgrid, FAR_THREADS, 0, st>>>(a));
@@ -816,7 +825,7 @@ int launch_refract_batch(RefractTab &t, int n, bool has_I, int nmat, void *works
                                         (int)G::LDS));
         PSX_TIMED("k_refract_near", st, k_refract_near_batch<G, NM, HI><<<dim3((unsigned)nt, (unsigned)n), G::NT, G::LDS, st>>>(t));
         if (int rc = launch_check("k_refract_near")) return rc;
-        const int fgrid = ((int)nt + FAR_THREADS / 64 - 1) / (FAR_THREADS / 64);
+        const int fgrid = ((int)nt + FAR_LISTS - 1) / FAR_LISTS;
         const dim3 fg((unsigned)fgrid, (unsigned)n);
         if (t.e[0].det_acc) {
             PSX_TIMED("k_refract_far_prep", st, k_refract_far_batch<G, FAR_PREP><<<fg, FAR_THREADS, 0, st>>>(t));

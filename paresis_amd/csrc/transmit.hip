@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void k_transmit_wave(const float2 *__restrict_
         mats_eval<NM>(m, p, ph, la);
         float c, s;
         cis_f64(ph, c, s);
-        const float a = amp * expf((float)la);
+        const float a = amp * exp_att(la);
         float2 w = win ? win[p] : make_float2(1.f, 0.f);
         float2 o;
         o.x = a * (w.x * c - w.y * s);
