@@ -33,117 +33,17 @@
 #include <tuple>
 #include <vector>
 
-#include "fft_pk.hpp"
 #include "fresnel_plan.hpp"
+#include "fresnel_stages.hpp"
 
 using namespace psx;
-
-typedef unsigned v2u __attribute__((ext_vector_type(2)));
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
+using namespace psx::lines;
 
 namespace {
 
-// One 16-wave workgroup per CU owns the whole LDS.  Waves 0..11 (TC threads) are the butterfly engine -- 3 per SIMD are
-// needed to keep the vector pipes issuing -- and waves 12..15 (TL threads, one per SIMD) only move samples: they fetch
-// the NEXT line group from HBM while the engine transforms the current one, and spread it into LDS in the shadow of the
-// last butterfly + store.  Four waves per SIMD cap every wave at 128 VGPRs.  The workgroups are persistent (one per CU,
-// a strided list of line groups each), so the exposed fetch latency is paid once per launch instead of once per group.
-constexpr int TC = 768;       // engine threads = radix-24 butterflies per stage
-constexpr int TL = 256;       // loader threads
-constexpr int T = TC + TL;
-constexpr int TOT = 18432;    // complex points resident in LDS per workgroup = LINES * M
-constexpr int RAD = 24;       // radix of the two big stages
-// The intermediate between the two passes is stored in blocks of IB samples of a pass-1 line: [Nx/IB][Ny][IB].  Pass 1
-// still writes whole 128-byte lines (2 image rows x 8 samples), and the 16-byte pieces a pass-2 workgroup reads (two
-// adjacent pass-2 lines) sit 64 bytes apart instead of a whole image row: half the cache lines per wave load.
-#ifndef PSX_IB
-#define PSX_IB 8              // build-time A/B of the block shape (tools/ab_ib.sh): 4, 8, 16
-#endif
-constexpr int IB = PSX_IB;
-constexpr int IBS = IB == 4 ? 2 : (IB == 8 ? 3 : 4);      // log2(IB)
-static_assert((1 << IBS) == IB, "intermediate block size");
-constexpr int QUEUE_WORDS = 16 * 257;     // work queues: a counter per workgroup (<= 256, 64 bytes apart) + the count of workgroups done
-#ifndef PSX_DIF_NHA
-#define PSX_DIF_NHA 52        // DIF rounds: window positions (of 72 per loader thread) that travel during the transform
-#endif
-
-__host__ __device__ constexpr int phys(int p) { return p + (p >> 5); }   // one pad slot per 32: conflict-free slabs
-
-// (distance, source) pairs one line launch can carry: the PSX_MAX_DIST distances of one source wave, or -- a batch of source
-// waves, e.g. the energies of a detector bin -- up to MAX_LINE (source, distance) pairs, each with its own input and tables
-constexpr int MAX_LINE = 32;
-
-struct LineArgs {
-    int n_dist;             // distances merged into this launch: work item w = d * ngroups + g  (d-th table / buffers, group g)
-    int dist_inner;         // 1: every distance reads the SAME source (pass 1): a workgroup takes the n_dist work items of a
-                            // line group in consecutive rounds and its loaders fetch the group once, spreading it n_dist times
-    const float2 *src[MAX_LINE];        // input wave of each distance
-    int N, nlines, margin, P, L;
-    int64_t in_si, in_sl;   // sample i of line l is element i*in_si + l*in_sl of src ...
-    int in_blocked;         // ... or, blocked: element ((l / IB)*N + i)*IB + l % IB  (the intermediate, see IB)
-    int64_t out_ld;         // output sample i of line l goes to l*out_ld + i ...
-    int out_blocked;        // ... or, blocked: element ((i / IB)*nlines + l)*IB + i % IB
-    const float2 *twA, *twB;   // [n][24] stage twiddles
-    const float2 *H[MAX_LINE];          // kernel spectrum FFT_M(h) of each distance, digit-reversed, 1/M folded in
-    float2 *wave_out[MAX_LINE];         // complex result (pass 1: the blocked intermediate) or null
-    float *inten_out[MAX_LINE];         // scale * |result|^2 or null
-    float scale[MAX_LINE];
-    float2 gph[MAX_LINE];               // global phase factor exp(i k z / M) of the complex result
-    int accumulate;
-    // Partitioned convolution (PART instantiations; lines too long for one M-point transform in LDS): the N outputs of a
-    // line are cut into NB blocks of B, the P-tap kernel into S segments of Lh (B + Lh - 1 <= M); a work unit is
-    // (distance, line group, block) and takes S consecutive rounds, one per segment, whose results add up in `part`
-    // (complex, same layout as the complex output; it IS the complex output when that is wanted).  H[d] then holds S spectra.
-    int B, Lh, S, NB;
-    float2 *part[MAX_LINE];
-    const float2 *w2;       // PAIR: w_2M^{k0} of each 16-point slab, k0 = q1 + 24 q2  (576 entries)
-    // DIF (see k_fresnel_lines): one 4M-point convolution per line in two PAIR rounds
-    const float2 *w4;       // exp(+2 pi i n0 / 4M), n0 < 2*S1 = 768: the thread-dependent factor of the radix-2 twiddle w_4M^{-n}
-    float2 *wgpart;         // [workgroups][2M]: the even half-spectrum's result of a line, private to the workgroup, between its two rounds
-    int wg_groups;          // line buffers in wgpart (host-side check against the grid)
-    int dsh, thr;           // D = 2M - P: L[n + D] = e[n + 2M] (the extension is P-periodic); thr = N + P - 1 - 2M: positions that have one
-    unsigned *queue;        // work queues of the one-transform passes (null: static shares): the counter of workgroup w at [16 w], workgroups done at [16 * 256]
-    unsigned long long *stamps;   // optional diagnostics: 32 phase timestamps per workgroup (psx_debug_stamps)
-    int stamp_j;                  // ... of this round of every workgroup (PSX_STAMP_ROUND, default 1: a steady-state round)
-};
-
-// phase timestamp of wave 0 for the SECOND line group of each workgroup, a steady-state round (diagnostic runs only)
-#define PSX_STAMP(k)                                                             \
-    do {                                                                         \
-        if (a.stamps && (DIF ? (j == a.stamp_j && ftid() == 0) : (tid == 0 && j == a.stamp_j)))                       \
-            a.stamps[(size_t)blockIdx.x * 32 + (k)] = wall_clock64();                                                \
-    } while (0)
-
-// orders the LDS traffic of ONE wave (cross-lane exchange through LDS without a workgroup barrier): no instruction is
-// emitted beyond the wait the fence implies; the compiler may not move LDS accesses across it
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// One ds_read_b64 per value.  Left alone, the compiler pairs neighbouring reads into ds_read2_b64, which moves the same
-// 16 bytes per lane in 8 LDS cycles instead of 2 x 2 (MI355X_MICROARCH.md, LDS table); a volatile access is not paired.
-__device__ __forceinline__ v2f lds_read(const v2f *p) {
-    typedef const volatile __attribute__((address_space(3))) v2f *lds_ptr;   // explicit: a volatile generic load is a flat load
-    return *(lds_ptr)p;
-}
-
-// workgroup barrier that orders LDS traffic only: a loader wave passes it with its global loads still in flight
-// (__syncthreads() would wait vmcnt(0) and stall the engine behind an HBM round trip)
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
+// ---- lines that fit one LDS transform (N <= 4593) ------------------------------------------------------------------------------------
 // CONTIG: the samples of a line are adjacent in memory (in_si == 1) -- the lanes of a loader wave then walk along the line;
 // otherwise they walk across the LINES lines of the group (adjacent columns of a row-major image).
-// PAIR (partitioned convolution only): the two LDS lines of a round hold the EVEN and the ODD samples of ONE sequence of
-// 2M = 18432 points, and the middle stage couples them with the radix-2 butterfly of a 2M-point transform
-//     X[k] = E[k] + w^k O[k],  X[k+M] = E[k] - w^k O[k]   ...x H...   E'[k] = Y[k] + Y[k+M],  O'[k] = (Y[k] - Y[k+M]) w^-k
-// (E, O = the two M-point spectra the engine computes anyway; w = exp(-2 pi i / 2M)).  One round is then ONE block x segment
-// product of twice the size: a 16384-sample line needs 2 x 2 of them instead of 5 x 3 M-point products for two lines.
 // DUAL (pass 1 of a call with several distances): a round is HALF the LDS lines' worth of image lines (one at R3 = 16) and
 // TWO distances.  The lines are transformed forward once (stages A and B on the first half of the LDS lines, by six of the
 // twelve engine waves); the middle stage reads each spectrum slab once and writes its product with the first distance's
@@ -152,64 +52,39 @@ __device__ __forceinline__ void lds_barrier() {
 // for the other.
 // That is the only way of sharing the forward transform between distances that fits LDS: 4.3 stage-units of work per two
 // (line, distance) results instead of 5.3, and half the samples to fetch and spread per round.
-// DIF (lines of 9202 <= N <= 18402 samples, the 16384^2 grid of BASELINE config 5): the whole line is ONE circular
-// convolution of 4M = 36864 >= N + P - 1 points, split by a decimation-in-frequency radix-2 step over TWO PAIR rounds:
-//     round E:  ye = IDFT_2M( FFT_2M( x[n] + x[n + 2M] )          * H4[2k]   )
-//     round O:  yo = IDFT_2M( FFT_2M((x[n] - x[n + 2M]) w_4M^n )  * H4[2k+1] )        y[m] = (ye[m'] + w_4M^-m yo[m']) / 2,  m' = m mod 2M
-// (the block x segment partition needs 2 x 2 such rounds at N = 16384, each re-reading a 16398-sample window).  The
-// extension e of the line is P-periodic, so x[n + 2M] = e[n + 2M - P]: the loaders write ONE copy L[n] = e[n], n < 2M, and
-// forward stage A forms L[n] +- L[n + D] itself from LDS (one more workgroup barrier: everybody reads before anybody writes
-// in place); the twiddle w_4M^n = (thread factor) x (compile-time 48th root per butterfly leg) rides on stage A's input and
-// output multiplies.  Round E leaves ye in a line buffer private to the workgroup (it is read back 20 us later by the same
-// CU: L2 / MALL traffic), round O combines and stores the N wanted samples, whose index wraps once along the 24 outputs of a
-// butterfly.  Per line: 2 rounds and 2 x 18432 loads instead of 4 and 4 x 16398; no partial sums in the output image.
-template <int R3, bool CONTIG, bool PART = false, bool PAIR = false, bool DUAL = false, bool QUEUE = false, bool DIF = false>
+// phase timestamp of the oldest engine wave in round a.stamp_j of each workgroup (diagnostic runs only: psx_debug_stamps)
+#define PSX_STAMP(k) PSX_STAMP_IF(k, tid == 0)
+template <int R3, bool CONTIG, bool DUAL = false, bool QUEUE = false>
 __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
-    static_assert(!DIF || (PART && PAIR), "DIF rounds are PAIR rounds of the partitioned engine");
-    // PAIR: the second LDS line starts 16 points further, so that a point of line 0 and the same point of line 1 sit 32 banks
-    // apart: stage A then gives adjacent lanes the even and the odd sample of a pair without a bank conflict
-    constexpr int M = 576 * R3, LINES = TOT / M, S1 = M / RAD, MP = M + M / 32 + (PAIR ? 16 : 0);
+    using GE = LineGeom<R3, false>;
+    constexpr int M = GE::M, LINES = GE::LINES, S1 = GE::S1, MP = GE::MP;
     constexpr int LH = DUAL ? LINES / 2 : LINES;        // DUAL: image lines of a round = half the LDS lines (the other half
                                                         // receives the second distance's products)
-    constexpr int LPG = PAIR ? 1 : LH;                  // image lines per round
+    constexpr int LPG = LH;                             // image lines per round
     constexpr int LL = LH;                              // LDS lines the loaders fill
-    static_assert(!PAIR || (PART && R3 == 16 && LINES == 2), "PAIR couples the two lines of the R3 = 16 partitioned engine");
-    static_assert(!DUAL || (!PART && CONTIG && LINES % 2 == 0), "DUAL: LINES/2 image lines x two distances per round");
-    constexpr int SLAB = 16, NSLABS = TOT / SLAB;       // 16 contiguous points per slab in the middle stage
-    constexpr int WSLABS = 64 * RAD / SLAB;              // slabs inside the 1536 points one wave owns between barriers
-    constexpr int NSLAB = (WSLABS + 63) / 64;            // slab rounds per lane (the last one is partly idle)
-    static_assert(R3 <= 16 && SLAB % R3 == 0 && TOT == RAD * TC && 64 % R3 == 0 && NSLABS == (TC / 64) * WSLABS,
-                  "unsupported geometry");
+    static_assert(!DUAL || (CONTIG && LINES % 2 == 0), "DUAL: LINES/2 image lines x two distances per round");
+    constexpr int SLAB = GE::SLAB, WSLABS = GE::WSLABS, TWB_LD = GE::TWB_LD;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
     const int N = a.N, mg = a.margin;
     // A fresh copy of the thread index for values that are re-derived inside the round loop instead of being kept across it
-    // (the engine waves have no register to spare).  DIF: not even the index itself stays in a VGPR -- the wave's base sits in
-    // an SGPR and the lane number comes from v_mbcnt (it was the one value the DIF instance spilled: reloaded once a round
-    // from scratch memory, behind a full memory wait).
-    const int wave_base = DIF ? __builtin_amdgcn_readfirstlane(tid & ~63) : 0;
+    // (the engine waves have no register to spare)
     auto ftid = [&]() __attribute__((always_inline)) {
-        int t;
-        if constexpr (DIF) {
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(t));
-            t += wave_base;
-        } else {
-            t = tid;
-            asm volatile("" : "+v"(t));
-        }
+        int t = tid;
+        asm volatile("" : "+v"(t));
         return t;
     };
 
     // ---- line groups of this workgroup: XCD x = blockIdx % 8 owns a contiguous chunk of groups (its 32 CUs then read
     // neighbouring columns at the same time: the 128-byte lines of the strided source are shared in that XCD's L2)
     const int ngroups = (a.nlines + LPG - 1) / LPG;
-    const int nwork = PART ? ngroups * a.n_dist * a.NB : (a.dist_inner ? ngroups : ngroups * a.n_dist);   // all distances of a call in ONE launch
+    const int nwork = a.dist_inner ? ngroups : ngroups * a.n_dist;   // all distances of a call in ONE launch
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     const int cq = nwork >> 3, cr = nwork & 7;
     const int cstart = xcd * cq + (xcd < cr ? xcd : cr), clen = cq + (xcd < cr ? 1 : 0);
     const int nunits = slot < clen ? (clen - slot + nslot - 1) / nslot : 0;   // units cstart + slot + u*nslot, u < nunits
     const int nsub = DUAL ? (a.n_dist + 1) / 2 : a.n_dist;       // rounds per line group when the distances are taken inside
-    const int nj = PART ? nunits * a.S : (a.dist_inner ? nunits * nsub : nunits);   // rounds of this workgroup (static order)
+    const int nj = a.dist_inner ? nunits * nsub : nunits;   // rounds of this workgroup (static order)
     // One-transform passes can take their units from QUEUES instead (DYN).  A static share per workgroup assumes that all 256
     // workgroups start together: one CU busy with anything else (the copy kernels of an RCCL transfer, another stream) makes
     // one workgroup start when the first of the others ends and DOUBLES the pass (tools/contention_probe.py: one foreign
@@ -220,21 +95,11 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     // workgroup that starts late finds its share taken and leaves.  uq: ring of the units claimed (index inside the chunk,
     // -1: nothing left).
     constexpr bool DYN = QUEUE;                          // its own instantiations: the engine waves have no register to spare
-    static_assert(!QUEUE || !PART, "the queue serves the one-transform passes");
     const int nsubr = a.dist_inner ? nsub : 1;                   // rounds per unit
     int *const uq = reinterpret_cast<int *>(lds + LINES * MP + (2 * R3 + RAD) * (RAD + 1));   // behind the three twiddle tables
-    // round j -> (distance, line group) [, output block, kernel segment]
-    int pb = 0, ps = 0;       // PART: block and segment of the round last decoded
+    // round j -> (distance, line group)
     auto item = [&](int j, int &d, int &g) __attribute__((always_inline)) {
-        if (PART) {
-            const int u = j / a.S;
-            ps = j - u * a.S;
-            const int w = cstart + slot + u * nslot;         // unit: ((d * NB) + b) * ngroups + g
-            const int db = w / ngroups;
-            g = w - db * ngroups;
-            d = db / a.NB;
-            pb = db - d * a.NB;
-        } else if (a.dist_inner) {
+        if (a.dist_inner) {
             const int u = j / nsub;
             d = j - u * nsub;                                // DUAL: index of the distance PAIR
             g = cstart + (DYN ? uq[u & 3] : slot + u * nslot);
@@ -275,29 +140,10 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         return -1;
     };
 
-    // Stage B's twiddles w_S1^{n q} (n < R3, q < 24: 3 KiB) live in LDS behind the line buffers, rows padded to 25 so that
-    // the 16 rows start on 16 different bank pairs: a ds_read_b64 costs 2 LDS cycles where the 16-byte global loads of
-    // the same table (L1 hits) took the CU's 64 B/clk vector-memory return path that the loaders and the other tables need.
-    // Stage A's twiddles w_M^{n q}, n < S1 = 24 R3, would be 72 KiB; with n = R3 n1 + n0 they factor into
-    // w_576^{n1 q} * w_M^{n0 q}: a [24][24] and an [R3][24] table (rows R3*n1 and n0 of the global table), 7.8 KiB, at the
-    // price of one more complex multiply per point and stage (+46 packed instructions per butterfly).  With all three
-    // tables in LDS the engine's only global loads are the kernel spectrum's.
     // the first two units of this workgroup: one atomic, in flight while the twiddle tables are copied
     unsigned first2 = 0u;
     if (DYN && tid == TC) first2 = atomicAdd(qcount(slot), 2u);
-    constexpr int TWB_LD = RAD + 1;
-    v2f *twl = reinterpret_cast<v2f *>(lds) + LINES * MP;          // [R3][25]  stage B
-    v2f *tw1 = twl + R3 * TWB_LD;                                  // [24][25]  stage A, n1 part
-    v2f *tw0 = tw1 + RAD * TWB_LD;                                 // [R3][25]  stage A, n0 part
-    for (int idx = tid; idx < R3 * RAD; idx += T) {
-        const float2 w = a.twB[idx], w0 = a.twA[idx];
-        twl[(idx / RAD) * TWB_LD + idx % RAD] = (v2f){w.x, w.y};
-        tw0[(idx / RAD) * TWB_LD + idx % RAD] = (v2f){w0.x, w0.y};
-    }
-    for (int idx = tid; idx < RAD * RAD; idx += T) {
-        const float2 w = a.twA[(size_t)(idx / RAD) * R3 * RAD + idx % RAD];     // row n = R3 * n1
-        tw1[(idx / RAD) * TWB_LD + idx % RAD] = (v2f){w.x, w.y};
-    }
+    const TwTables tw = fill_tables<GE>(lds, a, tid);          // stage twiddles into LDS, behind the line buffers
 
     if constexpr (DYN) {
         if (tid == TC) {                                 // the first loader thread runs the queue
@@ -307,153 +153,8 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         lds_barrier();                                   // the first two units are known to every wave
     }
 
-    // LDS index of butterfly element j: with S1 a multiple of 32 (and R3 | 32) the pad term of phys() is affine in j, so
-    // every element is one base register + a compile-time offset (ds_read/ds_write immediate offsets)
-    constexpr bool AFF = (S1 % 32 == 0);
-    auto idxA = [&](int n, int j) __attribute__((always_inline)) {
-        return AFF ? phys(n) + j * (S1 + S1 / 32) : phys(n + j * S1);
-    };
-    auto idxB = [&](int p0, int j) __attribute__((always_inline)) {      // p0 = q1*S1 + n,  n < R3
-        return AFF ? phys(p0) + j * R3 + ((j * R3) >> 5) : phys(p0 + j * R3);
-    };
-
 
     if (tid >= TC) {
-        if constexpr (PART) {
-            // =========================== loader waves, partitioned convolution ============================================
-            // LDS position t of a line holds e[a0 + t], e = the periodic / mirrored extension of the line the linear
-            // convolution runs over (e[te] = x_per[te - (P-1) + margin]), a0 = b*B + P - (s+1)*Lh; zeros outside the window of
-            // B + Lh - 1 positions.  A window is twice a regular line's share of registers, so it moves in two halves: the
-            // first is fetched during the transform (as in the regular engine), the second between barriers (3) and (4), after
-            // the first has been written out of the same registers.
-            const int lt = tid - TC;
-            constexpr int STEP = TL / LINES, NH = M / STEP / 2, PSTEP = STEP + STEP / 32;
-            static_assert(STEP % 32 == 0 && (M / STEP) % 2 == 0, "affine LDS addressing of the loader halves");
-            // (DIF: adjacent lanes take adjacent samples whatever the source layout -- 512 contiguous bytes per wave load in pass 1)
-            const int line = (CONTIG && !DIF) ? lt / STEP : lt % LINES, i0 = (CONTIG && !DIF) ? lt % STEP : lt / LINES;
-            float2 *base = lds + line * MP + phys(i0);
-            const int P = a.P, Lw = a.B + a.Lh - 1, Etot = N + P - 1;
-            // DIF: every one of the 2M window positions holds a sample (no validity masks), position t is sample
-            // reflect(((t + 1 + mg) mod P) - mg) of the line: five vector instructions and a buffer load whose descriptor is the
-            // line.  The 72 positions of a thread then move as NHA + NHB instead of 36 + 36: the more of them travel during the
-            // transform, the shorter the fetch that is exposed between barriers (3) and (4).
-            constexpr int NHA = DIF ? PSX_DIF_NHA : NH, NHB = 2 * NH - NHA;
-            float2 xs[NHA];
-            auto fetch_dif = [&](int j, auto k0_tag, auto cnt_tag) __attribute__((always_inline)) {
-                constexpr int K0 = decltype(k0_tag)::value, CNT = decltype(cnt_tag)::value;
-                int d, g;
-                item(j, d, g);
-                const int lc = min(g, a.nlines - 1);
-                const float2 *srcl = a.src[d] + (a.in_blocked ? ((int64_t)(lc / IB) * N) * IB + lc % IB : (int64_t)lc * a.in_sl);
-                const int sh = a.in_blocked ? IBS + 3 : 3;                     // byte stride of a sample: 8 IB (blocked) or 8
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<float2 *>(srcl), 0, g < a.nlines ? (int)((unsigned)N << sh) : 0, 0x00020000);   // a line past the image reads zeros
-                int jb = 2 * i0 + line + mg + 1;
-                asm volatile("" : "+v"(jb));
-#pragma unroll
-                for (int k = 0; k < CNT; ++k) {
-                    const unsigned j0 = (unsigned)(jb + 2 * STEP * (K0 + k));
-                    const unsigned jp = min(j0, j0 - (unsigned)P);                   // mod P (j0 < 2P)
-                    unsigned i1, i2;       // |a - b| in one instruction (the compiler expands __sad into sub, neg, max)
-                    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(i1) : "v"(jp), "s"(mg));           // np.pad 'reflect' (EXP:237) on the left ...
-                    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(i2) : "v"(i1), "s"(N - 1));
-                    const unsigned i = (unsigned)(N - 1) - i2;                                 // ... and on the right
-                    xs[k] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(i << sh), 0, 0));
-                }
-            };
-            auto spread_dif = [&](auto k0_tag, auto cnt_tag) __attribute__((always_inline)) {
-                constexpr int K0 = decltype(k0_tag)::value, CNT = decltype(cnt_tag)::value;
-#pragma unroll
-                for (int k = 0; k < CNT; ++k) base[(K0 + k) * PSTEP] = xs[k];
-            };
-            using KA0 = std::integral_constant<int, 0>;
-            using KAN = std::integral_constant<int, NHA>;
-            using KBN = std::integral_constant<int, NHB>;
-            unsigned vm0 = 0u, vm1 = 0u;                    // which of the NH positions hold a sample (the rest are zeros)
-            static_assert(NH <= 64, "validity mask");
-            auto fetch_half = [&](int j, int h) __attribute__((always_inline)) {
-                int d, g;
-                item(j, d, g);
-                const int l = PAIR ? g : g * LINES + line;
-                const int lc = min(l, a.nlines - 1);          // addresses stay inside the image for the idle lines of the last group
-                // PART sources are the blocked intermediate or contiguous lines (in_si == 1): 32-bit element offsets from the line's base
-                const float2 *srcl = a.src[d] + (a.in_blocked ? ((int64_t)(lc / IB) * N) * IB + lc % IB : (int64_t)lc * a.in_sl);
-                const int istep = a.in_blocked ? IB : 1;
-                // DIF: the window is the first 2M points of the extension, every position holds a sample
-                const int a0 = DIF ? 0 : pb * a.B + P - (ps + 1) * a.Lh;
-                const unsigned tlim = l < a.nlines ? (unsigned)(DIF ? 2 * M : Lw) : 0u;
-                int tb = PAIR ? 2 * i0 + line : i0;          // window position of this thread's first sample; opaque, so that the
-                asm volatile("" : "+v"(tb));                 // 72 positions are formed here and not kept across the rounds
-                vm0 = 0u;
-                vm1 = 0u;
-#pragma unroll
-                for (int k = 0; k < NH; ++k) {
-                    // PAIR: LDS line `line` holds the samples of parity `line`, LDS index = window position / 2
-                    const int t = tb + (PAIR ? 2 : 1) * STEP * (k + NH * h);
-                    const int te = a0 + t;
-                    const bool ok = (unsigned)t < tlim && (unsigned)te < (unsigned)Etot;
-                    int jp = te - (P - 1) + mg;                  // index into the padded line, one period either side
-                    jp += (jp >> 31) & P;
-                    int i = abs(jp - mg);                        // np.pad 'reflect' (EXP:237): -r on the left ...
-                    i = i >= N ? 2 * N - 2 - i : i;              // ... 2N-2-r on the right
-                    i = ok ? i : 0;                              // unconditional loads issue back to back
-                    xs[k] = srcl[(unsigned)(i * istep)];
-                    if (k < 32) vm0 |= (ok ? 1u : 0u) << (k & 31);
-                    else vm1 |= (ok ? 1u : 0u) << (k & 31);
-                }
-            };
-            auto spread_half = [&](int h) __attribute__((always_inline)) {
-#pragma unroll
-                for (int k = 0; k < NH; ++k) {
-                    const bool ok = ((k < 32 ? vm0 : vm1) >> (k & 31)) & 1u;
-                    base[(k + NH * h) * PSTEP] = ok ? xs[k] : make_float2(0.f, 0.f);
-                }
-            };
-            if (nj > 0) {
-                if constexpr (DIF) {
-                    fetch_dif(0, KA0{}, KAN{});
-                    spread_dif(KA0{}, KAN{});
-                    fetch_dif(0, KAN{}, KBN{});
-                    spread_dif(KAN{}, KBN{});
-                } else {
-                    fetch_half(0, 0);
-                    spread_half(0);
-                    fetch_half(0, 1);
-                    spread_half(1);
-                }
-            }
-            lds_barrier();                                   // (0)
-            for (int j = 0; j < nj; ++j) {
-                const bool more = j + 1 < nj;
-                if constexpr (DIF) lds_barrier();            // (1a) engine: stage A has read its inputs and their partners
-                lds_barrier();                               // (1)
-                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 16] = wall_clock64();
-                if (more) {
-                    if constexpr (DIF) fetch_dif(j + 1, KA0{}, KAN{});
-                    else fetch_half(j + 1, 0);
-                }
-                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 17] = wall_clock64();
-                lds_barrier();                               // (2)
-                lds_barrier();                               // (3)
-                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 18] = wall_clock64();
-                __builtin_amdgcn_s_setprio(3);
-                if (more) {
-                    if constexpr (DIF) spread_dif(KA0{}, KAN{});
-                    else spread_half(0);
-                    if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 21] = wall_clock64();
-                    if constexpr (DIF) fetch_dif(j + 1, KAN{}, KBN{});
-                    else fetch_half(j + 1, 1);
-                    if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 22] = wall_clock64();
-                    if constexpr (DIF) spread_dif(KAN{}, KBN{});
-                    else spread_half(1);
-                }
-                __builtin_amdgcn_s_setprio(0);
-                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 19] = wall_clock64();
-                lds_barrier();                               // (4)
-                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 20] = wall_clock64();
-            }
-            return;
-        }
         // =============================== loader waves =====================================================================
         // Thread lt owns the samples i0 + STEP*k (k < NLD) of ONE line.  STEP is a multiple of 32 (R3 >= 4), so the padded
         // LDS index of sample k is the index of sample 0 plus a compile-time offset.
@@ -606,15 +307,11 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 
     // =================================== engine waves =========================================================================
     // stage A and B thread mapping (one butterfly per thread per stage)
-    // PAIR: adjacent lanes take butterfly n of the even line and of the odd line -- their outputs are adjacent samples, so a
-    // wave's stores (and its partial-sum loads) cover whole cache lines
-    const int lineA = PAIR ? (tid & 1) : tid / S1, nA = PAIR ? (tid >> 1) : tid % S1;
-    // stage B: thread -> (line, block q1 of S1 points, element n < R3).  PAIR: a wave takes blocks {2w, 2w+1} of BOTH lines
-    // (lanes 0-31 line 0, 32-63 line 1), so that the points it owns between the barriers are the same range of the two lines
-    // the middle stage couples
-    // (the PAIR values are re-derived inside the round loop from an opaque copy of the thread index: hoisted out of it
-    // they would stay live through inverse stage A, which has no register to spare)
-    const int remB = tid % S1, q1B = remB / R3, nB = (PAIR || DUAL) ? (tid & 31) % R3 : remB % R3, p0B = q1B * S1 + nB;
+    const int lineA = tid / S1, nA = tid % S1;
+    // stage B: thread -> (line, block q1 of S1 points, element n < R3).  DUAL: in the inverse stage a wave takes blocks
+    // {2w, 2w+1} of BOTH halves of the LDS lines (lanes 0-31 first half, 32-63 second half), so that the points it owns between
+    // the barriers are the same range of the two buffers the middle stage wrote
+    const int remB = tid % S1, q1B = remB / R3, nB = DUAL ? (tid & 31) % R3 : remB % R3, p0B = q1B * S1 + nB;
     v2f *baseA = reinterpret_cast<v2f *>(lds) + lineA * MP;
     auto stageB_at = [&](v2f *&bB, int &pB, bool paired) __attribute__((always_inline)) {
         bB = baseA;
@@ -624,7 +321,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
             // a half-wave (32 butterflies = 768 points) takes the wave's range of the first LH lines (lanes 0-31) or of the
             // second LH lines (lanes 32-63); blocks are counted through the concatenated half
             const int gb = (to >> 6) * (32 / R3) + (to & 31) / R3;          // block inside the half: 24 blocks per line
-            bB = reinterpret_cast<v2f *>(lds) + (gb / RAD + ((to & 63) >> 5) * (PAIR ? 1 : LH)) * MP;
+            bB = reinterpret_cast<v2f *>(lds) + (gb / RAD + ((to & 63) >> 5) * LH) * MP;
             pB = (gb % RAD) * S1 + (to & 31) % R3;
         }
     };
@@ -633,26 +330,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
     // different pad offsets (one pad slot per TWO slabs) and hit 16 different bank pairs instead of 8.
     const int slabw = ((tid & 63) & 32) + ((tid & 31) < 16 ? 2 * (tid & 31) : 2 * ((tid & 31) - 16) + 1);
     const int slab0 = (tid >> 6) * WSLABS + slabw;
-    const v2f *rowA1 = tw1 + (nA / R3) * TWB_LD, *rowA0 = tw0 + (nA % R3) * TWB_LD;
-    // v[q] *= (or conj-*=) row1[q] * row0[q] for q in [Q0, Q1): half of the 23 twiddles at a time (128-VGPR budget)
-    auto twiddle_A = [&](v2f(&v)[RAD], auto q0_tag, auto q1_tag, auto conj_tag) __attribute__((always_inline)) {
-        constexpr int Q0 = decltype(q0_tag)::value, Q1 = decltype(q1_tag)::value;
-        constexpr bool CONJ = decltype(conj_tag)::value;
-        v2f w1[Q1 - Q0], w0[Q1 - Q0];
-#pragma unroll
-        for (int q = Q0; q < Q1; ++q) {
-            w1[q - Q0] = lds_read(rowA1 + q);
-            w0[q - Q0] = lds_read(rowA0 + q);
-        }
-#pragma unroll
-        for (int q = Q0; q < Q1; ++q) {
-            const v2f w = pk_cmul(w1[q - Q0], w0[q - Q0]);
-            v[q] = CONJ ? pk_cmulc(v[q], w) : pk_cmul(v[q], w);
-        }
-    };
-    using Q1 = std::integral_constant<int, 1>;
-    using Q12 = std::integral_constant<int, 12>;
-    using Q24 = std::integral_constant<int, 24>;
+    const v2f *rowA1 = tw.tw1 + (nA / R3) * TWB_LD, *rowA0 = tw.tw0 + (nA % R3) * TWB_LD;
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 0] = wall_clock64();
     lds_barrier();                                       // (0) first group is in LDS
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 1] = wall_clock64();
@@ -668,79 +346,15 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         PSX_STAMP(2);
 
         // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}  (DUAL: LDS line 0 only = engine waves 0..5)
-        if constexpr (DIF) {
-            // leg q of this thread's butterfly is position n = n0 + 768 q of the 2M-point sequence, n0 = 2 nA + lineA = tid; its
-            // partner x[n + 2M] = L[n + D] exists for n < thr.  Round E transforms L[n] + L[n + D], round O (L[n] - L[n + D]) w_4M^n
-            // with w_4M^n = conj(w4[n0]) x exp(-2 pi i q / 48), the second factor a compile-time constant.
-            v2f v[RAD];
-            int to = ftid();
-            const int np = to + a.dsh;
-            const v2f *pp = reinterpret_cast<const v2f *>(lds) + (np & 1) * MP + phys(np >> 1);
-            const int qb = (a.thr - to + 2 * S1 - 1) / (2 * S1);          // legs q < qb have a partner
-            const float sg = ps == 0 ? 1.f : -1.f;                       // wave-uniform
-#pragma unroll
-            for (int q = 0; q < RAD; ++q) v[q] = baseA[idxA(nA, q)];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                v2f b[RAD / 2];
-#pragma unroll
-                for (int q = 0; q < RAD / 2; ++q) b[q] = lds_read(pp + (h * (RAD / 2) + q) * (S1 + S1 / 32));
-#pragma unroll
-                for (int q = 0; q < RAD / 2; ++q) {
-                    // A leg without partner (q >= qb) reads whatever lies at its would-be partner's address and drops it.  That
-                    // address can lie behind the twiddle tables, and for short DIF lines (large D = 2M - P) past the end of
-                    // the workgroup's LDS allocation: furthest byte = 8 * (MP + phys((767 + D) / 2) + 23 * 396) <= 184 KB for
-                    // P >= 12 310.  An out-of-range DS read is defined on gfx9: it returns 0 and touches nothing (the LDS
-                    // aperture check; it does set MEM_VIOL in TRAPSTS, which only matters under a trap handler).  Clamping
-                    // the 24 addresses instead costs 24 vector instructions in the stage that has none to spare (ADVICE r3).
-                    const v2f bm = (h * (RAD / 2) + q) < qb ? b[q] : (v2f){0.f, 0.f};
-                    v[h * (RAD / 2) + q] = pk_fma_k(bm, sg, v[h * (RAD / 2) + q]);
-                }
-            }
-            lds_barrier();                           // (1a) every input and partner has been read: the in-place writes may start
-            if (ps != 0) {
-                // both factors on the inputs: the thread factor would otherwise stay live through the butterfly
-                const float2 wf = a.w4[to];
-                const v2f wb = (v2f){wf.x, wf.y};
-                pk_static_for<0, RAD>([&](auto qc) __attribute__((always_inline)) {
-                    constexpr int q = decltype(qc)::value;
-                    v[q] = pk_cmulc(v[q], pk_twiddle<2 * RAD, q, true>(wb));      // x conj(w4[n0] exp(+2 pi i q / 48)) = w_4M^n
-                });
-            }
-            DftPk<RAD, false>::run(v);
-            __builtin_amdgcn_sched_barrier(0);
-            twiddle_A(v, Q1{}, Q12{}, std::false_type{});
-            twiddle_A(v, Q12{}, Q24{}, std::false_type{});
-#pragma unroll
-            for (int q = 0; q < RAD; ++q) baseA[idxA(nA, q)] = v[q];
-        } else if (!DUAL || tid < TC / 2) {
-            v2f v[RAD];
-#pragma unroll
-            for (int q = 0; q < RAD; ++q) v[q] = baseA[idxA(nA, q)];
-            DftPk<RAD, false>::run(v);
-            __builtin_amdgcn_sched_barrier(0);
-            twiddle_A(v, Q1{}, Q12{}, std::false_type{});
-            twiddle_A(v, Q12{}, Q24{}, std::false_type{});
-#pragma unroll
-            for (int q = 0; q < RAD; ++q) baseA[idxA(nA, q)] = v[q];
-        }
+        if (!DUAL || tid < TC / 2) fwd_stage_A<GE>(baseA, nA, rowA1, rowA0);
         // The kernel spectrum (the engine's only global loads) travels one step ahead of its use: the first slab's 128
         // bytes are requested here, before barrier (1); the second slab's right after the first one's multiply.
         float4 hh[SLAB / 2];
-        // PAIR: lane u < 48 of wave w couples slab 48 w + u of line 0 with the same slab of line 1; its table is the interleaved
-        // pair (H[k], H[k + M]) per point: 4 points = 4 float4 per chunk; the first chunk travels here, the others under the
-        // arithmetic of the chunk before (a slab pair already holds 64 registers of data)
-        const int tp = (PAIR || DUAL) ? ftid() : tid;
-        const int pslab = 48 * (tp >> 6) + (tp & 63);                         // slab index inside a line (PAIR)
+        // DUAL: lane u < 48 of wave w takes slab 48 w + u of the first half of the LDS lines
+        const int tp = DUAL ? ftid() : tid;
+        const int pslab = 48 * (tp >> 6) + (tp & 63);
         const bool pact = (tp & 63) < 48;
-        const float4 *hp4 = reinterpret_cast<const float4 *>(a.H[d] + (size_t)(PART ? ps : 0) * 2 * M) + (size_t)(pact ? pslab : 0) * SLAB;
-        v2f w0p = (v2f){1.f, 0.f};
-        if constexpr (PAIR) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) hh[q] = hp4[q];
-            const float2 w = a.w2[pact ? pslab : 0];
-            w0p = (v2f){w.x, w.y};
-        } else if constexpr (DUAL) {
+        if constexpr (DUAL) {
             // the whole slab of the FIRST distance's spectrum (16 points = 8 float4); the second one's comes under the arithmetic
             const float4 *h4 = reinterpret_cast<const float4 *>(a.H[2 * d] + ((pact ? pslab : 0) % (M / SLAB)) * SLAB);
 #pragma unroll
@@ -751,7 +365,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 int to = ftid();
                 sl = (to >> 6) * WSLABS + ((to & 63) & 32) + ((to & 31) < 16 ? 2 * (to & 31) : 2 * ((to & 31) - 16) + 1);
             }
-            const float4 *h4 = reinterpret_cast<const float4 *>(a.H[d] + (PART ? ps * M : 0) + (unsigned)((sl % (M / SLAB)) * SLAB));
+            const float4 *h4 = reinterpret_cast<const float4 *>(a.H[d] + (unsigned)((sl % (M / SLAB)) * SLAB));
 #pragma unroll
             for (int q = 0; q < SLAB / 2; ++q) hh[q] = h4[q];
         }
@@ -760,27 +374,8 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         PSX_STAMP(4);
         // ---- 3. forward stage B: radix 24 inside each block of S1, stride R3, twiddle w_S1^{n q}
         if (!DUAL || tid < TC / 2) {
-            v2f v[RAD];
-            v2f *bB;
-            int pB;
-            stageB_at(bB, pB, PAIR);
-            const v2f *rowB = twl + (DUAL ? remB % R3 : nB) * TWB_LD;     // DUAL: plain thread map (line 0), n = remB % R3
-            if constexpr (DUAL) pB = (remB / R3) * S1 + remB % R3;
-#pragma unroll
-            for (int q = 0; q < RAD; ++q) v[q] = lds_read(bB + idxB(pB, q));
-            DftPk<RAD, false>::run(v);
-            __builtin_amdgcn_sched_barrier(0);
-            // twiddles in two halves: the kernel spectrum of the first slab (hh0, 32 registers) is in flight here
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                v2f w[RAD / 2];
-#pragma unroll
-                for (int q = (h == 0 ? 1 : 0); q < RAD / 2; ++q) w[q] = lds_read(rowB + h * (RAD / 2) + q);
-#pragma unroll
-                for (int q = (h == 0 ? 1 : 0); q < RAD / 2; ++q) v[h * (RAD / 2) + q] = pk_cmul(v[h * (RAD / 2) + q], w[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < RAD; ++q) bB[idxB(pB, q)] = v[q];
+            // DUAL: plain thread map (line 0), n = remB % R3
+            fwd_stage_B<GE>(baseA, DUAL ? (remB / R3) * S1 + remB % R3 : p0B, tw.twl + (DUAL ? remB % R3 : nB) * TWB_LD);
         }
         if constexpr (DUAL) lds_barrier();           // (1b) the middle stage's slabs were written by other waves
         PSX_STAMP(5);
@@ -847,7 +442,437 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
 #pragma unroll
                 for (int q = 0; q < SLAB; ++q) b1[q] = x[q];
             }
-        } else if constexpr (PAIR) {
+        } else {
+            middle_plain<GE>(lds, a.H[d], slabw, slab0, hh);
+        }
+        PSX_STAMP(7);
+        wave_sync();
+        PSX_STAMP(8);
+
+        // ---- 6. inverse stage B: conjugate twiddle on the inputs, then the inverse radix-24 butterfly
+        {
+            v2f *bB;
+            int pB;
+            stageB_at(bB, pB, DUAL);
+            inv_stage_B<GE>(bB, pB, tw.twl + (DUAL ? pB % R3 : nB) * TWB_LD);     // DUAL: pB = block * S1 + n, n < R3 | S1
+        }
+        PSX_STAMP(9);
+        lds_barrier();                               // (2)
+        PSX_STAMP(10);
+
+        // ---- 7. inverse stage A; the wanted outputs y[n + P - 1] leave for HBM straight from the registers.  Once
+        // every engine thread holds its 24 inputs LDS is free: the loaders fill it with the next group meanwhile.
+        {
+            v2f v[RAD];
+#pragma unroll
+            for (int q = 0; q < RAD; ++q) v[q] = baseA[GE::idxA(nA, q)];
+            lds_barrier();                           // (3)
+            PSX_STAMP(11);
+            twiddle_A<1, 12, true>(v, rowA1, rowA0);
+            twiddle_A<12, 24, true>(v, rowA1, rowA0);
+            __builtin_amdgcn_sched_barrier(0);
+            DftPk<RAD, true>::run(v);
+            // output sample i = nA + q*S1 - jout (jout = LDS position of output sample 0).  The first index is made opaque
+            // so that the 48 per-q addresses are formed here from ONE pointer, not hoisted out of the group loop (they
+            // would occupy 96 VGPRs there and spill).
+            // (R3 < 16: formed from an opaque copy of nA as well -- hoisted out of the group loop it has no register left and
+            // comes back from scratch memory once a round, behind a full memory wait)
+            int nAo = nA, lineAo = lineA;
+            if constexpr (R3 < 16) {
+                int to = ftid();
+                nAo = to % S1;
+                lineAo = to / S1;
+            }
+            int ifirst = nAo - (N + 2 * mg - 1);
+            asm volatile("" : "+v"(ifirst));
+            // DUAL: LDS line 0 carries the first distance of the pair, line 1 the second (a wave belongs to one line)
+            const int dd = DUAL ? 2 * d + __builtin_amdgcn_readfirstlane(tid >= TC / 2 ? 1 : 0) : d;
+            v2f *wo = reinterpret_cast<v2f *>(a.wave_out[dd]);
+            float *io = a.inten_out[dd];
+            const float sc = a.scale[dd];
+            const v2f gp = (v2f){a.gph[dd].x, a.gph[dd].y};
+            static_assert(S1 % IB == 0, "blocked output stride; the block index below is i >> IBS");
+            if constexpr (S1 % 64 == 0) {
+                // A wave's 64 butterflies belong to ONE line, so its outputs go through a buffer descriptor whose range is
+                // exactly the window they may touch: the hardware drops the stores of the unwanted outputs (i < 0 wraps to
+                // a huge offset, i >= N lies past the window).  No compare, no exec-mask bookkeeping per output -- the
+                // scalar unit is shared by the whole CU (0.9 instructions per cycle, tools/salu_bench.hip) and the masked
+                // form of this loop issued 500 scalar instructions per wave.
+                const int l = l0 + __builtin_amdgcn_readfirstlane(DUAL ? lineAo % LH : lineAo);
+                const bool lok = l < a.nlines;
+                // element index of output i inside the window: plain rows: i (window = row l); blocked: ((i>>3)*nlines+l)*8 + i%8
+                const int e0 = a.out_blocked ? ((ifirst >> IBS) * a.nlines + l) * IB + (ifirst & (IB - 1)) : ifirst;
+                const int estep = a.out_blocked ? (S1 / IB) * a.nlines * IB : S1;
+                const int64_t wbase = a.out_blocked ? 0 : (int64_t)l * a.out_ld;
+                const int welems = lok ? (a.out_blocked ? ((N + IB - 1) / IB) * IB * a.nlines : N) : 0;
+                store_window(v, wo, io, wbase, welems, e0, estep, gp, sc, a.accumulate);
+            } else if (l0 + (DUAL ? lineAo % LH : lineAo) < a.nlines) {
+                // short lines (R3 <= 4): a wave straddles lines, per-lane pointers and masks
+                const int lsh = l0 + (DUAL ? lineAo % LH : lineAo);
+                const int64_t ob = a.out_blocked ? ((int64_t)(ifirst >> IBS) * a.nlines + lsh) * IB + (ifirst & (IB - 1))
+                                                 : (int64_t)lsh * a.out_ld + ifirst;
+                const int64_t oq = a.out_blocked ? (int64_t)(S1 / IB) * a.nlines * IB : (int64_t)S1;
+                if (wo) wo += ob;
+                if (io) io += ob;
+#pragma unroll
+                for (int q = 0; q < RAD; ++q) {
+                    const int i = ifirst + q * S1;
+                    if (i >= 0 && i < N) {
+                        if (wo) wo[q * oq] = pk_cmul_s(v[q], gp);
+                        if (io) {
+                            const float I = sc * (v[q].x * v[q].x + v[q].y * v[q].y);
+                            io[q * oq] = a.accumulate ? io[q * oq] + I : I;
+                        }
+                    }
+                }
+            }
+        }
+        PSX_STAMP(12);
+        lds_barrier();                               // (4)
+        PSX_STAMP(13);
+    }
+}
+
+
+#undef PSX_STAMP
+#define PSX_STAMP(k) PSX_STAMP_IF(k, (DIF ? ftid() == 0 : tid == 0))
+// ---- lines too long for one LDS transform (N > 4593): partitioned convolution, coupled lines, DIF rounds ---------------------------
+// PAIR: the two LDS lines of a round hold the EVEN and the ODD samples of ONE sequence of 2M = 18432 points, and the middle
+// stage couples them with the radix-2 butterfly of a 2M-point transform
+//     X[k] = E[k] + w^k O[k],  X[k+M] = E[k] - w^k O[k]   ...x H...   E'[k] = Y[k] + Y[k+M],  O'[k] = (Y[k] - Y[k+M]) w^-k
+// (E, O = the two M-point spectra the engine computes anyway; w = exp(-2 pi i / 2M)).  One round is then ONE block x segment
+// product of twice the size: a 16384-sample line needs 2 x 2 of them instead of 5 x 3 M-point products for two lines.
+// DIF (lines of 12 280 <= N <= 18 402 samples, the 16384^2 grid of BASELINE config 5): the whole line is ONE circular
+// convolution of 4M = 36864 >= N + P - 1 points, split by a decimation-in-frequency radix-2 step over TWO PAIR rounds:
+//     round E:  ye = IDFT_2M( FFT_2M( x[n] + x[n + 2M] )          * H4[2k]   )
+//     round O:  yo = IDFT_2M( FFT_2M((x[n] - x[n + 2M]) w_4M^n )  * H4[2k+1] )        y[m] = (ye[m'] + w_4M^-m yo[m']) / 2,  m' = m mod 2M
+// (the block x segment partition needs 2 x 2 such rounds at N = 16384, each re-reading a 16398-sample window).  The
+// extension e of the line is P-periodic, so x[n + 2M] = e[n + 2M - P]: the loaders write ONE copy L[n] = e[n], n < 2M, and
+// forward stage A forms L[n] +- L[n + D] itself from LDS (one more workgroup barrier: everybody reads before anybody writes
+// in place); the twiddle w_4M^n = (thread factor) x (compile-time 48th root per butterfly leg) rides on stage A's input and
+// output multiplies.  Round E leaves ye in a line buffer private to the workgroup (it is read back 20 us later by the same
+// CU: L2 / MALL traffic), round O combines and stores the N wanted samples, whose index wraps once along the 24 outputs of a
+// butterfly.  Per line: 2 rounds and 2 x 18432 loads instead of 4 and 4 x 16398; no partial sums in the output image.
+template <bool CONTIG, bool PAIR, bool DIF = false>
+__global__ __launch_bounds__(T) void k_fresnel_part(LineArgs a) {
+    static_assert(!DIF || PAIR, "DIF rounds are PAIR rounds");
+    constexpr int R3 = 16;
+    using GE = LineGeom<R3, PAIR>;
+    constexpr int M = GE::M, LINES = GE::LINES, S1 = GE::S1, MP = GE::MP;
+    static_assert(LINES == 2, "the partitioned engine works on the two LDS lines of the M = 9216 transform");
+    constexpr int LPG = PAIR ? 1 : LINES;               // image lines per round
+    constexpr int SLAB = GE::SLAB, WSLABS = GE::WSLABS, TWB_LD = GE::TWB_LD;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int tid = threadIdx.x;
+    const int N = a.N, mg = a.margin;
+    // A fresh copy of the thread index for values that are re-derived inside the round loop instead of being kept across it
+    // (the engine waves have no register to spare).  DIF: not even the index itself stays in a VGPR -- the wave's base sits in
+    // an SGPR and the lane number comes from v_mbcnt (it was the one value the DIF instance spilled: reloaded once a round
+    // from scratch memory, behind a full memory wait).
+    const int wave_base = DIF ? __builtin_amdgcn_readfirstlane(tid & ~63) : 0;
+    auto ftid = [&]() __attribute__((always_inline)) {
+        int t;
+        if constexpr (DIF) {
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(t));
+            t += wave_base;
+        } else {
+            t = tid;
+            asm volatile("" : "+v"(t));
+        }
+        return t;
+    };
+
+    // ---- work units of this workgroup: (distance, output block, line group), S consecutive rounds each (one per kernel
+    // segment).  XCD x = blockIdx % 8 owns a contiguous chunk of units (its 32 CUs then read neighbouring columns at the same
+    // time: the 128-byte lines of the strided source are shared in that XCD's L2); static shares.
+    const int ngroups = (a.nlines + LPG - 1) / LPG;
+    const int nwork = ngroups * a.n_dist * a.NB;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int cq = nwork >> 3, cr = nwork & 7;
+    const int cstart = xcd * cq + (xcd < cr ? xcd : cr), clen = cq + (xcd < cr ? 1 : 0);
+    const int nunits = slot < clen ? (clen - slot + nslot - 1) / nslot : 0;   // units cstart + slot + u*nslot, u < nunits
+    const int nj = nunits * a.S;                                              // rounds of this workgroup
+    // round j -> (distance, line group), output block pb, kernel segment ps
+    int pb = 0, ps = 0;
+    auto item = [&](int j, int &d, int &g) __attribute__((always_inline)) {
+        const int u = j / a.S;
+        ps = j - u * a.S;
+        const int w = cstart + slot + u * nslot;         // unit: ((d * NB) + b) * ngroups + g
+        const int db = w / ngroups;
+        g = w - db * ngroups;
+        d = db / a.NB;
+        pb = db - d * a.NB;
+    };
+
+    const TwTables tw = fill_tables<GE>(lds, a, tid);          // stage twiddles into LDS, behind the line buffers
+
+    if (tid >= TC) {
+        // =========================== loader waves, partitioned convolution ============================================
+        // LDS position t of a line holds e[a0 + t], e = the periodic / mirrored extension of the line the linear
+        // convolution runs over (e[te] = x_per[te - (P-1) + margin]), a0 = b*B + P - (s+1)*Lh; zeros outside the window of
+        // B + Lh - 1 positions.  A window is twice a regular line's share of registers, so it moves in two halves: the
+        // first is fetched during the transform (as in the regular engine), the second between barriers (3) and (4), after
+        // the first has been written out of the same registers.
+        const int lt = tid - TC;
+        constexpr int STEP = TL / LINES, NH = M / STEP / 2, PSTEP = STEP + STEP / 32;
+        static_assert(STEP % 32 == 0 && (M / STEP) % 2 == 0, "affine LDS addressing of the loader halves");
+        // (DIF: adjacent lanes take adjacent samples whatever the source layout -- 512 contiguous bytes per wave load in pass 1)
+        const int line = (CONTIG && !DIF) ? lt / STEP : lt % LINES, i0 = (CONTIG && !DIF) ? lt % STEP : lt / LINES;
+        float2 *base = lds + line * MP + phys(i0);
+        const int P = a.P, Lw = a.B + a.Lh - 1, Etot = N + P - 1;
+        // DIF: every one of the 2M window positions holds a sample (no validity masks), position t is sample
+        // reflect(((t + 1 + mg) mod P) - mg) of the line: five vector instructions and a buffer load whose descriptor is the
+        // line.  The 72 positions of a thread then move as NHA + NHB instead of 36 + 36: the more of them travel during the
+        // transform, the shorter the fetch that is exposed between barriers (3) and (4).
+        constexpr int NHA = DIF ? PSX_DIF_NHA : NH, NHB = 2 * NH - NHA;
+        float2 xs[NHA];
+        auto fetch_dif = [&](int j, auto k0_tag, auto cnt_tag) __attribute__((always_inline)) {
+            constexpr int K0 = decltype(k0_tag)::value, CNT = decltype(cnt_tag)::value;
+            int d, g;
+            item(j, d, g);
+            const int lc = min(g, a.nlines - 1);
+            const float2 *srcl = a.src[d] + (a.in_blocked ? ((int64_t)(lc / IB) * N) * IB + lc % IB : (int64_t)lc * a.in_sl);
+            const int sh = a.in_blocked ? IBS + 3 : 3;                     // byte stride of a sample: 8 IB (blocked) or 8
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float2 *>(srcl), 0, g < a.nlines ? (int)((unsigned)N << sh) : 0, 0x00020000);   // a line past the image reads zeros
+            int jb = 2 * i0 + line + mg + 1;
+            asm volatile("" : "+v"(jb));
+#pragma unroll
+            for (int k = 0; k < CNT; ++k) {
+                const unsigned j0 = (unsigned)(jb + 2 * STEP * (K0 + k));
+                const unsigned jp = min(j0, j0 - (unsigned)P);                   // mod P (j0 < 2P)
+                unsigned i1, i2;       // |a - b| in one instruction (the compiler expands __sad into sub, neg, max)
+                asm("v_sad_u32 %0, %1, %2, 0" : "=v"(i1) : "v"(jp), "s"(mg));           // np.pad 'reflect' (EXP:237) on the left ...
+                asm("v_sad_u32 %0, %1, %2, 0" : "=v"(i2) : "v"(i1), "s"(N - 1));
+                const unsigned i = (unsigned)(N - 1) - i2;                                 // ... and on the right
+                xs[k] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(i << sh), 0, 0));
+            }
+        };
+        auto spread_dif = [&](auto k0_tag, auto cnt_tag) __attribute__((always_inline)) {
+            constexpr int K0 = decltype(k0_tag)::value, CNT = decltype(cnt_tag)::value;
+#pragma unroll
+            for (int k = 0; k < CNT; ++k) base[(K0 + k) * PSTEP] = xs[k];
+        };
+        using KA0 = std::integral_constant<int, 0>;
+        using KAN = std::integral_constant<int, NHA>;
+        using KBN = std::integral_constant<int, NHB>;
+        unsigned vm0 = 0u, vm1 = 0u;                    // which of the NH positions hold a sample (the rest are zeros)
+        static_assert(NH <= 64, "validity mask");
+        auto fetch_half = [&](int j, int h) __attribute__((always_inline)) {
+            int d, g;
+            item(j, d, g);
+            const int l = PAIR ? g : g * LINES + line;
+            const int lc = min(l, a.nlines - 1);          // addresses stay inside the image for the idle lines of the last group
+            // PART sources are the blocked intermediate or contiguous lines (in_si == 1): 32-bit element offsets from the line's base
+            const float2 *srcl = a.src[d] + (a.in_blocked ? ((int64_t)(lc / IB) * N) * IB + lc % IB : (int64_t)lc * a.in_sl);
+            const int istep = a.in_blocked ? IB : 1;
+            // DIF: the window is the first 2M points of the extension, every position holds a sample
+            const int a0 = DIF ? 0 : pb * a.B + P - (ps + 1) * a.Lh;
+            const unsigned tlim = l < a.nlines ? (unsigned)(DIF ? 2 * M : Lw) : 0u;
+            int tb = PAIR ? 2 * i0 + line : i0;          // window position of this thread's first sample; opaque, so that the
+            asm volatile("" : "+v"(tb));                 // 72 positions are formed here and not kept across the rounds
+            vm0 = 0u;
+            vm1 = 0u;
+#pragma unroll
+            for (int k = 0; k < NH; ++k) {
+                // PAIR: LDS line `line` holds the samples of parity `line`, LDS index = window position / 2
+                const int t = tb + (PAIR ? 2 : 1) * STEP * (k + NH * h);
+                const int te = a0 + t;
+                const bool ok = (unsigned)t < tlim && (unsigned)te < (unsigned)Etot;
+                int jp = te - (P - 1) + mg;                  // index into the padded line, one period either side
+                jp += (jp >> 31) & P;
+                int i = abs(jp - mg);                        // np.pad 'reflect' (EXP:237): -r on the left ...
+                i = i >= N ? 2 * N - 2 - i : i;              // ... 2N-2-r on the right
+                i = ok ? i : 0;                              // unconditional loads issue back to back
+                xs[k] = srcl[(unsigned)(i * istep)];
+                if (k < 32) vm0 |= (ok ? 1u : 0u) << (k & 31);
+                else vm1 |= (ok ? 1u : 0u) << (k & 31);
+            }
+        };
+        auto spread_half = [&](int h) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < NH; ++k) {
+                const bool ok = ((k < 32 ? vm0 : vm1) >> (k & 31)) & 1u;
+                base[(k + NH * h) * PSTEP] = ok ? xs[k] : make_float2(0.f, 0.f);
+            }
+        };
+        if (nj > 0) {
+            if constexpr (DIF) {
+                fetch_dif(0, KA0{}, KAN{});
+                spread_dif(KA0{}, KAN{});
+                fetch_dif(0, KAN{}, KBN{});
+                spread_dif(KAN{}, KBN{});
+            } else {
+                fetch_half(0, 0);
+                spread_half(0);
+                fetch_half(0, 1);
+                spread_half(1);
+            }
+        }
+        lds_barrier();                                   // (0)
+        for (int j = 0; j < nj; ++j) {
+            const bool more = j + 1 < nj;
+            if constexpr (DIF) lds_barrier();            // (1a) engine: stage A has read its inputs and their partners
+            lds_barrier();                               // (1)
+            if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 16] = wall_clock64();
+            if (more) {
+                if constexpr (DIF) fetch_dif(j + 1, KA0{}, KAN{});
+                else fetch_half(j + 1, 0);
+            }
+            if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 17] = wall_clock64();
+            lds_barrier();                               // (2)
+            lds_barrier();                               // (3)
+            if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 18] = wall_clock64();
+            __builtin_amdgcn_s_setprio(3);
+            if (more) {
+                if constexpr (DIF) spread_dif(KA0{}, KAN{});
+                else spread_half(0);
+                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 21] = wall_clock64();
+                if constexpr (DIF) fetch_dif(j + 1, KAN{}, KBN{});
+                else fetch_half(j + 1, 1);
+                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 22] = wall_clock64();
+                if constexpr (DIF) spread_dif(KAN{}, KBN{});
+                else spread_half(1);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 19] = wall_clock64();
+            lds_barrier();                               // (4)
+            if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 20] = wall_clock64();
+        }
+        return;
+    }
+
+    // =================================== engine waves =========================================================================
+    // stage A and B thread mapping (one butterfly per thread per stage)
+    // PAIR: adjacent lanes take butterfly n of the even line and of the odd line -- their outputs are adjacent samples, so a
+    // wave's stores (and its partial-sum loads) cover whole cache lines
+    const int lineA = PAIR ? (tid & 1) : tid / S1, nA = PAIR ? (tid >> 1) : tid % S1;
+    // stage B: thread -> (line, block q1 of S1 points, element n < R3).  PAIR: a wave takes blocks {2w, 2w+1} of BOTH lines
+    // (lanes 0-31 line 0, 32-63 line 1), so that the points it owns between the barriers are the same range of the two lines
+    // the middle stage couples
+    // (the PAIR values are re-derived inside the round loop from an opaque copy of the thread index: hoisted out of it
+    // they would stay live through inverse stage A, which has no register to spare)
+    const int remB = tid % S1, q1B = remB / R3, nB = PAIR ? (tid & 31) % R3 : remB % R3, p0B = q1B * S1 + nB;
+    v2f *baseA = reinterpret_cast<v2f *>(lds) + lineA * MP;
+    auto stageB_at = [&](v2f *&bB, int &pB, bool paired) __attribute__((always_inline)) {
+        bB = baseA;
+        pB = p0B;
+        if (paired) {
+            int to = ftid();
+            // a half-wave (32 butterflies = 768 points) takes the wave's range of line 0 (lanes 0-31) or of line 1 (lanes 32-63)
+            const int gb = (to >> 6) * (32 / R3) + (to & 31) / R3;          // block inside the half: 24 blocks per line
+            bB = reinterpret_cast<v2f *>(lds) + (gb / RAD + ((to & 63) >> 5)) * MP;
+            pB = (gb % RAD) * S1 + (to & 31) % R3;
+        }
+    };
+    // middle stage: slab of this lane inside the wave's own 96 (round 2: 32 lanes).  Within each half-wave the first 16
+    // lanes take the even slabs and the last 16 the odd ones: the 16 lanes of a ds_write_b64 group then carry 16
+    // different pad offsets (one pad slot per TWO slabs) and hit 16 different bank pairs instead of 8.
+    const int slabw = ((tid & 63) & 32) + ((tid & 31) < 16 ? 2 * (tid & 31) : 2 * ((tid & 31) - 16) + 1);
+    const int slab0 = (tid >> 6) * WSLABS + slabw;
+    const v2f *rowA1 = tw.tw1 + (nA / R3) * TWB_LD, *rowA0 = tw.tw0 + (nA % R3) * TWB_LD;
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 0] = wall_clock64();
+    lds_barrier();                                       // (0) first group is in LDS
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 1] = wall_clock64();
+    for (int j = 0; j < nj; ++j) {
+        int d, g;
+        item(j, d, g);
+        const int l0 = g * LPG;
+        PSX_STAMP(2);
+
+        // ---- 2. forward stage A: radix 24 over stride S1, twiddle w_M^{n q}
+        if constexpr (DIF) {
+            // leg q of this thread's butterfly is position n = n0 + 768 q of the 2M-point sequence, n0 = 2 nA + lineA = tid; its
+            // partner x[n + 2M] = L[n + D] exists for n < thr.  Round E transforms L[n] + L[n + D], round O (L[n] - L[n + D]) w_4M^n
+            // with w_4M^n = conj(w4[n0]) x exp(-2 pi i q / 48), the second factor a compile-time constant.
+            v2f v[RAD];
+            int to = ftid();
+            const int np = to + a.dsh;
+            const v2f *pp = reinterpret_cast<const v2f *>(lds) + (np & 1) * MP + phys(np >> 1);
+            const int qb = (a.thr - to + 2 * S1 - 1) / (2 * S1);          // legs q < qb have a partner
+            const float sg = ps == 0 ? 1.f : -1.f;                       // wave-uniform
+#pragma unroll
+            for (int q = 0; q < RAD; ++q) v[q] = baseA[GE::idxA(nA, q)];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                v2f b[RAD / 2];
+#pragma unroll
+                for (int q = 0; q < RAD / 2; ++q) b[q] = lds_read(pp + (h * (RAD / 2) + q) * (S1 + S1 / 32));
+#pragma unroll
+                for (int q = 0; q < RAD / 2; ++q) {
+                    // A leg without partner (q >= qb) reads whatever lies at its would-be partner's address and drops it.  That
+                    // address can lie behind the twiddle tables, and for short DIF lines (large D = 2M - P) past the end of
+                    // the workgroup's LDS allocation: furthest byte = 8 * (MP + phys((767 + D) / 2) + 23 * 396) <= 184 KB for
+                    // P >= 12 310.  An out-of-range DS read is defined on gfx9: it returns 0 and touches nothing (the LDS
+                    // aperture check; it does set MEM_VIOL in TRAPSTS, which only matters under a trap handler).  Clamping
+                    // the 24 addresses instead costs 24 vector instructions in the stage that has none to spare (ADVICE r3).
+                    const v2f bm = (h * (RAD / 2) + q) < qb ? b[q] : (v2f){0.f, 0.f};
+                    v[h * (RAD / 2) + q] = pk_fma_k(bm, sg, v[h * (RAD / 2) + q]);
+                }
+            }
+            lds_barrier();                           // (1a) every input and partner has been read: the in-place writes may start
+            if (ps != 0) {
+                // both factors on the inputs: the thread factor would otherwise stay live through the butterfly
+                const float2 wf = a.w4[to];
+                const v2f wb = (v2f){wf.x, wf.y};
+                pk_static_for<0, RAD>([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int q = decltype(qc)::value;
+                    v[q] = pk_cmulc(v[q], pk_twiddle<2 * RAD, q, true>(wb));      // x conj(w4[n0] exp(+2 pi i q / 48)) = w_4M^n
+                });
+            }
+            DftPk<RAD, false>::run(v);
+            __builtin_amdgcn_sched_barrier(0);
+            twiddle_A<1, 12, false>(v, rowA1, rowA0);
+            twiddle_A<12, 24, false>(v, rowA1, rowA0);
+#pragma unroll
+            for (int q = 0; q < RAD; ++q) baseA[GE::idxA(nA, q)] = v[q];
+        } else {
+            fwd_stage_A<GE>(baseA, nA, rowA1, rowA0);
+        }
+        // The kernel spectrum (the engine's only global loads) travels one step ahead of its use: the first slab's 128
+        // bytes are requested here, before barrier (1); the second slab's right after the first one's multiply.
+        float4 hh[SLAB / 2];
+        // PAIR: lane u < 48 of wave w couples slab 48 w + u of line 0 with the same slab of line 1; its table is the interleaved
+        // pair (H[k], H[k + M]) per point: 4 points = 4 float4 per chunk; the first chunk travels here, the others under the
+        // arithmetic of the chunk before (a slab pair already holds 64 registers of data)
+        const int tp = PAIR ? ftid() : tid;
+        const int pslab = 48 * (tp >> 6) + (tp & 63);                         // slab index inside a line (PAIR)
+        const bool pact = (tp & 63) < 48;
+        const float4 *hp4 = reinterpret_cast<const float4 *>(a.H[d] + (size_t)ps * 2 * M) + (size_t)(pact ? pslab : 0) * SLAB;
+        v2f w0p = (v2f){1.f, 0.f};
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hh[q] = hp4[q];
+            const float2 w = a.w2[pact ? pslab : 0];
+            w0p = (v2f){w.x, w.y};
+        } else {
+            const int sl = slab0;
+            const float4 *h4 = reinterpret_cast<const float4 *>(a.H[d] + ps * M + (unsigned)((sl % (M / SLAB)) * SLAB));
+#pragma unroll
+            for (int q = 0; q < SLAB / 2; ++q) hh[q] = h4[q];
+        }
+        PSX_STAMP(3);
+        lds_barrier();                               // (1)
+        PSX_STAMP(4);
+        // ---- 3. forward stage B: radix 24 inside each block of S1, stride R3, twiddle w_S1^{n q}
+        {
+            v2f *bB;
+            int pB;
+            stageB_at(bB, pB, PAIR);
+            fwd_stage_B<GE>(bB, pB, tw.twl + nB * TWB_LD);
+        }
+        PSX_STAMP(5);
+        // From here to the end of inverse stage B every wave works on LDS points that only IT touches: its 64
+        // radix-24 butterflies of stage B cover 64/R3 whole blocks of S1 points = the 1536 consecutive points
+        // [1536 w, 1536 (w+1)), and the middle stage takes its slabs from the same range.  A wave's LDS operations
+        // execute in order, so no workgroup barrier is needed -- the waves drift apart and overlap each other's LDS
+        // and VALU phases.
+        wave_sync();
+        PSX_STAMP(6);
+
+        // ---- 4+5. middle stage, slab by slab: forward radix R3 on contiguous chunks, x FFT_M(h_d), inverse radix R3,
+        // back to LDS.  Each thread rewrites exactly the slabs it read.
+        if constexpr (PAIR) {
             if (pact) {
                 v2f *b0 = reinterpret_cast<v2f *>(lds) + phys(pslab * SLAB), *b1 = b0 + MP;
                 v2f f0[SLAB], f1[SLAB];
@@ -885,68 +910,18 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                 for (int q = 0; q < SLAB; ++q) b1[q] = f1[q];
             }
         } else {
-        const float2 *Hd = a.H[d] + (PART ? ps * M : 0);
-#pragma unroll
-        for (int r = 0; r < NSLAB; ++r) {
-            if (slabw + 64 * r >= WSLABS) break;
-            const int s = slab0 + 64 * r, line = s / (M / SLAB), p0 = (s % (M / SLAB)) * SLAB;
-            v2f *base = reinterpret_cast<v2f *>(lds) + line * MP + phys(p0);   // p0 % 16 == 0: no pad slot inside a slab
-            v2f f[SLAB];
-#pragma unroll
-            for (int q = 0; q < SLAB; ++q) f[q] = lds_read(base + q);
-#pragma unroll
-            for (int c = 0; c < SLAB / R3; ++c) {
-                v2f w[R3];
-#pragma unroll
-                for (int q = 0; q < R3; ++q) w[q] = f[c * R3 + q];
-                DftPk<R3, false>::run(w);
-#pragma unroll
-                for (int q = 0; q < R3; ++q) f[c * R3 + q] = w[q];
-            }
-#pragma unroll
-            for (int q = 0; q < SLAB / 2; ++q) {
-                f[2 * q] = pk_cmul(f[2 * q], (v2f){hh[q].x, hh[q].y});
-                f[2 * q + 1] = pk_cmul(f[2 * q + 1], (v2f){hh[q].z, hh[q].w});
-            }
-            if (r + 1 < NSLAB && slabw + 64 * (r + 1) < WSLABS) {      // next slab's spectrum, under this one's inverse DFT
-                __builtin_amdgcn_sched_barrier(0);
-                const float4 *h4 = reinterpret_cast<const float4 *>(Hd + ((slab0 + 64 * (r + 1)) % (M / SLAB)) * SLAB);
-#pragma unroll
-                for (int q = 0; q < SLAB / 2; ++q) hh[q] = h4[q];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int c = 0; c < SLAB / R3; ++c) {
-                v2f w[R3];
-#pragma unroll
-                for (int q = 0; q < R3; ++q) w[q] = f[c * R3 + q];
-                DftPk<R3, true>::run(w);
-#pragma unroll
-                for (int q = 0; q < R3; ++q) base[c * R3 + q] = w[q];
-            }
+            middle_plain<GE>(lds, a.H[d] + ps * M, slabw, slab0, hh);
         }
-        }   // !PAIR
         PSX_STAMP(7);
         wave_sync();
         PSX_STAMP(8);
 
         // ---- 6. inverse stage B: conjugate twiddle on the inputs, then the inverse radix-24 butterfly
         {
-            v2f v[RAD], w[RAD];
             v2f *bB;
             int pB;
-            stageB_at(bB, pB, PAIR || DUAL);
-            const v2f *rowB = twl + nB * TWB_LD;
-#pragma unroll
-            for (int q = 0; q < RAD; ++q) v[q] = lds_read(bB + idxB(pB, q));
-#pragma unroll
-            for (int q = 1; q < RAD; ++q) w[q] = lds_read(rowB + q);
-#pragma unroll
-            for (int q = 1; q < RAD; ++q) v[q] = pk_cmulc(v[q], w[q]);
-            __builtin_amdgcn_sched_barrier(0);
-            DftPk<RAD, true>::run(v);
-#pragma unroll
-            for (int q = 0; q < RAD; ++q) bB[idxB(pB, q)] = v[q];
+            stageB_at(bB, pB, PAIR);
+            inv_stage_B<GE>(bB, pB, tw.twl + nB * TWB_LD);
         }
         PSX_STAMP(9);
         lds_barrier();                               // (2)
@@ -957,39 +932,31 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         {
             v2f v[RAD];
 #pragma unroll
-            for (int q = 0; q < RAD; ++q) v[q] = baseA[idxA(nA, q)];
+            for (int q = 0; q < RAD; ++q) v[q] = baseA[GE::idxA(nA, q)];
             // DIF, round O: the thread factor of the recombination twiddle is requested here, ahead of the loaders' second
             // fetch (the CU's loads return in order: behind that fetch it would come back microseconds later)
             v2f wdif = (v2f){1.f, 0.f};
             if constexpr (DIF) {
                 if (ps != 0) {
-                    int tw = ftid();
-                    const float2 wf = a.w4[tw];
+                    int tq = ftid();
+                    const float2 wf = a.w4[tq];
                     wdif = (v2f){wf.x, wf.y};
                 }
             }
             lds_barrier();                           // (3)
             PSX_STAMP(11);
-            twiddle_A(v, Q1{}, Q12{}, std::true_type{});
-            twiddle_A(v, Q12{}, Q24{}, std::true_type{});
+            twiddle_A<1, 12, true>(v, rowA1, rowA0);
+            twiddle_A<12, 24, true>(v, rowA1, rowA0);
             __builtin_amdgcn_sched_barrier(0);
             DftPk<RAD, true>::run(v);
             // output sample i = nA + q*S1 - jout (jout = LDS position of output sample 0).  The first index is made opaque
             // so that the 48 per-q addresses are formed here from ONE pointer, not hoisted out of the group loop (they
             // would occupy 96 VGPRs there and spill).
             // PART: index inside the output block; PAIR: LDS line = parity of the position in the 2M-point result
-            // (R3 < 16: formed from an opaque copy of nA as well -- hoisted out of the group loop it has no register left and
-            // comes back from scratch memory once a round, behind a full memory wait)
-            int nAo = nA, lineAo = lineA;
-            if constexpr (R3 < 16 && !PAIR) {
-                int to = ftid();
-                nAo = to % S1;
-                lineAo = to / S1;
-            }
-            int ifirst = (PAIR ? 2 * nA + lineA : nAo) - (PART ? a.Lh - 1 : N + 2 * mg - 1);
+            int ifirst = (PAIR ? 2 * nA + lineA : nA) - (a.Lh - 1);
+
             asm volatile("" : "+v"(ifirst));
-            // DUAL: LDS line 0 carries the first distance of the pair, line 1 the second (a wave belongs to one line)
-            const int dd = DUAL ? 2 * d + __builtin_amdgcn_readfirstlane(tid >= TC / 2 ? 1 : 0) : d;
+            const int dd = d;
             v2f *wo = reinterpret_cast<v2f *>(a.wave_out[dd]);
             float *io = a.inten_out[dd];
             const float sc = a.scale[dd];
@@ -1087,26 +1054,22 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                         __builtin_amdgcn_raw_buffer_store_b128((v4u){lo.x, lo.y, hi.x, hi.y}, rp, to * 16, q * TC * 16, 0);
                     }
                 }
-            } else if constexpr (S1 % 64 == 0) {
-                // A wave's 64 butterflies belong to ONE line, so its outputs go through a buffer descriptor whose range is
-                // exactly the window they may touch: the hardware drops the stores of the unwanted outputs (i < 0 wraps to
-                // a huge offset, i >= N lies past the window).  No compare, no exec-mask bookkeeping per output -- the
-                // scalar unit is shared by the whole CU (0.9 instructions per cycle, tools/salu_bench.hip) and the masked
-                // form of this loop issued 500 scalar instructions per wave.
-                const int l = l0 + (PAIR ? 0 : __builtin_amdgcn_readfirstlane(DUAL ? lineAo % LH : lineAo));
+            } else {
+                // A wave's 64 butterflies belong to ONE line: its outputs go through a buffer descriptor whose range is exactly
+                // the window they may touch (store_window)
+                const int l = l0 + (PAIR ? 0 : __builtin_amdgcn_readfirstlane(lineA));
                 const bool lok = l < a.nlines;
                 // element index of output i inside the window: plain rows: i (window = row l); blocked: ((i>>3)*nlines+l)*8 + i%8
                 const int e0 = a.out_blocked ? ((ifirst >> IBS) * a.nlines + l) * IB + (ifirst & (IB - 1)) : ifirst;
                 constexpr int QS = PAIR ? 2 * S1 : S1;                    // output samples between two outputs of a butterfly
                 const int estep = a.out_blocked ? (QS / IB) * a.nlines * IB : QS;
-                // PART: the window is the output block only -- samples [b*B, b*B + Bv) of the line; in the blocked layout
+                // the window is the output block only -- samples [b*B, b*B + Bv) of the line; in the blocked layout
                 // they are the contiguous range of B/8 sample-blocks (B is a multiple of 8)
-                const int nout = PART ? min(a.B, N - pb * a.B) : N;
-                const int64_t wbase = a.out_blocked ? (PART ? (int64_t)(pb * a.B / IB) * a.nlines * IB : 0)
-                                                    : (int64_t)l * a.out_ld + (PART ? pb * a.B : 0);
+                const int nout = min(a.B, N - pb * a.B);
+                const int64_t wbase = a.out_blocked ? (int64_t)(pb * a.B / IB) * a.nlines * IB : (int64_t)l * a.out_ld + pb * a.B;
                 const int welems = lok ? (a.out_blocked ? ((nout + IB - 1) / IB) * IB * a.nlines : nout) : 0;
-                bool emit = true;                // PART: only the last kernel segment produces the outputs proper
-                if constexpr (PART) {
+                bool emit = true;                // only the last kernel segment produces the outputs proper
+                {
                     // segments 0..S-2 leave their sum in `part`, the last one adds it to its own result.  Every round of a
                     // unit maps output element -> (wave, lane, q) identically, so a lane re-reads what it wrote itself.
                     const bool first = ps == 0, last = ps == a.S - 1;
@@ -1137,63 +1100,7 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
                         }
                     }
                 }
-                if (wo && emit) {
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wo + wbase, 0, welems * 8, 0x00020000);
-                    int off = e0 * 8;
-                    if (gp.x == 1.f && gp.y == 0.f) {     // pass 1 (and z-independent callers): no global phase to apply
-#pragma unroll
-                        for (int q = 0; q < RAD; ++q) {
-                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v[q]), rs, off, 0, 0);
-                            off += estep * 8;
-                        }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < RAD; ++q) {
-                            const v2f r = pk_cmul_s(v[q], gp);
-                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, r), rs, off, 0, 0);
-                            off += estep * 8;
-                        }
-                    }
-                }
-                if (io && emit) {
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(io + wbase, 0, welems * 4, 0x00020000);
-                    int off = e0 * 4;
-                    if (a.accumulate) {
-#pragma unroll
-                        for (int q = 0; q < RAD; ++q) {
-                            const float I = sc * (v[q].x * v[q].x + v[q].y * v[q].y);
-                            const float old = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, old + I), rs, off, 0, 0);
-                            off += estep * 4;
-                        }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < RAD; ++q) {
-                            const float I = sc * (v[q].x * v[q].x + v[q].y * v[q].y);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, I), rs, off, 0, 0);
-                            off += estep * 4;
-                        }
-                    }
-                }
-            } else if (l0 + (DUAL ? lineAo % LH : lineAo) < a.nlines) {
-                // short lines (R3 <= 4): a wave straddles lines, per-lane pointers and masks
-                const int lsh = l0 + (DUAL ? lineAo % LH : lineAo);
-                const int64_t ob = a.out_blocked ? ((int64_t)(ifirst >> IBS) * a.nlines + lsh) * IB + (ifirst & (IB - 1))
-                                                 : (int64_t)lsh * a.out_ld + ifirst;
-                const int64_t oq = a.out_blocked ? (int64_t)(S1 / IB) * a.nlines * IB : (int64_t)S1;
-                if (wo) wo += ob;
-                if (io) io += ob;
-#pragma unroll
-                for (int q = 0; q < RAD; ++q) {
-                    const int i = ifirst + q * S1;
-                    if (i >= 0 && i < N) {
-                        if (wo) wo[q * oq] = pk_cmul_s(v[q], gp);
-                        if (io) {
-                            const float I = sc * (v[q].x * v[q].x + v[q].y * v[q].y);
-                            io[q * oq] = a.accumulate ? io[q * oq] + I : I;
-                        }
-                    }
-                }
+                if (emit) store_window(v, wo, io, wbase, welems, e0, estep, gp, sc, a.accumulate);
             }
         }
         PSX_STAMP(12);
@@ -1201,6 +1108,9 @@ __global__ __launch_bounds__(T) void k_fresnel_lines(LineArgs a) {
         PSX_STAMP(13);
     }
 }
+
+
+#undef PSX_STAMP
 
 // z == 0 (EXP:233-234): out = psi, |psi|^2
 template <int NM>
@@ -1746,33 +1656,32 @@ static int kernel_spectrum(psx_fresnel_plan *p, AxisTables &t, double a, double 
     return 0;
 }
 
-template <int R3, bool CONTIG, bool PART = false, bool PAIR = false, bool DUAL = false, bool QUEUE = false, bool DIF = false>
+// persistent workgroups: one per CU (the LDS footprint allows no more), a multiple of the 8 XCDs
+static int line_grid_slots(int nwork, int cap) {
+    int nslot = current_cu_count() / 8;
+    if (nslot > (nwork + 7) / 8) nslot = (nwork + 7) / 8;
+    if (cap && nslot > cap) nslot = cap;
+    return nslot;
+}
+
+// lines that fit one LDS transform
+template <int R3, bool CONTIG, bool DUAL = false, bool QUEUE = false>
 static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
-    if constexpr (!PART && !QUEUE) {
-        if (la.queue) return launch_lines<R3, CONTIG, PART, PAIR, DUAL, true>(la, st, name);
+    if constexpr (!QUEUE) {
+        if (la.queue) return launch_lines<R3, CONTIG, DUAL, true>(la, st, name);
     }
-    constexpr int M = 576 * R3, LINES = PAIR ? 1 : (DUAL ? TOT / M / 2 : TOT / M);        // LINES here: image lines per round
-    constexpr size_t lds_bytes = sizeof(float2) * ((size_t)(TOT / M) * (M + M / 32 + (PAIR ? 16 : 0)) + (2 * R3 + RAD) * (RAD + 1)) + 16;   // lines + the three twiddle tables + the unit ring
+    using GE = LineGeom<R3, false>;
+    constexpr int LPG = DUAL ? GE::LINES / 2 : GE::LINES;        // image lines per round
     static std::atomic<unsigned long long> attr_mask{0};
     if (first_on_device(attr_mask))
-        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG, PART, PAIR, DUAL, QUEUE, DIF>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_bytes));
-    // persistent workgroups: one per CU (the LDS footprint allows no more), a multiple of the 8 XCDs
-    const int n_cu = current_cu_count();
-    const int nwork = ((la.nlines + LINES - 1) / LINES) * (PART ? la.n_dist * la.NB : (la.dist_inner ? 1 : la.n_dist));
-    int nslot = n_cu / 8;
-    if (nslot > (nwork + 7) / 8) nslot = (nwork + 7) / 8;
-    if constexpr (QUEUE) {
-        // the queue buffer holds a counter per workgroup of at most 256 (QUEUE_WORDS) and a thief looks at the queues of its
-        // XCD with one lane each, 32 at most: a device with more than 256 CUs runs the queued passes on 256 workgroups
-        static_assert(QUEUE_WORDS == 16 * 257, "queue layout: 256 counters 64 bytes apart + the count of workgroups done");
-        if (nslot > 32) nslot = 32;
-    }
-    if constexpr (DIF) {
-        if (!la.wgpart || !la.w4 || 8 * nslot > la.wg_groups)
-            return fail(PSX_E_STATE, "LDS engine: %d workgroups for %d private line buffers", 8 * nslot, la.wg_groups);
-    }
-    PSX_TIMED(name, st, k_fresnel_lines<R3, CONTIG, PART, PAIR, DUAL, QUEUE, DIF><<<8 * nslot, T, lds_bytes, st>>>(la));
+        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_lines<R3, CONTIG, DUAL, QUEUE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)GE::lds_bytes));
+    const int nwork = ((la.nlines + LPG - 1) / LPG) * (la.dist_inner ? 1 : la.n_dist);
+    // the queue buffer holds a counter per workgroup of at most 256 (QUEUE_WORDS) and a thief looks at the queues of its
+    // XCD with one lane each, 32 at most: a device with more than 256 CUs runs the queued passes on 256 workgroups
+    static_assert(QUEUE_WORDS == 16 * 257, "queue layout: 256 counters 64 bytes apart + the count of workgroups done");
+    const int nslot = line_grid_slots(nwork, QUEUE ? 32 : 0);
+    PSX_TIMED(name, st, k_fresnel_lines<R3, CONTIG, DUAL, QUEUE><<<8 * nslot, T, GE::lds_bytes, st>>>(la));
     const int rc = launch_check(name);
     if constexpr (QUEUE) {
         // a launch that did not start leaves nobody to re-arm the counters: zero them here, or every later launch would
@@ -1782,12 +1691,31 @@ static int launch_lines(const LineArgs &la, hipStream_t st, const char *name) {
     return rc;
 }
 
+// longer lines: partitioned convolution, coupled lines (PAIR), DIF rounds
+template <bool CONTIG, bool PAIR, bool DIF = false>
+static int launch_part(const LineArgs &la, hipStream_t st, const char *name) {
+    using GE = LineGeom<16, PAIR>;
+    constexpr int LPG = PAIR ? 1 : GE::LINES;
+    static std::atomic<unsigned long long> attr_mask{0};
+    if (first_on_device(attr_mask))
+        PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_part<CONTIG, PAIR, DIF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)GE::lds_bytes));
+    const int nwork = ((la.nlines + LPG - 1) / LPG) * la.n_dist * la.NB;
+    const int nslot = line_grid_slots(nwork, 0);
+    if constexpr (DIF) {
+        if (!la.wgpart || !la.w4 || 8 * nslot > la.wg_groups)
+            return fail(PSX_E_STATE, "LDS engine: %d workgroups for %d private line buffers", 8 * nslot, la.wg_groups);
+    }
+    PSX_TIMED(name, st, k_fresnel_part<CONTIG, PAIR, DIF><<<8 * nslot, T, GE::lds_bytes, st>>>(la));
+    return launch_check(name);
+}
+
 template <bool CONTIG>
 static int launch_lines_r3(int R3, const LineArgs &la, hipStream_t st, const char *name, bool part = false, bool pair = false,
                            bool dif = false) {
-    if (part && pair && dif) return launch_lines<16, CONTIG, true, true, false, false, true>(la, st, name);
-    if (part && pair) return launch_lines<16, CONTIG, true, true>(la, st, name);
-    if (part) return launch_lines<16, CONTIG, true>(la, st, name);
+    if (part && pair && dif) return launch_part<CONTIG, true, true>(la, st, name);
+    if (part && pair) return launch_part<CONTIG, true>(la, st, name);
+    if (part) return launch_part<CONTIG, false>(la, st, name);
     switch (R3) {
         case 4: return launch_lines<4, CONTIG>(la, st, name);
         case 8: return launch_lines<8, CONTIG>(la, st, name);
@@ -1874,9 +1802,9 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
             }
             int rc = 0;
             switch (e->ax[0].R3) {
-                case 4: rc = launch_lines<4, true, false, false, true>(la, st, "k_fresnel_cols"); break;
-                case 8: rc = launch_lines<8, true, false, false, true>(la, st, "k_fresnel_cols"); break;
-                default: rc = launch_lines<16, true, false, false, true>(la, st, "k_fresnel_cols"); break;
+                case 4: rc = launch_lines<4, true, true>(la, st, "k_fresnel_cols"); break;
+                case 8: rc = launch_lines<8, true, true>(la, st, "k_fresnel_cols"); break;
+                default: rc = launch_lines<16, true, true>(la, st, "k_fresnel_cols"); break;
             }
             if (rc) return rc;
         } else if (int rc = launch_lines_r3<true>(e->ax[0].R3, la, st, "k_fresnel_cols", e->ax[0].part, e->ax[0].pair, e->ax[0].dif)) return rc;
