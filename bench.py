@@ -901,10 +901,14 @@ def pmc_value(prof, kernel, field):
         if not isinstance(e, dict):
             continue
         if kernel in ("k_fresnel_rows", "k_fresnel_cols"):
-            # pass 2 (k_fresnel_rows) is the <R3, false, .> instance of the line kernel (strided reads), pass 1 <R3, true, .>
-            if not name.startswith("k_fresnel_lines<"):
+            # pass 2 (k_fresnel_rows) is the CONTIG = false instance of a line kernel (strided reads), pass 1 CONTIG = true:
+            # k_fresnel_lines<R3, CONTIG, ...> (lines that fit one LDS transform), k_fresnel_part<CONTIG, PAIR, DIF> (longer lines)
+            if name.startswith("k_fresnel_lines<"):
+                contig = name.split(",")[1].strip()
+            elif name.startswith("k_fresnel_part<"):
+                contig = name.split("<")[1].split(",")[0].strip()
+            else:
                 continue
-            contig = name.split(",")[1].strip()
             if contig != ("true" if kernel == "k_fresnel_cols" else "false"):
                 continue
             return e.get(field)
