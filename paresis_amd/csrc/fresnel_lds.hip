@@ -585,23 +585,33 @@ __global__ __launch_bounds__(T) void k_fresnel_part(LineArgs a) {
     // ---- work units of this workgroup: (distance, output block, line group), S consecutive rounds each (one per kernel
     // segment).  XCD x = blockIdx % 8 owns a contiguous chunk of units (its 32 CUs then read neighbouring columns at the same
     // time: the 128-byte lines of the strided source are shared in that XCD's L2); static shares.
+    // a.dist_inner (pass 1: every distance reads the SAME source): the chunks are cut over (block, line group) pairs and a
+    // workgroup takes the n_dist distances of its pair in consecutive units -- the DIF loaders then keep most of the line in
+    // registers for all of them (below) instead of fetching it 2 n_dist times.
     const int ngroups = (a.nlines + LPG - 1) / LPG;
-    const int nwork = ngroups * a.n_dist * a.NB;
+    const int ndin = a.dist_inner ? a.n_dist : 1;                             // distances inside a chunk item
+    const int nwork = ngroups * a.NB * (a.dist_inner ? 1 : a.n_dist);
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
     const int cq = nwork >> 3, cr = nwork & 7;
     const int cstart = xcd * cq + (xcd < cr ? xcd : cr), clen = cq + (xcd < cr ? 1 : 0);
-    const int nunits = slot < clen ? (clen - slot + nslot - 1) / nslot : 0;   // units cstart + slot + u*nslot, u < nunits
+    const int nunits = (slot < clen ? (clen - slot + nslot - 1) / nslot : 0) * ndin;   // chunk items cstart + slot + k*nslot, x distances inside
     const int nj = nunits * a.S;                                              // rounds of this workgroup
     // round j -> (distance, line group), output block pb, kernel segment ps
     int pb = 0, ps = 0;
     auto item = [&](int j, int &d, int &g) __attribute__((always_inline)) {
         const int u = j / a.S;
         ps = j - u * a.S;
-        const int w = cstart + slot + u * nslot;         // unit: ((d * NB) + b) * ngroups + g
+        const int ui = u / ndin, di = u - ui * ndin;     // chunk item of this workgroup, distance inside it
+        const int w = cstart + slot + ui * nslot;        // item: ((d * NB) + b) * ngroups + g, or (b * ngroups + g) with d = di
         const int db = w / ngroups;
         g = w - db * ngroups;
-        d = db / a.NB;
-        pb = db - d * a.NB;
+        if (a.dist_inner) {
+            d = di;
+            pb = db;
+        } else {
+            d = db / a.NB;
+            pb = db - d * a.NB;
+        }
     };
 
     const TwTables tw = fill_tables<GE>(lds, a, tid);          // stage twiddles into LDS, behind the line buffers
@@ -696,6 +706,107 @@ __global__ __launch_bounds__(T) void k_fresnel_part(LineArgs a) {
                 base[(k + NH * h) * PSTEP] = ok ? xs[k] : make_float2(0.f, 0.f);
             }
         };
+        if constexpr (DIF) {
+            // DIF rounds, round 4: most of a line STAYS in the loaders' registers.  The two rounds of a line (and, in pass 1,
+            // the rounds of all distances of a line: dist_inner order) spread the SAME 2M samples; only what is formed from them
+            // differs (L[n] + L[n + D] or (L[n] - L[n + D]) w^n, by the engine).  A thread's 72 positions are therefore split
+            // into NK that are fetched once per line and kept (2 NK registers) and two chunks of NR that rotate through one
+            // small buffer every round: chunk A travels during the transform, chunk B between barriers (3) and (4).  Stamps of
+            // the previous form (all 72 fetched every round, 60 + 12): the loaders needed 13-18 us to ISSUE a round's loads --
+            // pass 2 reads one 64-byte sector per 8-byte sample and is bound by the L2 -> L1 path, pass 1 by HBM -- and the engine
+            // waited for them at barrier (2) for 2.7-9.3 us of every round (gpurun_out/r4s10).
+            constexpr int NK = PSX_DIF_KEEP, NR = (2 * NH - NK) / 2;
+            static_assert(NK + 2 * NR == 2 * NH && NK >= 0 && NR >= 1, "kept + 2 rotating chunks = the 72 positions of a loader thread");
+            float2 xk[NK > 0 ? NK : 1], xr[NR];
+            auto fetch_pos = [&](int j, auto k0_tag, auto cnt_tag, auto &dst) __attribute__((always_inline)) {
+                constexpr int K0 = decltype(k0_tag)::value, CNT = decltype(cnt_tag)::value;
+                int d, g;
+                item(j, d, g);
+                const int lc = min(g, a.nlines - 1);
+                const float2 *srcl = a.src[d] + (a.in_blocked ? ((int64_t)(lc / IB) * N) * IB + lc % IB : (int64_t)lc * a.in_sl);
+                const int sh = a.in_blocked ? IBS + 3 : 3;                     // byte stride of a sample: 8 IB (blocked) or 8
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float2 *>(srcl), 0, g < a.nlines ? (int)((unsigned)N << sh) : 0, 0x00020000);   // a line past the image reads zeros
+                int jb = 2 * i0 + line + mg + 1;
+                asm volatile("" : "+v"(jb));
+#pragma unroll
+                for (int k = 0; k < CNT; ++k) {
+                    const unsigned j0 = (unsigned)(jb + 2 * STEP * (K0 + k));
+                    const unsigned jp = min(j0, j0 - (unsigned)P);                   // mod P (j0 < 2P)
+                    unsigned i1, i2;       // |a - b| in one instruction (the compiler expands __sad into sub, neg, max)
+                    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(i1) : "v"(jp), "s"(mg));           // np.pad 'reflect' (EXP:237) on the left ...
+                    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(i2) : "v"(i1), "s"(N - 1));
+                    const unsigned i = (unsigned)(N - 1) - i2;                                 // ... and on the right
+                    dst[k] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(i << sh), 0, 0));
+                }
+            };
+            auto spread_pos = [&](auto k0_tag, auto cnt_tag, const auto &srcv) __attribute__((always_inline)) {
+                constexpr int K0 = decltype(k0_tag)::value, CNT = decltype(cnt_tag)::value;
+#pragma unroll
+                for (int k = 0; k < CNT; ++k) base[(K0 + k) * PSTEP] = srcv[k];
+            };
+            using K0 = std::integral_constant<int, 0>;
+            using KK = std::integral_constant<int, NK>;
+            using KR = std::integral_constant<int, NR>;
+            using KB = std::integral_constant<int, NK + NR>;
+            // which line the kept registers hold: (source plane, line); a round of another line re-fetches them
+            const float2 *ksrc = nullptr;
+            int kg = -1;
+            auto line_of = [&](int j, const float2 *&sp, int &g) __attribute__((always_inline)) {
+                int d;
+                item(j, d, g);
+                sp = a.src[d];
+            };
+            if (nj > 0) {
+                if constexpr (NK > 0) {
+                    fetch_pos(0, K0{}, KK{}, xk);
+                    spread_pos(K0{}, KK{}, xk);
+                    line_of(0, ksrc, kg);
+                }
+                fetch_pos(0, KK{}, KR{}, xr);
+                spread_pos(KK{}, KR{}, xr);
+                fetch_pos(0, KB{}, KR{}, xr);
+                spread_pos(KB{}, KR{}, xr);
+            }
+            lds_barrier();                                   // (0)
+            for (int j = 0; j < nj; ++j) {
+                const bool more = j + 1 < nj;
+                lds_barrier();                               // (1a) engine: stage A has read its inputs and their partners
+                lds_barrier();                               // (1)
+                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 16] = wall_clock64();
+                if (more) {
+                    if constexpr (NK > 0) {
+                        const float2 *sp;
+                        int g;
+                        line_of(j + 1, sp, g);
+                        if (sp != ksrc || g != kg) {         // uniform: a new line
+                            fetch_pos(j + 1, K0{}, KK{}, xk);
+                            ksrc = sp;
+                            kg = g;
+                        }
+                    }
+                    fetch_pos(j + 1, KK{}, KR{}, xr);
+                }
+                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 17] = wall_clock64();
+                lds_barrier();                               // (2)
+                lds_barrier();                               // (3)
+                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 18] = wall_clock64();
+                __builtin_amdgcn_s_setprio(3);
+                if (more) {
+                    if constexpr (NK > 0) spread_pos(K0{}, KK{}, xk);
+                    spread_pos(KK{}, KR{}, xr);
+                    if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 21] = wall_clock64();
+                    fetch_pos(j + 1, KB{}, KR{}, xr);
+                    if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 22] = wall_clock64();
+                    spread_pos(KB{}, KR{}, xr);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 19] = wall_clock64();
+                lds_barrier();                               // (4)
+                if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 20] = wall_clock64();
+            }
+            return;
+        }
         if (nj > 0) {
             if constexpr (DIF) {
                 fetch_dif(0, KA0{}, KAN{});
@@ -1702,7 +1813,7 @@ static int launch_part(const LineArgs &la, hipStream_t st, const char *name) {
     if (first_on_device(attr_mask))
         PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_part<CONTIG, PAIR, DIF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)GE::lds_bytes));
-    const int nwork = ((la.nlines + LPG - 1) / LPG) * la.n_dist * la.NB;
+    const int nwork = ((la.nlines + LPG - 1) / LPG) * la.NB * (la.dist_inner ? 1 : la.n_dist);
     const int nslot = line_grid_slots(nwork, 0);
     if constexpr (DIF) {
         if (!la.wgpart || !la.w4 || 8 * nslot > la.wg_groups)
@@ -1777,6 +1888,9 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         const int lines_per_group = (nnz >= 2 && !e->ax[0].part) ? lds_lines / 2 : lds_lines;   // shared-forward rounds take half the LDS lines
         const int ngroups0 = (p->Ny + lines_per_group - 1) / lines_per_group;
         la.dist_inner = (no_inner || e->ax[0].part || ngroups0 < current_cu_count()) ? 0 : 1;
+        // DIF rounds: the distances of a line in consecutive units of one workgroup, whose loaders keep the line in registers
+        // (k_fresnel_part) -- when the lines alone fill the chip
+        if (e->ax[0].dif && !no_inner && nnz >= 2 && p->Ny >= current_cu_count()) la.dist_inner = 1;
         la.B = e->ax[0].B; la.Lh = e->ax[0].Lh; la.S = e->ax[0].S; la.NB = e->ax[0].NB;
         for (int i = 0; i < PSX_MAX_DIST; ++i) {
             const int k = i < nnz ? i : 0;

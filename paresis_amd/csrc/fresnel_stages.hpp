@@ -38,6 +38,9 @@ constexpr int IB = PSX_IB;
 constexpr int IBS = IB == 4 ? 2 : (IB == 8 ? 3 : 4);      // log2(IB)
 static_assert((1 << IBS) == IB, "intermediate block size");
 constexpr int QUEUE_WORDS = 16 * 257;     // work queues: a counter per workgroup (<= 256, 64 bytes apart) + the count of workgroups done
+#ifndef PSX_DIF_KEEP
+#define PSX_DIF_KEEP 48       // DIF rounds: positions (of 72 per loader thread) fetched once per line and kept in registers for its
+#endif                        // later rounds; the other 24 rotate through a 12-position buffer every round (0: nothing kept)
 #ifndef PSX_DIF_NHA
 #define PSX_DIF_NHA 60        // DIF rounds: window positions (of 72 per loader thread) that travel during the transform; the rest is
 #endif                        // fetched between barriers (3) and (4).  52 / 56 / 60: 16384^2 passes 13.17 + 10.99 / 13.02 + 11.05 / 13.00 + 10.88 ms
