@@ -245,7 +245,9 @@ int psx_unpack_counts_u16(const uint16_t *src, float *dst, int64_t n, const int3
 size_t psx_darkfield_workspace_bytes(int Nx, int Ny);
 int psx_darkfield_blur_f32(const float *I2DF, const float *DF, const float *I2, float *out, int Nx, int Ny, int R,
                            void *workspace, void *stream);
-/* The front of fastRefractionDF in one pass (refractionFileNumba2.py:114-150): DF_px = DF_rad * scale (float64), its largest
+/* The front of fastRefractionDF in one pass (refractionFileNumba2.py:114-150): DF_px = DF_rad * num / den in float64 and in
+ * that order -- RF2:114 with num = propagationDistance, den = studyPixelSize*1e-6*magnification, so that the step functions
+ * of it (margin, DF > Nx/4 rule, patch sides) fall where the reference's fall --, its largest
  * value before and after the rule DF_px > limit -> 0 (RF2:135; words[0], words[1]: the doubles' bit patterns, device memory,
  * read back by the caller only when it does not know the maximum), the split of I by DF_px != 0 into I_nodf / I_df
  * (RF2:147-150) and the per-source patch table `prep` (psx_darkfield_workspace_bytes) of the re-splat, which depends on
@@ -253,8 +255,8 @@ int psx_darkfield_blur_f32(const float *I2DF, const float *DF, const float *I2, 
  * psx_darkfield_merge_f32: I = a + b (the caller's array after the clamped rays were zeroed in both halves, RF2:128-129);
  * psx_repad_f32: the centre [Nx][Ny] of a map padded by margin_src, re-padded with zeros to margin_dst (the displacement
  * maps fastRefractionDF returns are padded by ceil(6 max DF), RF2:117,139-140). */
-int psx_darkfield_split_f32(const float *I, const double *DF_rad, double scale, double limit, float *I_nodf, float *I_df,
-                            float *DF_px, void *prep, unsigned long long *words, int Nx, int Ny, void *stream);
+int psx_darkfield_split_f32(const float *I, const double *DF_rad, double num, double den, double limit, float *I_nodf,
+                            float *I_df, float *DF_px, void *prep, unsigned long long *words, int Nx, int Ny, void *stream);
 int psx_darkfield_blur_prepared_f32(const float *I2DF, const float *DF, const void *prep, const float *I2, float *out, int Nx,
                                     int Ny, int R, unsigned *status, void *stream);   /* status: optional word, PSX_STATUS_NONFINITE (RF2:190-193) */
 int psx_darkfield_merge_f32(float *I, const float *a, const float *b, int64_t n, void *stream);

@@ -159,27 +159,32 @@ __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict
 // intensity by DF != 0 (RF2:147-150), and -- the width map being all the patch normalisation depends on -- the per-source
 // patch half-size and 1/normalisation that k_df_prepare would compute after the refraction.
 // words[0] / words[1]: bit patterns of the largest width before / after the rule (non-negative doubles order like integers).
-__global__ __launch_bounds__(256) void k_df_split(const float *__restrict__ I, const double *__restrict__ DFrad, double scale,
-                                                  double limit, float *__restrict__ I_nodf, float *__restrict__ I_df,
+__global__ __launch_bounds__(256) void k_df_split(const float *__restrict__ I, const double *__restrict__ DFrad, double num,
+                                                  double den, double limit, float *__restrict__ I_nodf, float *__restrict__ I_df,
                                                   float *__restrict__ DFpx, float2 *__restrict__ prep,
                                                   unsigned long long *__restrict__ words, int64_t n) {
     double m0 = 0.0, m1 = 0.0;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        double d = DFrad[p] * scale;
+        // RF2:114 in the reference's own order of operations, (DF * z) / (h M), in float64: the margin ceil(6 max), the
+        // DF > Nx/4 rule and the patch sides round(3 DF/2) are step functions of this number, and a product with a
+        // pre-divided z / (h M) differs from it in the last bit often enough to move a step (found by tests/test_gpu_fuzz.py)
+        const double q = DFrad[p] * num;
+        double d = 0.0;
+        if (q != 0.0) d = q / den;            // (most of a width map is zero: outside the scattering sample)
         m0 = fmax(m0, d);
         if (d > limit) d = 0.0;
         m1 = fmax(m1, d);
         const float df = (float)d, v = I[p];
         DFpx[p] = df;
-        I_nodf[p] = df != 0.f ? 0.f : v;
-        I_df[p] = df != 0.f ? v : 0.f;
+        I_nodf[p] = d != 0.0 ? 0.f : v;
+        I_df[p] = d != 0.0 ? v : 0.f;
         float half = 0.f, inv = 1.f;                  // DF == 0: plain deposit (RF2:183-184)
-        if (df != 0.f) {                              // RF2:171-178
-            const float sigma = 0.5f * df;
-            const int h = patch_half(sigma);
+        if (d != 0.0) {                               // RF2:171-178
+            const double sigma = d / 2;               // RF2:174; the side of its patch from the float64 value (RF2:15)
+            const int h = (int)rint(sigma * 3);
             // sum_{|k| <= h} exp(-k^2 a) with ONE exponential: the terms obey t_k = t_{k-1} q_k, q_k = q_{k-1} e^{-2a}, q_1 = e^{-a}
             // (float64 throughout: 1e-15 per step; the direct sum of 2h+1 float64 exponentials was 0.6 ms of this pass at 4096^2)
-            const double e1 = exp(-1.0 / 2.0 / ((double)sigma * sigma)), r = e1 * e1;
+            const double e1 = exp(-1.0 / 2.0 / (sigma * sigma)), r = e1 * e1;
             double t = 1.0, q = e1, sum = 1.0;
             for (int k = 1; k <= h; ++k) {
                 t *= q;
@@ -232,14 +237,15 @@ __global__ __launch_bounds__(256) void k_repad(const float *__restrict__ src, in
 
 extern "C" {
 
-int psx_darkfield_split_f32(const float *I, const double *DF_rad, double scale, double limit, float *I_nodf, float *I_df,
-                            float *DF_px, void *prep, unsigned long long *words, int Nx, int Ny, void *stream) {
-    PSX_REQUIRE(I && DF_rad && I_nodf && I_df && DF_px && prep && words && Nx > 0 && Ny > 0, "psx_darkfield_split_f32: bad argument");
+int psx_darkfield_split_f32(const float *I, const double *DF_rad, double num, double den, double limit, float *I_nodf,
+                            float *I_df, float *DF_px, void *prep, unsigned long long *words, int Nx, int Ny, void *stream) {
+    PSX_REQUIRE(I && DF_rad && I_nodf && I_df && DF_px && prep && words && Nx > 0 && Ny > 0 && den != 0.0,
+                "psx_darkfield_split_f32: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)Nx * Ny;
     PSX_HIP(hipMemsetAsync(words, 0, 2 * sizeof(unsigned long long), st));
     const int grid = (int)std::min<int64_t>(1024, cdiv(n, 256));
-    PSX_TIMED("k_df_split", st, k_df_split<<<grid, 256, 0, st>>>(I, DF_rad, scale, limit, I_nodf, I_df, DF_px,
+    PSX_TIMED("k_df_split", st, k_df_split<<<grid, 256, 0, st>>>(I, DF_rad, num, den, limit, I_nodf, I_df, DF_px,
                                                                             (float2 *)prep, words, n));
     return launch_check("k_df_split");
 }

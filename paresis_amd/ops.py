@@ -423,8 +423,9 @@ def darkfield_blur(I2DF, DF, I2, R):
     return out
 
 
-def darkfield_split(I, DF_rad, scale, limit):
-    """The front of fastRefractionDF in one pass (psx_darkfield_split_f32).  Returns (I_nodf, I_df, DF_px float32, prep,
+def darkfield_split(I, DF_rad, num, den, limit):
+    """The front of fastRefractionDF in one pass (psx_darkfield_split_f32); DF_px = DF_rad * num / den, float64, in the
+    reference's order (RF2:114: num = propagationDistance, den = studyPixelSize*1e-6*magnification).  Returns (I_nodf, I_df, DF_px float32, prep,
     words): words = two device uint64 holding the float64 bit patterns of max(DF_px) before / after the DF > limit -> 0 rule
     -- read them with darkfield_maxima() only when the caller does not know the maximum (one host synchronisation)."""
     _need(I, torch.float32, "I")
@@ -434,7 +435,7 @@ def darkfield_split(I, DF_rad, scale, limit):
     I_nodf, I_df, DF_px = (torch.empty((Nx, Ny), dtype=torch.float32, device=dev) for _ in range(3))
     prep = torch.empty(lib().psx_darkfield_workspace_bytes(Nx, Ny), dtype=torch.uint8, device=dev)
     words = torch.empty(2, dtype=torch.int64, device=dev)
-    check(lib().psx_darkfield_split_f32(_ptr(I), _ptr(DF_rad), c_double(scale), c_double(limit), _ptr(I_nodf), _ptr(I_df),
+    check(lib().psx_darkfield_split_f32(_ptr(I), _ptr(DF_rad), c_double(num), c_double(den), c_double(limit), _ptr(I_nodf), _ptr(I_df),
                                         _ptr(DF_px), _ptr(prep), _ptr(words), Nx, Ny, _stream()), "psx_darkfield_split_f32")
     return I_nodf, I_df, DF_px, prep, words
 

@@ -66,11 +66,11 @@ def fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magni
     k = k_refraction(Energy)
     h = studyPixelSize * 1e-6
     dscale = propagationDistance / k / (h * magnification) / h
-    scale = propagationDistance / (h * magnification)                                      # RF2:114 rad -> pixels
+    den = studyPixelSize * 1e-6 * magnification           # RF2:114 rad -> pixels: DF * z / den, evaluated in that order
     limit = Nx / 4                                                                         # RF2:135
-    I_nodf, I_df, DF, prep, words = ops.darkfield_split(I, to_dev(darkField, torch.float64), scale, limit)
-    if darkFieldMax is not None and float(darkFieldMax) * scale <= limit:
-        maxDF = maxDFc = float(darkFieldMax) * scale        # the rule removes nothing: both maxima are the known one
+    I_nodf, I_df, DF, prep, words = ops.darkfield_split(I, to_dev(darkField, torch.float64), propagationDistance, den, limit)
+    if darkFieldMax is not None and float(darkFieldMax) * propagationDistance / den <= limit:
+        maxDF = maxDFc = float(darkFieldMax) * propagationDistance / den    # the rule removes nothing: both maxima are the known one
     else:
         maxDF, maxDFc = ops.darkfield_maxima(words)
     margin2 = int(np.ceil(maxDF * 6))                                                      # RF2:117

@@ -717,9 +717,9 @@ def test_darkfield_front_kernels_against_numpy(ops):
     I = rng.uniform(1.0, 9.0, (Nx, Ny)).astype(np.float32)
     DFrad = np.where(rng.uniform(size=(Nx, Ny)) < 0.4, 0.0, rng.uniform(1e-7, 3e-6, (Nx, Ny)))
     DFrad[5, 7] = 1.0e-4                       # becomes > Nx/4 pixels: zeroed by the rule, but counts for the margin
-    scale = 3.6 / (2.9e-6 * 1.02)
-    a, b, dfpx, prep, words = ops.darkfield_split(dev(I, torch.float32), dev(DFrad, torch.float64), scale, Nx / 4)
-    px = DFrad * scale
+    num, den = 3.6, 2.9 * 1e-6 * 1.02
+    a, b, dfpx, prep, words = ops.darkfield_split(dev(I, torch.float32), dev(DFrad, torch.float64), num, den, Nx / 4)
+    px = DFrad * num / den                     # RF2:114, the reference's order of operations
     mx0 = px.max()
     pxc = np.where(px > Nx / 4, 0.0, px)
     m0, m1 = ops.darkfield_maxima(words)
@@ -731,7 +731,7 @@ def test_darkfield_front_kernels_against_numpy(ops):
     # patch table: (half-size, 1/normalisation) of gaussian_shape(DF/2) (RF2:14-23: side round(3 sigma)*2+1, banker's rounding)
     tab = prep.view(torch.float32).view(Nx, Ny, 2).cpu().numpy()
     for (i, j) in [(0, 0), (5, 7), (40, 33), (92, 69), (17, 2)]:
-        s = 0.5 * float(df32[i, j])
+        s = float(pxc[i, j]) / 2                # RF2:174: the patch side comes from the float64 width
         if s == 0:
             assert tab[i, j, 0] == 0 and tab[i, j, 1] == 1
             continue
@@ -762,7 +762,7 @@ def test_darkfield_resplat_all_tile_shapes(ops, max_df):
     DFpx = np.where(rng.uniform(size=(Nx, Ny)) < 0.3, 0.0, rng.uniform(0.3, max_df, (Nx, Ny)))
     DFpx[10, 10] = max_df
     # psx_darkfield_split_f32 with scale 1 turns the width map into the float32 pixels + patch table the gather uses
-    _, _, DF32, prep, words = ops.darkfield_split(dev(I2DF, torch.float32), dev(DFpx, torch.float64), 1.0, 1e9)
+    _, _, DF32, prep, words = ops.darkfield_split(dev(I2DF, torch.float32), dev(DFpx, torch.float64), 1.0, 1.0, 1e9)
     R = int(round(1.5 * max_df)) + 1
     out = ops.darkfield_blur_prepared(dev(I2DF, torch.float32), DF32, prep, dev(I2, torch.float32), R)
     ops.check_status(out.device)
