@@ -325,17 +325,9 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     const double hscale = 0.5 * dscale;
     float *const I_out = a.I_out[d];
     FarRay *const far_list = a.far_list + ((size_t)d * nt + tile) * (TH * TW);
-    auto gather = [&](auto inside_tag) __attribute__((always_inline)) {
-    constexpr bool IN = decltype(inside_tag)::value && (GR * GC) % NTHREADS == 0;   // every slot is a pixel inside the image
-    for (int it = 0; it < ITERS; ++it) {
-        const int idx = IN ? it * NTHREADS + tl : min(it * NTHREADS + tl, GR * GC - 1);
-        const bool live = IN || it * NTHREADS + tl < GR * GC;
-        const int gr = (int)((unsigned)idx / (unsigned)GC), gc = (int)((unsigned)idx % (unsigned)GC);
-        const int i = r0 - H + gr, j = c0 - H + gc;
-        const bool inside = IN || (live && i >= 0 && i < a.Nx && j >= 0 && j < a.Ny);
-        const bool core = gr >= H && gr < H + TH && gc >= H && gc < H + TW;
-        float I = live ? sI[idx] : 0.f;                              // 0 outside the image
-        const int sidx = (gr + 1) * SC + (gc + 1);                   // this pixel in the staged phase tile
+    // D = gradient(phi) * dscale at staged pixel `sidx` (image pixel (i, j)), float64 differencing, float32 result
+    auto displacement = [&](auto inside_tag, int i, int j, int sidx, bool inside, float &dx, float &dy) __attribute__((always_inline)) {
+        constexpr bool IN = decltype(inside_tag)::value && (GR * GC) % NTHREADS == 0;
         double gx, gy;
         // gx, gy hold gradient * dscale.  (d * 0.5) * dscale == d * (0.5 * dscale) bit for bit: halving is exact.
         if (IN || (i > 0 && i < a.Nx - 1 && j > 0 && j < a.Ny - 1)) {   // interior: central differences (RF2:54)
@@ -361,7 +353,22 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
             gy = 0.0;
         }
         // the displacement is a small number: everything after the float64 differencing runs in float32
-        float dx = (float)gx, dy = (float)gy;
+        dx = (float)gx;
+        dy = (float)gy;
+    };
+    auto gather = [&](auto inside_tag) __attribute__((always_inline)) {
+    constexpr bool IN = decltype(inside_tag)::value && (GR * GC) % NTHREADS == 0;   // every slot is a pixel inside the image
+    for (int it = 0; it < ITERS; ++it) {
+        const int idx = IN ? it * NTHREADS + tl : min(it * NTHREADS + tl, GR * GC - 1);
+        const bool live = IN || it * NTHREADS + tl < GR * GC;
+        const int gr = (int)((unsigned)idx / (unsigned)GC), gc = (int)((unsigned)idx % (unsigned)GC);
+        const int i = r0 - H + gr, j = c0 - H + gc;
+        const bool inside = IN || (live && i >= 0 && i < a.Nx && j >= 0 && j < a.Ny);
+        const bool core = gr >= H && gr < H + TH && gc >= H && gc < H + TW;
+        float I = live ? sI[idx] : 0.f;                              // 0 outside the image
+        const int sidx = (gr + 1) * SC + (gc + 1);                   // this pixel in the staged phase tile
+        float dx, dy;
+        displacement(inside_tag, i, j, sidx, inside, dx, dy);
         // RF2:59-60 zeroes |D| < 1e-12.  For the deposit that is a no-op in float32 -- such a ray puts weight 1.0f on its
         // own pixel and less than 2^-30 of a unit elsewhere either way -- so only the displacement maps apply it.
         const bool clx = fabsf(dx) > a.clamp_xf, cly = fabsf(dy) > a.clamp_yf;   // RF2:61-64
@@ -378,6 +385,8 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
         const bool own = (unsigned)(gr - H + ifx) < (unsigned)(TH - 1) && (unsigned)(gc - H + ify) < (unsigned)(TW - 1);
         const bool far = core && inside && !near && !own && I != 0.f;
         const float Dxs = dx, Dys = dy, Is = I;
+        // (moved into a pass of its own over the tile's core, out of this loop, the block below makes the kernel SLOWER: 0.269 ->
+        // 0.276 ms at 4096^2, gpurun_out/r4s17 -- fewer instructions, another schedule)
         if (a.Dx_out || a.I_mut) {                                   // wave-uniform: only the class API asks for these
             if (core && inside) {
                 if (a.Dx_out) {
@@ -431,7 +440,9 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
             if (lane == leader) base = atomicAdd(sfar, (unsigned)__popcll(mask));
             base = __shfl(base, leader);
             if (far) {
-                const unsigned rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+                // set bits of `mask` below this lane: two v_mbcnt, formed here (the shift-and-popcount form was hoisted out of
+                // this rare branch into every iteration of the deposit loop: a 64-bit shift and two v_not per source pixel; -0.8 %)
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                 FarRay fr;
                 fr.dx = Dxs; fr.dy = Dys; fr.I = Is; fr.src = i * a.Ny + j;
                 far_list[base + rank] = fr;

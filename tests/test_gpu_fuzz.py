@@ -338,3 +338,69 @@ def test_fuzz_chain(ops, case, sim):
         if sim == "RT" and point == 0:
             dmax = max(np.max(np.abs(ref[4])), 1e-30)
             assert np.max(np.abs(out[4].cpu().numpy() - ref[4])) / dmax < 2e-6, (what, "Dx")
+
+
+# --------------------------------------------------------------------------------------- membrane synthesis
+@pytest.mark.parametrize("case", range(6 * MULT))
+def test_fuzz_membrane(ops, case):
+    """getMembraneSegmentedFromFile on random sphere lists, grids that need stitching along either axis, 1-4 layers."""
+    import types
+    from paresis_amd.Samples.getMembraneFromFile import getMembraneSegmentedFromFile
+    rng = np.random.default_rng(70_000 + case)
+    n = int(rng.choice([40, 900, 6000]))
+    lst = np.stack([rng.uniform(-4870.0, 4870.0, n), rng.uniform(-4051.0, 4051.0, n), rng.uniform(6.0, 19.0, n)], axis=1)
+    dimX, dimY = _size(rng, 40, 600), _size(rng, 40, 600)
+    meanR = float(rng.uniform(3.0, 22.0))
+    pix = float(rng.uniform(0.6, 5.0))
+    layers = int(rng.integers(1, 5))
+    support = float(rng.uniform(0.0, 8000.0))
+    seed = int(rng.integers(0, 2 ** 31 - 1))
+    smp = types.SimpleNamespace(myMeanSphereRadius=meanR, myNbOfLayers=layers)
+    geom, _ = getMembraneSegmentedFromFile(smp, dimX, dimY, pix, 0, support, seed=seed, sphere_list=lst)
+    ref = orc.membrane_segmented(lst, dimX, dimY, pix, meanR, layers, support, seed)
+    what = (case, n, dimX, dimY, meanR, pix, layers)
+    assert relmax(geom[0].cpu().numpy(), ref[0]) < 1e-6, what
+    assert relmax(geom[1].cpu().numpy(), ref[1]) < 1e-6, what
+
+
+@pytest.mark.parametrize("case", range(3 * MULT))
+def test_fuzz_chain_darkfield(ops, case):
+    """The ray-tracing chain with a scattering sample (Sample.py:322-344: 'Lung' material or the sample named
+    'cylinder_beeds'): fastRefractionDF inside the energy loop, the dark-field map of position 0."""
+    import copy
+    from tests._build import build_experiment
+    rng = np.random.default_rng(80_000 + case)
+    cfg = _chain_cfg(rng, "RT")
+    lung = bool(rng.random() < 0.5)
+    N0, N1 = cfg["N"]
+    nE = len(cfg["spectrum"])
+    h = cfg["pix_um"] * 1e-6
+    delta = rng.uniform(2e-7, 6e-7, (1, nE))
+    radius, fraction = (47, 0.5) if lung else (15, 0.6)
+    # thickness for a dark field of `px` pixels at the detector (SAM:324-343 solved for the thickness, first energy)
+    px = float(rng.choice([0.7, 1.9, 3.3]))
+    d0 = delta[0, 0]
+    c = (fraction * 3 / 4 / np.pi / radius ** 3) ** (1 / 3)
+    t_um = (px * h * cfg["M"] / (cfg["dOD"] * 2 * d0 * np.sqrt(np.log(2 / d0) + 1))) ** 2 / c
+    shape = np.clip(_smooth(rng, (N0, N1), float(rng.uniform(8.0, 30.0))) + 0.2, 0.0, None)
+    geom = (t_um * 1e-6 * shape / shape.max())[None].astype(np.float32).astype(np.float64)
+    beta = np.array([[rng.uniform(0.05, 1.0) / (2 * orc.k_sample(e) * geom.max()) for e, _ in cfg["spectrum"]]])
+    name = "lungs" if lung else "cylinder_beeds"
+    mats = ["Lung"] if lung else ["PMMA"]
+    cfg["sample"] = orc.Obj(geom, delta, beta, materials=mats, my_type="sample_of_interest", name=name)
+    ref_cfg = copy.deepcopy(cfg)
+    exp = build_experiment(cfg, "RT", sample_materials=tuple(mats), sample_name=name)
+    what = dict(case=case, N=cfg["N"], lung=lung, px=px, nE=nE, bins=cfg["bins"])
+    for point in (0, 1):
+        exp.exp_dict["meanEnergy"] = 0
+        out = exp.computeSampleAndReferenceImages(point)
+        ref = orc.compute_rt(ref_cfg, point)
+        for k, nm in enumerate(("Sample", "Reference", "Propag", "White")):
+            if point == 1 and nm in ("Propag", "White"):
+                continue
+            assert relmax(out[k].cpu().numpy(), ref[k]) < TOL, (what, point, nm, relmax(out[k].cpu().numpy(), ref[k]))
+        if point == 0:
+            assert tuple(out[4].shape) == ref[4].shape, (what, "Dx shape")
+            assert relmax(out[6].cpu().numpy(), ref_cfg["_darkFieldPropag"]) < 2e-6, (what, "dark-field map")
+        else:
+            assert float(out[6].abs().max()) == 0.0
