@@ -107,6 +107,39 @@ def test_fuzz_fresnel(ops, case):
     plan.close()
 
 
+@pytest.mark.parametrize("case", range(5 * MULT))
+def test_fuzz_fresnel_long_lines(ops, case):
+    """Lines longer than one LDS transform (partitioned, coupled and two-round kernels: 4594 ... 18402 samples) on either
+    axis of a thin grid, whole images against the oracle."""
+    rng = np.random.default_rng(15_000 + case)
+    edges = [4594, 4600, 9202, 9203, 12278, 12279, 12280, 16384, 18402]
+    long = int(rng.choice(edges)) if rng.random() < 0.4 else int(rng.integers(4594, 18403))
+    short = _size(rng, 16, 200)
+    Nx, Ny = (long, short) if rng.random() < 0.5 else (short, long)
+    E = float(rng.uniform(15.0, 80.0))
+    M = float(rng.uniform(1.0, 2.0))
+    pix = float(rng.uniform(0.2, 2.0))
+    nd = int(rng.integers(1, 4))
+    zs = [float(z) for z in rng.uniform(0.05, 8.0, nd)]
+    amp = float(rng.uniform(0.5, 2.0))
+    k = orc.k_sample(E)
+    T = np.abs((rng.uniform(0, 1) + _smooth(rng, (Nx, Ny), rng.uniform(5, 60))) * rng.uniform(1e-6, 2e-4))[None].astype(np.float32)
+    delta, beta = [float(rng.uniform(5e-8, 8e-7))], [float(rng.uniform(1e-11, 5e-9))]
+    m = ops.MaterialStack(dev(T, torch.float32), cphase=[-k * delta[0]], catt=[-k * beta[0]])
+    w0 = orc.set_wave(np.full((Nx, Ny), amp, dtype=np.complex128), T.astype(np.float64), delta, beta, E)
+    kk = orc.getk(E * 1000)
+    du = (2 * np.pi / (Nx * pix * 1e-6), 2 * np.pi / (Ny * pix * 1e-6))
+    plan = ops.FresnelPlan(Nx, Ny, max_dist=nd, engine=2)
+    assert plan.engine == 2
+    inten = [torch.zeros((Nx, Ny), dtype=torch.float32, device="cuda") for _ in zs]
+    outs = plan.propagate([z / (2 * kk * M) for z in zs], [kk * z / M for z in zs], du, amp=amp, mats=m, inten_out=inten)
+    for d in range(nd):
+        ref = orc.wave_propagation(w0, zs[d], E, M, (Nx, Ny), pix)
+        assert relmax(outs[d].cpu().numpy(), ref) < TOL, (case, Nx, Ny, nd, d)
+        assert relmax(inten[d].cpu().numpy(), np.abs(ref) ** 2) < TOL, (case, Nx, Ny, nd, d, "intensity")
+    plan.close()
+
+
 # --------------------------------------------------------------------------------------------- refraction
 @pytest.mark.parametrize("case", range(24 * MULT))
 def test_fuzz_refraction(ops, case):
