@@ -74,6 +74,66 @@ __global__ __launch_bounds__(256) void k_df_gather(const float *__restrict__ I2D
 // as far as the widest patch actually present in the staged window (most tiles of an image lie outside the scattering
 // sample: half-size 0, one term).  Same terms in the same order as k_df_gather (the exponent is formed as d^2 * (-log2(e)/2 sigma^2)
 // and goes through v_exp_f32, 1 ulp, instead of expf(-d^2 / (2 sigma^2)): 0.50 -> 0.39 ms at 4096^2).
+// One source row of the gather with a compile-time reach: the 2 RE + 1 entries are requested together (one LDS latency per row, not
+// one per term), offsets, squared distances and the ring test `half-size >= max(|di|, |dj|)` are constants.  Same terms in the same
+// order as the run-time loop it replaces (round 4: that loop waited out a full LDS round trip per term and spent eight scalar
+// instructions on its bookkeeping: 0.317 -> 0.235 ms at 4096^2, gpurun_out/r4s23).
+template <int RE, bool UNI>
+__device__ __forceinline__ float df_row_terms(const float4 *row, int di, float acc) {
+    const float di2 = (float)(di * di);
+    const int adi = abs(di);
+    // h == 0: coefficient 0, exp2(0) = 1, selected only at di = dj = 0 (same value as the plain deposit)
+    // e.w (always 0) rides in the multiply-add so that the entry is fetched with ONE ds_read_b128 (4 LDS cycles per wave
+    // instruction): left unused, the compiler narrows the load to ds_read_b96 (8 cycles: MI355X_MICROARCH.md)
+    auto term = [&](const float4 &e, int dj) __attribute__((always_inline)) {
+        const float need = (float)max(adi, abs(dj));
+        const float ex = __builtin_amdgcn_exp2f((di2 + (float)(dj * dj)) * e.y);
+        // UNI: every source of the window that carries weight has the widest patch -- no ring test, and only (weight, coefficient)
+        // are read: one ds_read_b64 (with e.w in the expression the compiler fetches x, y and w as three 4-byte pieces)
+        if constexpr (UNI) return e.x * ex;
+        const float t = fmaf(e.x, ex, e.w);
+        return e.z >= need ? t : 0.f;
+    };
+    if constexpr (RE <= 4) {
+        float4 e[2 * RE + 1];
+#pragma unroll
+        for (int dj = -RE; dj <= RE; ++dj) e[dj + RE] = row[dj];
+#pragma unroll
+        for (int dj = -RE; dj <= RE; ++dj) acc += term(e[dj + RE], dj);
+    } else {
+        // wider rows in pieces of CH entries, a real loop over the pieces: unrolled, every piece's loads are hoisted to the front
+        // (29 entries = 116 registers at RE = 14) whatever separates them
+        constexpr int CH = 2 * RE + 1 <= 15 ? (2 * RE + 1 + 1) / 2 : ((2 * RE + 1) % 3 == 0 ? (2 * RE + 1) / 3 : (2 * RE + 1 + 2) / 3);
+        constexpr int NP = (2 * RE + 1 + CH - 1) / CH;
+#pragma unroll 1
+        for (int pc = 0; pc < NP; ++pc) {
+            const int c0 = -RE + pc * CH;
+            float4 e[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) e[u] = row[min(c0 + u, RE)];         // the last piece may repeat the last entry ...
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const float t = term(e[u], c0 + u);
+                acc += c0 + u <= RE ? t : 0.f;                                  // ... which then adds nothing (uniform test)
+            }
+        }
+    }
+    return acc;
+}
+
+template <int RE, bool UNI>
+__device__ __forceinline__ float df_terms(const float4 *centre, int W) {
+    float acc = 0.f;
+    if constexpr (RE <= 4) {
+#pragma unroll
+        for (int di = -RE; di <= RE; ++di) acc = df_row_terms<RE, UNI>(centre + di * W, di, acc);
+    } else {
+#pragma unroll 1
+        for (int di = -RE; di <= RE; ++di) acc = df_row_terms<RE, UNI>(centre + di * W, di, acc);
+    }
+    return acc;
+}
+
 constexpr int DT = 32;
 // Round 4: one 16-byte LDS entry per staged source -- (weight, exponent coefficient, patch half-size, unused) read with ONE
 // ds_read_b128 -- and a branch-free inner loop: the term of a source is formed for every (di, dj) of the window's widest
@@ -94,11 +154,14 @@ __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict
     extern __shared__ __attribute__((aligned(16))) char sdf[];
     const int W = DT + 2 * R;
     float4 *swc = reinterpret_cast<float4 *>(sdf);                 // [W][W] (weight, coefficient, half-size, -)
-    __shared__ int hmax;
+    __shared__ int hmax, hlow;
     const int t0 = (blockIdx.x / tiles_y) * DT, c0 = (blockIdx.x % tiles_y) * DT;
-    if (threadIdx.x == 0) hmax = 0;
+    if (threadIdx.x == 0) {
+        hmax = 0;
+        hlow = 1 << 20;
+    }
     __syncthreads();
-    int hm = 0;
+    int hm = 0, hl = 1 << 20;                            // widest patch of the window; narrowest among the sources that carry weight
     for (int e = threadIdx.x; e < W * W; e += 256) {
         const int a = e / W, b = e - a * W;
         const int si = t0 - R + a, sj = c0 - R + b;
@@ -118,33 +181,51 @@ __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict
         }
         swc[e] = make_float4(w, c, (float)h, 0.f);
         hm = max(hm, h);
+        if (w != 0.f) hl = min(hl, h);
     }
-    for (int o = 32; o > 0; o >>= 1) hm = max(hm, __shfl_xor(hm, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(&hmax, hm);
+    for (int o = 32; o > 0; o >>= 1) {
+        hm = max(hm, __shfl_xor(hm, o));
+        hl = min(hl, __shfl_xor(hl, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&hmax, hm);
+        atomicMin(&hlow, hl);
+    }
     __syncthreads();
-    const int Re = min(R, hmax);
+    const int Re = __builtin_amdgcn_readfirstlane(min(R, hmax));      // LDS words: uniform, but the compiler must be told
+    // every source with weight has the window's widest patch (the inside of a sample whose width map varies slowly): the ring test
+    // of a term is then always true and is compiled out -- a third of a term's vector instructions (a source without weight adds
+    // 0 * 2^x = 0 either way; NaN / inf weights are != 0 and so take part in the test)
+    const bool uniform = __builtin_amdgcn_readfirstlane(hlow) >= Re;
     const int tj = threadIdx.x & 31, ti0 = threadIdx.x >> 5;
     bool bad = false;
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < 4; ++k) {
         const int ti = ti0 + 8 * k, i = t0 + ti, j = c0 + tj;
         if (i >= Nx || j >= Ny) continue;
         float acc = 0.f;
-        if (Re == 0) {                                   // no patch reaches this tile: every source deposits on itself
-            const float4 e = swc[(ti + R) * W + tj + R];
-            acc = e.z >= 0.f ? e.x : 0.f;
-        } else {
-            for (int di = -Re; di <= Re; ++di) {
-                const float4 *row = swc + (ti + di + R) * W + tj + R;
-                const float di2 = (float)(di * di);
-                for (int dj = -Re; dj <= Re; ++dj) {
-                    const float4 e = row[dj];
-                    const float need = (float)max(abs(di), abs(dj));          // scalar: di, dj are uniform
-                    // h == 0: coefficient 0, exp2(0) = 1, selected only at di = dj = 0 (same value as the plain deposit)
-                    const float t = e.x * __builtin_amdgcn_exp2f((di2 + (float)(dj * dj)) * e.y);
-                    acc += e.z >= need ? t : 0.f;
-                }
+        const float4 *centre = swc + (ti + R) * W + tj + R;
+        switch (Re) {                                    // uniform over the workgroup
+            case 0: {                                    // no patch reaches this tile: every source deposits on itself
+                const float4 e = *centre;
+                acc = e.z >= 0.f ? e.x : 0.f;
+                break;
             }
+#define PSX_DF_CASE(n) case n: acc = uniform ? df_terms<n, true>(centre, W) : df_terms<n, false>(centre, W); break;
+            PSX_DF_CASE(1) PSX_DF_CASE(2) PSX_DF_CASE(3) PSX_DF_CASE(4) PSX_DF_CASE(5) PSX_DF_CASE(6) PSX_DF_CASE(7)
+            PSX_DF_CASE(8) PSX_DF_CASE(9) PSX_DF_CASE(10) PSX_DF_CASE(11) PSX_DF_CASE(12) PSX_DF_CASE(13) PSX_DF_CASE(14)
+#undef PSX_DF_CASE
+            default:                                     // (the launch admits R <= 14: 60 KiB of LDS)
+                for (int di = -Re; di <= Re; ++di) {
+                    const float4 *row = centre + di * W;
+                    const float di2 = (float)(di * di);
+                    for (int dj = -Re; dj <= Re; ++dj) {
+                        const float4 e = row[dj];
+                        const float need = (float)max(abs(di), abs(dj));
+                        const float t = fmaf(e.x, __builtin_amdgcn_exp2f((di2 + (float)(dj * dj)) * e.y), e.w);
+                        acc += e.z >= need ? t : 0.f;
+                    }
+                }
         }
         const int64_t p = (int64_t)i * Ny + j;
         const float v = acc + (I2 ? I2[p] : 0.f);

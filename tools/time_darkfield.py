@@ -12,7 +12,9 @@ pix, M = geo["pix_um"], geo["M"]
 k = 2 * np.pi * 52e3 * 1.6e-19 / (6.626e-34 * 2.998e8)
 phi = torch.from_numpy(-k * 6.2e-7 * geo["membrane"][0].astype(np.float64)).cuda()
 I = torch.full((N, N), 7500.0, dtype=torch.float32, device="cuda")
-df = torch.from_numpy(np.where(geo["sample"][0] > 0, 2.0e-6, 0.0)).cuda()
+WHERE = sys.argv[3] if len(sys.argv) > 3 else "sample"         # sample | all | none | <float: a disc of that fraction of the width>
+mask = geo["sample"][0] > 0 if WHERE == "sample" else (np.ones((N, N), bool) if WHERE == "all" else np.zeros((N, N), bool))
+df = torch.from_numpy(np.where(mask, 2.0e-6, 0.0 if WHERE != "none" else 1e-12)).cuda()
 dfmax = float(df.max().item())
 Iw = I.clone()
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 20
@@ -29,4 +31,4 @@ torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / REPS * 1e3
 lib.psx_profile_enable(1); f(); torch.cuda.synchronize()
 buf = ctypes.create_string_buffer(1 << 16); lib.psx_profile_summary(buf, len(buf)); lib.psx_profile_enable(0)
-print("fastRefractionDF %dx%d (mutate=%s): %.2f ms wall; library kernels: %s" % (N, N, MUTATE, wall, buf.value.decode().replace("\n", "; ")))
+print("fastRefractionDF %dx%d (mutate=%s, dark field: %s, %.0f %% of the pixels): %.2f ms wall; library kernels: %s" % (N, N, MUTATE, WHERE, 100 * mask.mean(), wall, buf.value.decode().replace("\n", "; ")))
