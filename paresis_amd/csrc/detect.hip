@@ -348,9 +348,22 @@ __global__ __launch_bounds__(256) void k_band_pair(PairArgs a) {
     const int s0 = a.c_blk[cbk].x & ~3, s1 = a.c_blk[cbk].y;
     const int n4 = (s1 - s0 + 3) >> 2;                                 // float4 per row (<= 64 * MIT, checked by the host)
     const int off = a.c_start[cl] - s0;
-    float w[WC];
+    // The column's taps are read from LDS as whole, 16-byte aligned float4s starting at off & ~3 (consecutive outputs start
+    // `ov` floats apart: at ov = 4 their 4-byte reads of one tap landed on 8 of the 32 banks, a four-way conflict on every
+    // tap -- MI355X_MICROARCH.md, LDS table), and the weights are shifted by off & 3 to match: NQ float4s cover any shift of up
+    // to WC taps, the shifted-in weights are zeros (a zero weight times a finite sample adds nothing: same sums as before).
+    constexpr int NQ = (WC + 3 + 3) / 4;
+    const int sh = off & 3, offa = off & ~3;
+    float w[4 * NQ];
 #pragma unroll
-    for (int k = 0; k < WC; ++k) w[k] = k < a.c_W ? a.c_wT[(int64_t)k * a.Cout + cl] : 0.f;
+    for (int j = 0; j < 4 * NQ; ++j) {
+        const int k = j - sh;
+        w[j] = (k >= 0 && k < a.c_W) ? a.c_wT[(int64_t)k * a.Cout + cl] : 0.f;
+    }
+    // the tail of a staged row beyond the block's span is never written by the rounds below, but the aligned reads may touch
+    // it (with zero weights): make it zeros once (stale LDS could hold NaN bit patterns)
+    for (int rr = 0; rr < RG; ++rr)
+        for (int t = 4 * n4 + (int)threadIdx.x; t < a.span_ld; t += 256) sdet[rr * a.span_ld + t] = 0.f;
     float4 v[H][MIT];
     auto fetch = [&](int i0, int ihi) __attribute__((always_inline)) {
 #pragma unroll
@@ -402,11 +415,18 @@ __global__ __launch_bounds__(256) void k_band_pair(PairArgs a) {
 #pragma unroll
             for (int rr = 0; rr < RG; ++rr) {
                 if (i0 + rr < ihi) {
-                    const float *x = sdet + rr * a.span_ld + off;
+                    const float4 *x = reinterpret_cast<const float4 *>(sdet + rr * a.span_ld + offa);
+                    float4 q[NQ];
+#pragma unroll
+                    for (int m = 0; m < NQ; ++m) q[m] = x[m];          // offa + 4 NQ <= span_ld (host: span + 24)
                     float acc = 0.f;
 #pragma unroll
-                    for (int k = 0; k < WC; ++k)
-                        if (k < a.c_W) acc = fmaf(w[k], x[k], acc);   // off + k < span for every k < W by construction
+                    for (int m = 0; m < NQ; ++m) {
+                        acc = fmaf(w[4 * m], q[m].x, acc);
+                        acc = fmaf(w[4 * m + 1], q[m].y, acc);
+                        acc = fmaf(w[4 * m + 2], q[m].z, acc);
+                        acc = fmaf(w[4 * m + 3], q[m].w, acc);
+                    }
                     mid[(i0 + rr - ilo) * 256 + threadIdx.x] = acc;
                 }
             }
@@ -773,7 +793,7 @@ int psx_detector_plan_create(int Nx, int Ny, int ov, int nx, int ny, int margin,
     auto pair = [&](BandPair &pr, const BandOp &C, const BandOp &R) -> int {
         pr.ok = false;
         if (C.W > 16 || C.span + 3 + 3 > 4 * 64 * PAIR_MIT) return 0;
-        pr.span_ld = (C.span + 3 + 3 + 4) / 4 * 4;
+        pr.span_ld = (C.span + 3 + 24) / 4 * 4;      // + alignment slack of the block's first input + the aligned tap reads' overshoot
         for (int RT : {16, 8, 4}) {
             std::vector<int2> tiles;
             int mid = 1;

@@ -8,7 +8,8 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from paresis_amd import ops
+import ctypes
+from paresis_amd import _lib, ops
 import _switches                      # PSX_SWITCHES="no_dif=1 ..." -> psx_debug_switch (the library reads no environment)
 _switches.apply()
 
@@ -28,3 +29,11 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 50
 print("detector %dx%d -> %dx%d: %.1f us per image (%.2f TB/s of the %d MB that must move)"
       % (N, N, N // ov, N // ov, dt * 1e6, (img.numel() + out.numel()) * 4 / dt / 1e12, (img.numel() + out.numel()) * 4 >> 20))
+lib = _lib.lib()
+lib.psx_profile_enable(1)
+for _ in range(10):
+    plan.detect(img, out=out)
+torch.cuda.synchronize()
+buf = ctypes.create_string_buffer(1 << 16); lib.psx_profile_summary(buf, len(buf)); lib.psx_profile_enable(0)
+print("   library kernels per image (us):", ", ".join("%s x%d %.1f" % (l.split()[0], int(l.split()[1]) // 10, float(l.split()[2]) * 100 / 1)
+                                                      for l in buf.value.decode().splitlines()))
