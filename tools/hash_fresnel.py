@@ -6,6 +6,8 @@ import hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from paresis_amd import ops
+import _switches                      # PSX_SWITCHES="no_park=1 ..." -> psx_debug_switch (the library reads no environment)
+_switches.apply()
 from paresis_amd.getk import getk
 kk = getk(52000.0)
 h = 2.9e-6
