@@ -285,6 +285,25 @@ def main():
         run_step()
     barrier()
     dt_steady = time.perf_counter() - t1
+    # ... and K steps in the OTHER far-ray mode (order-independent fixed-point replay <-> float atomics), so that the cost of
+    # reproducible sums is on the line whichever mode `value` was measured in
+    other_mode = {"far_rays": "float atomics" if ops.get_deterministic() else "order-independent fixed-point replay"}
+    if not a.graph:
+        ops.set_deterministic(not ops.get_deterministic())
+        for _ in range(a.warmup):
+            step()
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        barrier()
+        dt_other = time.perf_counter() - t2
+        ops.check_status(dev, "bench (other far-ray mode)")
+        ops.set_deterministic(not ops.get_deterministic())
+        other_mode.update(ms_per_step=round(dt_other / a.steps * 1e3, 4),
+                          value=round(len(DISTANCES) * N * N * world / (dt_other / a.steps) / 1e6, 1),
+                          vs_steady_pct=round((dt_other / dt_steady - 1.0) * 100.0, 2),
+                          note="the same K steps with the far rays summed the other way, timed right after `steady` (this rank's clock)")
     cpu_dev = dev if a.backend == "nccl" else torch.device("cpu")
     ranks_seen = 1
     if cold is None:
@@ -318,7 +337,8 @@ def main():
                             "rounds 1-2, for comparison across rounds"},
            "debug_switches": ops.debug_switches_active(),
            "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("PSX_")},
-           "far_rays": "order-independent fixed-point replay" if a.deterministic_step else "float atomics",
+           "far_rays": "order-independent fixed-point replay" if ops.get_deterministic() else "float atomics",
+           "other_far_ray_mode": other_mode,
            "spinup": {"ms": spin["ms"], "steps": spin["steps"],
                       "note": "the same step run untimed BEFORE the W warm-up steps until the clocks have ramped (--spinup-ms)"},
            "steady": {"ms_per_step": round(dt_steady / a.steps * 1e3, 4),
@@ -335,12 +355,14 @@ def main():
             # ray tracing twice: far rays replayed with float atomics (the faster form: last bits depend on the arrival order, a
             # Poisson draw may flip) and with the order-independent replay (bit-reproducible on any number of GPUs, main.run's
             # `reproducible` switch; measured cost in DESIGN.md section 4.3)
-            for key in ("Fresnel", "RayT", "RayT_reproducible"):
+            # (round 5: the order-independent replay is the Experiment class's default -- `RayT` is that, `RayT_float_atomics` the
+            # opt-out, exp_dict['reproducible'] = False)
+            for key in ("Fresnel", "RayT", "RayT_float_atomics"):
                 sim = key.split("_")[0]
-                if key == "RayT_reproducible" and a.no_reproducible_batch:
+                if key == "RayT_float_atomics" and a.no_reproducible_batch:
                     continue
                 try:
-                    out["positions_batch"][key] = positions_batch(a, sim, pn, rank, world, dev, reproducible=key.endswith("_reproducible"))
+                    out["positions_batch"][key] = positions_batch(a, sim, pn, rank, world, dev, reproducible=not key.endswith("_float_atomics"))
                 except Exception as exc:
                     import traceback
                     traceback.print_exc()
@@ -521,7 +543,7 @@ def positions_batch(a, sim, N, rank, world, dev, reproducible=False):
     # ray tracing: far rays through the order-independent replay, so that a position's images are the same bits on 1 GPU and on
     # 8 (float atomics let a last bit flip a Poisson draw); the Fresnel chain has no float atomics anywhere
     det_mode = sim == "RayT" and reproducible
-    ops.set_deterministic(det_mode)
+    exp.exp_dict['reproducible'] = bool(reproducible)     # the Experiment sets the library's mode around its ray-tracing chain
     cpu_dev = dev if (world == 1 or a.backend == "nccl") else torch.device("cpu")
 
     def position(p):
@@ -639,7 +661,6 @@ def positions_batch(a, sim, N, rank, world, dev, reproducible=False):
     if rank != sink:
         if world > 1:                                    # the sink recomputes a few positions meanwhile: wait for it
             td.barrier()
-        ops.set_deterministic(False)
         if rank == 0 and world > 1:                      # rank 0 prints the line: it receives the sink's report
             box = [None]
             td.broadcast_object_list(box, src=sink, device=cpu_dev)
@@ -685,7 +706,6 @@ def positions_batch(a, sim, N, rank, world, dev, reproducible=False):
                     "ok": bool(equal) if (sim == "Fresnel" or det_mode) else bool(worst < 1e-3)}
     res["far_rays"] = "order-independent fixed-point replay" if det_mode else ("float atomics" if sim == "RayT" else None)
     res["sink_rank"] = sink
-    ops.set_deterministic(False)
     if world > 1:
         td.barrier()
         if sink != 0:

@@ -141,15 +141,19 @@ int psx_refract_batch_f32(int n, const float *const *I_in, const float *I0, cons
 /* Order-independent scatter (the reference's scatter is a single-threaded raster loop, RF2:217-263; the
  * tile gathers are fixed point and reproducible as they are, but far rays and psx_fastloop_f32 deposit with global float
  * atomics in arrival order, and a last-bit difference can flip a Poisson draw downstream).  With on != 0 the far-ray replay of
- * psx_refract_f32 / _multi_f32 / _batch_f32 runs as three passes over the same lists -- clear the touched 64-bit scratch
- * words; add every share as a fixed-point integer in the unit of its target's tile with a returning atomic (the thread that
- * reads back zero was first at that pixel); let the first depositor of each pixel add the complete sum ONCE to the float
- * image -- so that two runs of the same call are bitwise equal, whatever the GPU count.  One atomic per share, as before.
- * Allocates nothing and synchronises nothing: the scratch ([ndist][Nx*Ny] words) is part of the caller's workspace, needs
- * no initial state, and psx_refract_*_workspace_bytes() includes it WHILE THE MODE IS ON (set the mode, then size the
- * workspace).  psx_fastloop_f32, which has no workspace argument, keeps the allocating form (hipMalloc + a stream
- * synchronisation per call).  A setting of the calling host thread; off by default (measured cost: DESIGN.md section 4.3). */
+ * psx_refract_f32 / _multi_f32 / _batch_f32 sums in fixed point: the tile kernel clears the 64-bit scratch words a far ray may
+ * reach when it lists the ray; the replay adds every share as an integer -- ONE unit per call, 2^-30 of the power of two
+ * above the largest intensity the call stages, so every share fits whatever tile it lands in -- with a returning atomic (the
+ * thread that reads back zero was first at that pixel and notes the pixel in its list's fold table); a second pass adds each
+ * pixel's complete sum ONCE to the float image.  Two runs of the same call are then bitwise equal, whatever the GPU count.
+ * One atomic per share, as in the float form.  Allocates nothing and synchronises nothing: the scratch ([ndist][Nx*Ny] words)
+ * is part of the caller's workspace, needs no initial state, and psx_refract_*_workspace_bytes() includes it WHILE THE MODE
+ * IS ON (set the mode, then size the workspace).  psx_fastloop_f32, which has no workspace argument, keeps the allocating
+ * form (hipMalloc + a stream synchronisation per call).  A setting of the calling host thread, off by default in the library;
+ * the Experiment class turns it on around its ray-tracing chain unless exp_dict['reproducible'] is False (measured cost:
+ * DESIGN.md section 4.3).  psx_get_deterministic returns the calling thread's setting (callers that restore it). */
 int psx_set_deterministic(int on);
+int psx_get_deterministic(void);
 
 /* The raw scatter loop on explicit displacement fields: fastloopNumba (refractionFileNumba2.py:198-263).
  * I, Dx, Dy, I2 are [Nx][Ny]; I2 is accumulated into (float atomics; order-dependent in the last bits). */

@@ -206,13 +206,21 @@ class Experiment:
         """Experiment.py:255-277.  (_mutate=False: the chain's own calls, whose input is a temporary, skip the in-place zeroing
         of clamped rays in the dark-field variant.)"""
         from .refractionFileNumba2 import fastRefraction, fastRefractionDF
-        if type(darkField) == int or type(darkField) == float:
-            return fastRefraction(intensityRefracted, phi, propagationDistance, Energy, magnification,
-                                  self.exp_dict["studyPixelSize"])
-        known = self.mySampleofInterest.dark_field_max(darkField) if hasattr(self.mySampleofInterest, "dark_field_max") else None
-        return fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magnification,
-                                self.exp_dict["studyPixelSize"], darkField, darkFieldMax=known,
-                                check=not self.exp_dict.get('deferStatus'), mutate=_mutate)
+        with ops.deterministic(self._reproducible()):
+            if type(darkField) == int or type(darkField) == float:
+                return fastRefraction(intensityRefracted, phi, propagationDistance, Energy, magnification,
+                                      self.exp_dict["studyPixelSize"])
+            known = self.mySampleofInterest.dark_field_max(darkField) if hasattr(self.mySampleofInterest, "dark_field_max") else None
+            return fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magnification,
+                                    self.exp_dict["studyPixelSize"], darkField, darkFieldMax=known,
+                                    check=not self.exp_dict.get('deferStatus'), mutate=_mutate)
+
+    def _reproducible(self):
+        """exp_dict['reproducible'] (default True): the far rays of every refraction of this experiment are summed in fixed
+        point (psx_set_deterministic), so an image is the same bits on every run and on any number of GPUs -- the reference's
+        scatter is one raster-order loop (RF2:217-263) and has that property by construction.  False: float atomics in arrival
+        order (last-bit differences that can flip a Poisson draw), a few per cent faster."""
+        return bool(self.exp_dict.get('reproducible', True))
 
     def computeSampleAndReferenceImages(self, pointNum):
         """Dispatcher on exp_dict['simulation_type'] (main.py:68-73)."""
@@ -532,9 +540,17 @@ class Experiment:
         """exp_dict['refractionHalo']: 4 (default), 6, 8 or 'auto' -- the gather halo of the refraction tiles is a speed knob whose
         best value depends on how far the rays of THIS experiment travel in study pixels (oversampling, distances, membrane).
         'auto' times the experiment's own longest hop with each halo once, on the first call (ops.tune_refract_halo: three host
-        synchronisations), and keeps the winner for the life of the object."""
+        synchronisations), and keeps the winner for the life of the object -- unless the experiment is reproducible (the
+        default), where a timing must not decide the bits of an image: see below."""
         if self._halo is None:
             want = self.exp_dict.get('refractionHalo', 4)
+            if want == 'auto' and self._reproducible():
+                # The halo decides which shares are gathered in the tiles and which are replayed, i.e. how a pixel's sum is
+                # split into float(tile sum) + float(far sum): the last bit of an image depends on it.  A halo picked by TIMING
+                # may differ between ranks and between runs, so a reproducible experiment takes it from a rule instead: what
+                # the timings picked on every membrane measured so far (DESIGN.md section 4.3: 4 px at oversampling <= 2, 8 px
+                # from oversampling 4 on, where rays travel twice as many study pixels).
+                want = 8 if int(self.exp_dict.get('overSampling', 1)) >= 4 else 4
             if want == 'auto':
                 ed = self.exp_dict
                 E = self.mySource.mySpectrum[-1][0]
@@ -596,6 +612,12 @@ class Experiment:
     def computeSampleAndReferenceImages_RT(self, pointNum):
         """Experiment.py:407-526.  Returns (SampleImage, ReferenceImage, PropagImage, detectedWhite, Dxreal, Dyreal,
         darkFieldPropag); Dxreal/Dyreal are the PADDED [N+30, N+30] maps of the last energy (point 0 only)."""
+        # the replay mode is this experiment's (exp_dict['reproducible']), whoever calls -- main.run or a user of the class --
+        # and the calling thread gets back the mode it had
+        with ops.deterministic(self._reproducible()):
+            return self._rt_chain(pointNum)
+
+    def _rt_chain(self, pointNum):
         ed = self.exp_dict
         stacks, accs, N, dev, sums = self._begin(pointNum)
         accS, accR, accP, white = accs

@@ -642,7 +642,7 @@ __global__ __launch_bounds__(T) void k_fresnel_part(LineArgs a) {
             item(j, d, g);
             const int lc = min(g, a.nlines - 1);
             const float2 *srcl = a.src[d] + (a.in_blocked ? ((int64_t)(lc / IB) * N) * IB + lc % IB : (int64_t)lc * a.in_sl);
-            const int sh = a.in_blocked ? IBS + 3 : 3;                     // byte stride of a sample: 8 IB (blocked) or 8
+            const int sh = a.in_blocked ? BLOCKED_SAMPLE_SHIFT : SAMPLE_SHIFT;                     // byte stride of a sample: 8 IB (blocked) or 8
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float2 *>(srcl), 0, g < a.nlines ? (int)((unsigned)N << sh) : 0, 0x00020000);   // a line past the image reads zeros
             int jb = 2 * i0 + line + mg + 1;
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(T) void k_fresnel_part(LineArgs a) {
                 item(j, d, g);
                 const int lc = min(g, a.nlines - 1);
                 const float2 *srcl = a.src[d] + (a.in_blocked ? ((int64_t)(lc / IB) * N) * IB + lc % IB : (int64_t)lc * a.in_sl);
-                const int sh = a.in_blocked ? IBS + 3 : 3;                     // byte stride of a sample: 8 IB (blocked) or 8
+                const int sh = a.in_blocked ? BLOCKED_SAMPLE_SHIFT : SAMPLE_SHIFT;                     // byte stride of a sample: 8 IB (blocked) or 8
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float2 *>(srcl), 0, g < a.nlines ? (int)((unsigned)N << sh) : 0, 0x00020000);   // a line past the image reads zeros
                 int jb = 2 * i0 + line + mg + 1;

@@ -37,6 +37,13 @@ constexpr int RAD = 24;       // radix of the two big stages
 constexpr int IB = PSX_IB;
 constexpr int IBS = IB == 4 ? 2 : (IB == 8 ? 3 : 4);      // log2(IB)
 static_assert((1 << IBS) == IB, "intermediate block size");
+// Byte stride of consecutive samples of ONE pass-1 line inside the blocked intermediate, as a shift: the ONLY place it is
+// derived.  (Round 4, gpurun_out/r4s2: a loader's buffer-descriptor range was written `N << 6` -- right for IB = 8 only -- and
+// the IB = 4 A/B build read twice past its intermediate until 5b1bf8b; every such stride now comes from these two constants.)
+constexpr int SAMPLE_SHIFT = 3;                           // log2(sizeof(float2)): contiguous lines
+constexpr int BLOCKED_SAMPLE_SHIFT = IBS + SAMPLE_SHIFT;  // log2(IB * sizeof(float2)): lines of the blocked intermediate
+static_assert((1 << SAMPLE_SHIFT) == sizeof(float2) && (1 << BLOCKED_SAMPLE_SHIFT) == IB * sizeof(float2),
+              "sample strides of the intermediate");
 constexpr int QUEUE_WORDS = 16 * 257;     // work queues: a counter per workgroup (<= 256, 64 bytes apart) + the count of workgroups done
 #ifndef PSX_DIF_KEEP
 #define PSX_DIF_KEEP 48       // DIF rounds: positions (of 72 per loader thread) fetched once per line and kept in registers for its

@@ -68,15 +68,11 @@ using GeoMid = Geo<52, 52, 6, 1024>;     // 76 KiB; 1.51 evaluations
 using GeoWide = Geo<48, 48, 8, 1024>;    // 73 KiB: two workgroups per CU (one stages while the other deposits); 1.78 evaluations
 constexpr int FAR_THREADS = 256;
 // Lanes per far-ray list: a whole wave.  Fewer lanes per list (several lists per wave, on the idea that the replay is a chain
-// of dependent latencies and most lists are short) was measured as a build-time A/B in round 4 (tools/ab_far.sh,
-// gpurun_out/r4s7) and is SLOWER the fewer lanes a list gets -- 4096^2 step, k_refract_far: 64 lanes 33.6 us, 32: 36.4,
-// 16: 46.3, 8: 69.4, 4: 107.5; config 5 (halo 8): 3.01 / 3.17 / 3.33 / 3.50 / 3.69 ms; the three passes of the
-// order-independent form scale the same way -- the records of a list are what runs in parallel.
-#ifndef PSX_FAR_SUB
-#define PSX_FAR_SUB 64
-#endif
-constexpr int FAR_SUB = PSX_FAR_SUB, FAR_LISTS = FAR_THREADS / FAR_SUB;     // lists per workgroup
-constexpr int DET_NO_UNIT = -(1 << 30);     // det_sexp entry of a tile without a fixed-point unit (all-zero or non-finite window)
+// of dependent latencies and most lists are short) was measured as a build-time A/B in round 4 (gpurun_out/r4s7) and is SLOWER
+// the fewer lanes a list gets -- 4096^2 step, k_refract_far: 64 lanes 33.6 us, 32: 36.4, 16: 46.3, 8: 69.4, 4: 107.5; config 5
+// (halo 8): 3.01 / 3.17 / 3.33 / 3.50 / 3.69 ms -- the records of a list are what runs in parallel.  The order-independent
+// replay compacts with wave ballots, so the switch is gone.
+constexpr int FAR_SUB = 64, FAR_LISTS = FAR_THREADS / FAR_SUB;     // lists per workgroup
 
 // a far ray, already evaluated by the tile that owns its source pixel
 struct FarRay {
@@ -104,8 +100,8 @@ struct RefractArgs {
     int tiles_x, tiles_y, tile_cap;
     unsigned long long *stamps;   // diagnostics (psx_debug_stamps): 16 phase timestamps per workgroup
     // order-independent far-ray replay (psx_set_deterministic; null otherwise), all inside the caller's workspace:
-    int *det_sexp;                // [ntiles] fixed-point exponent of each tile (written by the tile kernel: no initial state)
-    unsigned char *det_marks;     // [ndist][ntiles][TH*TW] which shares of a far ray were the first to reach their pixel
+    unsigned *det_gmax;           // largest finite |source intensity| any tile staged (float bits; cleared by a 16-byte memset node)
+    unsigned *det_fold_count;     // [ndist][ntiles] entries of each list's fold table (written by the ADD pass for EVERY list)
     long long *det_acc;           // [ndist][Nx*Ny] scratch words (only touched words are ever looked at: no initial state)
 };
 
@@ -283,9 +279,12 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     const int sexp = min(120, max(-120, 30 - (mbits ? ilogbf(__uint_as_float(mbits)) + 1 : 0)));
     const float fscale_f = finite_in ? ldexpf(1.f, sexp) : 0.f;     // power of two: scaling a float by it is exact
     const double finv = finite_in ? ldexp(1.0, -sexp) : 0.0;
-    // order-independent far-ray replay: far shares that land in this tile are summed in THIS tile's fixed-point unit (every
-    // tile writes its entry on every call; DET_NO_UNIT: the tile has no finite non-zero intensity to take a unit from)
-    if (a.det_sexp && tid == 0) a.det_sexp[tile] = (finite_in && mbits) ? sexp : DET_NO_UNIT;
+    // order-independent far-ray replay: the far shares of the WHOLE call are summed in one fixed-point unit, 2^-30 of the
+    // power of two above the largest finite intensity any tile staged.  A tile only sends its maximum when it beats what the
+    // word already holds (a stale read costs one more atomic, nothing else): a few hundred atomics per call, not one per tile.
+    if (a.det_gmax && tid == 0 && finite_in && mbits &&
+        mbits > __hip_atomic_load(a.det_gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(a.det_gmax, mbits);
     // A window that holds no intensity at all deposits nothing, lists nothing and leaves zeros: skip the deposit loops (the
     // halves of the dark-field split, RF2:147-150, are zero over most of the image; so is any masked input).  Not when the
     // displacement maps are wanted (they do not depend on the intensity), nor when a foreign array is to be zeroed.
@@ -451,6 +450,22 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
                 FarRay fr;
                 fr.dx = Dxs; fr.dy = Dys; fr.I = Is; fr.src = i * a.Ny + j;
                 far_list[base + rank] = fr;
+                // order-independent replay: the scratch words this ray's shares may be added to start at zero.  (Round 4 did
+                // this in a pass of its own over the lists, FAR_PREP: 0.020 ms at 4096^2, 1.12 ms on config 5.)  A superset of
+                // what the replay deposits is fine -- only words that receive a share are ever read back.
+                if (a.det_acc) {                                     // wave-uniform
+                    long long *const accd = a.det_acc + (size_t)d * a.Nx * a.Ny;
+                    int bi, ni, bj, nj;
+                    float w0, w1, w2, w3;
+                    axis_split_ref(Dxs, i, bi, ni, w0, w1);
+                    axis_split_ref(Dys, j, bj, nj, w2, w3);
+                    const bool bio = (unsigned)bi < (unsigned)a.Nx, nio = (unsigned)ni < (unsigned)a.Nx;
+                    const bool bjo = (unsigned)bj < (unsigned)a.Ny, njo = (unsigned)nj < (unsigned)a.Ny;
+                    if (bio && bjo) accd[(int64_t)bi * a.Ny + bj] = 0ll;
+                    if (nio && bjo) accd[(int64_t)ni * a.Ny + bj] = 0ll;
+                    if (nio && njo) accd[(int64_t)ni * a.Ny + nj] = 0ll;
+                    if (bio && njo) accd[(int64_t)bi * a.Ny + nj] = 0ll;
+                }
             }
         }
     }
@@ -526,7 +541,7 @@ __device__ __forceinline__ RefractArgs one_distance_block(const RefractTab &t, i
     a.Nx = s.Nx; a.Ny = s.Ny; a.margin = s.margin; a.clamp_xf = s.clamp_xf; a.clamp_yf = s.clamp_yf;
     a.status = s.status; a.far_count = s.far_count; a.far_list = s.far_list;
     a.tiles_x = s.tiles_x; a.tiles_y = s.tiles_y; a.tile_cap = s.tile_cap; a.stamps = nullptr;
-    a.det_sexp = s.det_sexp; a.det_marks = s.det_marks; a.det_acc = s.det_acc;
+    a.det_gmax = s.det_gmax; a.det_fold_count = s.det_fold_count; a.det_acc = s.det_acc;
     return a;
 }
 
@@ -541,30 +556,35 @@ __global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // One WAVE per list (list = distance * ntiles + tile): a list holds a few dozen records and the kernel is a chain of
 // dependent latencies (count -> records -> atomics), so it wants as many lists in flight per CU as there are wave slots.
 //
-// Order-independent form (psx_set_deterministic; SURVEY.md section 5, "race detection"): the reference
-// deposits in raster order, float atomics deposit in whatever order the waves arrive, and a far ray's last bit can flip a
-// Poisson draw downstream.  With the mode on the replay runs as THREE passes over the same lists, none of which allocates,
-// synchronises or relies on anything a previous call left behind:
-//   FAR_PREP  every share the plain replay would deposit stores 0 into the 64-bit scratch word of its target pixel (scratch
-//             = [ndist][Nx*Ny] words inside the caller's workspace; only touched words are ever looked at, so the region
-//             needs no initial state);
-//   FAR_ADD   the share goes into that word as a fixed-point integer in the unit of the TARGET's tile (2^-30 of the power
-//             of two above the largest intensity that tile staged: the tile kernel leaves it in det_sexp[tile] on every call)
-//             with a RETURNING atomic add.  The word is [12-bit deposit counter | 52-bit two's-complement sum]: every deposit
-//             also adds 1 << 52, so the word is zero only before the first deposit -- whatever the signs of the shares --
-//             and the thread that reads back 0 knows it was first; it notes that in the ray's mark byte;
-//   FAR_FOLD  the first depositor of a pixel reads the complete sum (plain load: the kernel boundary ordered every add
-//             before it) and adds it, ONCE, to the float image the tile kernel wrote.
+// Order-independent form (psx_set_deterministic; SURVEY.md section 5, "race detection"): the
+// reference deposits in raster order, float atomics deposit in whatever order the waves arrive, and a far ray's last bit can
+// flip a Poisson draw downstream.  With the mode on the replay is TWO passes over the lists (three in round 4), neither of
+// which allocates, synchronises or relies on anything a previous call left behind:
+//   (the tile kernel, when it appends a far ray, stores 0 into the 64-bit scratch words of the four pixels its shares may
+//    reach -- scratch = [ndist][Nx*Ny] words inside the caller's workspace; only touched words are ever looked at, so the
+//    region needs no initial state -- and folds its largest staged intensity into one word per call, det_gmax;)
+//   FAR_ADD   a share goes into its pixel's word as a fixed-point integer with a RETURNING atomic add.  ONE unit per call:
+//             2^-30 of the power of two above det_gmax -- every share is a product of a staged intensity and weights <= 1,
+//             so |share| <= 2^30 units whatever tile it lands in: no tile without a unit, no share that does not fit (round
+//             4 took the unit of the TARGET's tile and fell back to float atomics for dark targets and large shares: ADVICE
+//             r4).  The word is [12-bit deposit counter | 52-bit two's-complement sum]: every deposit also adds 1 << 52, so
+//             the word is zero only before the first deposit and the thread that reads back 0 knows it was first: it appends
+//             the pixel to the list's FOLD TABLE (wave ballot, no atomic), written over the records the wave has consumed;
+//   FAR_FOLD  walks the fold tables: the complete sum of a pixel (plain load: the kernel boundary ordered every add before it)
+//             is added, ONCE, to the float image the tile kernel wrote.
 // float(tile sum) + float(far sum) is then a function of the inputs alone: two runs are bitwise equal, on any number of GPUs.
-// One atomic per share, as in the float form; the other two passes are plain stores / loads.  Shares that have no unit (the
-// target tile staged nothing but zeros, or something non-finite) or exceed 2^20 times the tile's largest intensity keep the
-// float atomic: a black tile next to a bright one, not a case the order of the sums can matter in beyond that tile.
+// One atomic per share, as in the float form.  Headroom: 2^21 shares of the call's largest intensity per pixel.
 struct DetAcc {
     long long *acc;          // psx_fastloop_f32's deterministic mode (see below)
     const unsigned *mx;
 };
-enum { FAR_FLOAT = 0, FAR_PREP = 1, FAR_ADD = 2, FAR_FOLD = 3 };
+enum { FAR_FLOAT = 0, FAR_ADD = 2, FAR_FOLD = 3 };
 constexpr unsigned long long DET_ONE = 1ull << 52, DET_MASK = DET_ONE - 1ull;
+
+// exponent s of the call's fixed-point unit 2^-s: the largest staged intensity times 2^s lies in [2^29, 2^30)
+__device__ __forceinline__ int det_unit_exp(unsigned gmax_bits) {
+    return min(120, max(-120, 30 - (gmax_bits ? ilogbf(__uint_as_float(gmax_bits)) + 1 : 0)));
+}
 
 // psx_fastloop_f32's deterministic mode (no workspace there: scratch image + max word allocated per call)
 __device__ __forceinline__ double det_scale(const unsigned *mx) {
@@ -587,24 +607,52 @@ __device__ __forceinline__ void refract_far_body(const RefractArgs &a) {
     const unsigned nlists = (unsigned)(a.tiles_x * a.tiles_y) * (unsigned)a.ndist;
     const unsigned lst = blockIdx.x * FAR_LISTS + threadIdx.x / FAR_SUB;
     if (lst >= nlists) return;
-    const unsigned n = a.far_count[lst];
-    if (n == 0) return;
-    const FarRay *list = a.far_list + (size_t)lst * (TH * TW);
+    const unsigned lane = threadIdx.x % FAR_SUB;
     const unsigned dist = ONE ? 0u : lst / (unsigned)(a.tiles_x * a.tiles_y);
     float *const I_out = a.I_out[ONE ? 0 : dist];
     (void)dist;
     long long *const acc = MODE == FAR_FLOAT ? nullptr : a.det_acc + (size_t)dist * a.Nx * a.Ny;
-    unsigned char *const marks = MODE == FAR_FLOAT ? nullptr : a.det_marks + (size_t)lst * (TH * TW);
+    FarRay *const list = a.far_list + (size_t)lst * (TH * TW);
+    if constexpr (MODE == FAR_FOLD) {
+        const unsigned nf = a.det_fold_count[lst];
+        if (nf == 0) return;
+        const unsigned *fold = reinterpret_cast<const unsigned *>(list);
+        const double inv = ldexp(1.0, -det_unit_exp(*a.det_gmax));
+        bool bad = false;
+        for (unsigned e = lane; e < nf; e += FAR_SUB) {
+            const unsigned p = fold[e];
+            const long long w = acc[p];
+            const long long sum = (long long)((unsigned long long)w << 12) >> 12;      // sign-extend the 52-bit sum
+            const float add = a.out_scale * (float)((double)sum * inv);
+            bad |= !(fabsf(add) <= 3.0e38f);
+            I_out[p] += add;                                       // the only thread that owns this pixel's sum
+        }
+        if (a.status && bad) atomicOr(a.status, PSX_STATUS_NONFINITE);
+        return;
+    }
+    const unsigned n = a.far_count[lst];
+    if (n == 0) {
+        if (MODE == FAR_ADD && lane == 0) a.det_fold_count[lst] = 0u;
+        return;
+    }
     const int Px = a.Nx + 2 * a.margin, Py = a.Ny + 2 * a.margin;
-    for (unsigned e = threadIdx.x % FAR_SUB; e < n; e += FAR_SUB) {
-        const FarRay fr = list[e];
+    const float unit = MODE == FAR_ADD ? ldexpf(1.f, det_unit_exp(*a.det_gmax)) : 0.f;     // exact scaling
+    unsigned *const fold = reinterpret_cast<unsigned *>(list);     // FAR_ADD: fold table, over the records already consumed --
+    unsigned nf = 0;                                               // after t rounds it holds <= 4 * 64 t entries of 4 bytes = the
+    (void)unit; (void)fold;                                        // 64 t records of 16 bytes every lane has read (wave-uniform nf)
+    // uniform trip count: FAR_ADD's rounds hold wave ballots
+    for (unsigned e0 = 0; e0 < n; e0 += FAR_SUB) {
+        const unsigned e = e0 + lane;
+        const bool live = e < n;
+        FarRay fr = list[live ? e : n - 1];
         const int i = fr.src / a.Ny, j = fr.src - i * a.Ny;
-        const float I = fr.I;
+        const float I = live ? fr.I : 0.f;                       // a share of 0 deposits nothing
         int bi, ni, bj, nj;
         float wbi, wni, wbj, wnj;
         axis_split_ref(fr.dx, i + a.margin, bi, ni, wbi, wni);
         axis_split_ref(fr.dy, j + a.margin, bj, nj, wbj, wnj);
-        unsigned mark = MODE == FAR_FOLD ? (unsigned)marks[e] : 0u;      // bit k: share k was the first deposit of its pixel
+        unsigned first[4] = {~0u, ~0u, ~0u, ~0u};                // pixels whose first deposit was this lane's share k
+        (void)first;
         if (bi >= 0 && bi < Px && bj >= 0 && bj < Py) {                  // RF2:235-236
             auto deposit = [&](int k, int pi, int pj, float v) {
                 const int ui = pi - a.margin, uj = pj - a.margin;           // crop (RF2:78)
@@ -617,30 +665,16 @@ __device__ __forceinline__ void refract_far_body(const RefractArgs &a) {
                         const float add = a.out_scale * v;
                         if (a.status && !(fabsf(add) <= 3.0e38f)) atomicOr(a.status, PSX_STATUS_NONFINITE);
                         atomicAdd(&I_out[p], add);
-                    } else if constexpr (MODE == FAR_PREP) {
-                        acc[p] = 0ll;
-                    } else if constexpr (MODE == FAR_ADD) {
-                        const int sx = a.det_sexp[tr * a.tiles_y + tc];
-                        const float x = v * ldexpf(1.f, max(sx, -120));         // exact scaling (or overflow to inf)
-                        if (sx == DET_NO_UNIT || !(fabsf(x) < 1.1258999e15f)) { // no unit / beyond 2^50 units / NaN: float atomic
-                            const float add = a.out_scale * v;
-                            if (a.status && !(fabsf(add) <= 3.0e38f)) atomicOr(a.status, PSX_STATUS_NONFINITE);
-                            atomicAdd(&I_out[p], add);
+                    } else {
+                        if (!(fabsf(v) <= 3.0e38f)) {                          // a NaN / inf source: the tile kernel has raised the status
+                            if (a.status) atomicOr(a.status, PSX_STATUS_NONFINITE);
                             return;
                         }
-                        const long long q = llrintf(x);
+                        const long long q = llrintf(v * unit);                  // |q| <= 2^30: |v| <= the call's largest intensity
                         if (q == 0) return;                                     // below the unit: contributes nothing
                         const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(acc + p),
                                                                  DET_ONE + ((unsigned long long)q & DET_MASK));
-                        if (old == 0ull) mark |= 1u << k;
-                    } else {
-                        if (!(mark & (1u << k))) return;
-                        const int sx = a.det_sexp[tr * a.tiles_y + tc];
-                        const long long w = acc[p];
-                        const long long sum = (long long)((unsigned long long)w << 12) >> 12;      // sign-extend the 52-bit sum
-                        const float add = a.out_scale * (float)((double)sum * ldexp(1.0, -sx));
-                        if (a.status && !(fabsf(add) <= 3.0e38f)) atomicOr(a.status, PSX_STATUS_NONFINITE);
-                        I_out[p] += add;                                       // the only thread that owns this pixel's sum
+                        if (old == 0ull) first[k] = (unsigned)p;
                     }
                 }
             };
@@ -651,8 +685,19 @@ __device__ __forceinline__ void refract_far_body(const RefractArgs &a) {
                 deposit(3, bi, nj, I * wbi * wnj);
             }
         }
-        if constexpr (MODE == FAR_ADD) marks[e] = (unsigned char)mark;
+        if constexpr (MODE == FAR_ADD) {
+            // (the records of this round have been read by every lane: the ballots below wait for every lane's atomics, which
+            // wait for its record)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool f = first[k] != ~0u;
+                const unsigned long long mask = __ballot(f);
+                if (f) fold[nf + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] = first[k];
+                nf += (unsigned)__popcll(mask);
+            }
+        }
     }
+    if (MODE == FAR_ADD && lane == 0) a.det_fold_count[lst] = nf;
 }
 
 template <class G, int MODE = FAR_FLOAT>
@@ -746,19 +791,20 @@ size_t lists_bytes(int Nx, int Ny, int ndist) {
     const size_t nt = (size_t)cdiv(Nx, G::TH) * (size_t)cdiv(Ny, G::TW) * (size_t)ndist;
     return 16 * ((sizeof(unsigned) * nt + 15) / 16) + sizeof(FarRay) * nt * G::TH * G::TW;
 }
-// + (order-independent replay) behind the lists: the tiles' exponents, a mark byte per list entry, [ndist][Nx*Ny] scratch words
+// + (order-independent replay) behind the lists: the call's maximum word (16 bytes), a fold-table count per list,
+// [ndist][Nx*Ny] scratch words
 inline size_t pad16(size_t b) { return (b + 15) / 16 * 16; }
 template <class G>
 size_t det_bytes(int Nx, int Ny, int ndist) {
     const size_t nt = (size_t)cdiv(Nx, G::TH) * (size_t)cdiv(Ny, G::TW);
-    return pad16(sizeof(int) * nt) + pad16(nt * ndist * G::TH * G::TW) + sizeof(long long) * (size_t)Nx * (size_t)Ny * (size_t)ndist;
+    return 16 + pad16(sizeof(unsigned) * nt * ndist) + sizeof(long long) * (size_t)Nx * (size_t)Ny * (size_t)ndist;
 }
 template <class G>
-void det_pointers(RefractArgs &a, char *base, int ndist) {
+void det_pointers(RefractArgs &a, char *gmax, char *rest, int ndist) {      // rest: det_bytes() - 16 bytes
     const size_t nt = (size_t)a.tiles_x * a.tiles_y;
-    a.det_sexp = (int *)base;
-    a.det_marks = (unsigned char *)(base + pad16(sizeof(int) * nt));
-    a.det_acc = (long long *)(base + pad16(sizeof(int) * nt) + pad16(nt * ndist * G::TH * G::TW));
+    a.det_gmax = (unsigned *)gmax;
+    a.det_fold_count = (unsigned *)rest;
+    a.det_acc = (long long *)(rest + pad16(sizeof(unsigned) * nt * ndist));
 }
 template <class G>
 size_t workspace_for(int Nx, int Ny, int ndist) {
@@ -781,8 +827,12 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
     a.tile_cap = G::TH * G::TW;
     a.far_count = (unsigned *)workspace;
     a.far_list = (FarRay *)((char *)workspace + 16 * ((sizeof(unsigned) * (size_t)a.tiles_x * a.tiles_y * a.ndist + 15) / 16));
-    a.det_sexp = nullptr; a.det_marks = nullptr; a.det_acc = nullptr;
-    if (g_deterministic) det_pointers<G>(a, (char *)workspace + lists_bytes<G>(a.Nx, a.Ny, a.ndist), a.ndist);
+    a.det_gmax = nullptr; a.det_fold_count = nullptr; a.det_acc = nullptr;
+    if (g_deterministic) {
+        char *const det = (char *)workspace + lists_bytes<G>(a.Nx, a.Ny, a.ndist);
+        det_pointers<G>(a, det, det + 16, a.ndist);
+        PSX_HIP(hipMemsetAsync(a.det_gmax, 0, 16, st));      // the only word of the mode with an initial state: set per call
+    }
     int rc_launch = 0;
     auto launch = [&](auto nm, auto hi, auto hp) -> int {
         constexpr int NM = decltype(nm)::value;
@@ -796,8 +846,7 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
         if (int rc = launch_check("k_refract_near")) return rc;
         const int nlists = a.tiles_x * a.tiles_y * a.ndist;
         const int fgrid = (nlists + FAR_LISTS - 1) / FAR_LISTS;
-        if (a.det_acc) {      // order-independent replay: three passes over the lists, scratch from the workspace
-            PSX_TIMED("k_refract_far_prep", st, k_refract_far<G, FAR_PREP><<<fgrid, FAR_THREADS, 0, st>>>(a));
+        if (a.det_acc) {      // order-independent replay: two passes over the lists, scratch from the workspace
             PSX_TIMED("k_refract_far_add", st, k_refract_far<G, FAR_ADD><<<fgrid, FAR_THREADS, 0, st>>>(a));
             PSX_TIMED("k_refract_far_fold", st, k_refract_far<G, FAR_FOLD><<<fgrid, FAR_THREADS, 0, st>>>(a));
             return 0;
@@ -827,10 +876,14 @@ int launch_refract_batch(RefractTab &t, int n, bool has_I, int nmat, void *works
         a.far_count = (unsigned *)workspace + (size_t)k * nt;
         a.far_list = (FarRay *)((char *)workspace + 16 * ((sizeof(unsigned) * nt * REFRACT_TAB + 15) / 16)) + (size_t)k * nt * a.tile_cap;
         // order-independent replay: every refraction of the chunk its own exponents, marks and scratch words behind the chunk's lists
-        a.det_sexp = nullptr; a.det_marks = nullptr; a.det_acc = nullptr;
-        if (g_deterministic)
-            det_pointers<G>(a, (char *)workspace + lists_bytes<G>(a.Nx, a.Ny, REFRACT_TAB) + (size_t)k * det_bytes<G>(a.Nx, a.Ny, 1), 1);
+        a.det_gmax = nullptr; a.det_fold_count = nullptr; a.det_acc = nullptr;
+        if (g_deterministic) {    // the chunk's maximum words side by side (one memset node), then each refraction's counts and words
+            char *const det = (char *)workspace + lists_bytes<G>(a.Nx, a.Ny, REFRACT_TAB);
+            det_pointers<G>(a, det + 16 * k, det + 16 * REFRACT_TAB + (size_t)k * (det_bytes<G>(a.Nx, a.Ny, 1) - 16), 1);
+        }
     }
+    if (g_deterministic)      // every refraction of the chunk its own maximum word (its own unit: an image of its own)
+        PSX_HIP(hipMemsetAsync(t.e[0].det_gmax, 0, 16 * REFRACT_TAB, st));
     int rc_launch = 0;
     auto launch = [&](auto nm, auto hi) -> int {
         constexpr int NM = decltype(nm)::value;
@@ -844,7 +897,6 @@ int launch_refract_batch(RefractTab &t, int n, bool has_I, int nmat, void *works
         const int fgrid = ((int)nt + FAR_LISTS - 1) / FAR_LISTS;
         const dim3 fg((unsigned)fgrid, (unsigned)n);
         if (t.e[0].det_acc) {
-            PSX_TIMED("k_refract_far_prep", st, k_refract_far_batch<G, FAR_PREP><<<fg, FAR_THREADS, 0, st>>>(t));
             PSX_TIMED("k_refract_far_add", st, k_refract_far_batch<G, FAR_ADD><<<fg, FAR_THREADS, 0, st>>>(t));
             PSX_TIMED("k_refract_far_fold", st, k_refract_far_batch<G, FAR_FOLD><<<fg, FAR_THREADS, 0, st>>>(t));
         } else {
@@ -948,6 +1000,8 @@ int psx_set_deterministic(int on) {
     g_deterministic = on ? 1 : 0;
     return 0;
 }
+
+int psx_get_deterministic(void) { return g_deterministic; }
 
 size_t psx_refract_batch_workspace_bytes(int Nx, int Ny, int n) {
     if (Nx <= 0 || Ny <= 0) return 16;

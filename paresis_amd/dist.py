@@ -166,7 +166,7 @@ class _CountsWire:
         return out
 
 
-def gather_positions(results, n_positions, rank, world, dst=0, to_host=True, pack=True, force_collectives=False):
+def gather_positions(results, n_positions, rank, world, dst=0, to_host=True, pack=True, force_collectives=False, timeout=None):
     """results: {position: tuple of tensors} computed on this rank.  Returns on `dst` a dict with every position
     (tensors on the host, or left in `dst`'s HBM with to_host=False), {} elsewhere.
 
@@ -236,7 +236,7 @@ def gather_positions(results, n_positions, rank, world, dst=0, to_host=True, pac
                 q = t * world + r
                 if q < n_positions:
                     out[q] = (bucket[r][t, 0], bucket[r][t, 1])
-    extras = move_extras(results, rank, world, dst, to_host) if n_positions > 0 else None   # Propag / White / Dx,Dy: position 0 only
+    extras = move_extras(results, rank, world, dst, to_host, timeout=timeout) if n_positions > 0 else None   # Propag / White / Dx,Dy: position 0 only
     if extras is not None:
         out[0] = extras
     return out if rank == dst else {}
@@ -315,8 +315,10 @@ class PositionGatherer:
         self.buckets.append(bucket)
 
     def add(self, p, images):
-        """images: the tuple computeSampleAndReferenceImages returned for position p (owned by this rank)."""
-        self.results[p] = images
+        """images: the tuple computeSampleAndReferenceImages returned for position p (owned by this rank).  Only position 0's
+        extras (Propag, White, the RT chain's displacement and dark-field maps) are ever gathered: the other positions keep
+        their two detector stacks and nothing else alive (a scattering sample returns a fresh study-grid map per position)."""
+        self.results[p] = images if p == 0 else tuple(images[:2])
         if self.local:
             return
         if self.shape is None:
@@ -329,12 +331,10 @@ class PositionGatherer:
             self._issue(self.next_round)
             self.next_round += 1
 
-    def _move_extras(self, host):
-        if 0 not in self.results and self.rank == owner(0, self.world) and self.dst != self.rank:
-            raise DistError("PositionGatherer: rank %d owns position 0 but never added it" % self.rank)
+    def _move_extras(self, timeout):
         if self.P <= 0:
             return None
-        return move_extras(self.results, self.rank, self.world, self.dst, self.to_host)
+        return move_extras(self.results, self.rank, self.world, self.dst, self.to_host, timeout=timeout)
 
     def finish(self, timeout=None):
         """Waits for the rounds in flight -- at most `timeout` seconds each (default: timeout_s()), then DistError: a rank
@@ -367,15 +367,16 @@ class PositionGatherer:
                     time.sleep(nap)
                     nap = min(0.001, nap * 1.5)
                 w.wait()
-            extras = self._move_extras(host)
             td.all_reduce(self.flag, op=td.ReduceOp.MAX)
+            if int(self.flag.item()):                                   # something was not photon counts: float32, all together
+                # (gather_positions moves position 0's extras itself: they cross ONCE, after the decision -- ADVICE r4)
+                return gather_positions(self.results, self.P, self.rank, self.world, dst=self.dst, to_host=self.to_host,
+                                        pack=False, force_collectives=self.force, timeout=timeout)
+            extras = self._move_extras(timeout)
         except RuntimeError as exc:           # includes DistError; a peer that died surfaces here as a transport error
             if isinstance(exc, DistError):
                 raise
             raise DistError("PositionGatherer.finish: rank %d lost a peer: %s" % (self.rank, exc)) from exc
-        if int(self.flag.item()):                                       # something was not photon counts: float32, all together
-            return gather_positions(self.results, self.P, self.rank, self.world, dst=self.dst, to_host=self.to_host, pack=False,
-                                    force_collectives=self.force)
         out = {}
         wire_bytes = 0
         if self.rank == self.dst:
@@ -397,13 +398,37 @@ class PositionGatherer:
         return out if self.rank == self.dst else {}
 
 
-def move_extras(results, rank, world, dst, to_host):
+def _wait_p2p(work, timeout, what, rank):
+    """A point-to-point transfer under the same regime as the gather rounds: polled with a deadline, not wait() -- a sink
+    waiting for a stalled owner of position 0 must not sit there until the process-group timeout."""
+    if td.get_backend() == "gloo":
+        # gloo's send / receive requests report completion only from inside wait(): bounded there (waitSend / waitRecv take the
+        # timeout and raise when it passes)
+        try:
+            work.wait(datetime.timedelta(seconds=timeout))
+        except RuntimeError as exc:
+            raise DistError("move_extras: %s did not complete within %.0f s on rank %d: %s" % (what, timeout, rank, exc)) from exc
+        return
+    deadline = time.monotonic() + timeout
+    nap = 0.00005
+    while not work.is_completed():
+        if time.monotonic() > deadline:
+            raise DistError("move_extras: %s did not complete within %.0f s on rank %d" % (what, timeout, rank))
+        time.sleep(nap)
+        nap = min(0.001, nap * 1.5)
+    work.wait()
+
+
+def move_extras(results, rank, world, dst, to_host, timeout=None):
     """Position 0's full tuple (Sample, Reference, Propag, White[, Dx, Dy, DF]) on `dst`, None elsewhere.  Propag / White and
     the displacement maps exist for position 0 only (EXP:363-375, 488-498) and live on its owner, rank 0.  With dst == 0
     nothing moves.  With another sink (the straggler that computes the extras and the rank that receives everybody's images
     are then two different GPUs) they cross in ONE point-to-point transfer per tensor: a small int64 header (count, ndim and
-    shape of each) first -- the sink cannot know the shapes of the RT chain's padded maps -- then float32 payloads.
+    shape of each) first -- the sink cannot know the shapes of the RT chain's padded maps -- then float32 payloads, each
+    transfer polled against `timeout` seconds (default: timeout_s()).  An owner that never computed position 0 says so in
+    the header (count -1) before it raises, so the sink raises too instead of waiting.
     Every rank calls this at the same point of its sequence; ranks other than 0 and dst do nothing."""
+    timeout = timeout_s() if timeout is None else float(timeout)
     host = lambda tup: tuple(t.detach().cpu() if isinstance(t, torch.Tensor) and to_host else t for t in tup)
     src = owner(0, world)
     if dst == src:
@@ -411,8 +436,12 @@ def move_extras(results, rank, world, dst, to_host):
     dev = _dev()
     HDR = 64
     if rank == src:
-        tens = [t for t in results[0]]
         hdr = torch.zeros(HDR, dtype=torch.int64)
+        if 0 not in results:
+            hdr[0] = -1
+            _wait_p2p(td.isend(hdr.to(dev), dst=dst), timeout, "the header to rank %d" % dst, rank)
+            raise DistError("move_extras: rank %d owns position 0 but never computed it" % rank)
+        tens = [t for t in results[0]]
         hdr[0] = len(tens)
         k = 1
         for t in tens:
@@ -423,17 +452,20 @@ def move_extras(results, rank, world, dst, to_host):
             hdr[k] = t.dim()
             hdr[k + 1:k + 1 + t.dim()] = torch.tensor(list(t.shape), dtype=torch.int64)
             k += 1 + t.dim()
-        td.send(hdr.to(dev), dst=dst)
-        for t in tens:
+        _wait_p2p(td.isend(hdr.to(dev), dst=dst), timeout, "the header to rank %d" % dst, rank)
+        for i, t in enumerate(tens):
             if isinstance(t, torch.Tensor):
-                td.send(t.detach().to(dev, torch.float32).contiguous(), dst=dst)
+                _wait_p2p(td.isend(t.detach().to(dev, torch.float32).contiguous(), dst=dst), timeout,
+                          "tensor %d of position 0 to rank %d" % (i, dst), rank)
         return None
     if rank == dst:
         hdr = torch.zeros(HDR, dtype=torch.int64, device=dev)
-        td.recv(hdr, src=src)
+        _wait_p2p(td.irecv(hdr, src=src), timeout, "the header from rank %d" % src, rank)
         hdr = hdr.cpu().tolist()
+        if hdr[0] < 0:
+            raise DistError("move_extras: rank %d, the owner of position 0, never computed it" % src)
         out, k = [], 1
-        for _ in range(hdr[0]):
+        for i in range(hdr[0]):
             nd = hdr[k]
             if nd < 0:
                 out.append(None)
@@ -442,7 +474,7 @@ def move_extras(results, rank, world, dst, to_host):
             shape = tuple(hdr[k + 1:k + 1 + nd])
             k += 1 + nd
             t = torch.empty(shape, dtype=torch.float32, device=dev)
-            td.recv(t, src=src)
+            _wait_p2p(td.irecv(t, src=src), timeout, "tensor %d of position 0 from rank %d" % (i, src), rank)
             out.append(t)
         return host(tuple(out))
     return None

@@ -27,11 +27,10 @@ def run(exp_dict, save=True, saving_format=".tif", backend=None):
     # one experiment ID for all ranks (the reference takes the wall clock, main.py:30; ranks would disagree by a second)
     exp_dict['expID'] = dist.broadcast_object(datetime.datetime.now().strftime("%Y%m%d-%H%M%S"), rank, world)
     exp_dict.setdefault('deferMeanEnergy', True)       # no host synchronisation per position (resolved before the dump)
-    # exp_dict['reproducible'] (--reproducible): the ray-tracing chain's far rays through the order-independent replay
-    # (psx_set_deterministic): every image is then the same bits on 1 GPU and on 8, at +5...9 % of the chain's time; the
-    # Fresnel chain has no float atomics and is reproducible as it is
-    from . import ops
-    ops.set_deterministic(bool(exp_dict.get('reproducible', False)))
+    # exp_dict['reproducible'] (default True; --float-atomics turns it off): the ray-tracing chain's far rays go through the
+    # order-independent replay (the Experiment class sets psx_set_deterministic around its chain and restores the caller's
+    # mode): every image is then the same bits on 1 GPU and on 8; the Fresnel chain has no float atomics and is reproducible
+    # as it is
     print("\n\nINITIALIZING EXPERIMENT PARAMETERS AND GEOMETRIES")
     experiment = Experiment(exp_dict)
     sim = exp_dict['simulation_type']
@@ -94,7 +93,6 @@ def run(exp_dict, save=True, saving_format=".tif", backend=None):
         os._exit(6)
     finally:
         gc.unfreeze()                         # run() is also an API: leave the collector as it was found
-        ops.set_deterministic(False)
     experiment.resolve_mean_energy()
     if rank == 0 and save:
         os.makedirs(root, exist_ok=True)
@@ -139,15 +137,17 @@ def main(argv=None):
     ap.add_argument("--xml", default=None)
     ap.add_argument("--no-noise", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--reproducible", action="store_true",
-                    help="ray tracing: order-independent far-ray sums (bit-identical images on any number of GPUs; a few per cent slower)")
+    ap.add_argument("--reproducible", action="store_true", help="accepted and ignored: the default since round 5")
+    ap.add_argument("--float-atomics", action="store_true",
+                    help="ray tracing: far rays summed with float atomics in arrival order (a few per cent faster; the last bit of "
+                         "an image, and with it a Poisson draw, may differ between runs and GPU counts)")
     ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"],
                     help="torch.distributed backend under torchrun (default: nccl = RCCL on a GPU node; gloo rehearses several "
                          "ranks on one GPU)")
     a = ap.parse_args(argv)
     exp_dict = {'experimentName': a.experiment, 'filepath': a.out if a.out.endswith('/') else a.out + '/',
                 'overSampling': a.oversampling, 'nbExpPoints': a.points, 'simulation_type': a.type,
-                'noise': not a.no_noise, 'seed': a.seed, 'reproducible': a.reproducible}
+                'noise': not a.no_noise, 'seed': a.seed, 'reproducible': not a.float_atomics}
     if a.xml:
         exp_dict['xmlDir'] = a.xml
     os.makedirs(exp_dict['filepath'], exist_ok=True)

@@ -476,9 +476,30 @@ def repad(src, margin_src, margin_dst, shape):
 
 
 def set_deterministic(on=True):
-    """Deterministic-order debug mode of the scatter paths that use float atomics (far rays, fastloop): order-independent
-    fixed-point deposits, bitwise reproducible results, slower.  Per host thread; off by default."""
+    """Order-independent sums in the scatter paths that otherwise use float atomics (far rays, fastloop): fixed-point
+    deposits, bitwise reproducible results, a few per cent slower.  Per host thread; off by default in the
+    library, ON around the Experiment class's ray-tracing chain unless exp_dict['reproducible'] is False."""
     check(lib().psx_set_deterministic(1 if on else 0), "psx_set_deterministic")
+
+
+def get_deterministic():
+    return bool(lib().psx_get_deterministic())
+
+
+class deterministic:
+    """with ops.deterministic(on): ... -- sets the mode and puts back what the caller had."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = get_deterministic()
+        set_deterministic(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        set_deterministic(self.prev)
+        return False
 
 
 def debug_switch(name, value=1):

@@ -138,6 +138,40 @@ def test_gather_sink_elsewhere_float_fallback():
     _run_ranks(3, 5, "one_rank_fractions", True, 2)
 
 
+def _worker_missing_zero(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import time
+    from paresis_amd import dist
+    r, w = dist.init(backend="gloo")
+    results = {} if r == 0 else {1: (torch.ones((1, 3, 4)), torch.ones((1, 3, 4)))}      # rank 0 never computed position 0
+    t0 = time.monotonic()
+    try:
+        dist.gather_positions(results, 2, r, w, dst=1, to_host=True, pack=False, timeout=20)
+        q.put(("no error", r, 0.0))
+    except dist.DistError as exc:
+        q.put(("DistError", r, time.monotonic() - t0))
+    q.close()
+    q.join_thread()      # the queue's feeder thread has written the result
+    os._exit(0)          # the contract after a DistError: leave without tearing the group down
+
+
+def test_owner_without_position_zero_fails_both_ends_at_once():
+    """with a foreign sink, position 0's extras cross point to point.  An owner that never computed position 0 used
+    to raise KeyError on its side while the sink sat in recv until the process-group timeout; now the header says so and both
+    ends raise DistError within the transfer's own deadline (here: at once, far below the 20 s given)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_missing_zero, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=60) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert sorted(r[1] for r in res) == [0, 1]
+    assert all(r[0] == "DistError" and r[2] < 10.0 for r in res), res
+
+
 def test_single_process_is_world_one(monkeypatch):
     monkeypatch.delenv("RANK", raising=False)
     from paresis_amd import dist

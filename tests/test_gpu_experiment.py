@@ -245,6 +245,33 @@ def test_darkfield_chain():
             assert relmax(DF0.cpu().numpy(), g["chain/p0/DF"]) < 1e-6
 
 
+def test_darkfield_chain_is_bitwise_repeatable_and_restores_the_callers_mode():
+    """the reproducibility tests had no scattering sample.  The halves of the dark-field split (RF2:147-150) are
+    zero over half the image each -- tiles that stage nothing, which round 4's replay could only serve with float atomics.  The
+    chain of a scattering sample, run twice by the class alone (no main.run): same bits; the calling thread's replay mode is
+    what it was before the call, whichever it was; exp_dict['reproducible'] = False stays within float rounding."""
+    from paresis_amd import ops
+    g = load("darkfield.npz")
+    cfg = experiment_cfg(g, "chain", orc.Obj)
+    exp = build_experiment(cfg, "RT", sample_materials=("Lung",), sample_name="lungs")
+    exp.myMembrane.myGeometry = g["chain/p0/membrane"]
+    runs = []
+    for mode in (False, True):
+        ops.set_deterministic(mode)
+        exp.exp_dict["meanEnergy"] = 0
+        out = exp.computeSampleAndReferenceImages_RT(0)
+        assert ops.get_deterministic() == mode
+        runs.append([t.clone() for t in out[:4]])
+    ops.set_deterministic(False)
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    exp.exp_dict["reproducible"] = False
+    exp.exp_dict["meanEnergy"] = 0
+    out = exp.computeSampleAndReferenceImages_RT(0)
+    for a, b in zip(out[:4], runs[0]):
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-6
+
+
 @pytest.mark.parametrize("sim", ["RT", "Fresnel"])
 def test_polychromatic_frontend_chain(sim):
     """the energy loop as a reduced axis -- 5 energies from the re-binned tabulated spectrum, table-walk

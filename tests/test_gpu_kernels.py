@@ -532,6 +532,77 @@ def test_order_independent_far_replay_needs_no_workspace_state(ops):
     assert (gx * ds[3]).max() > 6
 
 
+@pytest.mark.parametrize("case", ["masked", "black_beside_bright", "pile_up"])
+@pytest.mark.parametrize("halo", [4, 8])
+def test_order_independent_replay_has_no_float_fallback(ops, case, halo):
+    """round 4's replay took its fixed-point unit from the TARGET tile and fell back to arrival-order float
+    atomics where that tile had none (all-zero window: masked inputs, the zero halves of the dark-field split) or where a share
+    was too large for it (a bright tile beside a near-black one).  The unit is now one per call (2^-30 of the power of two above
+    the largest staged intensity), so every far share is summed as an integer.  Each case puts MANY far shares on pixels of dark
+    tiles; the image must be bitwise repeatable over runs with a garbage-filled workspace, equal to the oracle within the
+    tolerance, and -- the far sums being exact integers -- independent of the ORDER of the atomics, which the test provokes by
+    running once alone and once while another stream keeps the GPU busy."""
+    import paresis_amd.ops as O
+    rng = np.random.default_rng({"masked": 21, "black_beside_bright": 22, "pile_up": 23}[case])
+    Nx, Ny = 236, 301
+    I = rng.uniform(0.5, 1.5, (Nx, Ny))
+    if case == "masked":
+        I[:, : Ny // 2] = 0.0                                      # the left half stages nothing but zeros: tiles without a unit
+        I[60:120, Ny // 2:] = 0.0
+    elif case == "black_beside_bright":
+        I[:, : Ny // 2] *= 1e-9                                    # near-black tiles ...
+        I[:, Ny // 2:] *= 1e4                                      # ... beside bright ones: a share is 2^43 of the target tile's largest
+    else:
+        I *= 100.0
+    if case == "pile_up":
+        # a lens: every ray of a 90-pixel disc is sent to (almost) the same few pixels, far beyond any halo
+        x, y = np.meshgrid(np.arange(Nx) - 118.0, np.arange(Ny) - 150.0, indexing="ij")
+        phi = -0.5 * (x * x + y * y) * (np.hypot(x, y) < 90) * 0.97
+        dscale = 1.0
+    else:
+        # rays travel 10..60 pixels towards smaller j (from the bright half into the dark one), a few pixels along i
+        phi = np.cumsum(rng.uniform(-60, -10, (Nx, Ny)), axis=1) + np.cumsum(rng.uniform(-4, 4, (Nx, Ny)), axis=0)
+        dscale = 1.0
+    I32 = I.astype(np.float32).astype(np.float64)
+    h = 1e-6
+    z = dscale * orc.k_refraction(52.0) * h * h
+    ref, Dxr, Dyr = orc.fast_refraction(I32.copy(), phi.copy(), z, 52.0, 1.0, 1.0)
+    assert max(np.abs(Dxr).max(), np.abs(Dyr).max()) > 9           # far beyond the widest halo
+    It, pt = dev(I32, torch.float32), dev(phi, torch.float64)
+    run = lambda: ops.refract((Nx, Ny), None, dscale, (Nx, Ny), I_in=It, phi_in=pt)[0].clone()
+
+    def trash():
+        for buf in O._workspaces.values():
+            buf.random_(0, 255)
+
+    ops.set_refract_halo(halo)
+    try:
+        ops.set_deterministic(True)
+        trash()
+        a = run()
+        trash()
+        b = run()
+        # the same call while a second stream hammers the memory system: another arrival order of the atomics
+        side = torch.cuda.Stream()
+        junk = torch.empty(1 << 26, dtype=torch.float32, device="cuda")
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                junk.add_(1.0)
+        c = run()
+        side.synchronize()
+        ops.check_status(It.device)
+        assert torch.equal(a, b) and torch.equal(a, c)
+        assert relmax(a.cpu().numpy(), ref) < TOL
+        if case == "pile_up":
+            assert ref.max() > 50 * I32.max()                       # hundreds of shares on one pixel
+        else:
+            dark = ref[:, Ny // 2 - 40: Ny // 2 - 8]
+            assert dark.max() > 0.1 * I32.max()                    # the dark tiles did receive far shares
+    finally:
+        ops.set_deterministic(False)
+        ops.set_refract_halo(4)
+
+
 def test_pack_counts_roundtrip_and_overflow(ops):
     """psx_pack_counts_u16 / psx_unpack_counts_u16 (the gather of the per-position stacks moves photon counts as 16-bit
     integers): exact round trip for every count 0..65534 and, through the exception table, for larger counts up to 2^24;
