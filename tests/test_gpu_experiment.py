@@ -41,6 +41,7 @@ def test_chain_rt_with_measured_halo():
     cfg = experiment_cfg(g, "mono/RT", orc.Obj)
     exp = build_experiment(cfg, "RT")
     exp.exp_dict["refractionHalo"] = "auto"
+    exp.exp_dict["reproducible"] = False          # a timing may only decide where the last bit of an image is allowed to move
     try:
         exp.myMembrane.myGeometry = g["mono/RT/p0/membrane"]
         exp.exp_dict["meanEnergy"] = 0
@@ -48,6 +49,13 @@ def test_chain_rt_with_measured_halo():
         assert exp._halo in (4, 6, 8) and sorted(exp._halo_times) == [4, 6, 8]
         for nm, a in (("Sample", S), ("Reference", R), ("Propag", Pg), ("White", W)):
             assert relmax(a.cpu().numpy(), g["mono/RT/p0/" + nm]) < TOL, nm
+        # reproducible (the default): 'auto' is a RULE of the oversampling, the same on every rank and in every run
+        for ov, want in ((2, 4), (4, 8)):
+            exp2 = build_experiment(cfg, "RT")
+            exp2.exp_dict["refractionHalo"] = "auto"
+            exp2.exp_dict["overSampling"] = ov
+            exp2._set_halo(None, None, None)
+            assert exp2._halo == want and not hasattr(exp2, "_halo_times")
     finally:
         ops.set_refract_halo(4)
 

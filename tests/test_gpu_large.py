@@ -317,6 +317,35 @@ def test_refraction_2048_against_cpu_restatement():
     assert relmax(inten.cpu().numpy(), ref) < 1e-5
 
 
+@pytest.mark.parametrize("det", [False, True])
+def test_refraction_4096_whole_image_against_cpu_restatement(det):
+    """the HEADLINE configuration's refraction (4096^2, the longest distance of its batch, 7.2 m) as a WHOLE
+    image against the float64 C++ restatement of RF2:25-86 + 198-263 (raster-order scatter, ~4 s on 8 host threads) -- with the
+    narrowest and the widest gather halo (another split of the same sums between tile gathers and far-ray replay), and with the far
+    rays summed by float atomics (det False) or by the order-independent fixed-point replay (det True, the Experiment default)."""
+    from oracle import cpu_baseline as cb
+    from paresis_amd import ops, synth
+    from paresis_amd.getk import k_refraction
+    N, E, z = 4096, 52.0, 7.2
+    g, T = _membrane(N, 2)
+    _, rt = _stacks(ops, T)
+    d_b = [synth.DELTA_BETA_52KEV[m] for m in ("CuSn", "PMMA")]
+    delta, beta = [x[0] for x in d_b], [x[1] for x in d_b]
+    h = g["pix_um"] * 1e-6
+    ref = cb.refraction_intensity(g["membrane"], delta, beta, 7500.0, z, E, g["M"], g["pix_um"], 8)
+    try:
+        ops.set_deterministic(det)
+        for halo in (4, 8):
+            ops.set_refract_halo(halo)
+            r, _, _ = ops.refract((N, N), rt, z / k_refraction(E) / (h * g["M"]) / h, (N, N), I0=7500.0)
+            ops.check_status(r.device)
+            err = relmax(r.cpu().numpy(), ref)
+            assert err < 1e-5, (halo, det, err)
+    finally:
+        ops.set_refract_halo(4)
+        ops.set_deterministic(False)
+
+
 def test_refraction_16384_properties():
     """BASELINE config 5's grid through the refraction: flux that stays on the grid is conserved, the distance batch equals
     the one-distance calls, and a 512-row band equals the same band computed on its own (the gradient stencil and the gather
