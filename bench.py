@@ -89,6 +89,11 @@ def parse():
     ap.add_argument("--only-configs", action="store_true",
                     help="run ONLY the `configs` entries (no headline step, no positions batch): the command rocprofv3 profiles for "
                          "the config-5 variant of the driver's line (tools/collect_profiles.sh _cfg5 --only-configs --configs 16384)")
+    ap.add_argument("--emulate-world", type=int, default=8,
+                    help="one GPU only: after the positions batch, run the share of rank 0 and of the last rank of a world of this "
+                         "size, each in a fresh process, and put the predicted speed-up on the line (0: skip)")
+    ap.add_argument("--emulate-rank", type=int, default=-1, help=argparse.SUPPRESS)     # child mode of --emulate-world
+    ap.add_argument("--emulate-sim", default="Fresnel", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -158,6 +163,12 @@ def main():
         ops.debug_switch(name, int(val) if val else 1)
     if a.deterministic_step:
         ops.set_deterministic(True)
+    if a.emulate_rank >= 0:
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):
+            res = emulated_rank_share(a, a.emulate_sim, a.positions_size or min(a.size, 4096), a.emulate_rank, a.emulate_world, dev)
+        print(json.dumps(res))
+        sys.exit(0)
     if a.only_configs:
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):
@@ -363,6 +374,8 @@ def main():
                     continue
                 try:
                     out["positions_batch"][key] = positions_batch(a, sim, pn, rank, world, dev, reproducible=not key.endswith("_float_atomics"))
+                    if world == 1 and a.emulate_world > 1 and key in ("Fresnel", "RayT") and a.positions >= a.emulate_world:
+                        out["positions_batch"][key]["rank_share"] = emulate_world(a, sim, out["positions_batch"][key])
                 except Exception as exc:
                     import traceback
                     traceback.print_exc()
@@ -561,6 +574,7 @@ def positions_batch(a, sim, N, rank, world, dev, reproducible=False):
     nbins = exp._close_bins()
     dims = exp.myDetector.det_param["myDimensions"]
     stack_shape = (nbins, int(dims[0]), int(dims[1]))
+    exp.reserve_outputs(len(mine) + 2)        # as main.run: every position's images are kept, none of them costs a hipMalloc
     overlap = world > 1 and a.gather == "overlap"
     gat = None
     if overlap:
@@ -676,11 +690,12 @@ def positions_batch(a, sim, N, rank, world, dev, reproducible=False):
            "clock": "cold: barrier + synchronize on both sides, host clock, GPU idle at the start",
            "per_rank_compute_ms": [round(float(t[1]) * 1e3, 3) for t in per_rank],
            "gather_ms": round(max(float(t[2]) for t in per_rank) * 1e3, 3),
-           "gathered_bytes": int(sum(v[0].numel() + v[1].numel() for v in gathered.values()) * 4),
+           "gathered_bytes": int(len(gathered) * 2 * stack_shape[0] * stack_shape[1] * stack_shape[2] * 4),
            "gather_wire_bytes": dist.last_gather.get("wire_bytes"), "gather_packed_u16": dist.last_gather.get("packed"),
            "gather_overlapped": bool(dist.last_gather.get("overlapped")),
-           "timed_region": "synthesis + chain + detection + shot noise of every position + the gather onto rank 0 (images stay "
-                           "in rank 0's HBM)", "backend": a.backend if world > 1 else None}
+           "timed_region": "synthesis + chain + detection + shot noise of every position + the gather onto the sink rank (images "
+                           "stay in its HBM; those that crossed as 16-bit counts are widened to float32 when they are read)",
+           "backend": a.backend if world > 1 else None}
     if warm_ms is not None:
         wmax = max(float(t[3]) for t in per_rank)
         res["warm"] = {"ms_total": round(wmax * 1e3, 3), "ms_per_position": round(wmax * 1e3 / P, 4),
@@ -711,6 +726,136 @@ def positions_batch(a, sim, N, rank, world, dev, reproducible=False):
         if sink != 0:
             td.broadcast_object_list([res], src=sink, device=cpu_dev)
     return res
+
+
+def emulated_rank_share(a, sim, N, r, W, dev):
+    """What rank r of a world of W would do for the --positions batch, on THIS GPU alone, in this (fresh) process: the same
+    set-up positions_batch() runs untimed (two positions: plans, sphere list, allocator pools; the packing kernels once), then
+    between two host synchronisations with the GPU idle at the start -- the `cold` clock of positions_batch -- its positions
+    r, r + W, ... (position 0 with its Propag / White extras on rank 0), each packed into its 16-bit wire buffer as
+    dist.PositionGatherer does before it hands the round to RCCL (the sink keeps what arrives in that form: nothing to add for
+    rank 0).  No collective is issued: what is missing from a real rank's time is the
+    transfer itself (priced on the line from the wire bytes) and whatever the copy kernels of RCCL cost the chain
+    (+3 % per position with the Fresnel plan's work queue).  A prediction, not a measurement."""
+    import gc
+
+    import torch
+    from paresis_amd import dist, ops, synth
+
+    P = a.positions
+    exp, place = synth.bench_experiment(N, sim, noise=True, seed=7)
+    mine = dist.my_positions(P, r, W)
+
+    def position(p):
+        place(p)
+        return exp.computeSampleAndReferenceImages(p)[:2]
+
+    for p in (P + 1 + r, P + 1 + W + r):
+        position(p)
+    nbins = exp._close_bins()
+    dims = exp.myDetector.det_param["myDimensions"]
+    per_img = nbins * int(dims[0]) * int(dims[1])
+    wires = [dist._CountsWire(2 * per_img, dev) for _ in mine]
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    if sim == "Fresnel":
+        exp._plan().work_queue(True)          # as positions_batch does while transfers share the GPU
+
+    trace = {"host_ms": [], "ev": []}
+
+    def share(traced=False):
+        th = time.perf_counter()
+        for t, p in enumerate(mine):
+            S, R = position(p)
+            wires[t].head.zero_()
+            wires[t].pack(S, 0, flag)
+            wires[t].pack(R, per_img, flag)
+            if traced:                        # host time spent issuing this position, and an event behind its last kernel
+                now = time.perf_counter()
+                trace["host_ms"].append(round((now - th) * 1e3, 3))
+                if os.environ.get("PSX_EMULATE_ALLOC_TRACE"):
+                    trace.setdefault("allocs", []).append(torch.cuda.memory_stats()["num_device_alloc"])
+                th = now
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                trace["ev"].append(ev)
+
+    # the gather warm-up of positions_batch (world > 1): the packing / unpacking kernels once, untimed
+    S, R = position(P + 1 + r)
+    wires[0].head.zero_()
+    wires[0].pack(S, 0, flag)
+    wires[0].unpack()
+    del S, R
+    exp.reserve_outputs(len(mine) + 2)
+    gc.collect()
+    gc.freeze()
+    torch.cuda.synchronize()
+    # the barrier of a real run: the GPU is idle when the clock starts, the host thread has been polling (RCCL's barrier spins:
+    # a sleeping thread would add the wake-up of its core to the first position).  The length of the idle does not matter
+    # between 0.1 and 100 ms (gpurun_out/r5s5).
+    t_idle = time.perf_counter() + float(os.environ.get("PSX_EMULATE_IDLE_MS", "2")) * 1e-3
+    while time.perf_counter() < t_idle:
+        pass
+    ev0 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    share(traced=True)
+    torch.cuda.synchronize()
+    cold = time.perf_counter() - t0
+    gpu_done = [round(ev0.elapsed_time(e), 3) for e in trace["ev"]]
+    exp.resolve_mean_energy()
+    ops.check_status(dev, "emulated rank share")
+    # warm: the same share with the GPU kept under load up to the start (as positions_batch's `warm`)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(max(4, int(0.06 / max(3e-4, cold / max(1, len(mine)))))):
+        position(P + 1 + r)
+    e0.record()
+    share()
+    e1.record()
+    torch.cuda.synchronize()
+    gc.unfreeze()
+    return {"rank": r, "world": W, "positions": mine, "cold_ms": round(cold * 1e3, 3), "warm_ms": round(e0.elapsed_time(e1), 3),
+            "packed_ok": int(flag.item()) == 0, "wire_bytes_per_position": int(wires[0].bytes.numel()),
+            "cold_host_issue_ms_per_position": trace["host_ms"], "cold_gpu_done_at_ms": gpu_done, "allocs": trace.get("allocs")}
+
+
+def emulate_world(a, sim, one_gpu):
+    """positions_batch.<sim>.rank_share: no 8-GPU node was ever available to this repository, so the share
+    of rank 0 (position 0's extras, the sink's unpacking) and of the last rank of --emulate-world ranks is run on ONE GPU, each
+    in a fresh process (a real rank is one: cold clocks, cold caches), and the 8-GPU time is PREDICTED as the slower share +
+    the part of the gather that cannot hide behind the computation, priced at SURVEY.md section 5's xGMI figure (one
+    point-to-point link per peer, ~153 GB/s each, all 7 into the sink at once)."""
+    import subprocess
+    W = a.emulate_world
+    out = {"world": W, "note": "prediction, not a measurement: each share run alone on one GPU in a fresh process; no collective issued"}
+    if any(k.startswith("ROCPROFILER_") or k.startswith("ROCPROF_") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        out["skipped"] = "under rocprofv3 (a child process would be profiled as well)"
+        return out
+    shares = {}
+    for r in sorted({0, W - 1}):
+        cmd = [sys.executable, os.path.abspath(__file__), "--emulate-rank", str(r), "--emulate-world", str(W), "--emulate-sim", sim,
+               "--positions", str(a.positions), "--size", str(a.size), "--positions-size", str(a.positions_size)]
+        pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        if pr.returncode != 0:
+            out["error"] = "rank %d: rc %d: %s" % (r, pr.returncode, pr.stderr.strip().splitlines()[-1:] or "")
+            return out
+        shares[r] = json.loads(pr.stdout.strip().splitlines()[-1])
+    XGMI_LINK_GBS = 153.0
+    per_pos = shares[0]["wire_bytes_per_position"]
+    rounds = (a.positions + W - 1) // W
+    gather_all_ms = rounds * per_pos / XGMI_LINK_GBS / 1e6          # one peer's whole contribution over its own link
+    gather_last_ms = per_pos / XGMI_LINK_GBS / 1e6                  # what the overlapped gather leaves exposed: the last round
+    slow_cold = max(v["cold_ms"] for v in shares.values())
+    slow_warm = max(v["warm_ms"] for v in shares.values())
+    out.update(rank0_ms=shares[0]["cold_ms"], rank0_warm_ms=shares[0]["warm_ms"],
+               **{"rank%d_ms" % (W - 1): shares[W - 1]["cold_ms"], "rank%d_warm_ms" % (W - 1): shares[W - 1]["warm_ms"]},
+               one_gpu_64_ms=one_gpu["ms_total"], one_gpu_64_warm_ms=one_gpu.get("warm", {}).get("ms_total"),
+               gather_ms_last_round=round(gather_last_ms, 3), gather_ms_if_fully_exposed=round(gather_all_ms, 3),
+               xgmi_link_GBs_assumed=XGMI_LINK_GBS, wire_bytes_per_position=per_pos, packed_ok=all(v["packed_ok"] for v in shares.values()))
+    out["predicted_speedup_%d" % W] = round(one_gpu["ms_total"] / (slow_cold + gather_last_ms), 2)
+    out["predicted_speedup_%d_gather_exposed" % W] = round(one_gpu["ms_total"] / (slow_cold + gather_all_ms), 2)
+    if one_gpu.get("warm"):
+        out["predicted_speedup_%d_warm" % W] = round(one_gpu["warm"]["ms_total"] / (slow_warm + gather_last_ms), 2)
+    return out
 
 
 def run_configs(a, dev):

@@ -261,6 +261,19 @@ class Experiment:
         self._sums_next += 1
         return [out[0], out[1], out[2], out[3]], [self._accs[0], self._accs[1], self._accs[2], self._accs[3]], N, dev, sums
 
+    def reserve_outputs(self, n_positions):
+        """Lets the caching allocator own the output blocks of `n_positions` positions BEFORE the position loop: a caller that
+        keeps every position's images (main.run, dist.PositionGatherer) otherwise sends the allocator to hipMalloc once per
+        position -- a synchronous call of 0.2 to 2.5 ms depending on the box (gpurun_out/r5s6 against r5s8), in a loop whose
+        positions take 0.6 to 1.1 ms.  Allocates the blocks and returns them to the allocator's pool; nothing is kept."""
+        if not torch.cuda.is_available():          # the CPU rehearsals of the multi-rank path (gloo tests) compute elsewhere
+            return
+        dp = self.myDetector.det_param
+        nbins = self._close_bins()
+        n0, n1 = int(dp['myDimensions'][0]), int(dp['myDimensions'][1])
+        blocks = [torch.empty((4, nbins, n0, n1), dtype=torch.float32, device=device()) for _ in range(int(n_positions))]
+        del blocks
+
     def _close_bins(self):
         """EXP:296-301, once per Experiment: thresholds inside the spectrum, last spectrum energy appended.  Returns nbins."""
         thr, spec = self.myDetector.det_param["myBinsThersholds"], self.mySource.mySpectrum
@@ -537,20 +550,21 @@ class Experiment:
         return z / k_refraction(Energy) / (h * self.exp_dict['magnification']) / h
 
     def _set_halo(self, N, clamp, air):
-        """exp_dict['refractionHalo']: 4 (default), 6, 8 or 'auto' -- the gather halo of the refraction tiles is a speed knob whose
+        """exp_dict['refractionHalo']: 'auto' (default), 4, 6 or 8 -- the gather halo of the refraction tiles is a speed knob whose
         best value depends on how far the rays of THIS experiment travel in study pixels (oversampling, distances, membrane).
         'auto' times the experiment's own longest hop with each halo once, on the first call (ops.tune_refract_halo: three host
         synchronisations), and keeps the winner for the life of the object -- unless the experiment is reproducible (the
         default), where a timing must not decide the bits of an image: see below."""
         if self._halo is None:
-            want = self.exp_dict.get('refractionHalo', 4)
+            want = self.exp_dict.get('refractionHalo', 'auto')
             if want == 'auto' and self._reproducible():
                 # The halo decides which shares are gathered in the tiles and which are replayed, i.e. how a pixel's sum is
                 # split into float(tile sum) + float(far sum): the last bit of an image depends on it.  A halo picked by TIMING
                 # may differ between ranks and between runs, so a reproducible experiment takes it from a rule instead: what
-                # the timings picked on every membrane measured so far (DESIGN.md section 4.3: 4 px at oversampling <= 2, 8 px
-                # from oversampling 4 on, where rays travel twice as many study pixels).
-                want = 8 if int(self.exp_dict.get('overSampling', 1)) >= 4 else 4
+                # the timings of the fixed-point replay picked on the membranes measured so far (DESIGN.md section 4.3,
+                # gpurun_out/r5s1, r5s3: a replayed share costs 1.75x a float atomic, which moves the optimum one step up --
+                # 6 px at oversampling <= 2, 8 px from oversampling 4 on, where rays travel twice as many study pixels).
+                want = 8 if int(self.exp_dict.get('overSampling', 1)) >= 4 else 6
             if want == 'auto':
                 ed = self.exp_dict
                 E = self.mySource.mySpectrum[-1][0]

@@ -154,11 +154,11 @@ class _CountsWire:
             tab[e0:e0 + big.numel(), 1] = q[big]
         out.copy_(q.clamp(max=65535).to(torch.int16))     # two's complement wrap: the uint16 bit pattern
 
-    def unpack(self):
+    def unpack(self, out=None):
         if self.bytes.is_cuda:
             from . import ops
-            return ops.unpack_counts(self.counts, torch.empty(self.n, dtype=torch.float32, device=self.bytes.device),
-                                     self.exc, self.head[:1])
+            out = torch.empty(self.n, dtype=torch.float32, device=self.bytes.device) if out is None else out
+            return ops.unpack_counts(self.counts, out, self.exc, self.head[:1])
         out = (self.counts.to(torch.int32) & 0xFFFF).to(torch.float32)
         m = min(int(self.head[0]), self.cap)
         tab = self.exc.view(-1, 2)[:m]
@@ -240,6 +240,50 @@ def gather_positions(results, n_positions, rank, world, dst=0, to_host=True, pac
     if extras is not None:
         out[0] = extras
     return out if rank == dst else {}
+
+
+class PackedPositions(dict):
+    """{position: (Sample, Reference[, extras])} on a sink whose images stay in HBM (to_host=False): the stacks are kept as they
+    crossed -- 16-bit photon counts + the table of brighter pixels, lossless -- and widened to float32 the first time a
+    position is read; plain dict entries (position 0 with its extras) are served as they are.  A 64-position run otherwise
+    ends with 2 x 64 widening launches on the sink that nobody may ever look at (0.8 ms of rank 0's 10 ms share: bench.py
+    rank_share, round 5); main.run's host copies are widened on the host in either case."""
+
+    def __init__(self, packed, per_img, shape, ready):
+        super().__init__(ready)
+        self._packed, self._per_img, self._shape = dict(packed), per_img, tuple(shape)
+
+    def _widen(self, p):
+        b = self._packed.pop(p)
+        img = _CountsWire(2 * self._per_img, b.device, like=b).unpack().view((2,) + self._shape)
+        super().__setitem__(p, (img[0], img[1]))
+
+    def __getitem__(self, p):
+        if p in self._packed and not super().__contains__(p):
+            self._widen(p)
+        return super().__getitem__(p)
+
+    def __contains__(self, p):
+        return super().__contains__(p) or p in self._packed
+
+    def __len__(self):
+        return len(set(super().keys()) | set(self._packed))
+
+    def __iter__(self):
+        return iter(sorted(set(super().keys()) | set(self._packed)))
+
+    def keys(self):
+        return list(iter(self))
+
+    def values(self):
+        return [self[p] for p in self]
+
+    def items(self):
+        return [(p, self[p]) for p in self]
+
+    def stack_numel(self):
+        """Elements of one position's pair of stacks (no widening)."""
+        return 2 * self._per_img
 
 
 class PositionGatherer:
@@ -377,7 +421,7 @@ class PositionGatherer:
             if isinstance(exc, DistError):
                 raise
             raise DistError("PositionGatherer.finish: rank %d lost a peer: %s" % (self.rank, exc)) from exc
-        out = {}
+        out, lazy = {}, {}
         wire_bytes = 0
         if self.rank == self.dst:
             per_img = self.shape[0] * self.shape[1] * self.shape[2]
@@ -388,13 +432,18 @@ class PositionGatherer:
                         continue
                     b = self.buckets[t][r]
                     wire_bytes += b.numel() if r != self.rank else 0
+                    if not self.to_host and b.is_cuda:
+                        lazy[q] = b              # stays in the sink's HBM as it crossed: widened when (if) somebody reads it
+                        continue
                     if self.to_host:
                         b = b.cpu()
                     img = _CountsWire(2 * per_img, b.device, like=b).unpack().view((2,) + self.shape)
                     out[q] = (img[0], img[1])
+            if lazy:
+                out = PackedPositions(lazy, per_img, self.shape, out)
             if extras is not None:                                       # Propag / White / Dx,Dy exist for position 0 only
                 out[0] = extras
-        last_gather.update(packed=True, wire_bytes=wire_bytes, overlapped=True)
+        last_gather.update(packed=True, wire_bytes=wire_bytes, overlapped=True, lazy=bool(lazy))
         return out if self.rank == self.dst else {}
 
 

@@ -61,6 +61,7 @@ def run(exp_dict, save=True, saving_format=".tif", backend=None):
             overlapped, gatherer = False, None
     if overlapped and sim == "Fresnel":
         experiment._plan().work_queue(True)
+    experiment.reserve_outputs(len(dist.my_positions(exp_dict['nbExpPoints'], rank, world)) + 1)   # no hipMalloc inside the loop
     results = {}
     # the loop and the final gather share ONE failure path: PositionGatherer.add() issues collectives too, and a DistError
     # raised there must not unwind through the process group's teardown (its contract: leave with os._exit)

@@ -50,7 +50,7 @@ def test_chain_rt_with_measured_halo():
         for nm, a in (("Sample", S), ("Reference", R), ("Propag", Pg), ("White", W)):
             assert relmax(a.cpu().numpy(), g["mono/RT/p0/" + nm]) < TOL, nm
         # reproducible (the default): 'auto' is a RULE of the oversampling, the same on every rank and in every run
-        for ov, want in ((2, 4), (4, 8)):
+        for ov, want in ((2, 6), (4, 8)):
             exp2 = build_experiment(cfg, "RT")
             exp2.exp_dict["refractionHalo"] = "auto"
             exp2.exp_dict["overSampling"] = ov

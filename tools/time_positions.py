@@ -4,6 +4,7 @@ synthesis (seeded offsets, sphere splat on the GPU) + the image-formation chain 
 BASELINE.json config 4 is 64 such positions over 8 GPUs (8 per GPU, no data-path collective).
 
     python tools/time_positions.py [N] [NPOS] [--poly 25]      # --poly E: a tube spectrum of E energies (polychromatic position)
+                                   [--float-atomics] [--halo 4|6|8] [--sim RT|Fresnel]
 """
 import ctypes
 import os
@@ -16,19 +17,29 @@ import torch
 
 from paresis_amd import _lib, ops, synth
 
-_args = [a for a in sys.argv[1:] if not a.startswith('--')]
+def _opt(name, default=None):
+    return sys.argv[sys.argv.index(name) + 1] if name in sys.argv else default
+
+
+_skip = set()
+for _o in ('--poly', '--halo', '--sim'):
+    if _o in sys.argv:
+        _skip.add(sys.argv.index(_o) + 1)
+_args = [a for i, a in enumerate(sys.argv) if i > 0 and not a.startswith('--') and i not in _skip]
 N = int(_args[0]) if len(_args) > 0 else 4096
 NPOS = int(_args[1]) if len(_args) > 1 else 16
 npoly = int(sys.argv[sys.argv.index('--poly') + 1]) if '--poly' in sys.argv else 0
 spectrum = None
 if npoly:
-    _args = [a for a in _args if a != str(npoly)] if False else _args
     e = np.linspace(20.0, 20.0 + 2.0 * (npoly - 1), npoly)
     w = np.exp(-0.5 * ((e - e.mean()) / (0.3 * (e[-1] - e[0] + 1))) ** 2)
     spectrum = [(float(a), float(b)) for a, b in zip(e, w / w.sum())]
 lib = _lib.lib()
-for sim in ("Fresnel", "RT"):
+for sim in ([_opt('--sim')] if _opt('--sim') else ["Fresnel", "RT"]):
     exp, place = synth.bench_experiment(N, sim, noise=True, seed=3, spectrum=spectrum)
+    exp.exp_dict['reproducible'] = '--float-atomics' not in sys.argv
+    if _opt('--halo'):
+        exp.exp_dict['refractionHalo'] = int(_opt('--halo'))
 
     def position(p):
         place(p)
