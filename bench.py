@@ -81,6 +81,7 @@ def parse():
                          "owns position 0 and its extra images: with another sink the straggler and the receiver are two GPUs)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (BASELINE configs 1, 2 and 5)")
     ap.add_argument("--configs", default="512,2048,16384", help="study grids of the `configs` object")
+    ap.add_argument("--no-config-graph", action="store_true", help="configs: time the small grids launch by launch only")
     ap.add_argument("--no-config-parity", action="store_true",
                     help="`configs` entries without their parity leg (profiling runs: the strips' small launches would mix into the "
                          "kernel statistics)")
@@ -933,6 +934,28 @@ def run_configs(a, dev):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / K
         ops.check_status(dev, "configs %d" % N)
+        # Small grids: a step is seven launches of 6-45 us, so the gaps between dispatches are a large part
+        # of it.  The whole step is captured once into a hipGraph (every library call is asynchronous on the current stream and
+        # allocates nothing once its plans and kernel spectra exist) and replayed: `ms_hipgraph_replay` beside `ms` (launch by
+        # launch).  Measured (gpurun_out/r5s12): the replay is not faster on this stack -- 512^2 0.101 against 0.097 ms, 2048^2
+        # 0.130 against 0.125 -- a graph's kernel nodes are dispatched one by one with the same barrier packets between them.
+        dt_graph = None
+        if N <= 2048 and not a.no_config_graph:
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    step()
+                for _ in range(int(min(K, max(3, 0.05 / one)))):
+                    g.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(K):
+                    g.replay()
+                torch.cuda.synchronize()
+                dt_graph = (time.perf_counter() - t0) / K
+                ops.check_status(dev, "configs %d (graph)" % N)
+            except Exception as exc:                       # capture refused (a plan would have had to allocate): report, keep going
+                sys.stderr.write("configs %d: hipGraph capture failed: %s\n" % (N, exc))
         # one more step with the library's event pairs: where the step's time goes
         import ctypes
         lib = _lib.lib()
@@ -959,7 +982,9 @@ def run_configs(a, dev):
             step_bytes_pp += det_bytes
         e = {"workload": "%dx%d fp32 study grid (detector %d x oversampling %d), %d distance(s)%s" %
                          (N, N, n, ov, len(zs), ", Detector.detection of all %d images in the step" % (2 * len(zs)) if detect else ""),
-             "steps": K, "ms": round(dt * 1e3, 4), "Mpixel_per_s": round(len(zs) * N * N / dt / 1e6, 1),
+             "steps": K, "ms": round(dt * 1e3, 4),
+             "ms_hipgraph_replay": round(dt_graph * 1e3, 4) if dt_graph is not None else None,
+             "Mpixel_per_s": round(len(zs) * N * N / dt / 1e6, 1),
              "step_bytes": step_bytes, "step_frac": round(step_bytes / dt / 1e9 / HBM_PEAK_GBS, 4),
              "step_frac_per_propagation": round(step_bytes_pp / dt / 1e9 / HBM_PEAK_GBS, 4),
              "fresnel_engine": {1: "rocfft", 2: "lds"}[plan.engine], "refraction_halo": halo,

@@ -16,6 +16,15 @@ using namespace psx;
 namespace {
 
 constexpr int MT = 32;   // tile side
+// Cell side of the plan's sphere bins (a build-time A/B: tools/ab_membrane.sh).  A tile's candidates are the spheres of every
+// cell its window (tile + the largest sphere window on either side) meets: with 32-pixel cells that is 96 x 96 pixels of cells
+// for a 46-pixel window at the bench's sphere size -- ~126 candidates for ~26 hits.  Finer cells stage fewer candidates but make
+// more (layer, cell row) jobs, i.e. more staging rounds with their barriers: k_membrane per 4096^2 position 0.084 ms (32-pixel
+// cells) / 0.098 (16) / 0.111 (8) -- gpurun_out/r5s13, two rounds on one box.  The candidates are not what costs; 32 stays.
+#ifndef PSX_MEMBRANE_CELL
+#define PSX_MEMBRANE_CELL 32
+#endif
+constexpr int MC = PSX_MEMBRANE_CELL;
 
 struct Sphere {
     double xf, yf, r;
@@ -67,7 +76,7 @@ __global__ __launch_bounds__(256) void k_membrane(const Sphere *__restrict__ sph
     }
 }
 
-// ---- plan variant: the sphere list lives on the GPU, binned ONCE by 32-pixel cell of its own frame -------------------
+// ---- plan variant: the sphere list lives on the GPU, binned ONCE by MC-pixel cell of its own frame -------------------
 // getMembraneSegmentedFromFile re-places the same (scaled, stitched) list for every membrane position and layer with a
 // new integer offset (getMembraneFromFile.py:139-142).  Binning by tile on the host per call -- what psx_membrane_f32
 // does -- then costs 6 ms per layer at 4096^2 against 0.1 ms for the kernel.  Here a tile finds its spheres itself: its
@@ -135,8 +144,8 @@ __global__ __launch_bounds__(256) void k_membrane_layers(const CellSphere *__res
             // cells whose spheres can reach this tile: |centre - pixel| <= radInt + 1/2 on each axis
             const double xlo = (double)(offx + tx0 - rmax_int - 1) - x0, xhi = (double)(offx + tx0 + MT + rmax_int + 1) - x0;
             const double ylo = (double)(offy + ty0 - rmax_int - 1) - y0, yhi = (double)(offy + ty0 + MT + rmax_int + 1) - y0;
-            const int cx = max(0, (int)floor(xlo / MT)) + g, cx1 = min(ncx - 1, (int)floor(xhi / MT));
-            const int cy0 = max(0, (int)floor(ylo / MT)), cy1 = min(ncy - 1, (int)floor(yhi / MT));
+            const int cx = max(0, (int)floor(xlo / MC)) + g, cx1 = min(ncx - 1, (int)floor(xhi / MC));
+            const int cy0 = max(0, (int)floor(ylo / MC)), cy1 = min(ncy - 1, (int)floor(yhi / MC));
             if (cx <= cx1 && cy0 <= cy1) {
                 beg = cell_off[cx * ncy + cy0];
                 end = cell_off[cx * ncy + cy1 + 1];
@@ -244,18 +253,18 @@ int psx_membrane_plan_create(const double *x, const double *y, const double *r, 
     }
     p->x0 = std::floor(xmin); p->y0 = std::floor(ymin);
     const double ex = xmax - p->x0, ey = ymax - p->y0;
-    if (!(ex / MT < 30000.0 && ey / MT < 30000.0 && (ex / MT + 1) * (ey / MT + 1) < 2.0e8 && rmax < 1.0e6)) {
+    if (!(ex / MC < 60000.0 && ey / MC < 60000.0 && (ex / MC + 1) * (ey / MC + 1) < 4.0e8 && rmax < 1.0e6)) {
         delete p;
         return fail(PSX_E_ARG, "psx_membrane_plan_create: sphere list spans %.3g x %.3g pixels (radius up to %.3g)", ex, ey, rmax);
     }
-    p->ncx = (int)(ex / MT) + 1; p->ncy = (int)(ey / MT) + 1;
+    p->ncx = (int)(ex / MC) + 1; p->ncy = (int)(ey / MC) + 1;
     p->rmax_int = (int)std::floor(rmax) + 1;
     const size_t nc = (size_t)p->ncx * p->ncy;
     std::vector<int> off(nc + 1, 0);
     std::vector<int> cell(n > 0 ? n : 1, -1);
     for (int64_t s = 0; s < n; ++s) {
         if (!(r[s] > 0.0) || !std::isfinite(x[s]) || !std::isfinite(y[s]) || !std::isfinite(r[s])) continue;
-        const int cx = (int)((x[s] - p->x0) / MT), cy = (int)((y[s] - p->y0) / MT);
+        const int cx = (int)((x[s] - p->x0) / MC), cy = (int)((y[s] - p->y0) / MC);
         cell[s] = cx * p->ncy + cy;
         off[cell[s] + 1]++;
     }
@@ -296,7 +305,7 @@ int psx_membrane_layers_f32(psx_membrane_plan *p, int nlayers, const int *offx, 
     for (int l0 = 0; l0 == 0 || l0 < nlayers; l0 += ML_MAX) {
         LayerArgs la = {};
         la.nlayers = std::min(ML_MAX, nlayers - l0);
-        la.rows = (MT + 2 * (p->rmax_int + 1)) / MT + 2;       // a window of that many pixels meets at most this many 32-pixel cells
+        la.rows = (MT + 2 * (p->rmax_int + 1)) / MC + 2;       // a window of that many pixels meets at most this many cells
         for (int l = 0; l < la.nlayers; ++l) {
             la.offx[l] = offx[l0 + l];
             la.offy[l] = offy[l0 + l];
