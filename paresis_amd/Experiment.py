@@ -202,7 +202,8 @@ class Experiment:
         a, g, du = self._fresnel_scalars(propagationDistance, Energy, magnification)
         return self._plan().propagate([a], [g], du, wave_in=to_dev(waveToPropagate, torch.complex64))[0]
 
-    def refraction(self, intensityRefracted, phi, propagationDistance, Energy, magnification, darkField=0, _mutate=True):
+    def refraction(self, intensityRefracted, phi, propagationDistance, Energy, magnification, darkField=0, _mutate=True,
+                   _want_D=True):
         """Experiment.py:255-277.  (_mutate=False: the chain's own calls, whose input is a temporary, skip the in-place zeroing
         of clamped rays in the dark-field variant.)"""
         from .refractionFileNumba2 import fastRefraction, fastRefractionDF
@@ -213,7 +214,7 @@ class Experiment:
             known = self.mySampleofInterest.dark_field_max(darkField) if hasattr(self.mySampleofInterest, "dark_field_max") else None
             return fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magnification,
                                     self.exp_dict["studyPixelSize"], darkField, darkFieldMax=known,
-                                    check=not self.exp_dict.get('deferStatus'), mutate=_mutate)
+                                    check=not self.exp_dict.get('deferStatus'), mutate=_mutate, want_D=_want_D)
 
     def _reproducible(self):
         """exp_dict['reproducible'] (default True): the far rays of every refraction of this experiment are summed in fixed
@@ -677,7 +678,7 @@ class Experiment:
             if scattering:                                       # Lung / cylinder_beeds: fastRefractionDF (EXP:272-275)
                 DF = self.mySampleofInterest.dark_field(currentEnergy)
                 Ias, phis = ops.transmit_rt(Ibs, 1.0, both)
-                img, _, _ = self.refraction(Ias, phis, dOD, currentEnergy, ed['magnification'], DF, _mutate=False)
+                img, _, _ = self.refraction(Ias, phis, dOD, currentEnergy, ed['magnification'], DF, _mutate=False, _want_D=False)
                 self._add_intensity(accS, img, plate_att, add=not first)
             elif plate_att is None:
                 ops.refract(N, both, self._dscale(dOD, currentEnergy), clamp, I_in=Ibs, out=accS, add=not first)

@@ -235,6 +235,102 @@ __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict
     if (status && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, PSX_STATUS_NONFINITE);
 }
 
+// Patches wider than the tiled kernel's LDS window (R > 14): the same gather with the sources staged in BANDS of rows.  A
+// workgroup owns a 32 x 32 tile of outputs and walks the source rows [t0 - R, t0 + 32 + R) in bands of `band` rows x (32 + 2 R)
+// columns of 16-byte entries (whatever fits the LDS budget); each thread keeps its four outputs in registers across the bands,
+// so the terms of an output are added in the order of the plain gather (rows, then columns).  A band knows the widest patch it
+// holds: rows and columns beyond it are skipped, so a tile outside the scattering sample costs its staging only.  Replaces the
+// global-memory gather k_df_gather as the path of wide dark fields (round 5: a 13-pixel dark field, R = 21, took 27.7 ms per
+// 4096^2 image there -- every term a dependent global load; its cost is now that of the terms, ~2 R^2 exponentials per pixel).
+__global__ __launch_bounds__(256) void k_df_gather_banded(const float *__restrict__ I2DF, const float *__restrict__ DF,
+                                                          const float2 *__restrict__ prep, const float *__restrict__ I2,
+                                                          float *__restrict__ out, int Nx, int Ny, int R, int band, int tiles_y,
+                                                          unsigned *status) {
+    extern __shared__ __attribute__((aligned(16))) char sdf[];
+    const int W = DT + 2 * R;
+    float4 *swc = reinterpret_cast<float4 *>(sdf);                 // [band][W] (weight, coefficient, half-size, 0)
+    __shared__ int hband;
+    const int t0 = (blockIdx.x / tiles_y) * DT, c0 = (blockIdx.x % tiles_y) * DT;
+    const int tj = threadIdx.x & 31, ti0 = threadIdx.x >> 5;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b0 = t0 - R; b0 < t0 + DT + R; b0 += band) {
+        const int rows = min(band, t0 + DT + R - b0);
+        __syncthreads();                                 // the previous band has been consumed
+        if (threadIdx.x == 0) hband = -1;
+        __syncthreads();
+        int hm = -1;
+        for (int e = threadIdx.x; e < rows * W; e += 256) {
+            const int a = e / W, b = e - a * W;
+            const int si = b0 + a, sj = c0 - R + b;
+            float w = 0.f, c = 0.f;
+            int h = -1;
+            if (si >= 0 && si < Nx && sj >= 0 && sj < Ny) {
+                const int64_t q = (int64_t)si * Ny + sj;
+                const float2 pr = prep[q];
+                h = (int)pr.x;
+                if (h >= 0) {
+                    w = I2DF[q] * pr.y;
+                    if (h > 0) {
+                        const float sigma = 0.5f * DF[q];
+                        c = -1.4426950408889634f / (2.f * sigma * sigma);
+                    }
+                    if (w == 0.f) h = -1;                // carries nothing: must not widen the band's reach
+                }
+            }
+            swc[e] = make_float4(w, c, (float)h, 0.f);
+            hm = max(hm, h);
+        }
+        for (int o = 32; o > 0; o >>= 1) hm = max(hm, __shfl_xor(hm, o));
+        if ((threadIdx.x & 63) == 0 && hm >= 0) atomicMax(&hband, hm);
+        __syncthreads();
+        const int hb = __builtin_amdgcn_readfirstlane(min(R, hband));
+        if (hb < 0) continue;                            // nothing in this band carries weight (uniform)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = t0 + ti0 + 8 * k;
+            // source rows of this band within the band's reach of output row i
+            const int r_lo = max(b0, i - hb), r_hi = min(b0 + rows - 1, i + hb);
+            float a = acc[k];
+            for (int si = r_lo; si <= r_hi; ++si) {
+                const int di = si - i, adi = abs(di);
+                const float di2 = (float)(di * di);
+                const float4 *row = swc + (si - b0) * W + tj + R;
+                int dj = -hb;
+                for (; dj + 3 <= hb; dj += 4) {          // four entries requested together
+                    float4 e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) e[u] = row[dj + u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float need = (float)max(adi, abs(dj + u));
+                        const float t = fmaf(e[u].x, __builtin_amdgcn_exp2f((di2 + (float)((dj + u) * (dj + u))) * e[u].y), e[u].w);
+                        a += e[u].z >= need ? t : 0.f;
+                    }
+                }
+                for (; dj <= hb; ++dj) {
+                    const float4 e = row[dj];
+                    const float need = (float)max(adi, abs(dj));
+                    const float t = fmaf(e.x, __builtin_amdgcn_exp2f((di2 + (float)(dj * dj)) * e.y), e.w);
+                    a += e.z >= need ? t : 0.f;
+                }
+            }
+            acc[k] = a;
+        }
+    }
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = t0 + ti0 + 8 * k, j = c0 + tj;
+        if (i < Nx && j < Ny) {
+            const int64_t p = (int64_t)i * Ny + j;
+            const float v = acc[k] + (I2 ? I2[p] : 0.f);
+            bad |= !(fabsf(v) <= 3.0e38f);
+            out[p] = v;
+        }
+    }
+    if (status && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, PSX_STATUS_NONFINITE);
+}
+
 // ---- the front of fastRefractionDF as ONE pass (RF2:114-150): width map in radians -> pixels (float64), its maximum (the
 // margin of the returned displacement maps is ceil(6 max), RF2:117), the DF > Nx/4 -> 0 rule (RF2:135), the split of the
 // intensity by DF != 0 (RF2:147-150), and -- the width map being all the patch normalisation depends on -- the per-source
@@ -314,6 +410,27 @@ __global__ __launch_bounds__(256) void k_repad(const float *__restrict__ src, in
     }
 }
 
+// wide patches: bands of source rows through LDS (64 KiB per workgroup: two workgroups per CU)
+int launch_banded(const float *I2DF, const float *DF, const float2 *prep, const float *I2, float *out, int Nx, int Ny, int R,
+                  unsigned *status, hipStream_t st) {
+    const int W = DT + 2 * R;
+    const int band = (int)std::min<size_t>((size_t)(DT + 2 * R), (64 * 1024) / (sizeof(float4) * (size_t)W));
+    if (band < 1) {      // a window row does not fit the budget (R > 2032): the plain gather from global memory
+        const int64_t n = (int64_t)Nx * Ny;
+        PSX_TIMED("k_df_gather", st, k_df_gather<<<ew_grid(n, 256), 256, 0, st>>>(I2DF, DF, prep, I2, out, Nx, Ny, R));
+        if (int rc = launch_check("k_df_gather")) return rc;
+        return status ? psx_status_scan_f32(out, n, status, (void *)st) : 0;
+    }
+    const size_t lds = sizeof(float4) * (size_t)band * (size_t)W;
+    static std::atomic<unsigned long long> attr_mask{0};
+    if (first_on_device(attr_mask))
+        PSX_HIP(hipFuncSetAttribute((const void *)k_df_gather_banded, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    const int tiles_x = (int)cdiv(Nx, DT), tiles_y = (int)cdiv(Ny, DT);
+    PSX_TIMED("k_df_gather", st, k_df_gather_banded<<<tiles_x * tiles_y, 256, lds, st>>>(I2DF, DF, prep, I2, out, Nx, Ny, R, band,
+                                                                                         tiles_y, status));
+    return launch_check("k_df_gather");
+}
+
 }  // namespace
 
 extern "C" {
@@ -358,9 +475,8 @@ int psx_darkfield_blur_prepared_f32(const float *I2DF, const float *DF, const vo
                                                                                             Nx, Ny, R, tiles_y, status));
         return launch_check("k_df_gather");
     }
-    PSX_TIMED("k_df_gather", st, k_df_gather<<<ew_grid(n, 256), 256, 0, st>>>(I2DF, DF, (const float2 *)prep, I2, out, Nx, Ny, R));
-    if (int rc = launch_check("k_df_gather")) return rc;
-    return status ? psx_status_scan_f32(out, n, status, stream) : 0;
+    (void)n;
+    return launch_banded(I2DF, DF, (const float2 *)prep, I2, out, Nx, Ny, R, status, st);
 }
 
 size_t psx_darkfield_workspace_bytes(int Nx, int Ny) { return sizeof(float2) * (size_t)(Nx > 0 ? Nx : 0) * (size_t)(Ny > 0 ? Ny : 0); }
@@ -378,9 +494,7 @@ int psx_darkfield_blur_f32(const float *I2DF, const float *DF, const float *I2, 
                                                                                             out, Nx, Ny, R, tiles_y, nullptr));
         return launch_check("k_df_gather");
     }
-    PSX_TIMED("k_df_gather", st, k_df_gather<<<ew_grid(n, 256), 256, 0, st>>>(I2DF, DF, (const float2 *)workspace, I2, out,
-                                                                              Nx, Ny, R));
-    return launch_check("k_df_gather");
+    return launch_banded(I2DF, DF, (const float2 *)workspace, I2, out, Nx, Ny, R, nullptr, st);
 }
 
 }  // extern "C"

@@ -48,7 +48,7 @@ def fastRefraction(intensityRefracted, phi, propagationDistance, Energy, magnifi
 
 
 def fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magnification, studyPixelSize, darkField,
-                     darkFieldMax=None, check=True, mutate=True):
+                     darkFieldMax=None, check=True, mutate=True, want_D=True):
     """RF2:88-196: refraction with a dark-field (small-angle scattering) width map `darkField` in radians.
 
     The intensity is split where the dark field is / is not zero (RF2:147-150), both parts are refracted with the same
@@ -59,7 +59,9 @@ def fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magni
     back from the GPU (one synchronisation).  Every array operation is a kernel of the library: the conversion to pixels,
     the DF > Nx/4 rule, the split and the patch table in one pass (psx_darkfield_split_f32), two refractions, the re-splat.
     The matplotlib pop-ups of RF2:152-167 are not reproduced.  mutate=False (extension; the chain's caller passes a temporary it
-    never reads again): the clamped rays are not zeroed in `intensityRefracted` (RF2:128-129), which saves one pass."""
+    never reads again): the clamped rays are not zeroed in `intensityRefracted` (RF2:128-129), which saves one pass.
+    want_D=False (extension; the chain's sample image, EXP:473, which drops the maps): Dx, Dy are not materialised (two padded
+    maps cleared and stored per call) and come back as None."""
     I = to_dev(intensityRefracted, torch.float32)
     mutate_host = intensityRefracted if isinstance(intensityRefracted, np.ndarray) else None
     Nx, Ny = I.shape
@@ -77,10 +79,13 @@ def fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magni
     phi64 = to_dev(phi, torch.float64)
     # the tile kernels need a margin >= their gather halo; a wider margin only changes deposits that the crop removes
     m = max(margin2, 8)
-    I2, Dxp, Dyp = ops.refract((Nx, Ny), None, dscale, (Nx, Ny), margin=m, I_in=I_nodf, phi_in=phi64, want_D=True,
+    need_D = want_D or margin2 < 1
+    I2, Dxp, Dyp = ops.refract((Nx, Ny), None, dscale, (Nx, Ny), margin=m, I_in=I_nodf, phi_in=phi64, want_D=need_D,
                                I_mut=I_nodf)
     I2DF, _, _ = ops.refract((Nx, Ny), None, dscale, (Nx, Ny), margin=m, I_in=I_df, phi_in=phi64, I_mut=I_df)
-    if margin2 == m:
+    if not need_D:
+        Dx = Dy = None
+    elif margin2 == m:
         Dx, Dy = Dxp, Dyp
     else:
         Dx, Dy = ops.repad(Dxp, m, margin2, (Nx, Ny)), ops.repad(Dyp, m, margin2, (Nx, Ny))
@@ -89,6 +94,8 @@ def fastRefractionDF(intensityRefracted, phi, propagationDistance, Energy, magni
         # loop is used on the un-padded arrays (RF2:235-262)
         I2 = ops.fastloop(I_nodf, Dx, Dy, ops.fill(torch.empty_like(I), 0.0))
         I2DF = ops.fastloop(I_df, Dx, Dy, ops.fill(torch.empty_like(I), 0.0))
+        if not want_D:
+            Dx = Dy = None
     if mutate:
         ops.darkfield_merge(I, I_nodf, I_df)             # clamped rays zeroed in the caller's array (RF2:128-129)
         if mutate_host is not None:

@@ -284,7 +284,7 @@ def test_fuzz_darkfield_refraction(ops, case):
     cells = float(rng.uniform(4.0, 20.0))
     phi = reach * cells * kr * h * M * h / z * _smooth(rng, (Nx, Ny), cells)
     I = rng.uniform(0.5, 2.0, (Nx, Ny)).astype(np.float32)
-    max_px = float(rng.choice([0.8, 2.0, 5.0]))
+    max_px = float(rng.choice([0.8, 2.0, 5.0, 12.0, 25.0]))     # up to 5: the LDS-tiled gather; beyond: bands of source rows
     df = np.clip(_smooth(rng, (Nx, Ny), cells), 0.0, None) * max_px * h * M / z           # radians
     if rng.random() < 0.5:
         df[:, : Ny // 2] = 0.0

@@ -820,12 +820,13 @@ def test_darkfield_front_kernels_against_numpy(ops):
         assert np.array_equal(got, np.pad(src[8:8 + Nx, 8:8 + Ny], md))
 
 
-@pytest.mark.parametrize("max_df", [1.1, 2.4, 6.6, 9.6])
+@pytest.mark.parametrize("max_df", [1.1, 2.4, 6.6, 9.6, 20.0, 41.0])
 def test_darkfield_resplat_all_tile_shapes(ops, max_df):
     """The variable-width Gaussian re-splat (RF2:168-186) through psx_darkfield_split_f32 + psx_darkfield_blur_prepared_f32
     against the reference's literal per-source patch loop in float64, for widths that take the LDS-tiled gather (window
-    <= 60 KB: R <= 14) and the plain one beyond; sources with and without dark field, zero sources, patches clipped by the
-    image border, a grid that is no multiple of the tile."""
+    <= 60 KB: R <= 14) and, beyond, the gather over bands of source rows (R = 15: one band; 31: three; 63: six, patches wider
+    than the image); sources with and without dark field, zero sources, patches clipped by the image border, a grid that is
+    no multiple of the tile."""
     rng = np.random.default_rng(int(max_df * 10))
     Nx, Ny = 75, 58
     I2DF = np.where(rng.uniform(size=(Nx, Ny)) < 0.2, 0.0, rng.uniform(1.0, 9.0, (Nx, Ny))).astype(np.float32)

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Round 5, GPU session 15: banded dark-field gather for wide patches (tests, fuzz), then the scattering 25-energy position again.
+cd "$(dirname "$0")/../.."
+OUT=$PWD/gpurun_out/r5s15
+mkdir -p $OUT
+PSX_FUZZ=5 timeout -k 10 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_fuzz.py tests/test_gpu_experiment.py -m gpu -x -q -p no:cacheprovider -k "darkfield" > $OUT/tests.out 2>&1; rc=$?; tail -3 $OUT/tests.out
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 300 python tools/time_positions.py 4096 16 --sim RT --scatter > $OUT/scatter_mono.out 2>&1; grep -v "per position (host" $OUT/scatter_mono.out | tail -2
+timeout -k 10 600 python tools/time_positions.py 4096 3 --sim RT --poly 25 --scatter > $OUT/scatter.out 2>&1; grep -v "per position (host" $OUT/scatter.out | tail -2
+for w in sample all; do timeout -k 10 200 python tools/time_darkfield.py 20 chain $w 2>&1 | tail -1 | tee -a $OUT/df.out; done

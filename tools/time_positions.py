@@ -4,7 +4,7 @@ synthesis (seeded offsets, sphere splat on the GPU) + the image-formation chain 
 BASELINE.json config 4 is 64 such positions over 8 GPUs (8 per GPU, no data-path collective).
 
     python tools/time_positions.py [N] [NPOS] [--poly 25]      # --poly E: a tube spectrum of E energies (polychromatic position)
-                                   [--float-atomics] [--halo 4|6|8] [--sim RT|Fresnel]
+                                   [--float-atomics] [--halo 4|6|8] [--sim RT|Fresnel] [--scatter]
 """
 import ctypes
 import os
@@ -40,6 +40,8 @@ for sim in ([_opt('--sim')] if _opt('--sim') else ["Fresnel", "RT"]):
     exp.exp_dict['reproducible'] = '--float-atomics' not in sys.argv
     if _opt('--halo'):
         exp.exp_dict['refractionHalo'] = int(_opt('--halo'))
+    if '--scatter' in sys.argv:               # the sample as a scattering one (SAM:322-344): fastRefractionDF on the chain's sample hop
+        exp.mySampleofInterest.myName = 'cylinder_beeds'
 
     def position(p):
         place(p)
