@@ -114,6 +114,18 @@ int psx_refract_f32(const float *I_in, float I0, const float *const *T, const do
                     int nmat, const double *phi_in, float *I_out, float out_scale, int accumulate, float *Dx_out,
                     float *Dy_out, float *I_mut, int Nx, int Ny, int margin, double dscale, double clamp_x,
                     double clamp_y, unsigned *status, void *workspace, void *stream);
+/* fastRefractionDF's split by its width map (refractionFileNumba2.py:147-150: I_nodf = I where DF == 0, I_df = I where
+ * DF != 0) and the refraction of both halves (RF2:153-154) in one call: I_out_zero receives the refraction of the sources
+ * where mask == 0, I_out_nonzero of those where mask != 0.  A tile is staged ONCE for both; a half runs its deposit loop only
+ * where the tile's window holds a source of its side.  With the thickness maps as the source of intensity and phase, the
+ * dark-field branch of the chain (EXP:469-473) needs neither the transmitted (I, phi) pair nor the two halves of the split in
+ * memory.  mask: [Nx][Ny] float32 (the width map in pixels).  The phase comes from the thickness maps (nmat > 0; phi_in must
+ * be NULL: the argument keeps the call's shape that of psx_refract_f32).  No displacement maps, no input mutation; workspace:
+ * psx_refract_multi_workspace_bytes(Nx, Ny, 2); everything else as psx_refract_f32. */
+int psx_refract_split_f32(const float *I_in, const float *mask, float I0, const float *const *T, const double *cphase,
+                          const double *catt, int nmat, const double *phi_in, float *I_out_zero, float *I_out_nonzero,
+                          float out_scale, int accumulate, int Nx, int Ny, int margin, double dscale, double clamp_x,
+                          double clamp_y, unsigned *status, void *workspace, void *stream);
 
 /* Propagation-distance batch (BASELINE.json north_star: "propagation-distance batches"; the reference would call
  * Experiment.refraction, Experiment.py:255-277, once per distance on the same (I, phi)): ndist <= PSX_MAX_DIST
@@ -262,7 +274,7 @@ int psx_darkfield_blur_f32(const float *I2DF, const float *DF, const float *I2, 
 int psx_darkfield_split_f32(const float *I, const double *DF_rad, double num, double den, double limit, float *I_nodf,
                             float *I_df, float *DF_px, void *prep, unsigned long long *words, int Nx, int Ny, void *stream);
 int psx_darkfield_blur_prepared_f32(const float *I2DF, const float *DF, const void *prep, const float *I2, float *out, int Nx,
-                                    int Ny, int R, unsigned *status, void *stream);   /* status: optional word, PSX_STATUS_NONFINITE (RF2:190-193) */
+                                    int Ny, int R, unsigned *status, int accumulate, void *stream);   /* status: optional word, PSX_STATUS_NONFINITE (RF2:190-193); accumulate: out += result (the chain's sum over energies, EXP:478-483) */
 int psx_darkfield_merge_f32(float *I, const float *a, const float *b, int64_t n, void *stream);
 int psx_repad_f32(const float *src, int margin_src, float *dst, int margin_dst, int Nx, int Ny, void *stream);
 

@@ -115,6 +115,7 @@ class Experiment:
         self._pending_means = []
         self._sums_pool, self._sums_next = None, 0
         self.darkFieldPropag = None
+        self._df_tmp = None           # dark-field half of the fused sample hop
         self._halo = None             # refraction gather halo of this experiment (exp_dict['refractionHalo']: 4 | 6 | 8 | 'auto')
 
     @classmethod
@@ -550,6 +551,55 @@ class Experiment:
         h = self.exp_dict['studyPixelSize'] * 1e-6
         return z / k_refraction(Energy) / (h * self.exp_dict['magnification']) / h
 
+    def _df_tables(self, DF, z, Energy, N):
+        """What fastRefractionDF derives from the width map alone (RF2:114-117,135,171-178): the map in pixels, the per-source
+        patch table of the re-splat, the largest patch half-size and the margin.  The map of a sample is static (thickness x a
+        scalar of the energy), so one position computes them per energy and the others find them here: the split pass
+        (0.10-0.20 ms at 4096^2) runs once per energy of an experiment, not once per position."""
+        ed = self.exp_dict
+        key = (float(Energy), float(z))
+        cache = self.__dict__.setdefault("_df_tab_cache", {})
+        hit = cache.get(key)
+        if hit is not None and hit[0] is DF:
+            cache[key] = cache.pop(key)
+            return hit[1:]
+        den = ed["studyPixelSize"] * 1e-6 * ed['magnification']      # RF2:114: DF * z / den, in that order
+        limit = N[0] / 4                                             # RF2:135
+        _, _, DF_px, prep, words = ops.darkfield_split(self._tmp[0], DF, z, den, limit)    # the split images are not used
+        known = self.mySampleofInterest.dark_field_max(DF) if hasattr(self.mySampleofInterest, "dark_field_max") else None
+        if known is not None and float(known) * z / den <= limit:
+            maxDF = maxDFc = float(known) * z / den
+        else:
+            maxDF, maxDFc = ops.darkfield_maxima(words)
+        margin2 = int(np.ceil(maxDF * 6))                            # RF2:117
+        R = int(round(1.5 * maxDFc)) + 1
+        limit = max(4, min(256, (16 << 30) // max(1, 12 * N[0] * N[1])))      # 12 bytes per pixel and entry, 16 GiB in all
+        while len(cache) >= limit:
+            cache.pop(next(iter(cache)))
+        cache[key] = (DF, DF_px, prep, R, margin2)
+        return DF_px, prep, R, margin2
+
+    def _refraction_df_fused(self, Ibs, both, z, Energy, DF, N, clamp, out=None, add=False):
+        """The chain's dark-field hop (EXP:469-473 -> RF2:88-196) without its intermediates: the reference forms the transmitted
+        (I, phi) pair (SAM:347-348), splits I by the width map (RF2:147-150), refracts both halves and re-splats the dark-field
+        half.  Here each halves come out of ONE refraction call straight from the thickness maps with the width map deciding
+        a source's half (psx_refract_split_f32: a tile is staged once for both): no (I, phi) pair (12 bytes per pixel written and read twice), no split images, and the tables
+        that depend on the width map alone come from _df_tables.  Same arithmetic per source pixel as the unfused calls."""
+        DF_px, prep, R, margin2 = self._df_tables(DF, z, Energy, N)
+        if margin2 < 1:      # a width map that is zero everywhere: the reference's margin-0 special case, through the literal path
+            Ias, phis = ops.transmit_rt(Ibs, 1.0, both)
+            img = self.refraction(Ias, phis, z, Energy, self.exp_dict['magnification'], DF, _mutate=False, _want_D=False)[0]
+            if out is not None:
+                ops.accumulate(out, img, 1.0, None, add=add)
+                return out
+            return img
+        m = max(margin2, 8)
+        dscale = self._dscale(z, Energy)
+        if self._df_tmp is None or tuple(self._df_tmp.shape) != N:
+            self._df_tmp = torch.empty(N, dtype=torch.float32, device=Ibs.device)
+        I2, I2DF = ops.refract_split(N, both, dscale, clamp, DF_px, margin=m, I_in=Ibs, outs=[self._tmp[0], self._df_tmp])
+        return ops.darkfield_blur_prepared(I2DF, DF_px, prep, I2, R, out=out, add=add)    # the NaN / inf scan (RF2:190-193) rides on its stores
+
     def _set_halo(self, N, clamp, air):
         """exp_dict['refractionHalo']: 'auto' (default), 4, 6 or 8 -- the gather halo of the refraction tiles is a speed knob whose
         best value depends on how far the rays of THIS experiment travel in study pixels (oversampling, distances, membrane).
@@ -677,9 +727,11 @@ class Experiment:
             both = ops.MaterialStack.concat(mem_phase, smp)
             if scattering:                                       # Lung / cylinder_beeds: fastRefractionDF (EXP:272-275)
                 DF = self.mySampleofInterest.dark_field(currentEnergy)
-                Ias, phis = ops.transmit_rt(Ibs, 1.0, both)
-                img, _, _ = self.refraction(Ias, phis, dOD, currentEnergy, ed['magnification'], DF, _mutate=False, _want_D=False)
-                self._add_intensity(accS, img, plate_att, add=not first)
+                if plate_att is None:         # the sum over energies (EXP:478-483) rides on the re-splat's store
+                    self._refraction_df_fused(Ibs, both, dOD, currentEnergy, DF, N, clamp, out=accS, add=not first)
+                else:
+                    img = self._refraction_df_fused(Ibs, both, dOD, currentEnergy, DF, N, clamp)
+                    self._add_intensity(accS, img, plate_att, add=not first)
             elif plate_att is None:
                 ops.refract(N, both, self._dscale(dOD, currentEnergy), clamp, I_in=Ibs, out=accS, add=not first)
             else:

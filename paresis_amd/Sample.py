@@ -189,7 +189,7 @@ class AnalyticalSample(Sample):
         return ops.MaterialStack(self.geometry_dev(), cphase=(-k * d * frac if phase else 0 * d),
                                  catt=(-2 * k * b * frac if att else 0 * b))
 
-    DF_CACHE_ENTRIES = 32      # width maps kept per sample (one per energy of a spectrum; a 50 kVp tube has ~25)
+    DF_CACHE_BYTES = 16 << 30  # width maps kept per sample: one float64 map per energy of a spectrum, least recently used out first
 
     def dark_field(self, energy):
         """newDf of setWaveRT (Sample.py:322-344): 2 delta sqrt(N_s) sqrt(ln(2/delta)+1) of the LAST scattering
@@ -201,6 +201,7 @@ class AnalyticalSample(Sample):
         cache = self.__dict__.setdefault("_df_cache", {})
         hit = cache.get(energy)
         if hit is not None and hit[0] is self.myGeometry and hit[1] == sig:
+            cache[energy] = cache.pop(energy)         # most recently used last: a spectrum walked cyclically keeps its maps
             return hit[2]
         newDf = 0
         for imat in range(len(self.myMaterials)):
@@ -214,9 +215,12 @@ class AnalyticalSample(Sample):
         if isinstance(newDf, torch.Tensor):
             # the map depends on the (static) thickness maps and the energy only: kept, with its maximum -- fastRefractionDF
             # sizes the displacement maps it returns by it (RF2:117) and would otherwise read it back on every call.
-            # Bounded: one float64 [Nx][Ny] map per energy adds up (25 energies at 4096^2 = 3.4 GB); the oldest entries go.
+            # Bounded by BYTES (25 energies at 4096^2 = 3.4 GB; at least 4 maps, at most 256): the least recently used go.  (Round 4
+            # evicted oldest-first at 32 entries: a spectrum of more than 32 energies then recomputed every map on every
+            # position -- ADVICE r4.)
             cache.pop(energy, None)
-            while len(cache) >= self.DF_CACHE_ENTRIES:
+            limit = max(4, min(256, self.DF_CACHE_BYTES // max(1, newDf.numel() * 8)))
+            while len(cache) >= limit:
                 cache.pop(next(iter(cache)))
             cache[energy] = (self.myGeometry, sig, newDf, float(newDf.max().item()))
         return newDf

@@ -17,7 +17,7 @@ PSX_MAX_SRC = 16
 PSX_SUM_SLOTS, PSX_SUM_STRIDE = 32, 16
 ENGINE_AUTO, ENGINE_ROCFFT, ENGINE_LDS = 0, 1, 2
 STATUS_NONFINITE = 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class PsxError(RuntimeError):
@@ -45,6 +45,8 @@ PROTOTYPES = {
     "psx_get_deterministic": (c_int, []),
     "psx_refract_f32": (c_int, [_vp, c_float, _vpp, _dp, _dp, c_int, _vp, _vp, c_float, c_int, _vp, _vp, _vp, c_int,
                                 c_int, c_int, c_double, c_double, c_double, _vp, _vp, _vp]),
+    "psx_refract_split_f32": (c_int, [_vp, _vp, c_float, _vpp, _dp, _dp, c_int, _vp, _vp, _vp, c_float, c_int, c_int, c_int,
+                                      c_int, c_double, c_double, c_double, _vp, _vp, _vp]),
     "psx_refract_multi_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "psx_refract_multi_f32": (c_int, [_vp, c_float, _vpp, _dp, _dp, c_int, _vp, _vpp, c_float, c_int, _vp, _vp, _vp,
                                       c_int, c_int, c_int, _dp, c_int, c_double, c_double, _vp, _vp, _vp]),
@@ -75,7 +77,7 @@ PROTOTYPES = {
     "psx_darkfield_workspace_bytes": (c_size_t, [c_int, c_int]),
     "psx_darkfield_blur_f32": (c_int, [_vp, _vp, _vp, _vp, c_int, c_int, c_int, _vp, _vp]),
     "psx_darkfield_split_f32": (c_int, [_vp, _vp, c_double, c_double, c_double, _vp, _vp, _vp, _vp, _vp, c_int, c_int, _vp]),
-    "psx_darkfield_blur_prepared_f32": (c_int, [_vp, _vp, _vp, _vp, _vp, c_int, c_int, c_int, _vp, _vp]),
+    "psx_darkfield_blur_prepared_f32": (c_int, [_vp, _vp, _vp, _vp, _vp, c_int, c_int, c_int, _vp, c_int, _vp]),
     "psx_darkfield_merge_f32": (c_int, [_vp, _vp, _vp, c_int64, _vp]),
     "psx_repad_f32": (c_int, [_vp, c_int, _vp, c_int, c_int, c_int, _vp]),
     "psx_membrane_f32": (c_int, [_dp, _dp, _dp, c_int64, c_int, c_int, c_int, c_int, c_double, c_int, _vp, _vp]),

@@ -150,7 +150,7 @@ constexpr int DT = 32;
 __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict__ I2DF, const float *__restrict__ DF,
                                                          const float2 *__restrict__ prep, const float *__restrict__ I2,
                                                          float *__restrict__ out, int Nx, int Ny, int R, int tiles_y,
-                                                         unsigned *status) {
+                                                         unsigned *status, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) char sdf[];
     const int W = DT + 2 * R;
     float4 *swc = reinterpret_cast<float4 *>(sdf);                 // [W][W] (weight, coefficient, half-size, -)
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict
         const int64_t p = (int64_t)i * Ny + j;
         const float v = acc + (I2 ? I2[p] : 0.f);
         bad |= !(fabsf(v) <= 3.0e38f);
-        out[p] = v;
+        out[p] = accumulate ? out[p] + v : v;            // accumulate: the chain's sum over energies (EXP:478-483) rides on the store
     }
     if (status && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, PSX_STATUS_NONFINITE);
 }
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void k_df_gather_tiled(const float *__restrict
 __global__ __launch_bounds__(256) void k_df_gather_banded(const float *__restrict__ I2DF, const float *__restrict__ DF,
                                                           const float2 *__restrict__ prep, const float *__restrict__ I2,
                                                           float *__restrict__ out, int Nx, int Ny, int R, int band, int tiles_y,
-                                                          unsigned *status) {
+                                                          unsigned *status, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) char sdf[];
     const int W = DT + 2 * R;
     float4 *swc = reinterpret_cast<float4 *>(sdf);                 // [band][W] (weight, coefficient, half-size, 0)
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void k_df_gather_banded(const float *__restric
             const int64_t p = (int64_t)i * Ny + j;
             const float v = acc[k] + (I2 ? I2[p] : 0.f);
             bad |= !(fabsf(v) <= 3.0e38f);
-            out[p] = v;
+            out[p] = accumulate ? out[p] + v : v;
         }
     }
     if (status && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(status, PSX_STATUS_NONFINITE);
@@ -412,11 +412,12 @@ __global__ __launch_bounds__(256) void k_repad(const float *__restrict__ src, in
 
 // wide patches: bands of source rows through LDS (64 KiB per workgroup: two workgroups per CU)
 int launch_banded(const float *I2DF, const float *DF, const float2 *prep, const float *I2, float *out, int Nx, int Ny, int R,
-                  unsigned *status, hipStream_t st) {
+                  unsigned *status, int accumulate, hipStream_t st) {
     const int W = DT + 2 * R;
     const int band = (int)std::min<size_t>((size_t)(DT + 2 * R), (64 * 1024) / (sizeof(float4) * (size_t)W));
     if (band < 1) {      // a window row does not fit the budget (R > 2032): the plain gather from global memory
         const int64_t n = (int64_t)Nx * Ny;
+        PSX_REQUIRE(!accumulate, "dark-field re-splat: patches of %d pixels cannot be accumulated in place", 2 * R + 1);
         PSX_TIMED("k_df_gather", st, k_df_gather<<<ew_grid(n, 256), 256, 0, st>>>(I2DF, DF, prep, I2, out, Nx, Ny, R));
         if (int rc = launch_check("k_df_gather")) return rc;
         return status ? psx_status_scan_f32(out, n, status, (void *)st) : 0;
@@ -427,7 +428,7 @@ int launch_banded(const float *I2DF, const float *DF, const float2 *prep, const 
         PSX_HIP(hipFuncSetAttribute((const void *)k_df_gather_banded, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     const int tiles_x = (int)cdiv(Nx, DT), tiles_y = (int)cdiv(Ny, DT);
     PSX_TIMED("k_df_gather", st, k_df_gather_banded<<<tiles_x * tiles_y, 256, lds, st>>>(I2DF, DF, prep, I2, out, Nx, Ny, R, band,
-                                                                                         tiles_y, status));
+                                                                                         tiles_y, status, accumulate));
     return launch_check("k_df_gather");
 }
 
@@ -464,7 +465,7 @@ int psx_repad_f32(const float *src, int margin_src, float *dst, int margin_dst, 
 }
 
 int psx_darkfield_blur_prepared_f32(const float *I2DF, const float *DF, const void *prep, const float *I2, float *out, int Nx,
-                                    int Ny, int R, unsigned *status, void *stream) {
+                                    int Ny, int R, unsigned *status, int accumulate, void *stream) {
     PSX_REQUIRE(I2DF && DF && out && prep && Nx > 0 && Ny > 0 && R >= 0, "psx_darkfield_blur_prepared_f32: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)Nx * Ny;
@@ -472,11 +473,11 @@ int psx_darkfield_blur_prepared_f32(const float *I2DF, const float *DF, const vo
     if (lds <= 60 * 1024) {
         const int tiles_x = (int)cdiv(Nx, DT), tiles_y = (int)cdiv(Ny, DT);
         PSX_TIMED("k_df_gather", st, k_df_gather_tiled<<<tiles_x * tiles_y, 256, lds, st>>>(I2DF, DF, (const float2 *)prep, I2, out,
-                                                                                            Nx, Ny, R, tiles_y, status));
+                                                                                            Nx, Ny, R, tiles_y, status, accumulate));
         return launch_check("k_df_gather");
     }
     (void)n;
-    return launch_banded(I2DF, DF, (const float2 *)prep, I2, out, Nx, Ny, R, status, st);
+    return launch_banded(I2DF, DF, (const float2 *)prep, I2, out, Nx, Ny, R, status, accumulate, st);
 }
 
 size_t psx_darkfield_workspace_bytes(int Nx, int Ny) { return sizeof(float2) * (size_t)(Nx > 0 ? Nx : 0) * (size_t)(Ny > 0 ? Ny : 0); }
@@ -491,10 +492,10 @@ int psx_darkfield_blur_f32(const float *I2DF, const float *DF, const float *I2, 
     if (lds <= 60 * 1024) {          // patches of up to 2 R + 1 = 29 pixels; wider ones take the plain gather
         const int tiles_x = (int)cdiv(Nx, DT), tiles_y = (int)cdiv(Ny, DT);
         PSX_TIMED("k_df_gather", st, k_df_gather_tiled<<<tiles_x * tiles_y, 256, lds, st>>>(I2DF, DF, (const float2 *)workspace, I2,
-                                                                                            out, Nx, Ny, R, tiles_y, nullptr));
+                                                                                            out, Nx, Ny, R, tiles_y, nullptr, 0));
         return launch_check("k_df_gather");
     }
-    return launch_banded(I2DF, DF, (const float2 *)workspace, I2, out, Nx, Ny, R, nullptr, st);
+    return launch_banded(I2DF, DF, (const float2 *)workspace, I2, out, Nx, Ny, R, nullptr, 0, st);
 }
 
 }  // extern "C"

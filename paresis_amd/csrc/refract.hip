@@ -82,6 +82,12 @@ struct FarRay {
 
 struct RefractArgs {
     const float *I_in;
+    // optional source split (psx_refract_split_f32): the call's TWO images are the refractions of the sources where mask == 0
+    // (image 0) and where mask != 0 (image 1) -- fastRefractionDF's split by its width map (RF2:147-150).  The tile is staged
+    // once; each source's side rides in the lowest mantissa bit of its staged float64 phase (1e-16 of the phase: the LDS
+    // budget of two workgroups per CU has no room for a flag array) and each half runs the deposit loop only if the window
+    // holds a source of its side.
+    const float *mask;
     float I0;
     Mats m;
     const double *phi_in;
@@ -138,7 +144,13 @@ __device__ __forceinline__ int xcd_tile(int b, int nt) {
     return x * q + (x < r ? x : r) + (b >> 3);
 }
 
-template <class G, int NM, bool HAS_I, bool HAS_PHI>
+// the side of a split call's source in the lowest mantissa bit of its staged phase (see RefractArgs::mask)
+__device__ __forceinline__ double with_side(double ph, unsigned side, bool split) {
+    if (!split) return ph;
+    return __longlong_as_double((__double_as_longlong(ph) & ~1ll) | (long long)side);
+}
+
+template <class G, int NM, bool HAS_I, bool HAS_PHI, bool SPLITC = false>       // SPLITC: a split call (RefractArgs::mask)
 __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     constexpr int TH = G::TH, TW = G::TW, H = G::H, SR = G::SR, SC = G::SC, GR = G::GR, GC = G::GC, NTHREADS = G::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -159,10 +171,11 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     // Addresses are clamped into the image so every load is unconditional (they can all be in flight together);
     // out-of-image entries are zeroed afterwards and never used as sources.
     constexpr int SITERS = (SR * SC + NTHREADS - 1) / NTHREADS;
-    unsigned imax = 0u;
+    unsigned imax = 0u, imax1 = 0u;       // largest staged |intensity| (of side 0 / side 1 of a split call)
     if (tid == 0) {
         *sfar = 0u;
-        *smax = 0u;
+        smax[0] = 0u;
+        smax[1] = 0u;
     }
     __syncthreads();
     // Tiles whose staged window (tile + halo + stencil ring) lies inside the image -- all but the outermost ring of
@@ -180,6 +193,7 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
             float t[U][NM > 0 ? NM : 1], Iin[U];
             double phin[U];
             bool ok[U];
+            unsigned sides = 0u;          // bit u: the side of staged pixel u (one register, not one per pixel)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int idx = min((it0 + u) * NTHREADS + tid, SR * SC - 1);   // the last pass re-stages the last pixel
@@ -192,6 +206,7 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
                 for (int m = 0; m < NM; ++m) t[u][m] = a.m.T[m][p];
                 Iin[u] = HAS_I ? a.I_in[p] : 1.f;
                 phin[u] = HAS_PHI ? a.phi_in[p] : 0.0;
+                if constexpr (SPLITC) sides |= (a.mask[p] != 0.f ? 1u : 0u) << u;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -208,10 +223,15 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
                 }
                 float I = a.I0 * Iin[u];
                 if (NM > 0) I *= exp2f(la2);
-                sphi[idx] = ok[u] ? ph : 0.0;
+                const unsigned side = (sides >> u) & 1u;
+                sphi[idx] = with_side(ok[u] ? ph : 0.0, side, SPLITC);
                 if (sr >= 1 && sr <= GR && sc >= 1 && sc <= GC) {
                     sI[(sr - 1) * GC + (sc - 1)] = ok[u] ? I : 0.f;
-                    if (ok[u]) imax = max(imax, __float_as_uint(fabsf(I)));   // NaN/inf sort above every finite value
+                    if (ok[u]) {                                              // NaN/inf sort above every finite value
+                        const unsigned b = __float_as_uint(fabsf(I));
+                        imax = max(imax, side ? 0u : b);
+                        imax1 = max(imax1, side ? b : 0u);
+                    }
                 }
             }
         }
@@ -223,6 +243,7 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
         constexpr int NP = GR * GC / NTHREADS;
         float t[NP + 1][NM > 0 ? NM : 1], Iin[NP + 1];
         double phin[NP + 1];
+        unsigned sides = 0u;
         // ring pixel of this thread (threads < 2*SC + 2*GR): top row, bottom row, left column, right column
         const int rt = tid;
         const bool ring = rt < 2 * SC + 2 * GR;
@@ -237,6 +258,9 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
             for (int m = 0; m < NM; ++m) t[u][m] = a.m.T[m][p];
             Iin[u] = (HAS_I && u < NP) ? a.I_in[p] : 1.f;
             phin[u] = HAS_PHI ? a.phi_in[p] : 0.0;
+            if constexpr (SPLITC) {
+                if (u < NP) sides |= (a.mask[p] != 0.f ? 1u : 0u) << u;
+            }
         }
 #pragma unroll
         for (int u = 0; u <= NP; ++u) {
@@ -251,9 +275,12 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
             if (u < NP) {
                 float I = a.I0 * Iin[u];
                 if (NM > 0) I *= exp2f(la2);
-                sphi[(1 + idx / GC) * SC + 1 + (idx & (GC - 1))] = ph;
+                const unsigned side = (sides >> u) & 1u;
+                sphi[(1 + idx / GC) * SC + 1 + (idx & (GC - 1))] = with_side(ph, side, SPLITC);
                 sI[idx] = I;
-                imax = max(imax, __float_as_uint(fabsf(I)));
+                const unsigned b = __float_as_uint(fabsf(I));
+                imax = max(imax, side ? 0u : b);
+                imax1 = max(imax1, side ? b : 0u);
             } else if (ring) {
                 sphi[rsr * SC + rsc] = ph;
             }
@@ -269,12 +296,19 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     }
     PSX_RSTAMP(1);
     for (int idx = tid; idx < ACC; idx += NTHREADS) sacc[idx] = 0ll;
-    for (int o = 32; o > 0; o >>= 1) imax = max(imax, (unsigned)__shfl_xor((int)imax, o));
-    if ((tid & 63) == 0) atomicMax(smax, imax);
+    for (int o = 32; o > 0; o >>= 1) {
+        imax = max(imax, (unsigned)__shfl_xor((int)imax, o));
+        imax1 = max(imax1, (unsigned)__shfl_xor((int)imax1, o));
+    }
+    if ((tid & 63) == 0) {
+        atomicMax(&smax[0], imax);
+        if constexpr (SPLITC) atomicMax(&smax[1], imax1);
+    }
     __syncthreads();
     PSX_RSTAMP(2);
     // fixed-point scale of this tile: one unit = 2^-30 of (the power of two above) the largest staged intensity
-    const unsigned mbits = *smax;
+    const unsigned mside0 = smax[0], mside1 = smax[1];
+    const unsigned mbits = max(mside0, mside1);
     const bool finite_in = mbits < 0x7f800000u;
     const int sexp = min(120, max(-120, 30 - (mbits ? ilogbf(__uint_as_float(mbits)) + 1 : 0)));
     const float fscale_f = finite_in ? ldexpf(1.f, sexp) : 0.f;     // power of two: scaling a float by it is exact
@@ -324,6 +358,16 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     const double hscale = 0.5 * dscale;
     float *const I_out = a.I_out[d];
     FarRay *const far_list = a.far_list + ((size_t)d * nt + tile) * (TH * TW);
+    if (SPLITC && (d == 0 ? mside0 : mside1) == 0u) {    // split call: no source of this side in the window (uniform)
+        if (!a.accumulate)
+            for (int idx = tl; idx < TH * TW; idx += NTHREADS) {
+                const int tr = idx / TW, tc = idx - tr * TW;
+                const int i = r0 + tr, j = c0 + tc;
+                if (i < a.Nx && j < a.Ny) I_out[(int64_t)i * a.Ny + j] = 0.f;
+            }
+        if (tl == 0) a.far_count[(size_t)d * nt + tile] = 0u;
+        continue;                                        // the accumulator and the list counter are untouched: no barrier owed
+    }
     // D = gradient(phi) * dscale at staged pixel `sidx` (image pixel (i, j)), float64 differencing, float32 result
     auto displacement = [&](auto inside_tag, int i, int j, int sidx, bool inside, float &dx, float &dy) __attribute__((always_inline)) {
         constexpr bool IN = decltype(inside_tag)::value && (GR * GC) % NTHREADS == 0;
@@ -371,6 +415,8 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
         const bool core = gr >= H && gr < H + TH && gc >= H && gc < H + TW;
         float I = live ? sI[idx] : 0.f;                              // 0 outside the image
         const int sidx = (gr + 1) * SC + (gc + 1);                   // this pixel in the staged phase tile
+        if constexpr (SPLITC)                                        // split call: only the sources of side d
+            I = (reinterpret_cast<const unsigned *>(sphi)[2 * sidx] & 1u) == (unsigned)d ? I : 0.f;
         float dx, dy;
         displacement(inside_tag, i, j, sidx, inside, dx, dy);
         // RF2:59-60 zeroes |D| < 1e-12.  For the deposit that is a no-op in float32 -- such a ray puts weight 1.0f on its
@@ -509,6 +555,12 @@ __global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     refract_near_body<G, NM, HAS_I, HAS_PHI>(a);
 }
 
+// the split call's own instantiations (phase from the thickness maps only): the plain kernels carry none of its tests
+template <class G, int NM, bool HAS_I>
+__global__ __launch_bounds__(G::NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_refract_near_split(RefractArgs a) {
+    refract_near_body<G, NM, HAS_I, false, true>(a);
+}
+
 // A batch of refractions in one launch -- the energies of a detector bin (EXP:448-486): refraction e = blockIdx.y has its own
 // argument block (input intensity or uniform I0, coefficients, displacement scale, output image, far-ray lists) in the
 // kernel-argument segment, which holds REFRACT_TAB of them; the kernels read theirs in place (scalar loads at a computed
@@ -527,7 +579,7 @@ template <int NM>
 __device__ __forceinline__ RefractArgs one_distance_block(const RefractTab &t, int e) {
     const RefractArgs &s = t.e[e];
     RefractArgs a;
-    a.I_in = s.I_in; a.I0 = s.I0; a.phi_in = nullptr;
+    a.I_in = s.I_in; a.mask = nullptr; a.I0 = s.I0; a.phi_in = nullptr;
     a.m.n = NM;
 #pragma unroll
     for (int i = 0; i < (NM > 0 ? NM : 1); ++i) {
@@ -837,12 +889,24 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
     auto launch = [&](auto nm, auto hi, auto hp) -> int {
         constexpr int NM = decltype(nm)::value;
         constexpr bool HI = decltype(hi)::value, HP = decltype(hp)::value;
-        static std::atomic<unsigned long long> attr_mask{0};
-        if (first_on_device(attr_mask))
-            PSX_HIP(hipFuncSetAttribute((const void *)k_refract_near<G, NM, HI, HP>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
-        PSX_TIMED("k_refract_near", st,
-                  k_refract_near<G, NM, HI, HP><<<a.tiles_x * a.tiles_y, G::NT, G::LDS, st>>>(a));
+        if constexpr (!HP && NM > 0) {
+            if (a.mask) {
+                static std::atomic<unsigned long long> attr_mask_s{0};
+                if (first_on_device(attr_mask_s))
+                    PSX_HIP(hipFuncSetAttribute((const void *)k_refract_near_split<G, NM, HI>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+                PSX_TIMED("k_refract_near", st,
+                          k_refract_near_split<G, NM, HI><<<a.tiles_x * a.tiles_y, G::NT, G::LDS, st>>>(a));
+            }
+        }
+        if (!a.mask) {
+            static std::atomic<unsigned long long> attr_mask{0};
+            if (first_on_device(attr_mask))
+                PSX_HIP(hipFuncSetAttribute((const void *)k_refract_near<G, NM, HI, HP>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+            PSX_TIMED("k_refract_near", st,
+                      k_refract_near<G, NM, HI, HP><<<a.tiles_x * a.tiles_y, G::NT, G::LDS, st>>>(a));
+        }
         if (int rc = launch_check("k_refract_near")) return rc;
         const int nlists = a.tiles_x * a.tiles_y * a.ndist;
         const int fgrid = (nlists + FAR_LISTS - 1) / FAR_LISTS;
@@ -931,10 +995,11 @@ int psx_refract_set_halo(int halo) {
     return 0;
 }
 
-int psx_refract_multi_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,
-                          int nmat, const double *phi_in, float *const *I_out, float out_scale, int accumulate,
-                          float *Dx_out, float *Dy_out, float *I_mut, int Nx, int Ny, int margin, const double *dscale,
-                          int ndist, double clamp_x, double clamp_y, unsigned *status, void *workspace, void *stream) {
+static int refract_multi_impl(const float *I_in, const float *mask, float I0, const float *const *T,
+                              const double *cphase, const double *catt, int nmat, const double *phi_in, float *const *I_out,
+                              float out_scale, int accumulate, float *Dx_out, float *Dy_out, float *I_mut, int Nx, int Ny,
+                              int margin, const double *dscale, int ndist, double clamp_x, double clamp_y, unsigned *status,
+                              void *workspace, void *stream) {
     PSX_REQUIRE(I_out != nullptr && dscale != nullptr && workspace != nullptr, "psx_refract_multi_f32: null outputs, distances or workspace");
     PSX_REQUIRE(ndist >= 1 && ndist <= PSX_MAX_DIST, "psx_refract_multi_f32: %d distances, 1..%d supported per call", ndist, PSX_MAX_DIST);
     PSX_REQUIRE(Nx >= 3 && Ny >= 3, "psx_refract_multi_f32: grid %dx%d too small for the edge_order=2 gradient", Nx, Ny);
@@ -956,7 +1021,7 @@ int psx_refract_multi_f32(const float *I_in, float I0, const float *const *T, co
         a.dscale[d] = dscale[e];
     }
     a.ndist = ndist;
-    a.I_in = I_in; a.I0 = I0; a.phi_in = phi_in; a.out_scale = out_scale; a.accumulate = accumulate;
+    a.I_in = I_in; a.mask = mask; a.I0 = I0; a.phi_in = phi_in; a.out_scale = out_scale; a.accumulate = accumulate;
     a.Dx_out = Dx_out; a.Dy_out = Dy_out; a.I_mut = I_mut; a.Nx = Nx; a.Ny = Ny; a.margin = margin;
     a.clamp_xf = (float)clamp_x; a.clamp_yf = (float)clamp_y; a.status = status; a.stamps = g_stamps;
     if (Dx_out) {
@@ -967,6 +1032,26 @@ int psx_refract_multi_f32(const float *I_in, float I0, const float *const *T, co
     return g_refract_geometry == 1   ? launch_refract<GeoWide>(a, I_in, phi_in, nmat, workspace, st)
            : g_refract_geometry == 2 ? launch_refract<GeoMid>(a, I_in, phi_in, nmat, workspace, st)
                                      : launch_refract<GeoSmall>(a, I_in, phi_in, nmat, workspace, st);
+}
+
+int psx_refract_multi_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,
+                          int nmat, const double *phi_in, float *const *I_out, float out_scale, int accumulate,
+                          float *Dx_out, float *Dy_out, float *I_mut, int Nx, int Ny, int margin, const double *dscale,
+                          int ndist, double clamp_x, double clamp_y, unsigned *status, void *workspace, void *stream) {
+    return refract_multi_impl(I_in, nullptr, I0, T, cphase, catt, nmat, phi_in, I_out, out_scale, accumulate, Dx_out, Dy_out,
+                              I_mut, Nx, Ny, margin, dscale, ndist, clamp_x, clamp_y, status, workspace, stream);
+}
+
+int psx_refract_split_f32(const float *I_in, const float *mask, float I0, const float *const *T, const double *cphase,
+                          const double *catt, int nmat, const double *phi_in, float *I_out_zero, float *I_out_nonzero,
+                          float out_scale, int accumulate, int Nx, int Ny, int margin, double dscale, double clamp_x,
+                          double clamp_y, unsigned *status, void *workspace, void *stream) {
+    PSX_REQUIRE(I_out_zero != nullptr && I_out_nonzero != nullptr && mask != nullptr, "psx_refract_split_f32: null output or mask");
+    PSX_REQUIRE(phi_in == nullptr && nmat > 0, "psx_refract_split_f32: the phase comes from the thickness maps (nmat > 0, phi_in = NULL)");
+    float *const outs[2] = {I_out_zero, I_out_nonzero};
+    const double ds[2] = {dscale, dscale};
+    return refract_multi_impl(I_in, mask, I0, T, cphase, catt, nmat, phi_in, outs, out_scale, accumulate, nullptr, nullptr, nullptr,
+                              Nx, Ny, margin, ds, 2, clamp_x, clamp_y, status, workspace, stream);
 }
 
 int psx_refract_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,
@@ -1037,7 +1122,7 @@ int psx_refract_batch_f32(int n, const float *const *I_in, const float *I0, cons
             if (int rc = pack_mats(a.m, T, cphase ? cphase + (size_t)e * nmat : nullptr, catt ? catt + (size_t)e * nmat : nullptr, nmat))
                 return rc;
             a.ndist = 1;
-            a.I_in = has_I ? I_in[e] : nullptr; a.I0 = I0 ? I0[e] : 1.f;
+            a.I_in = has_I ? I_in[e] : nullptr; a.mask = nullptr; a.I0 = I0 ? I0[e] : 1.f;
             for (int d = 0; d < PSX_MAX_DIST; ++d) {
                 a.I_out[d] = I_out[e];
                 a.dscale[d] = dscale[e];

@@ -316,6 +316,33 @@ def refract(shape, mats, dscale, clamp, margin=15, I_in=None, I0=1.0, phi_in=Non
     return out, Dx, Dy
 
 
+def refract_split(shape, mats, dscale, clamp, mask, margin=15, I_in=None, I0=1.0, phi_in=None, outs=None, out_scale=1.0,
+                  add=False):
+    """fastRefractionDF's split and its two refractions (RF2:147-154) in one call (psx_refract_split_f32): returns
+    (refraction of the sources where mask == 0, refraction of the sources where mask != 0); mask: float32 [Nx][Ny]."""
+    mats = _mats(mats)
+    Nx, Ny = int(shape[0]), int(shape[1])
+    _need(mask, torch.float32, "mask", (Nx, Ny))
+    dev = mask.device
+    if I_in is not None:
+        _need(I_in, torch.float32, "I_in", (Nx, Ny))
+    if phi_in is not None:
+        _need(phi_in, torch.float64, "phi_in", (Nx, Ny))
+    if outs is None:
+        if add:
+            raise PsxError("add=True needs existing output images")
+        outs = [torch.empty((Nx, Ny), dtype=torch.float32, device=dev) for _ in range(2)]
+    for o in outs:
+        _need(o, torch.float32, "I_out", (Nx, Ny))
+    ws = _workspace(dev, lib().psx_refract_multi_workspace_bytes(Nx, Ny, 2))
+    T, cp, ca, n = mats.cargs((Nx, Ny))
+    check(lib().psx_refract_split_f32(_ptr(I_in), _ptr(mask), c_float(I0), T, cp, ca, n, _ptr(phi_in), _ptr(outs[0]),
+                                      _ptr(outs[1]), c_float(out_scale), 1 if add else 0, Nx, Ny, int(margin), c_double(dscale),
+                                      c_double(clamp[0]), c_double(clamp[1]), _ptr(status_word(dev)), _ptr(ws), _stream()),
+          "psx_refract_split_f32")
+    return outs[0], outs[1]
+
+
 def refract_batch(shape, mats, dscales, clamp, margin=15, I_in=None, I0=None, outs=None, out_scale=1.0, add=False):
     """Several refractions over the SAME thickness maps in one launch per kernel (the energies of a detector bin,
     EXP:448-486): mats[e] (same maps, own coefficients), dscales[e], I_in[e] (all or None) or the uniform I0[e], outs[e].
@@ -447,15 +474,20 @@ def darkfield_maxima(words):
     return float(w[0]), float(w[1])
 
 
-def darkfield_blur_prepared(I2DF, DF, prep, I2, R, scan=True):
+def darkfield_blur_prepared(I2DF, DF, prep, I2, R, scan=True, out=None, add=False):
     """darkfield_blur() on the patch table darkfield_split() made from the width map; scan: NaN / inf in the result raise
-    the device status word (RF2:190-193), checked by the kernel that stores it."""
+    the device status word (RF2:190-193), checked by the kernel that stores it.  out / add: the result is stored into (added
+    to) an existing image -- the chain's sum over energies without a pass of its own."""
     _need(I2DF, torch.float32, "I2DF")
     _need(DF, torch.float32, "DF", I2DF.shape)
-    out = torch.empty_like(I2DF)
+    if out is None:
+        if add:
+            raise PsxError("add=True needs an existing output image")
+        out = torch.empty_like(I2DF)
+    _need(out, torch.float32, "out", I2DF.shape)
     Nx, Ny = I2DF.shape
     check(lib().psx_darkfield_blur_prepared_f32(_ptr(I2DF), _ptr(DF), _ptr(prep), _ptr(I2), _ptr(out), Nx, Ny, int(R),
-                                                _ptr(status_word(I2DF.device)) if scan else None, _stream()),
+                                                _ptr(status_word(I2DF.device)) if scan else None, 1 if add else 0, _stream()),
           "psx_darkfield_blur_prepared_f32")
     return out
 

@@ -4,7 +4,7 @@ synthesis (seeded offsets, sphere splat on the GPU) + the image-formation chain 
 BASELINE.json config 4 is 64 such positions over 8 GPUs (8 per GPU, no data-path collective).
 
     python tools/time_positions.py [N] [NPOS] [--poly 25]      # --poly E: a tube spectrum of E energies (polychromatic position)
-                                   [--float-atomics] [--halo 4|6|8] [--sim RT|Fresnel] [--scatter]
+                                   [--float-atomics] [--halo 4|6|8] [--sim RT|Fresnel] [--scatter [--thin F]]
 """
 import ctypes
 import os
@@ -22,7 +22,7 @@ def _opt(name, default=None):
 
 
 _skip = set()
-for _o in ('--poly', '--halo', '--sim'):
+for _o in ('--poly', '--halo', '--sim', '--thin'):
     if _o in sys.argv:
         _skip.add(sys.argv.index(_o) + 1)
 _args = [a for i, a in enumerate(sys.argv) if i > 0 and not a.startswith('--') and i not in _skip]
@@ -42,6 +42,8 @@ for sim in ([_opt('--sim')] if _opt('--sim') else ["Fresnel", "RT"]):
         exp.exp_dict['refractionHalo'] = int(_opt('--halo'))
     if '--scatter' in sys.argv:               # the sample as a scattering one (SAM:322-344): fastRefractionDF on the chain's sample hop
         exp.mySampleofInterest.myName = 'cylinder_beeds'
+        if _opt('--thin'):                    # ... of 1/F the thickness: the dark-field width goes with its square root
+            exp.mySampleofInterest.myGeometry = (np.asarray(exp.mySampleofInterest.myGeometry) / float(_opt('--thin'))).astype(np.float32)
 
     def position(p):
         place(p)
