@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--engine", default="auto", choices=["auto", "rocfft", "lds"])
-    ap.add_argument("--halo", type=int, default=4, choices=[4, 6, 8], help="refraction gather halo (speed knob)")
+    ap.add_argument("--halo", type=int, default=4, choices=[4, 6, 8, 12, 16], help="refraction gather halo (speed knob)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     ap.add_argument("--overlap", action="store_true",
                     help="issue the step's refractions on a second stream (no gain since the Fresnel call became two long "
@@ -906,7 +906,8 @@ def run_configs(a, dev):
         # displacements are four times as many pixels as at oversampling 2 and the 8-pixel halo pays (16384^2: tile kernel
         # 4.3 -> 5.5 ms, far-ray replay 5.7 -> 3.0 ms); the headline's 4-pixel halo elsewhere
         # (round 4: picked by measurement -- ops.tune_refract_halo times the step's own refraction call with each halo)
-        halo, halo_ms = ops.tune_refract_halo(lambda: ops.refract_multi((N, N), rt_mats, dsc, (N, N), I0=I0, outs=refr))
+        halo, halo_ms = ops.tune_refract_halo(lambda: ops.refract_multi((N, N), rt_mats, dsc, (N, N), I0=I0, outs=refr),
+                                              halos=(4, 6, 8, 12, 16) if ov >= 4 else (4, 6, 8))
         det = ops.DetectorPlan(N, N, ov, n, n, sig_src, sig_psf) if detect else None
         dets = [torch.empty((n, n), dtype=torch.float32, device=dev) for _ in range(2 * len(zs))] if detect else []
         amp = float(np.sqrt(I0))

@@ -106,7 +106,7 @@ int psx_accumulate_many_f32(float *acc, const float *const *imgs, const float *s
  *                   also the scratch words of the order-independent replay), caller-owned, no initial state needed.
  */
 size_t psx_refract_workspace_bytes(int Nx, int Ny);
-/* Gather halo of the tile kernel: 4, 6 or 8 pixels (default 4); a setting of the CALLING HOST THREAD (one thread per GPU).  A tile gathers every ray of its window (tile + halo)
+/* Gather halo of the tile kernel: 4, 6, 8, 12 or 16 pixels (default 4; the two widest for grids whose rays travel far in study pixels); a setting of the CALLING HOST THREAD (one thread per GPU).  A tile gathers every ray of its window (tile + halo)
  * that lands in it, however long; what remains for the slower far-ray replay are the shares whose source lies outside
  * the window of the target's tile.  A pure speed knob: results are identical up to the float-atomics order of those. */
 int psx_refract_set_halo(int halo);

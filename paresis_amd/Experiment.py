@@ -614,8 +614,9 @@ class Experiment:
                 # may differ between ranks and between runs, so a reproducible experiment takes it from a rule instead: what
                 # the timings of the fixed-point replay picked on the membranes measured so far (DESIGN.md section 4.3,
                 # gpurun_out/r5s1, r5s3: a replayed share costs 1.75x a float atomic, which moves the optimum one step up --
-                # 6 px at oversampling <= 2, 8 px from oversampling 4 on, where rays travel twice as many study pixels).
-                want = 8 if int(self.exp_dict.get('overSampling', 1)) >= 4 else 6
+                # 6 px at oversampling <= 2; 12 px from oversampling 4 on, where rays travel twice as many study pixels:
+                # 16384^2, 4 distances: 14.4 / 12.2 / 10.6 / 9.5 / 10.1 ms with 4 / 6 / 8 / 12 / 16 px, gpurun_out/r5s20).
+                want = 12 if int(self.exp_dict.get('overSampling', 1)) >= 4 else 6
             if want == 'auto':
                 ed = self.exp_dict
                 E = self.mySource.mySpectrum[-1][0]
@@ -623,7 +624,8 @@ class Experiment:
                 stack = ops.MaterialStack.concat(air.stack_rt(E, phase=False) if air is not None else None, self.myMembrane.stack_rt(E))
                 out = self._tmp[0]
                 self._halo, self._halo_times = ops.tune_refract_halo(
-                    lambda: ops.refract(N, stack, self._dscale(z, E), clamp, I0=1.0, out=out))
+                    lambda: ops.refract(N, stack, self._dscale(z, E), clamp, I0=1.0, out=out),
+                    halos=(4, 6, 8, 12, 16) if int(ed.get('overSampling', 1)) >= 4 else (4, 6, 8))
                 ops.check_status(out.device, "refraction halo tuning")
             else:
                 self._halo = int(want)

@@ -66,6 +66,25 @@ using GeoSmall = Geo<56, 56, 4, 1024>;   // 80 KiB of LDS: two workgroups per CU
 // threads: 134 us per 4096^2 launch, 1024: 123 us)
 using GeoMid = Geo<52, 52, 6, 1024>;     // 76 KiB; 1.51 evaluations
 using GeoWide = Geo<48, 48, 8, 1024>;    // 73 KiB: two workgroups per CU (one stages while the other deposits); 1.78 evaluations
+// Round 5 (VERDICT r4 item 3 i): the 64 x 64 gather window with 12- and 16-pixel halos, for grids whose rays travel far in study
+// pixels (oversampling >= 4): 2.56 and 4 evaluations per pixel against fewer replayed shares.  Measured in DESIGN.md section 4.3.
+using GeoH12 = Geo<40, 40, 12, 1024>;    // 66 KiB
+using GeoH16 = Geo<32, 32, 16, 1024>;    // 59 KiB
+// one switch over the geometry of the calling thread (psx_refract_set_halo)
+#define PSX_GEO_DISPATCH(G_, ...)                                             \
+    [&]() {                                                                   \
+        switch (g_refract_geometry) {                                         \
+            case 1: { using G_ = GeoWide; return __VA_ARGS__; }               \
+            case 2: { using G_ = GeoMid; return __VA_ARGS__; }                \
+            case 3: { using G_ = GeoH12; return __VA_ARGS__; }                \
+            case 4: { using G_ = GeoH16; return __VA_ARGS__; }                \
+            default: { using G_ = GeoSmall; return __VA_ARGS__; }             \
+        }                                                                     \
+    }()
+#define PSX_GEO_MAX(expr_of_G)                                                                                          \
+    std::max({[&]() { using G_ = GeoSmall; return expr_of_G; }(), [&]() { using G_ = GeoMid; return expr_of_G; }(),     \
+              [&]() { using G_ = GeoWide; return expr_of_G; }(), [&]() { using G_ = GeoH12; return expr_of_G; }(),      \
+              [&]() { using G_ = GeoH16; return expr_of_G; }()})
 constexpr int FAR_THREADS = 256;
 // Lanes per far-ray list: a whole wave.  Fewer lanes per list (several lists per wave, on the idea that the replay is a chain
 // of dependent latencies and most lists are short) was measured as a build-time A/B in round 4 (gpurun_out/r4s7) and is SLOWER
@@ -186,7 +205,9 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     // plentiful at 4 waves per SIMD) -- one memory latency per tile instead of one per batch of four
     // (more than four maps: in two batches -- 5 x 8 thickness values + intensities + phases do not fit the 64 VGPRs of a
     // kernel that keeps two 16-wave workgroups on a CU, and the nmat = 8 instances spilled 7-21 registers)
-    constexpr int U = NM > 4 ? (SITERS + 1) / 2 : SITERS;
+    // (and the one instantiation of the 16-pixel halo that would otherwise spill a register: four maps + image + phase)
+    constexpr bool TIGHT = NM > 4 || (NM == 4 && HAS_I && HAS_PHI && H >= 16);
+    constexpr int U = TIGHT ? (SITERS + 1) / 2 : SITERS;
     auto stage = [&](auto inside_tag) __attribute__((always_inline)) {
         constexpr bool IN = decltype(inside_tag)::value;
         for (int it0 = 0; it0 < SITERS; it0 += U) {
@@ -238,7 +259,7 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     };
     // Interior tiles, sources first: the GR x GC block of pixels that deposit is (GR*GC / NTHREADS) whole passes with
     // shift/mask indexing and no membership test; the one-pixel stencil ring around it only needs the phase.
-    constexpr bool SPLIT = NM <= 4 && (GC & (GC - 1)) == 0 && (GR * GC) % NTHREADS == 0 && 2 * (SR + SC) <= NTHREADS;
+    constexpr bool SPLIT = !TIGHT && (GC & (GC - 1)) == 0 && (GR * GC) % NTHREADS == 0 && 2 * (SR + SC) <= NTHREADS;
     auto stage_interior = [&]() __attribute__((always_inline)) {
         constexpr int NP = GR * GC / NTHREADS;
         float t[NP + 1][NM > 0 ? NM : 1], Iin[NP + 1];
@@ -814,7 +835,7 @@ __global__ __launch_bounds__(256) void k_fastloop(const float *__restrict__ I, c
 // Which geometry a call uses.  The wide halo costs ~20 % more source evaluations but keeps rays displaced by up to
 // 8 pixels inside the LDS gather; the far replay (scattered global float atomics, ~0.1 TB/s) is what it avoids.
 // Per HOST THREAD (the ABI's thread model is one host thread per GPU): a second thread driving another GPU keeps its own.
-thread_local int g_refract_geometry = 0;   // 0: GeoSmall (H=4), 1: GeoWide (H=8), 2: GeoMid (H=6)
+thread_local int g_refract_geometry = 0;   // 0: GeoSmall (H=4), 1: GeoWide (H=8), 2: GeoMid (H=6), 3: GeoH12, 4: GeoH16
 thread_local int g_deterministic = 0;      // psx_set_deterministic
 
 // scratch of psx_fastloop_f32's deterministic mode (that entry point has no workspace argument): accumulators + the max
@@ -869,7 +890,7 @@ size_t batch_chunk_bytes(int Nx, int Ny) {
     return lists_bytes<G>(Nx, Ny, REFRACT_TAB) + (g_deterministic ? (size_t)REFRACT_TAB * det_bytes<G>(Nx, Ny, 1) : 0);
 }
 static size_t batch_chunk_max(int Nx, int Ny) {
-    return std::max(batch_chunk_bytes<GeoSmall>(Nx, Ny), std::max(batch_chunk_bytes<GeoWide>(Nx, Ny), batch_chunk_bytes<GeoMid>(Nx, Ny)));
+    return PSX_GEO_MAX(batch_chunk_bytes<G_>(Nx, Ny));
 }
 
 template <class G>
@@ -982,16 +1003,15 @@ extern "C" {
 
 size_t psx_refract_multi_workspace_bytes(int Nx, int Ny, int ndist) {
     if (Nx <= 0 || Ny <= 0 || ndist <= 0) return 16;
-    const size_t a = workspace_for<GeoSmall>(Nx, Ny, ndist), b = workspace_for<GeoWide>(Nx, Ny, ndist),
-                 c = workspace_for<GeoMid>(Nx, Ny, ndist);
-    return std::max(a, std::max(b, c));
+    return PSX_GEO_MAX(workspace_for<G_>(Nx, Ny, ndist));
 }
 
 size_t psx_refract_workspace_bytes(int Nx, int Ny) { return psx_refract_multi_workspace_bytes(Nx, Ny, 1); }
 
 int psx_refract_set_halo(int halo) {
-    PSX_REQUIRE(halo == 4 || halo == 6 || halo == 8, "psx_refract_set_halo: halo must be 4, 6 or 8, got %d", halo);
-    g_refract_geometry = halo == 8 ? 1 : (halo == 6 ? 2 : 0);
+    PSX_REQUIRE(halo == 4 || halo == 6 || halo == 8 || halo == 12 || halo == 16,
+                "psx_refract_set_halo: halo must be 4, 6, 8, 12 or 16, got %d", halo);
+    g_refract_geometry = halo == 8 ? 1 : halo == 6 ? 2 : halo == 12 ? 3 : halo == 16 ? 4 : 0;
     return 0;
 }
 
@@ -1029,9 +1049,7 @@ static int refract_multi_impl(const float *I_in, const float *mask, float I0, co
         PSX_HIP(hipMemsetAsync(Dx_out, 0, padded, st));     // zero margins (RF2:65-66)
         PSX_HIP(hipMemsetAsync(Dy_out, 0, padded, st));
     }
-    return g_refract_geometry == 1   ? launch_refract<GeoWide>(a, I_in, phi_in, nmat, workspace, st)
-           : g_refract_geometry == 2 ? launch_refract<GeoMid>(a, I_in, phi_in, nmat, workspace, st)
-                                     : launch_refract<GeoSmall>(a, I_in, phi_in, nmat, workspace, st);
+    return PSX_GEO_DISPATCH(G_, launch_refract<G_>(a, I_in, phi_in, nmat, workspace, st));
 }
 
 int psx_refract_multi_f32(const float *I_in, float I0, const float *const *T, const double *cphase, const double *catt,
@@ -1132,9 +1150,7 @@ int psx_refract_batch_f32(int n, const float *const *I_in, const float *I0, cons
             a.clamp_xf = (float)clamp_x; a.clamp_yf = (float)clamp_y; a.status = status; a.stamps = nullptr;
         }
         void *ws = (char *)workspace + (size_t)(e0 / REFRACT_TAB) * chunk_ws;     // every chunk its own far-ray lists
-        const int rc = g_refract_geometry == 1   ? launch_refract_batch<GeoWide>(t, m, has_I, nmat, ws, st)
-                       : g_refract_geometry == 2 ? launch_refract_batch<GeoMid>(t, m, has_I, nmat, ws, st)
-                                                 : launch_refract_batch<GeoSmall>(t, m, has_I, nmat, ws, st);
+        const int rc = PSX_GEO_DISPATCH(G_, launch_refract_batch<G_>(t, m, has_I, nmat, ws, st));
         if (rc) return rc;
     }
     return 0;

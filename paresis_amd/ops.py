@@ -409,15 +409,17 @@ def refract_multi(shape, mats, dscales, clamp, margin=15, I_in=None, I0=1.0, phi
 
 
 def set_refract_halo(halo):
-    """Gather halo of the refraction tile kernel: 4, 6 or 8 pixels (psx_refract_set_halo; a pure speed knob)."""
+    """Gather halo of the refraction tile kernel: 4, 6, 8, 12 or 16 pixels (psx_refract_set_halo; a speed knob -- the halo decides
+    which shares are gathered in the tiles and which are replayed, so the last bit of an image may depend on it)."""
     check(lib().psx_refract_set_halo(int(halo)), "psx_refract_set_halo")
 
 
 def tune_refract_halo(call, halos=(4, 6, 8), reps=2):
     """Picks the gather halo by MEASUREMENT: `call()` (a refraction with the caller's real arguments) is timed with each halo --
     one untimed run, then `reps` runs between two events -- and the fastest stays set.  Which halo wins depends on how many
-    rays travel further than it (the far-ray replay costs ~15 global atomics per ns): 4 pixels at oversampling 2, 8 at
-    oversampling 4 with the bench's membranes.  The images do not depend on the choice (float-atomic order of far rays apart).
+    rays travel further than it (the far-ray replay costs ~11 global atomics per ns): 4 or 6 pixels at oversampling 2, 12 at
+    oversampling 4 with the bench's membranes (pass halos=(4, 6, 8, 12, 16) there).  The images agree to float rounding whatever the choice (a pixel's sum is split
+    differently between tile gather and replay: the last bit may move -- a reproducible run fixes the halo by rule instead).
     One host synchronisation per candidate: meant for the set-up of a run, not for its loop.  Returns (halo, {halo: ms})."""
     times = {}
     for h in halos:

@@ -46,11 +46,11 @@ def test_chain_rt_with_measured_halo():
         exp.myMembrane.myGeometry = g["mono/RT/p0/membrane"]
         exp.exp_dict["meanEnergy"] = 0
         S, R, Pg, W, Dx, Dy, DF = exp.computeSampleAndReferenceImages_RT(0)
-        assert exp._halo in (4, 6, 8) and sorted(exp._halo_times) == [4, 6, 8]
+        assert exp._halo in (4, 6, 8) and sorted(exp._halo_times) == [4, 6, 8]      # oversampling < 4: the three narrow halos
         for nm, a in (("Sample", S), ("Reference", R), ("Propag", Pg), ("White", W)):
             assert relmax(a.cpu().numpy(), g["mono/RT/p0/" + nm]) < TOL, nm
         # reproducible (the default): 'auto' is a RULE of the oversampling, the same on every rank and in every run
-        for ov, want in ((2, 6), (4, 8)):
+        for ov, want in ((2, 6), (4, 12)):
             exp2 = build_experiment(cfg, "RT")
             exp2.exp_dict["refractionHalo"] = "auto"
             exp2.exp_dict["overSampling"] = ov

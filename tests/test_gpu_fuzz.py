@@ -155,7 +155,7 @@ def test_fuzz_refraction(ops, case):
     M = float(rng.uniform(1.0, 2.5))
     pix = float(rng.uniform(0.5, 4.0))
     h = pix * 1e-6
-    halo = int(rng.choice([4, 6, 8]))
+    halo = int(rng.choice([4, 6, 8, 12, 16]))
     ops.set_refract_halo(halo)
     nd = int(rng.integers(1, 5))
     zs = [float(z) for z in rng.uniform(0.05, 4.0, nd)]
@@ -352,7 +352,7 @@ def test_fuzz_chain(ops, case, sim):
     cfg = _chain_cfg(rng, sim)
     ref_cfg = copy.deepcopy(cfg)
     exp = build_experiment(cfg, sim)
-    ops.set_refract_halo(int(rng.choice([4, 6, 8])))
+    ops.set_refract_halo(int(rng.choice([4, 6, 8, 12, 16])))
     what = dict(case=case, sim=sim, N=cfg["N"], ov=cfg["ov"], nE=len(cfg["spectrum"]), bins=cfg["bins"], vac=cfg["inVacuum"],
                 plate=cfg["plate"] is not None, scint=cfg["scintillator"] is not None, src=cfg["source_size_um"], psf=cfg["psf"])
     for point in (0, 1):

@@ -255,7 +255,7 @@ def test_refraction_far_rays_and_border_rules(ops):
     assert relmax(out.cpu().numpy(), ref) < TOL
 
 
-@pytest.mark.parametrize("halo", [4, 6, 8])
+@pytest.mark.parametrize("halo", [4, 6, 8, 12, 16])
 def test_refraction_distance_batch(ops, halo):
     """psx_refract_multi_f32: the distances of a call share one staged tile; every image equals the oracle's and the
     one-distance call's (bitwise where no ray is far, i.e. where no global float atomics are involved)."""
@@ -303,9 +303,9 @@ def test_refraction_distance_batch(ops, halo):
         lib().psx_refract_set_halo(4)
 
 
-@pytest.mark.parametrize("halo", [4, 6, 8])
+@pytest.mark.parametrize("halo", [4, 6, 8, 12, 16])
 def test_refraction_both_tile_geometries(ops, halo):
-    """The gather halo (4 or 8 pixels) is a pure speed knob: every golden case passes with either."""
+    """The gather halo (4 ... 16 pixels) is a speed knob: every golden case passes with each of the five tile geometries."""
     from paresis_amd._lib import lib
     g = load("refraction.npz")
     try:
@@ -533,7 +533,7 @@ def test_order_independent_far_replay_needs_no_workspace_state(ops):
 
 
 @pytest.mark.parametrize("case", ["masked", "black_beside_bright", "pile_up"])
-@pytest.mark.parametrize("halo", [4, 8])
+@pytest.mark.parametrize("halo", [4, 8, 16])
 def test_order_independent_replay_has_no_float_fallback(ops, case, halo):
     """round 4's replay took its fixed-point unit from the TARGET tile and fell back to arrival-order float
     atomics where that tile had none (all-zero window: masked inputs, the zero halves of the dark-field split) or where a share

@@ -173,7 +173,7 @@ def test_refraction_flux_and_halos_4096():
     dsc = 5.2 / k_refraction(52.0) / (h * g["M"]) / h
     outs = []
     try:
-        for halo in (4, 6, 8):
+        for halo in (4, 6, 8, 12, 16):
             lib().psx_refract_set_halo(halo)
             out, _, _ = ops.refract((N, N), rt, dsc, (N, N), I0=7500.0)
             outs.append(out)
@@ -335,7 +335,7 @@ def test_refraction_4096_whole_image_against_cpu_restatement(det):
     ref = cb.refraction_intensity(g["membrane"], delta, beta, 7500.0, z, E, g["M"], g["pix_um"], 8)
     try:
         ops.set_deterministic(det)
-        for halo in (4, 8):
+        for halo in (4, 8, 16):
             ops.set_refract_halo(halo)
             r, _, _ = ops.refract((N, N), rt, z / k_refraction(E) / (h * g["M"]) / h, (N, N), I0=7500.0)
             ops.check_status(r.device)

@@ -24,8 +24,8 @@ zs = (1.6, 3.6, 5.2, 7.2)
 dsc = [z / k_refraction(E) / (h * M) / h for z in zs]
 outs = [torch.empty((N, N), dtype=torch.float32, device="cuda") for _ in zs]
 ops.set_deterministic(rep)
-tiles = {4: 56, 6: 52, 8: 48}
-for halo in (4, 6, 8):
+tiles = {4: 56, 6: 52, 8: 48, 12: 40, 16: 32}
+for halo in ((4, 6, 8, 12, 16) if ov >= 4 or '--all' in sys.argv else (4, 6, 8)):
     ops.set_refract_halo(halo)
     f = lambda: ops.refract_multi((N, N), rt, dsc, (N, N), I0=I0, outs=outs)
     f(); f(); torch.cuda.synchronize()
