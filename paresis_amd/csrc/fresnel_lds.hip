@@ -917,6 +917,9 @@ __global__ __launch_bounds__(T) void k_fresnel_part(LineArgs a) {
                     // P >= 12 310.  An out-of-range DS read is defined on gfx9: it returns 0 and touches nothing (the LDS
                     // aperture check; it does set MEM_VIOL in TRAPSTS, which only matters under a trap handler).  Clamping
                     // the 24 addresses instead costs 24 vector instructions in the stage that has none to spare.
+                    // tests/test_host_cpu.py::test_dif_stage_a_partner_reads_stay_inside_the_lines restates this arithmetic for
+                    // every line length the DIF rounds take and pins both facts: a leg whose value is used reads inside the line
+                    // buffers; the furthest dropped read is 177 440 bytes (round 5).
                     const v2f bm = (h * (RAD / 2) + q) < qb ? b[q] : (v2f){0.f, 0.f};
                     v[h * (RAD / 2) + q] = pk_fma_k(bm, sg, v[h * (RAD / 2) + q]);
                 }

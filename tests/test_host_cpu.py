@@ -427,3 +427,46 @@ def test_no_shipped_kernel_spills_registers():
            if k["vgpr_spill_count"] or k["private_segment_fixed_size"]]
     assert not bad, bad
     assert any("k_fresnel_lines" in k["symbol"] for k in ks) and any("k_refract_near" in k["symbol"] for k in ks)
+
+
+def test_dif_stage_a_partner_reads_stay_inside_the_lines():
+    """k_fresnel_part's DIF stage A (csrc/fresnel_lds.hip, `if constexpr (DIF)`) reads, for each of a thread's 24 legs, the
+    partner sample x[n + 2M] = L[n + D] from LDS -- also for legs that HAVE no partner (q >= qb), whose value it drops: their
+    addresses can lie past the workgroup's allocation, where a DS read returns 0 (documented at the read).
+    This restates the kernel's address arithmetic for every line length the DIF rounds can take and pins the two facts the
+    kernel relies on: (1) a leg whose value is USED reads inside the two line buffers; (2) the furthest address of a dropped
+    read is the documented bound (<= 184 KiB) -- a change of geometry that moves either fails here, on the CPU."""
+    import re
+    src = open(os.path.join(ROOT, "paresis_amd", "csrc", "fresnel_stages.hpp")).read()
+    TOT = int(re.search(r"constexpr int TOT = (\d+);", src).group(1))
+    RAD = int(re.search(r"constexpr int RAD = (\d+);", src).group(1))
+    assert "return p + (p >> 5);" in src                       # phys(): one pad slot per 32 points
+    assert "MP = M + M / 32 + (PAIRPAD ? 16 : 0)" in src
+    R3 = 16
+    M = 576 * R3
+    S1 = M // RAD
+    MP = M + M // 32 + 16
+    assert TOT == 2 * M and S1 % 32 == 0                       # two lines in LDS; the pad term is affine in the leg index
+    lds_bytes = 8 * (2 * MP + (2 * R3 + RAD) * (RAD + 1)) + 16
+    assert lds_bytes <= 160 * 1024
+    margin = 15
+    to = np.arange(2 * S1)[:, None]                            # engine thread = position n0 of the 2M-point sequence
+    q = np.arange(RAD)[None, :]
+    worst_dropped = 0
+    for N in range(12279, 18403):                              # the lines the DIF rounds take (dif_geometry: 12 279 ... 18 402)
+        P = N + 2 * margin
+        dsh, thr = 2 * M - P, N + P - 1 - 2 * M
+        if not (P <= 2 * M and 2 * M <= N + P - 1 <= 4 * M):
+            continue
+        npos = to + dsh
+        addr = (npos & 1) * MP + (npos >> 1) + ((npos >> 1) >> 5) + q * (S1 + S1 // 32)          # in 8-byte entries
+        qb = (thr - to + 2 * S1 - 1) // (2 * S1)
+        used = q < qb
+        assert (addr[used] < 2 * MP).all(), N                  # (1): partners that are used lie inside the line buffers
+        # ... and they are the samples the algorithm means: position n + D of the line, n = to + 2 S1 q
+        pos = (npos >> 1) + q * S1
+        assert (pos[used] < M).all(), N
+        if (~used).any():
+            worst_dropped = max(worst_dropped, int(addr[~used].max()) * 8 + 8)
+    print("furthest dropped DS read:", worst_dropped, "bytes")
+    assert lds_bytes < worst_dropped <= 184 * 1024, worst_dropped          # (2): the documented bound of the dropped reads
