@@ -643,6 +643,24 @@ def positions_batch(a, sim, N, rank, world, dev, reproducible=False):
     ops.check_status(dev, "positions batch")
     per_pos_ms = [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(len(mine))] if marks else None
     marks = None
+    # the sink re-computes positions it did not own (every position when it is alone) and compares with what arrived -- here,
+    # so that the cold run's images can be released before the warm run asks the allocator for its own
+    n_gathered = len(gathered)
+    check = None
+    if rank == sink:
+        others = [p for p in range(P) if p % world != sink] if world > 1 else list(range(P))
+        sample = sorted(set(others[:2] + others[-1:])) if others else []
+        worst, equal = 0.0, True
+        for p in sample:
+            S, R = position(p)
+            for mine_t, got in ((S, gathered[p][0]), (R, gathered[p][1])):
+                got = got.to(mine_t.device)
+                equal = equal and bool(torch.equal(mine_t, got))
+                worst = max(worst, float((mine_t - got).abs().max() / got.abs().max()))
+            del S, R
+        torch.cuda.synchronize()
+        check = (sample, equal, worst)
+    del gathered
     # ---- warm: same work, the GPU loaded up to the first timed kernel.  ~60 ms of untimed positions are queued (the host runs
     # ahead of the GPU), then an all-reduce ON THE STREAM lines the ranks up without idling the GPUs (td.barrier() would
     # synchronise the host and the device), then the start event; the end event follows the last unpack kernel and one more
@@ -691,7 +709,7 @@ def positions_batch(a, sim, N, rank, world, dev, reproducible=False):
            "clock": "cold: barrier + synchronize on both sides, host clock, GPU idle at the start",
            "per_rank_compute_ms": [round(float(t[1]) * 1e3, 3) for t in per_rank],
            "gather_ms": round(max(float(t[2]) for t in per_rank) * 1e3, 3),
-           "gathered_bytes": int(len(gathered) * 2 * stack_shape[0] * stack_shape[1] * stack_shape[2] * 4),
+           "gathered_bytes": int(n_gathered * 2 * stack_shape[0] * stack_shape[1] * stack_shape[2] * 4),
            "gather_wire_bytes": dist.last_gather.get("wire_bytes"), "gather_packed_u16": dist.last_gather.get("packed"),
            "gather_overlapped": bool(dist.last_gather.get("overlapped")),
            "timed_region": "synthesis + chain + detection + shot noise of every position + the gather onto the sink rank (images "
@@ -705,17 +723,7 @@ def positions_batch(a, sim, N, rank, world, dev, reproducible=False):
                                 "all-reduce, no host synchronisation), HIP events around the region, MAX over ranks"}
     if per_pos_ms:
         res["per_position_ms_rank0"] = per_pos_ms
-    # the sink re-computes positions it did not own (every position when it is alone) and compares with what arrived
-    others = [p for p in range(P) if p % world != sink] if world > 1 else list(range(P))
-    sample = sorted(set(others[:2] + others[-1:])) if others else []
-    worst, equal = 0.0, True
-    for p in sample:
-        S, R = position(p)
-        for mine_t, got in ((S, gathered[p][0]), (R, gathered[p][1])):
-            got = got.to(mine_t.device)
-            equal = equal and bool(torch.equal(mine_t, got))
-            worst = max(worst, float((mine_t - got).abs().max() / got.abs().max()))
-    torch.cuda.synchronize()
+    sample, equal, worst = check
     # Fresnel chain: no float atomics anywhere -> bit for bit; ray tracing with the order-independent replay: bit for bit too;
     # with --float-atomics far rays are summed in arrival order, which the Poisson draw may turn into a different count
     res["check"] = {"positions_recomputed_on_sink": sample, "bit_equal": equal, "max_rel_diff": worst,
@@ -935,6 +943,20 @@ def run_configs(a, dev):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / K
         ops.check_status(dev, "configs %d" % N)
+        # one more step with the library's event pairs: where the step's time goes
+        import ctypes
+        lib = _lib.lib()
+        lib.psx_profile_enable(1)
+        step()
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 16)
+        _lib.check(lib.psx_profile_summary(buf, len(buf)), "psx_profile_summary")
+        lib.psx_profile_enable(0)
+        kern, kshort = {}, {}
+        for line in buf.value.decode().splitlines():
+            nm, cnt, tot = line.split()
+            # an event pair costs a few microseconds: launches under 30 us are a ranking, not durations
+            (kern if float(tot) / max(1, int(cnt)) >= 0.03 else kshort)[nm] = round(float(tot), 4)
         # Small grids: a step is seven launches of 6-45 us, so the gaps between dispatches are a large part
         # of it.  The whole step is captured once into a hipGraph (every library call is asynchronous on the current stream and
         # allocates nothing once its plans and kernel spectra exist) and replayed: `ms_hipgraph_replay` beside `ms` (launch by
@@ -957,20 +979,6 @@ def run_configs(a, dev):
                 ops.check_status(dev, "configs %d (graph)" % N)
             except Exception as exc:                       # capture refused (a plan would have had to allocate): report, keep going
                 sys.stderr.write("configs %d: hipGraph capture failed: %s\n" % (N, exc))
-        # one more step with the library's event pairs: where the step's time goes
-        import ctypes
-        lib = _lib.lib()
-        lib.psx_profile_enable(1)
-        step()
-        torch.cuda.synchronize()
-        buf = ctypes.create_string_buffer(1 << 16)
-        _lib.check(lib.psx_profile_summary(buf, len(buf)), "psx_profile_summary")
-        lib.psx_profile_enable(0)
-        kern, kshort = {}, {}
-        for line in buf.value.decode().splitlines():
-            nm, cnt, tot = line.split()
-            # an event pair costs a few microseconds: launches under 30 us are a ranking, not durations
-            (kern if float(tot) / max(1, int(cnt)) >= 0.03 else kshort)[nm] = round(float(tot), 4)
         P = N + 30
         nmat = 2
         # both price lists of `roofline`: the distance batch on one input wave (shared forward transform) and one full

@@ -263,7 +263,7 @@ class Experiment:
         self._sums_next += 1
         return [out[0], out[1], out[2], out[3]], [self._accs[0], self._accs[1], self._accs[2], self._accs[3]], N, dev, sums
 
-    def reserve_outputs(self, n_positions):
+    def reserve_outputs(self, n_positions, extras=True):
         """Lets the caching allocator own the output blocks of `n_positions` positions BEFORE the position loop: a caller that
         keeps every position's images (main.run, dist.PositionGatherer) otherwise sends the allocator to hipMalloc once per
         position -- a synchronous call of 0.2 to 2.5 ms depending on the box (gpurun_out/r5s6 against r5s8), in a loop whose
@@ -274,6 +274,11 @@ class Experiment:
         nbins = self._close_bins()
         n0, n1 = int(dp['myDimensions'][0]), int(dp['myDimensions'][1])
         blocks = [torch.empty((4, nbins, n0, n1), dtype=torch.float32, device=device()) for _ in range(int(n_positions))]
+        if extras and self.exp_dict.get('simulation_type') == "RayT":
+            # position 0 of the ray-tracing chain also returns two padded displacement maps and a dark-field map (EXP:488-498)
+            N = tuple(int(v) for v in self.exp_dict['studyDimensions'])
+            blocks += [torch.empty((N[0] + 30, N[1] + 30), dtype=torch.float32, device=device()) for _ in range(2)]
+            blocks += [torch.empty(N, dtype=torch.float32, device=device())]
         del blocks
 
     def _close_bins(self):
