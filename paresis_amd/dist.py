@@ -328,7 +328,9 @@ class PositionGatherer:
         self.pool = (wires, buckets)
 
     def reset(self):
-        """Ready for another run over the same positions with the buffers of prepare() (the bench: an untimed run first)."""
+        """Ready for another run over the same positions with the buffers of prepare() (the bench: an untimed run first).
+        The receive buckets are reused: positions of the PREVIOUS run's result that were never read (dist.PackedPositions
+        widens on first access) must not be read after the next run has started."""
         self.results, self.work, self.wires, self.buckets = {}, [], [], []
         self.next_round = 0
         self.issued = 0

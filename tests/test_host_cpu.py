@@ -470,3 +470,37 @@ def test_dif_stage_a_partner_reads_stay_inside_the_lines():
             worst_dropped = max(worst_dropped, int(addr[~used].max()) * 8 + 8)
     print("furthest dropped DS read:", worst_dropped, "bytes")
     assert lds_bytes < worst_dropped <= 184 * 1024, worst_dropped          # (2): the documented bound of the dropped reads
+
+
+def test_packed_positions_widen_on_first_read():
+    """dist.PackedPositions (round 5): the sink of a multi-GPU run keeps the gathered stacks as they crossed -- 16-bit counts
+    + the table of brighter pixels -- and widens a position the first time it is read; position 0's ready tuple (with its
+    extras) is served as it is.  Exercised here on CPU tensors through the wire format's host restatement."""
+    import torch
+    from paresis_amd import dist
+    shape = (2, 3, 5)
+    per_img = 2 * 3 * 5
+    flag = torch.zeros(1, dtype=torch.int32)
+    packed, truth = {}, {}
+    for p in (1, 2, 5):
+        S = torch.full(shape, 7.0 * p)
+        R = torch.full(shape, 7.0 * p + 1)
+        S[1, 2, 4], R[0, 0, 0] = 70000.0 + p, 65535.0                     # escapes
+        w = dist._CountsWire(2 * per_img, torch.device("cpu"))
+        w.head.zero_()
+        w.pack(S, 0, flag)
+        w.pack(R, per_img, flag)
+        packed[p], truth[p] = w.bytes, (S, R)
+    assert int(flag) == 0
+    ready = {0: (torch.zeros(shape), torch.ones(shape), torch.full(shape, 3.5), torch.full(shape, 4.0))}
+    out = dist.PackedPositions(packed, per_img, shape, ready)
+    assert sorted(out) == [0, 1, 2, 5] and len(out) == 4 and 2 in out and 3 not in out and out.keys() == [0, 1, 2, 5]
+    assert len(out._packed) == 3                                          # nothing widened yet
+    assert len(out[0]) == 4 and float(out[0][3][0, 0, 0]) == 4.0
+    for p in (5, 1):
+        S, R = out[p]
+        assert torch.equal(S, truth[p][0]) and torch.equal(R, truth[p][1]) and S.dtype == torch.float32
+    assert sorted(out._packed) == [2]                                     # position 2 is still as it crossed
+    assert out[1][0] is out[1][0]                                         # widened once, then kept
+    assert [p for p, _ in out.items()] == [0, 1, 2, 5] and not out._packed
+    assert out.stack_numel() == 2 * per_img
