@@ -650,16 +650,19 @@ def positions_batch(a, sim, N, rank, world, dev, reproducible=False):
     if rank == sink:
         others = [p for p in range(P) if p % world != sink] if world > 1 else list(range(P))
         sample = sorted(set(others[:2] + others[-1:])) if others else []
-        worst, equal = 0.0, True
+        worst, equal, ndiff, npix, peak = 0.0, True, 0, 0, 1.0
         for p in sample:
             S, R = position(p)
             for mine_t, got in ((S, gathered[p][0]), (R, gathered[p][1])):
                 got = got.to(mine_t.device)
                 equal = equal and bool(torch.equal(mine_t, got))
                 worst = max(worst, float((mine_t - got).abs().max() / got.abs().max()))
+                ndiff += int((mine_t != got).sum())
+                npix += got.numel()
+                peak = max(peak, float(got.abs().max()))
             del S, R
         torch.cuda.synchronize()
-        check = (sample, equal, worst)
+        check = (sample, equal, worst, ndiff, npix, peak)
     del gathered
     # ---- warm: same work, the GPU loaded up to the first timed kernel.  ~60 ms of untimed positions are queued (the host runs
     # ahead of the GPU), then an all-reduce ON THE STREAM lines the ranks up without idling the GPUs (td.barrier() would
@@ -723,11 +726,16 @@ def positions_batch(a, sim, N, rank, world, dev, reproducible=False):
                                 "all-reduce, no host synchronisation), HIP events around the region, MAX over ranks"}
     if per_pos_ms:
         res["per_position_ms_rank0"] = per_pos_ms
-    sample, equal, worst = check
+    sample, equal, worst, ndiff, npix, peak = check
     # Fresnel chain: no float atomics anywhere -> bit for bit; ray tracing with the order-independent replay: bit for bit too;
     # with --float-atomics far rays are summed in arrival order, which the Poisson draw may turn into a different count
+    # (float atomics: a far ray's last bit may flip a Poisson draw -- by one count when the inversion branch drew it, by a few
+    # standard deviations when a rejection sampler accepts another uniform: 1.4e-5 to 2e-3 of the peak have been seen.  The
+    # images are still draws of the same distributions: at most a handful of pixels may differ, each by a few sqrt(counts).)
     res["check"] = {"positions_recomputed_on_sink": sample, "bit_equal": equal, "max_rel_diff": worst,
-                    "ok": bool(equal) if (sim == "Fresnel" or det_mode) else bool(worst < 1e-3)}
+                    "pixels_differing": ndiff, "pixels_compared": npix,
+                    "ok": bool(equal) if (sim == "Fresnel" or det_mode)
+                          else bool(ndiff <= max(8, npix // 100000) and worst <= 8.0 / max(1.0, peak) ** 0.5)}
     res["far_rays"] = "order-independent fixed-point replay" if det_mode else ("float atomics" if sim == "RayT" else None)
     res["sink_rank"] = sink
     if world > 1:
