@@ -285,36 +285,51 @@ __global__ __launch_bounds__(256) void k_df_gather_banded(const float *__restric
         __syncthreads();
         const int hb = __builtin_amdgcn_readfirstlane(min(R, hband));
         if (hb < 0) continue;                            // nothing in this band carries weight (uniform)
+        // A thread's four outputs sit in ONE column, eight rows apart: a staged source entry serves all four (its row distance
+        // differs, its column distance does not), so the band is walked row by row and an entry is read once for the four --
+        // a quarter of the LDS reads of the output-by-output walk (5.55 -> 5.30 ms at R = 21, 745 -> 676 ms for a 25-energy spectrum down to
+        // R = 136, gpurun_out/r5s27: the exponentials, not the reads, are what a term costs).  Per output the terms
+        // still arrive in the plain gather's order (rows, then columns).
+        const int i0 = t0 + ti0;                         // rows i0, i0 + 8, i0 + 16, i0 + 24
+        const int r_lo = max(b0, i0 - hb), r_hi = min(b0 + rows - 1, i0 + 24 + hb);
+        for (int si = r_lo; si <= r_hi; ++si) {
+            const float4 *row = swc + (si - b0) * W + tj + R;
+            int adi[4];
+            float di2[4];
+            bool rowin = false;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = t0 + ti0 + 8 * k;
-            // source rows of this band within the band's reach of output row i
-            const int r_lo = max(b0, i - hb), r_hi = min(b0 + rows - 1, i + hb);
-            float a = acc[k];
-            for (int si = r_lo; si <= r_hi; ++si) {
-                const int di = si - i, adi = abs(di);
-                const float di2 = (float)(di * di);
-                const float4 *row = swc + (si - b0) * W + tj + R;
-                int dj = -hb;
-                for (; dj + 3 <= hb; dj += 4) {          // four entries requested together
-                    float4 e[4];
+            for (int k = 0; k < 4; ++k) {
+                const int di = si - (i0 + 8 * k);
+                adi[k] = abs(di);
+                di2[k] = (float)(di * di);
+                rowin = rowin || adi[k] <= hb;
+            }
+            if (!rowin) continue;                        // a gap between two outputs' reaches (hb < 4)
+            int dj = -hb;
+            for (; dj + 3 <= hb; dj += 4) {              // four entries requested together
+                float4 e[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) e[u] = row[dj + u];
+                for (int u = 0; u < 4; ++u) e[u] = row[dj + u];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (adi[k] > hb) continue;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const float need = (float)max(adi, abs(dj + u));
-                        const float t = fmaf(e[u].x, __builtin_amdgcn_exp2f((di2 + (float)((dj + u) * (dj + u))) * e[u].y), e[u].w);
-                        a += e[u].z >= need ? t : 0.f;
+                        const float need = (float)max(adi[k], abs(dj + u));
+                        const float t = fmaf(e[u].x, __builtin_amdgcn_exp2f((di2[k] + (float)((dj + u) * (dj + u))) * e[u].y), e[u].w);
+                        acc[k] += e[u].z >= need ? t : 0.f;
                     }
                 }
-                for (; dj <= hb; ++dj) {
-                    const float4 e = row[dj];
-                    const float need = (float)max(adi, abs(dj));
-                    const float t = fmaf(e.x, __builtin_amdgcn_exp2f((di2 + (float)(dj * dj)) * e.y), e.w);
-                    a += e.z >= need ? t : 0.f;
+            }
+            for (; dj <= hb; ++dj) {
+                const float4 e = row[dj];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float need = (float)max(adi[k], abs(dj));
+                    const float t = fmaf(e.x, __builtin_amdgcn_exp2f((di2[k] + (float)(dj * dj)) * e.y), e.w);
+                    acc[k] += (adi[k] <= hb && e.z >= need) ? t : 0.f;
                 }
             }
-            acc[k] = a;
         }
     }
     bool bad = false;
