@@ -504,3 +504,38 @@ def test_packed_positions_widen_on_first_read():
     assert out[1][0] is out[1][0]                                         # widened once, then kept
     assert [p for p, _ in out.items()] == [0, 1, 2, 5] and not out._packed
     assert out.stack_numel() == 2 * per_img
+
+
+def test_bench_rank_share_prediction_arithmetic(monkeypatch):
+    """bench.emulate_world (positions_batch.<sim>.rank_share): the predicted 8-GPU speed-up is the one-GPU time over the SLOWER of
+    the two emulated shares plus the exposed part of the gather, priced per point-to-point link; the children are fresh
+    processes started with the same batch arguments; nothing is predicted under a profiler."""
+    import types
+    import bench
+    calls = []
+
+    def fake_run(cmd, capture_output, text, timeout):
+        calls.append(cmd)
+        r = int(cmd[cmd.index("--emulate-rank") + 1])
+        share = {"rank": r, "world": 8, "positions": list(range(r, 64, 8)), "cold_ms": 11.0 if r == 0 else 10.0,
+                 "warm_ms": 9.5 if r == 0 else 9.0, "packed_ok": True, "wire_bytes_per_position": 17_000_000}
+        return types.SimpleNamespace(returncode=0, stdout="noise\n" + json.dumps(share) + "\n", stderr="")
+
+    import json
+    monkeypatch.setattr("subprocess.run", fake_run)
+    for k in list(os.environ):
+        if k.startswith("ROCPROF"):
+            monkeypatch.delenv(k)
+    a = types.SimpleNamespace(emulate_world=8, positions=64, size=4096, positions_size=0)
+    out = bench.emulate_world(a, "Fresnel", {"ms_total": 72.0, "warm": {"ms_total": 70.0}})
+    assert [int(c[c.index("--emulate-rank") + 1]) for c in calls] == [0, 7]
+    assert all(c[c.index("--emulate-sim") + 1] == "Fresnel" and c[c.index("--positions") + 1] == "64" for c in calls)
+    last = 17_000_000 / 153.0 / 1e6                                   # one position's wire bytes over one xGMI link, ms
+    assert abs(out["gather_ms_last_round"] - last) < 1e-3 and abs(out["gather_ms_if_fully_exposed"] - 8 * last) < 1e-3
+    assert out["rank0_ms"] == 11.0 and out["rank7_ms"] == 10.0 and out["one_gpu_64_ms"] == 72.0
+    assert out["predicted_speedup_8"] == round(72.0 / (11.0 + last), 2)
+    assert out["predicted_speedup_8_gather_exposed"] == round(72.0 / (11.0 + 8 * last), 2)
+    assert out["predicted_speedup_8_warm"] == round(70.0 / (9.5 + last), 2)
+    assert "prediction, not a measurement" in out["note"]
+    monkeypatch.setenv("ROCPROFILER_REGISTER_ROOT", "/opt/rocm")
+    assert "skipped" in bench.emulate_world(a, "Fresnel", {"ms_total": 72.0})
