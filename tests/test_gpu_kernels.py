@@ -854,3 +854,55 @@ def test_darkfield_resplat_all_tile_shapes(ops, max_df):
                 ref[m + i, m + j] += v
     ref = ref[m:m + Nx, m:m + Ny] + I2
     assert relmax(out.cpu().numpy(), ref) < 2e-6, max_df
+
+
+@pytest.mark.parametrize("halo", [4, 12])
+@pytest.mark.parametrize("det", [False, True])
+def test_refract_split_equals_two_masked_refractions(ops, halo, det):
+    """psx_refract_split_f32 (round 5): ONE call refracts the sources where a map is zero and those where it is not (the
+    two halves of fastRefractionDF's split, RF2:147-154) on one staging per tile.  Against two plain refractions of the
+    pre-masked intensity (same thickness maps, same phase) and against the oracle on each half; mask patterns: a half plane
+    (most tiles see one side only), a checkerboard of 5-pixel cells (every tile sees both) and an all-zero map."""
+    rng = np.random.default_rng(77 + halo)
+    Nx, Ny = 211, 187
+    T = dev(np.stack([np.cumsum(rng.uniform(0, 2.5e-5, (Nx, Ny)), axis=0), rng.uniform(0, 3e-4, (Nx, Ny))]), torch.float32)
+    k = 2.6e11
+    delta, beta = [6.2e-7, 9.9e-8], [4e-9, 4.5e-11]
+    mats = ops.MaterialStack(T, cphase=[-k * d for d in delta], catt=[-2 * k * b for b in beta])
+    I = rng.uniform(0.5, 2.0, (Nx, Ny)).astype(np.float32)
+    It = dev(I, torch.float32)
+    dscale = 2.4
+    ii, jj = np.meshgrid(np.arange(Nx), np.arange(Ny), indexing="ij")
+    masks = {"half": (jj >= Ny // 2) * 1.5, "checker": (((ii // 5) + (jj // 5)) % 2) * 0.7, "none": np.zeros((Nx, Ny))}
+    # oracle inputs: transmitted intensity and phase of the same float32 maps
+    T64 = T.cpu().numpy().astype(np.float64)
+    phi = -k * (delta[0] * T64[0] + delta[1] * T64[1])                                  # SAM:348 with the test's round k
+    I_t = 3.0 * I.astype(np.float64) * np.exp(-2 * k * (beta[0] * T64[0] + beta[1] * T64[1]))   # SAM:347
+    h = 1e-6
+    z = dscale * orc.k_refraction(52.0) * h * h
+    ops.set_refract_halo(halo)
+    try:
+        ops.set_deterministic(det)
+        for name, m in masks.items():
+            mt = dev(m, torch.float32)
+            a0, a1 = ops.refract_split((Nx, Ny), mats, dscale, (Nx, Ny), mt, I_in=It, I0=3.0)
+            a0, a1 = a0.clone(), a1.clone()
+            for side, got in ((0, a0), (1, a1)):
+                keep = (m != 0) == bool(side)
+                plain, _, _ = ops.refract((Nx, Ny), mats, dscale, (Nx, Ny), I_in=dev(I * keep, torch.float32), I0=3.0)
+                assert float((got - plain).abs().max()) <= 2e-6 * max(1.0, float(plain.abs().max())), (name, side)
+                ref, _, _ = orc.fast_refraction(I_t * keep, phi.copy(), z, 52.0, 1.0, 1.0)
+                assert relmax(got.cpu().numpy(), ref) < TOL or ref.max() == 0, (name, side)
+                if not keep.any():
+                    assert float(got.abs().max()) == 0.0
+            # accumulate mode: both halves added to existing images
+            b0, b1 = torch.full_like(a0, 2.0), torch.full_like(a1, 5.0)
+            ops.refract_split((Nx, Ny), mats, dscale, (Nx, Ny), mt, I_in=It, I0=3.0, outs=[b0, b1], add=True)
+            assert float((b0 - 2.0 - a0).abs().max()) < 1e-5 * max(1.0, float(a0.max()))
+            assert float((b1 - 5.0 - a1).abs().max()) < 1e-5 * max(1.0, float(a1.max()))
+        ops.check_status(T.device)
+        with pytest.raises(Exception):
+            ops.refract_split((Nx, Ny), mats, dscale, (Nx, Ny), mt, I_in=It, phi_in=torch.zeros((Nx, Ny), dtype=torch.float64, device="cuda"))
+    finally:
+        ops.set_deterministic(False)
+        ops.set_refract_halo(4)
