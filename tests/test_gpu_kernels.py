@@ -472,8 +472,8 @@ def test_deterministic_order_mode(ops):
 
 
 def test_order_independent_far_replay_needs_no_workspace_state(ops):
-    """the allocation-free order-independent replay (three passes over the far lists, scratch words inside
-    the caller's workspace).  The scratch has NO initial state: the workspace is filled with garbage before every call and
+    """the allocation-free order-independent replay (two passes over the far lists, scratch words
+    inside the caller's workspace, cleared by the tile kernel as it lists a ray).  The scratch has NO initial state: the workspace is filled with garbage before every call and
     shared between calls of different shapes (one distance, a distance batch, an energy batch, accumulate mode); every image is
     bitwise reproducible, equal to the one-distance call's, and within float rounding of the float-atomic replay."""
     import paresis_amd.ops as O
