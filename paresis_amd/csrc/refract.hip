@@ -495,10 +495,19 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
                 asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(qi) : "v"(v));
                 atomicAdd((unsigned long long *)(acc + off), (unsigned long long)(long long)qi);
             };
+            // Wide halos: a wave is one row of the 64-wide window, and the rows deep in the halo often hold no ray that reaches the
+            // tile -- such a wave skips its four LDS atomics and their weights (a uniform branch; build-time A/B PSX_SKIP_MISS,
+            // tools/ab_skipmiss.sh, gpurun_out/r5s32, two rounds on one box at 16384^2: halo 8 5.17 -> 5.08 ms, halo 12 6.37 -> 6.20,
+            // halo 16 8.09 -> 7.76).  Not for the narrow halos, whose few halo rows sit next to the tile and nearly always hold a hit.
+#ifndef PSX_SKIP_MISS
+#define PSX_SKIP_MISS 1
+#endif
+            if (!(PSX_SKIP_MISS && H >= 8) || __any(hit)) {
             dep(0, Is_ * ((1.f - wx) * (1.f - wy)));
             dep(AW, Is_ * (wx * (1.f - wy)));
             dep(1, Is_ * ((1.f - wx) * wy));
             dep(AW + 1, Is_ * (wx * wy));
+            }
             // (kept as the reference's products I * (wx-part * wy-part), RF2:241-262: regrouping them as (I * wy-part) * wx-part
             // would save two multiplies but round differently)
         }
