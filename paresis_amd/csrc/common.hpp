@@ -110,6 +110,7 @@ enum DebugSwitch {
     DBG_STAMP_PASS1,       // psx_debug_stamps records pass 1 instead of pass 2
     DBG_STAMP_ROUND,       // which round of a unit the stamps are taken in
     DBG_DETECT_4PASS,      // detector stages as four passes instead of fused pairs
+    DBG_FAR_STRIDE,        // far-ray replay: lists handed to the waves in a strided order (value = stride; 0: tile order)
     DBG_COUNT
 };
 int debug_switch(DebugSwitch s);

@@ -123,6 +123,7 @@ struct RefractArgs {
     unsigned *far_count;     // workspace: [ndist][ntiles] far rays found by each tile at each distance
     FarRay *far_list;        // then [ndist][ntiles][TH*TW] records (a tile can never overflow its slot)
     int tiles_x, tiles_y, tile_cap;
+    unsigned far_stride;          // diagnostics (psx_debug_switch "far_stride"): the replay walks the lists in a strided order
     unsigned long long *stamps;   // diagnostics (psx_debug_stamps): 16 phase timestamps per workgroup
     // order-independent far-ray replay (psx_set_deterministic; null otherwise), all inside the caller's workspace:
     unsigned *det_gmax;           // largest finite |source intensity| any tile staged (float bits; cleared by a 16-byte memset node)
@@ -622,7 +623,7 @@ __device__ __forceinline__ RefractArgs one_distance_block(const RefractTab &t, i
     a.Dx_out = nullptr; a.Dy_out = nullptr; a.I_mut = nullptr;
     a.Nx = s.Nx; a.Ny = s.Ny; a.margin = s.margin; a.clamp_xf = s.clamp_xf; a.clamp_yf = s.clamp_yf;
     a.status = s.status; a.far_count = s.far_count; a.far_list = s.far_list;
-    a.tiles_x = s.tiles_x; a.tiles_y = s.tiles_y; a.tile_cap = s.tile_cap; a.stamps = nullptr;
+    a.tiles_x = s.tiles_x; a.tiles_y = s.tiles_y; a.tile_cap = s.tile_cap; a.far_stride = s.far_stride; a.stamps = nullptr;
     a.det_gmax = s.det_gmax; a.det_fold_count = s.det_fold_count; a.det_acc = s.det_acc;
     return a;
 }
@@ -687,8 +688,9 @@ template <class G, int MODE = FAR_FLOAT, bool ONE = false>      // ONE: a single
 __device__ __forceinline__ void refract_far_body(const RefractArgs &a) {
     constexpr int TH = G::TH, TW = G::TW, H = G::H;
     const unsigned nlists = (unsigned)(a.tiles_x * a.tiles_y) * (unsigned)a.ndist;
-    const unsigned lst = blockIdx.x * FAR_LISTS + threadIdx.x / FAR_SUB;
+    unsigned lst = blockIdx.x * FAR_LISTS + threadIdx.x / FAR_SUB;
     if (lst >= nlists) return;
+    if (a.far_stride) lst = (unsigned)(((unsigned long long)lst * a.far_stride) % nlists);     // stride coprime to nlists (host)
     const unsigned lane = threadIdx.x % FAR_SUB;
     const unsigned dist = ONE ? 0u : lst / (unsigned)(a.tiles_x * a.tiles_y);
     float *const I_out = a.I_out[ONE ? 0 : dist];
@@ -867,6 +869,16 @@ struct DetScratch {
     }
 };
 
+// diagnostics: a stride for the replay's walk over the lists that is coprime to their number (0: the plain tile order)
+static unsigned far_stride_for(unsigned nlists) {
+    unsigned s = (unsigned)debug_switch(DBG_FAR_STRIDE);
+    if (s == 0 || nlists < 2) return 0;
+    auto gcd = [](unsigned x, unsigned y) { while (y) { const unsigned t = x % y; x = y; y = t; } return x; };
+    s %= nlists;
+    while (s < 2 || gcd(s, nlists) != 1) ++s;
+    return s;
+}
+
 // far-ray counters and lists of a call: [ndist][ntiles] counts, then [ndist][ntiles][TH*TW] records
 template <class G>
 size_t lists_bytes(int Nx, int Ny, int ndist) {
@@ -907,6 +919,7 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
     a.tiles_x = (int)cdiv(a.Nx, G::TH);
     a.tiles_y = (int)cdiv(a.Ny, G::TW);
     a.tile_cap = G::TH * G::TW;
+    a.far_stride = far_stride_for((unsigned)(a.tiles_x * a.tiles_y * a.ndist));
     a.far_count = (unsigned *)workspace;
     a.far_list = (FarRay *)((char *)workspace + 16 * ((sizeof(unsigned) * (size_t)a.tiles_x * a.tiles_y * a.ndist + 15) / 16));
     a.det_gmax = nullptr; a.det_fold_count = nullptr; a.det_acc = nullptr;
@@ -965,7 +978,7 @@ int launch_refract_batch(RefractTab &t, int n, bool has_I, int nmat, void *works
     const size_t nt = (size_t)tiles_x * tiles_y;
     for (int e = 0; e < REFRACT_TAB; ++e) {
         RefractArgs &a = t.e[e];
-        a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.tile_cap = G::TH * G::TW;
+        a.tiles_x = tiles_x; a.tiles_y = tiles_y; a.tile_cap = G::TH * G::TW; a.far_stride = far_stride_for((unsigned)nt);
         const int k = e < n ? e : 0;
         a.far_count = (unsigned *)workspace + (size_t)k * nt;
         a.far_list = (FarRay *)((char *)workspace + 16 * ((sizeof(unsigned) * nt * REFRACT_TAB + 15) / 16)) + (size_t)k * nt * a.tile_cap;

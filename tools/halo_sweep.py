@@ -11,6 +11,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 ov = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rep = len(sys.argv) > 3 and sys.argv[3] == "reproducible"
 lib = _lib.lib()
+import _switches                      # PSX_SWITCHES="far_stride=7919" -> psx_debug_switch
+_switches.apply()
 E, I0 = 52.0, 7500.0
 db = [synth.DELTA_BETA_52KEV[m] for m in ("CuSn", "PMMA")]
 k = k_sample(E)
