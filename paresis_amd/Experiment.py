@@ -116,6 +116,7 @@ class Experiment:
         self._sums_pool, self._sums_next = None, 0
         self.darkFieldPropag = None
         self._df_tmp = None           # dark-field half of the fused sample hop
+        self._zero_stack = None       # Propag / White of every position but 0
         self._halo = None             # refraction gather halo of this experiment (exp_dict['refractionHalo']: 4 | 6 | 8 | 'auto')
 
     @classmethod
@@ -243,11 +244,19 @@ class Experiment:
         nbins = self._close_bins()
         dev = device()
         n0, n1 = int(dp['myDimensions'][0]), int(dp['myDimensions'][1])
-        # one allocation for the four stacks; every slot of Sample/Reference is written by its bin's detection, Propag only at
-        # position 0 and White is zero elsewhere (the reference detects an all-zero white there: Poisson(0) = 0)
-        out = torch.empty((4, nbins, n0, n1), dtype=torch.float32, device=dev)
+        # one allocation for the stacks; every slot of Sample/Reference is written by its bin's detection, Propag only at
+        # position 0 and White is zero elsewhere (the reference detects an all-zero white there: Poisson(0) = 0).  Away from
+        # position 0 Propag and White are ONE zero stack per experiment, shared by every position's result (read-only by
+        # convention: the reference returns fresh zero arrays) -- not 33 MB filled per position (10 us at 2048^2 detectors, the
+        # kernel trace of gpurun_out/r5s36) and half the memory a caller keeps per position.
         if pointNum != 0:
-            ops.fill(out[2:], 0.0)
+            if self._zero_stack is None or tuple(self._zero_stack.shape) != (nbins, n0, n1) or self._zero_stack.device != dev:
+                self._zero_stack = ops.fill(torch.empty((nbins, n0, n1), dtype=torch.float32, device=dev), 0.0)
+            two = torch.empty((2, nbins, n0, n1), dtype=torch.float32, device=dev)
+            out = [two[0], two[1], self._zero_stack, self._zero_stack]
+        else:
+            four = torch.empty((4, nbins, n0, n1), dtype=torch.float32, device=dev)
+            out = [four[0], four[1], four[2], four[3]]
         N = tuple(int(v) for v in self.exp_dict['studyDimensions'])
         # the four study-grid accumulators live as long as the experiment; the first energy of a bin STORES into them, so they
         # are never cleared (the reference re-allocates zeros after every bin, EXP:396-399)
@@ -261,7 +270,7 @@ class Experiment:
             self._sums_next = 0
         sums = self._sums_pool[self._sums_next]
         self._sums_next += 1
-        return [out[0], out[1], out[2], out[3]], [self._accs[0], self._accs[1], self._accs[2], self._accs[3]], N, dev, sums
+        return out, [self._accs[0], self._accs[1], self._accs[2], self._accs[3]], N, dev, sums
 
     def reserve_outputs(self, n_positions, extras=True):
         """Lets the caching allocator own the output blocks of `n_positions` positions BEFORE the position loop: a caller that
@@ -273,7 +282,9 @@ class Experiment:
         dp = self.myDetector.det_param
         nbins = self._close_bins()
         n0, n1 = int(dp['myDimensions'][0]), int(dp['myDimensions'][1])
-        blocks = [torch.empty((4, nbins, n0, n1), dtype=torch.float32, device=device()) for _ in range(int(n_positions))]
+        # position 0 returns four stacks, every other position two (+ the experiment's shared zero stack)
+        blocks = [torch.empty((2, nbins, n0, n1), dtype=torch.float32, device=device()) for _ in range(int(n_positions))]
+        blocks.append(torch.empty((4, nbins, n0, n1), dtype=torch.float32, device=device()))
         if extras and self.exp_dict.get('simulation_type') == "RayT":
             # position 0 of the ray-tracing chain also returns two padded displacement maps and a dark-field map (EXP:488-498)
             N = tuple(int(v) for v in self.exp_dict['studyDimensions'])
