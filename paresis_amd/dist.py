@@ -281,6 +281,12 @@ class PackedPositions(dict):
     def items(self):
         return [(p, self[p]) for p in self]
 
+    def get(self, p, default=None):
+        return self[p] if p in self else default
+
+    def __repr__(self):
+        return "PackedPositions(%d positions, %d still packed)" % (len(self), len(self._packed))
+
     def stack_numel(self):
         """Elements of one position's pair of stacks (no widening)."""
         return 2 * self._per_img

@@ -504,6 +504,7 @@ def test_packed_positions_widen_on_first_read():
     assert out[1][0] is out[1][0]                                         # widened once, then kept
     assert [p for p, _ in out.items()] == [0, 1, 2, 5] and not out._packed
     assert out.stack_numel() == 2 * per_img
+    assert out.get(9) is None and out.get(2) is out[2] and "0 still packed" in repr(out)
 
 
 def test_bench_rank_share_prediction_arithmetic(monkeypatch):
