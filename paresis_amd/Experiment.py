@@ -627,12 +627,15 @@ class Experiment:
             if want == 'auto' and self._reproducible():
                 # The halo decides which shares are gathered in the tiles and which are replayed, i.e. how a pixel's sum is
                 # split into float(tile sum) + float(far sum): the last bit of an image depends on it.  A halo picked by TIMING
-                # may differ between ranks and between runs, so a reproducible experiment takes it from a rule instead: what
-                # the timings of the fixed-point replay picked on the membranes measured so far (DESIGN.md section 4.3,
-                # gpurun_out/r5s1, r5s3: a replayed share costs 1.75x a float atomic, which moves the optimum one step up --
-                # 6 px at oversampling <= 2; 12 px from oversampling 4 on, where rays travel twice as many study pixels:
-                # 16384^2, 4 distances: 14.4 / 12.2 / 10.6 / 9.5 / 10.1 ms with 4 / 6 / 8 / 12 / 16 px, gpurun_out/r5s20).
-                want = 12 if int(self.exp_dict.get('overSampling', 1)) >= 4 else 6
+                # may differ between ranks and between runs, so a reproducible experiment takes it from a rule instead: how far
+                # a ray of its longest hop travels in study pixels per radian of deflection, r = z / (h M).  Fitted to the
+                # fixed-point replay's measured optima: the class's own chain at oversampling 2 (hops
+                # 1.6 / 3.6 m, r = 1.2e6: halo 4 0.407 ms of refraction per position against 0.424 with 6) and at oversampling 4
+                # (r = 2.4e6: 8 wins, 2.52 ms against 2.60 / 2.80 with 6 / 12); a 7.2 m batch at oversampling 2 (r = 2.4e6:
+                # 6 or 8) and at oversampling 4 (r = 4.8e6: 12).
+                ed = self.exp_dict
+                r = max(ed['distMembraneToObject'], ed['distObjectToDetector']) / (ed['studyPixelSize'] * 1e-6 * ed['magnification'])
+                want = 4 if r < 1.8e6 else (8 if r < 3.6e6 else 12)
             if want == 'auto':
                 ed = self.exp_dict
                 E = self.mySource.mySpectrum[-1][0]
@@ -697,8 +700,17 @@ class Experiment:
         darkFieldPropag); Dxreal/Dyreal are the PADDED [N+30, N+30] maps of the last energy (point 0 only)."""
         # the replay mode is this experiment's (exp_dict['reproducible']), whoever calls -- main.run or a user of the class --
         # and the calling thread gets back the mode it had
-        with ops.deterministic(self._reproducible()):
+        with ops.deterministic(self._reproducible(), scale=self._replay_scale()):
             return self._rt_chain(pointNum)
+
+    def _replay_scale(self):
+        """The intensity scale of this experiment's ray-tracing images: the incident intensity per study pixel of its strongest
+        energy (EXP:308,320).  Every refraction of the chain then sums its far rays in one unit known before the call -- no
+        maximum to measure, no memset node per refraction -- and the unit is a function of exp_dict alone, i.e. the same on
+        every rank."""
+        ed = self.exp_dict
+        flux = max([f for _, f in self.mySource.mySpectrum] + [0.0])
+        return float(ed['meanShotCount'] / ed['overSampling'] ** 2 * flux)
 
     def _rt_chain(self, pointNum):
         ed = self.exp_dict

@@ -21,6 +21,7 @@
 // HBM traffic per pixel: 4*nmat (thickness maps) + 4 (intensity, if given) read, 4 written  (BASELINE.md section 4
 // prices the scatter at 12+4*nmat because the reference zero-initialises and read-modify-writes its output).
 #include <algorithm>
+#include <cstring>
 #include <type_traits>
 
 #include "common.hpp"
@@ -127,6 +128,7 @@ struct RefractArgs {
     unsigned long long *stamps;   // diagnostics (psx_debug_stamps): 16 phase timestamps per workgroup
     // order-independent far-ray replay (psx_set_deterministic; null otherwise), all inside the caller's workspace:
     unsigned *det_gmax;           // largest finite |source intensity| any tile staged (float bits; cleared by a 16-byte memset node)
+    unsigned det_scale_bits;      // != 0: the caller's intensity scale (psx_set_deterministic_scale) takes the place of det_gmax
     unsigned *det_fold_count;     // [ndist][ntiles] entries of each list's fold table (written by the ADD pass for EVERY list)
     long long *det_acc;           // [ndist][Nx*Ny] scratch words (only touched words are ever looked at: no initial state)
 };
@@ -338,7 +340,7 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     // order-independent far-ray replay: the far shares of the WHOLE call are summed in one fixed-point unit, 2^-30 of the
     // power of two above the largest finite intensity any tile staged.  A tile only sends its maximum when it beats what the
     // word already holds (a stale read costs one more atomic, nothing else): a few hundred atomics per call, not one per tile.
-    if (a.det_gmax && tid == 0 && finite_in && mbits &&
+    if (a.det_gmax && !a.det_scale_bits && tid == 0 && finite_in && mbits &&
         mbits > __hip_atomic_load(a.det_gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         atomicMax(a.det_gmax, mbits);
     // A window that holds no intensity at all deposits nothing, lists nothing and leaves zeros: skip the deposit loops (the
@@ -624,7 +626,7 @@ __device__ __forceinline__ RefractArgs one_distance_block(const RefractTab &t, i
     a.Nx = s.Nx; a.Ny = s.Ny; a.margin = s.margin; a.clamp_xf = s.clamp_xf; a.clamp_yf = s.clamp_yf;
     a.status = s.status; a.far_count = s.far_count; a.far_list = s.far_list;
     a.tiles_x = s.tiles_x; a.tiles_y = s.tiles_y; a.tile_cap = s.tile_cap; a.far_stride = s.far_stride; a.stamps = nullptr;
-    a.det_gmax = s.det_gmax; a.det_fold_count = s.det_fold_count; a.det_acc = s.det_acc;
+    a.det_gmax = s.det_gmax; a.det_scale_bits = s.det_scale_bits; a.det_fold_count = s.det_fold_count; a.det_acc = s.det_acc;
     return a;
 }
 
@@ -701,7 +703,7 @@ __device__ __forceinline__ void refract_far_body(const RefractArgs &a) {
         const unsigned nf = a.det_fold_count[lst];
         if (nf == 0) return;
         const unsigned *fold = reinterpret_cast<const unsigned *>(list);
-        const double inv = ldexp(1.0, -det_unit_exp(*a.det_gmax));
+        const double inv = ldexp(1.0, -det_unit_exp(a.det_scale_bits ? a.det_scale_bits : *a.det_gmax));
         bool bad = false;
         for (unsigned e = lane; e < nf; e += FAR_SUB) {
             const unsigned p = fold[e];
@@ -720,7 +722,7 @@ __device__ __forceinline__ void refract_far_body(const RefractArgs &a) {
         return;
     }
     const int Px = a.Nx + 2 * a.margin, Py = a.Ny + 2 * a.margin;
-    const float unit = MODE == FAR_ADD ? ldexpf(1.f, det_unit_exp(*a.det_gmax)) : 0.f;     // exact scaling
+    const float unit = MODE == FAR_ADD ? ldexpf(1.f, det_unit_exp(a.det_scale_bits ? a.det_scale_bits : *a.det_gmax)) : 0.f;     // exact scaling
     unsigned *const fold = reinterpret_cast<unsigned *>(list);     // FAR_ADD: fold table, over the records already consumed --
     unsigned nf = 0;                                               // after t rounds it holds <= 4 * 64 t entries of 4 bytes = the
     (void)unit; (void)fold;                                        // 64 t records of 16 bytes every lane has read (wave-uniform nf)
@@ -754,7 +756,12 @@ __device__ __forceinline__ void refract_far_body(const RefractArgs &a) {
                             if (a.status) atomicOr(a.status, PSX_STATUS_NONFINITE);
                             return;
                         }
-                        const long long q = llrintf(v * unit);                  // |q| <= 2^30: |v| <= the call's largest intensity
+                        const float xq = v * unit;                              // |xq| <= 2^30 when the unit comes from the call's maximum
+                        if (!(fabsf(xq) < 1.1258999e15f)) {                     // a caller's scale 2^20 times too small: an "insane value"
+                            if (a.status) atomicOr(a.status, PSX_STATUS_NONFINITE);
+                            return;
+                        }
+                        const long long q = llrintf(xq);
                         if (q == 0) return;                                     // below the unit: contributes nothing
                         const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(acc + p),
                                                                  DET_ONE + ((unsigned long long)q & DET_MASK));
@@ -848,6 +855,14 @@ __global__ __launch_bounds__(256) void k_fastloop(const float *__restrict__ I, c
 // Per HOST THREAD (the ABI's thread model is one host thread per GPU): a second thread driving another GPU keeps its own.
 thread_local int g_refract_geometry = 0;   // 0: GeoSmall (H=4), 1: GeoWide (H=8), 2: GeoMid (H=6), 3: GeoH12, 4: GeoH16
 thread_local int g_deterministic = 0;      // psx_set_deterministic
+thread_local float g_det_scale = 0.f;      // psx_set_deterministic_scale (0: the unit comes from the call's measured maximum)
+static unsigned det_scale_bits() {         // the scale with 2^6 of room for shares above it, as float bits (0: measure)
+    if (!(g_det_scale > 0.f) || !(g_det_scale < 1e30f)) return 0u;
+    const float s = g_det_scale * 64.f;
+    unsigned b;
+    std::memcpy(&b, &s, sizeof b);
+    return b;
+}
 
 // scratch of psx_fastloop_f32's deterministic mode (that entry point has no workspace argument): accumulators + the max
 // word, owned for the duration of one call -- a plain hipMalloc / synchronise / hipFree per call, a debugging aid.  The
@@ -922,11 +937,13 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
     a.far_stride = far_stride_for((unsigned)(a.tiles_x * a.tiles_y * a.ndist));
     a.far_count = (unsigned *)workspace;
     a.far_list = (FarRay *)((char *)workspace + 16 * ((sizeof(unsigned) * (size_t)a.tiles_x * a.tiles_y * a.ndist + 15) / 16));
-    a.det_gmax = nullptr; a.det_fold_count = nullptr; a.det_acc = nullptr;
+    a.det_gmax = nullptr; a.det_fold_count = nullptr; a.det_acc = nullptr; a.det_scale_bits = 0u;
     if (g_deterministic) {
         char *const det = (char *)workspace + lists_bytes<G>(a.Nx, a.Ny, a.ndist);
         det_pointers<G>(a, det, det + 16, a.ndist);
-        PSX_HIP(hipMemsetAsync(a.det_gmax, 0, 16, st));      // the only word of the mode with an initial state: set per call
+        a.det_scale_bits = det_scale_bits();
+        if (!a.det_scale_bits)
+            PSX_HIP(hipMemsetAsync(a.det_gmax, 0, 16, st));      // the only word of the mode with an initial state: set per call
     }
     int rc_launch = 0;
     auto launch = [&](auto nm, auto hi, auto hp) -> int {
@@ -983,13 +1000,13 @@ int launch_refract_batch(RefractTab &t, int n, bool has_I, int nmat, void *works
         a.far_count = (unsigned *)workspace + (size_t)k * nt;
         a.far_list = (FarRay *)((char *)workspace + 16 * ((sizeof(unsigned) * nt * REFRACT_TAB + 15) / 16)) + (size_t)k * nt * a.tile_cap;
         // order-independent replay: every refraction of the chunk its own exponents, marks and scratch words behind the chunk's lists
-        a.det_gmax = nullptr; a.det_fold_count = nullptr; a.det_acc = nullptr;
+        a.det_gmax = nullptr; a.det_fold_count = nullptr; a.det_acc = nullptr; a.det_scale_bits = g_deterministic ? det_scale_bits() : 0u;
         if (g_deterministic) {    // the chunk's maximum words side by side (one memset node), then each refraction's counts and words
             char *const det = (char *)workspace + lists_bytes<G>(a.Nx, a.Ny, REFRACT_TAB);
             det_pointers<G>(a, det + 16 * k, det + 16 * REFRACT_TAB + (size_t)k * (det_bytes<G>(a.Nx, a.Ny, 1) - 16), 1);
         }
     }
-    if (g_deterministic)      // every refraction of the chunk its own maximum word (its own unit: an image of its own)
+    if (g_deterministic && !t.e[0].det_scale_bits)      // every refraction of the chunk its own maximum word (its own unit: an image of its own)
         PSX_HIP(hipMemsetAsync(t.e[0].det_gmax, 0, 16 * REFRACT_TAB, st));
     int rc_launch = 0;
     auto launch = [&](auto nm, auto hi) -> int {
@@ -1127,6 +1144,12 @@ int psx_set_deterministic(int on) {
 }
 
 int psx_get_deterministic(void) { return g_deterministic; }
+
+int psx_set_deterministic_scale(float scale) {
+    PSX_REQUIRE(scale >= 0.f && scale < 1e30f, "psx_set_deterministic_scale: scale %g outside [0, 1e30)", (double)scale);
+    g_det_scale = scale;
+    return 0;
+}
 
 size_t psx_refract_batch_workspace_bytes(int Nx, int Ny, int n) {
     if (Nx <= 0 || Ny <= 0) return 16;

@@ -520,19 +520,28 @@ def get_deterministic():
     return bool(lib().psx_get_deterministic())
 
 
-class deterministic:
-    """with ops.deterministic(on): ... -- sets the mode and puts back what the caller had."""
+def set_deterministic_scale(scale=0.0):
+    """The replay's fixed-point unit from the caller's intensity scale (psx_set_deterministic_scale); 0: from the call's own
+    measured maximum (the default)."""
+    check(lib().psx_set_deterministic_scale(c_float(float(scale))), "psx_set_deterministic_scale")
 
-    def __init__(self, on=True):
-        self.on = bool(on)
+
+class deterministic:
+    """with ops.deterministic(on[, scale]): ... -- sets the mode (and the unit's scale) and puts back what the caller had
+    (the scale goes back to 0 = measured: the library has no getter for it and nothing else sets it)."""
+
+    def __init__(self, on=True, scale=0.0):
+        self.on, self.scale = bool(on), float(scale) if on else 0.0
 
     def __enter__(self):
         self.prev = get_deterministic()
         set_deterministic(self.on)
+        set_deterministic_scale(self.scale)
         return self
 
     def __exit__(self, *exc):
         set_deterministic(self.prev)
+        set_deterministic_scale(0.0)
         return False
 
 

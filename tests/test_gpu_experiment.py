@@ -49,13 +49,14 @@ def test_chain_rt_with_measured_halo():
         assert exp._halo in (4, 6, 8) and sorted(exp._halo_times) == [4, 6, 8]      # oversampling < 4: the three narrow halos
         for nm, a in (("Sample", S), ("Reference", R), ("Propag", Pg), ("White", W)):
             assert relmax(a.cpu().numpy(), g["mono/RT/p0/" + nm]) < TOL, nm
-        # reproducible (the default): 'auto' is a RULE of the oversampling, the same on every rank and in every run
-        for ov, want in ((2, 6), (4, 12)):
+        # reproducible (the default): 'auto' is a RULE of how far the longest hop's rays travel in study pixels, z / (h M) -- the
+        # same on every rank and in every run
+        for pix, want in ((2.9, 4), (1.46, 8), (0.7, 12)):
             exp2 = build_experiment(cfg, "RT")
             exp2.exp_dict["refractionHalo"] = "auto"
-            exp2.exp_dict["overSampling"] = ov
+            exp2.exp_dict.update(studyPixelSize=pix, distMembraneToObject=1.6, distObjectToDetector=3.6, magnification=1.025)
             exp2._set_halo(None, None, None)
-            assert exp2._halo == want and not hasattr(exp2, "_halo_times")
+            assert exp2._halo == want and not hasattr(exp2, "_halo_times"), (pix, exp2._halo)
     finally:
         ops.set_refract_halo(4)
 

@@ -906,3 +906,38 @@ def test_refract_split_equals_two_masked_refractions(ops, halo, det):
     finally:
         ops.set_deterministic(False)
         ops.set_refract_halo(4)
+
+
+def test_replay_unit_from_the_callers_scale(ops):
+    """psx_set_deterministic_scale (round 5): the order-independent replay takes its fixed-point unit from the caller's
+    intensity scale instead of measuring the call's maximum (no memset node, no atomicMax).  Bitwise repeatable, within float
+    rounding of the measured-unit result and of the oracle; a scale 2^20 times too small raises the status word instead of
+    overflowing a sum."""
+    from paresis_amd._lib import PsxError
+    rng = np.random.default_rng(31)
+    Nx, Ny = 240, 199
+    I = rng.uniform(50.0, 150.0, (Nx, Ny))
+    phi = np.cumsum(rng.uniform(-25, 25, (Nx, Ny)), axis=0) + np.cumsum(rng.uniform(-25, 25, (Nx, Ny)), axis=1)
+    I32 = I.astype(np.float32).astype(np.float64)
+    h = 1e-6
+    ref, Dxr, _ = orc.fast_refraction(I32.copy(), phi.copy(), orc.k_refraction(52.0) * h * h, 52.0, 1.0, 1.0)
+    assert np.abs(Dxr).max() > 15
+    It, pt = dev(I32, torch.float32), dev(phi, torch.float64)
+    run = lambda: ops.refract((Nx, Ny), None, 1.0, (Nx, Ny), I_in=It, phi_in=pt)[0].clone()
+    with ops.deterministic(True):
+        measured = run()
+    with ops.deterministic(True, scale=100.0):
+        a, b = run(), run()
+        ops.check_status(It.device)
+    assert torch.equal(a, b)
+    assert relmax(a.cpu().numpy(), ref) < TOL
+    assert float((a - measured).abs().max() / measured.abs().max()) < 1e-6
+    assert not ops.get_deterministic()
+    with ops.deterministic(True, scale=1e-4):                 # shares 1.5e6 times the scale: still inside the 2^20 x 64 of room
+        c = run()
+        ops.check_status(It.device)
+    assert float((c - measured).abs().max() / measured.abs().max()) < 1e-6
+    with ops.deterministic(True, scale=1e-20):                # 1e22 times the scale: refused, not wrapped
+        run()
+        with pytest.raises(PsxError):
+            ops.check_status(It.device)

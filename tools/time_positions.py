@@ -4,7 +4,7 @@ synthesis (seeded offsets, sphere splat on the GPU) + the image-formation chain 
 BASELINE.json config 4 is 64 such positions over 8 GPUs (8 per GPU, no data-path collective).
 
     python tools/time_positions.py [N] [NPOS] [--poly 25]      # --poly E: a tube spectrum of E energies (polychromatic position)
-                                   [--float-atomics] [--halo 4|6|8] [--sim RT|Fresnel] [--scatter [--thin F]]
+                                   [--float-atomics] [--halo 4|6|8] [--sim RT|Fresnel] [--scatter [--thin F]] [--ov 2|4]
 """
 import ctypes
 import os
@@ -22,7 +22,7 @@ def _opt(name, default=None):
 
 
 _skip = set()
-for _o in ('--poly', '--halo', '--sim', '--thin'):
+for _o in ('--poly', '--halo', '--sim', '--thin', '--ov'):
     if _o in sys.argv:
         _skip.add(sys.argv.index(_o) + 1)
 _args = [a for i, a in enumerate(sys.argv) if i > 0 and not a.startswith('--') and i not in _skip]
@@ -36,7 +36,7 @@ if npoly:
     spectrum = [(float(a), float(b)) for a, b in zip(e, w / w.sum())]
 lib = _lib.lib()
 for sim in ([_opt('--sim')] if _opt('--sim') else ["Fresnel", "RT"]):
-    exp, place = synth.bench_experiment(N, sim, noise=True, seed=3, spectrum=spectrum)
+    exp, place = synth.bench_experiment(N, sim, noise=True, seed=3, spectrum=spectrum, ov=int(_opt('--ov', 2)))
     exp.exp_dict['reproducible'] = '--float-atomics' not in sys.argv
     if _opt('--halo'):
         exp.exp_dict['refractionHalo'] = int(_opt('--halo'))
