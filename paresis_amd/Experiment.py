@@ -88,6 +88,13 @@ class Experiment:
             self.myDetector.getSpectralEfficiency()
         if ed['simulation_type'] == "RayT" and ed["overSampling"] < 2:      # EXP:103-105
             print(f'/!\\/!\\ OVERSAMPLING FACTOR < MIN OVERSAMPLING FOR RAY-T MODEL: {ed["overSampling"]} < 2')
+        if ed['simulation_type'] == "Fresnel":                              # EXP:106-110 (advisory print, host scalars)
+            from .usefullScripts.getSamplingFactor import is_overSampling_ok
+            kind = self.mySource.source_dict["myType"]
+            if kind == "Polychromatic":                                     # judged at half the top energy of the spectrum
+                is_overSampling_ok(ed, self.myDetector.det_param['myPixelSize'], self.mySource.mySpectrum[-1][0] / 2)
+            elif kind == "Monochromatic":
+                is_overSampling_ok(ed, self.myDetector.det_param['myPixelSize'], self.mySource.source_dict["Energy"])
         print('\nCurrent experiment:', self.name)
         print("  Magnification :", ed['magnification'])
         print(f'  Study dimensions: {ed["studyDimensions"]} pixels')

@@ -144,6 +144,36 @@ def test_xml_plate_and_psf_experiment():
     assert ed["studyDimensions"] == [300, 200]
 
 
+def test_fresnel_sampling_advisory(capsys):
+    """EXP:103-110 / getSamplingFactor.py:17-26: the constructor warns when overSampling is below what the Fresnel model
+    needs; the factor itself is ceil(pix/M / (sqrt(lambda z/M)/2)), checked on the reference script's own example
+    (22 keV, 50 um, 0.5 m + 1 m -> 8) and on hand arithmetic for the shipped plate experiment."""
+    import math
+    from paresis_amd.Experiment import Experiment
+    from paresis_amd.usefullScripts.getSamplingFactor import is_overSampling_ok, kevToLambda
+    d = dict(simulation_type="Fresnel", overSampling=2, distSourceToMembrane=0.5, distMembraneToObject=0, distObjectToDetector=1)
+    assert is_overSampling_ok(d, 50, 22) == 8.0
+    assert "FRESNEL MODEL: 2 < 8.0" in capsys.readouterr().out
+    d["overSampling"] = 8
+    assert is_overSampling_ok(d, 50, 22) == 8.0 and capsys.readouterr().out == ""
+    assert abs(kevToLambda(12.4) - 1e-10) < 1e-24
+    d["simulation_type"] = "RayT"
+    assert is_overSampling_ok(d, 50, 22) is None
+
+    ed = {"experimentName": "Sphere_PMMA_plate", "filepath": "/tmp/", "overSampling": 1, "nbExpPoints": 1,
+          "simulation_type": "Fresnel"}
+    exp = Experiment(ed)
+    out = capsys.readouterr().out
+    src = exp.mySource.source_dict
+    E = src["Energy"] if src["myType"] == "Monochromatic" else exp.mySource.mySpectrum[-1][0] / 2
+    M = ed["magnification"]
+    need = math.ceil(exp.myDetector.det_param["myPixelSize"] * 1e-6 / M / (math.sqrt(1240e-12 / E * ed["distObjectToDetector"] / M) / 2))
+    assert ("FRESNEL MODEL: 1 < %s" % float(need) in out) == (need > 1)
+    ed = {"experimentName": "Fil_Nylon_ID17", "filepath": "/tmp/", "overSampling": 1, "nbExpPoints": 1, "simulation_type": "RayT"}
+    Experiment(ed)
+    assert "RAY-T MODEL: 1 < 2" in capsys.readouterr().out
+
+
 def test_image_io_roundtrip(tmp_path):
     from paresis_amd.InputOutput.pagailleIO import openImage, save_image
     img = np.random.default_rng(0).uniform(0, 1e4, (37, 53)).astype(np.float32)
