@@ -232,6 +232,11 @@ int psx_detector_plan_create(int Nx, int Ny, int ov, int nx, int ny, int margin,
                              psx_detector_plan **plan);
 int psx_detector_plan_destroy(psx_detector_plan *plan);
 int psx_detect_f32(psx_detector_plan *plan, const float *img, float *out, void *stream);
+/* The detector operator on nimg <= PSX_MAX_DETECT images of the plan's shape in one call (imgs, outs: host arrays of device
+ * pointers; distinct outputs) -- the two to four images of an energy bin (Experiment.py:388-394 / 507-514).  When both stages run
+ * fused the images share each launch; out[i] is bit for bit what psx_detect_f32(plan, imgs[i], outs[i]) would write. */
+#define PSX_MAX_DETECT 4
+int psx_detect_multi_f32(psx_detector_plan *plan, const float *const *imgs, float *const *outs, int nimg, void *stream);
 /* Host-only view of one axis of the composed operator (no GPU needed): row r of the [n x N] banded matrix is
  * weights[r*wcap .. r*wcap+W) applied to study pixels start[r] .. start[r]+W.  *W_out receives the band width;
  * fails with PSX_E_ARG when it exceeds wcap. */

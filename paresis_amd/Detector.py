@@ -79,10 +79,12 @@ class Detector:
         sigma_src = effectiveSourceSize / 2.355 if effectiveSourceSize != 0 else 0.0     # DET:96-97
         outs = [None] * len(images) if outs is None else list(outs)
         keys = [None] * len(images) if keys is None else list(keys)
-        res = []
-        for im, o in zip(images, outs):
-            img = to_dev(im, torch.float32)
-            res.append(self._plan(img.shape, exp_param["overSampling"], sigma_src, img.device).detect(img, out=o))
+        imgs = [to_dev(im, torch.float32) for im in images]
+        if imgs and all(im.shape == imgs[0].shape and im.device == imgs[0].device for im in imgs):
+            res = self._plan(imgs[0].shape, exp_param["overSampling"], sigma_src, imgs[0].device).detect_many(imgs, outs)
+        else:
+            res = [self._plan(img.shape, exp_param["overSampling"], sigma_src, img.device).detect(img, out=o)
+                   for img, o in zip(imgs, outs)]
         if exp_param.get("noise", True):
             seed = int(exp_param.get("seed", 0))
             seeds = []

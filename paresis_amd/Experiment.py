@@ -539,11 +539,16 @@ class Experiment:
             a2, g2, _ = self._fresnel_scalars(dOD + dMO, currentEnergy, M)
             a3, g3, _ = self._fresnel_scalars(dOD, currentEnergy, M)
             # EXP:341 + EXP:349 in one call: membrane exit wave -> sample plane (complex field) and -> detector (|.|^2)
+            # (the first energy of a bin without a plate IS the bin's image so far: it is written in place and only summed)
+            direct = first and plate_att is None
             wbs = plan.propagate([a1, a2], [g1, g2], du, amp=amp, mats=mem, want_wave=[True, False],
-                                 inten_out=[None, tmp])[0]
+                                 inten_out=[None, accR if direct else tmp])[0]
             self.waveSampleBeforeSample = wbs
             # EXP:355-361: plate attenuation, sum over energies and the image sum for the mean energy in one pass
-            ops.accumulate_sum(accR, tmp, sums, currentEnergy, mats=plate_att, add=not first)
+            if direct:
+                ops.accumulate_sum(None, accR, sums, currentEnergy)
+            else:
+                ops.accumulate_sum(accR, tmp, sums, currentEnergy, mats=plate_att, add=not first)
             # EXP:344 + EXP:348: through the sample, on to the detector
             if plate_att is None:
                 plan.propagate([a3], [g3], du, wave_in=wbs, mats=smp, want_wave=[False], inten_out=[accS], add=not first)
@@ -757,9 +762,14 @@ class Experiment:
             self.IntensitySampleBeforeSample = Ibs
             mem_phase = mem.with_coeffs(catt=[0.0] * mem.n)
             # EXP:474 reference image: refracted again with the membrane phase only
-            ops.refract(N, mem_phase, self._dscale(dOD, currentEnergy), clamp, I_in=Ibs, out=tmp)
+            # (the first energy of a bin without a plate IS the bin's image so far: it is written in place and only summed)
+            direct = first and plate_att is None
+            ops.refract(N, mem_phase, self._dscale(dOD, currentEnergy), clamp, I_in=Ibs, out=accR if direct else tmp)
             # EXP:480-486: plate attenuation, sum over energies and the image sum for the mean energy in one pass
-            ops.accumulate_sum(accR, tmp, sums, currentEnergy, mats=plate_att, add=not first)
+            if direct:
+                ops.accumulate_sum(None, accR, sums, currentEnergy)
+            else:
+                ops.accumulate_sum(accR, tmp, sums, currentEnergy, mats=plate_att, add=not first)
             # EXP:469 + 473 sample image: sample attenuation and membrane+sample phase fused into the refraction
             both = ops.MaterialStack.concat(mem_phase, smp)
             if scattering:                                       # Lung / cylinder_beeds: fastRefractionDF (EXP:272-275)

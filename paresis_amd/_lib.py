@@ -13,11 +13,12 @@ LIB_PATH = os.path.join(_HERE, "libparesis_hip.so")
 PSX_MAX_MAT = 8
 PSX_MAX_DIST = 8
 PSX_MAX_POISSON = 8
+PSX_MAX_DETECT = 4
 PSX_MAX_SRC = 16
 PSX_SUM_SLOTS, PSX_SUM_STRIDE = 32, 16
 ENGINE_AUTO, ENGINE_ROCFFT, ENGINE_LDS = 0, 1, 2
 STATUS_NONFINITE = 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class PsxError(RuntimeError):
@@ -67,6 +68,7 @@ PROTOTYPES = {
     "psx_detector_plan_create": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double, _vpp]),
     "psx_detector_plan_destroy": (c_int, [_vp]),
     "psx_detect_f32": (c_int, [_vp, _vp, _vp, _vp]),
+    "psx_detect_multi_f32": (c_int, [_vp, _vpp, _vpp, c_int, _vp]),
     "psx_detector_operator_host": (c_int, [c_int, c_int, c_int, c_int, c_double, c_double, POINTER(c_int), _fp, c_int,
                                            POINTER(c_int)]),
     "psx_resize_f32": (c_int, [_vp, c_int, c_int, _vp, c_int, c_int, _vp]),

@@ -48,7 +48,8 @@ struct psx_detector_plan {
     float *t2 = nullptr;     // [fx.n_out][fy.n_out]   (only with a PSF)
     float *t3 = nullptr;     // [fx.n_out][ny]         (only with a PSF)
     BandPair front, back;    // fused (contiguous axis, axis 0) pairs; front writes t2p, back reads it
-    float *t2p = nullptr;    // [fx.n_out][pitch2], pitch2 = fy.n_out rounded up to 4 (16-byte rows for the back pair's loads)
+    float *t2p = nullptr;    // [PSX_MAX_DETECT][fx.n_out][pitch2], pitch2 = fy.n_out rounded up to 4 (16-byte rows for the back
+                             // pair's loads); one per image of a psx_detect_multi_f32 launch
     int pitch2 = 0;
     size_t bytes = 0;
 };
@@ -318,8 +319,8 @@ __global__ __launch_bounds__(256) void k_band_rows(const float *__restrict__ in,
 constexpr int PAIR_MIT = 5;      // float4 per lane and staged row: spans up to 1280 floats
 
 struct PairArgs {
-    const float *in;
-    float *out;
+    const float *in[PSX_MAX_DETECT];   // blockIdx.z = image of the launch (psx_detect_multi_f32: the images of one energy bin)
+    float *out[PSX_MAX_DETECT];
     int in_pitch, out_pitch;
     const int *c_start;
     const int2 *c_blk;
@@ -340,6 +341,8 @@ __global__ __launch_bounds__(256) void k_band_pair(PairArgs a) {
     float *wsh = mid + a.mid_rows * 256;
     int *ssh = reinterpret_cast<int *>(wsh + a.RT * a.r_W);
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const float *const img_in = a.in[blockIdx.z];
+    float *const img_out = a.out[blockIdx.z];
     // a workgroup keeps its column block: the column's weights and the staged span are set up once
     const int cbk = blockIdx.x;
     const int c = cbk * 256 + threadIdx.x;
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(256) void k_band_pair(PairArgs a) {
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             const int i = min(i0 + wv + 4 * h, ihi - 1);
-            const float4 *row = reinterpret_cast<const float4 *>(a.in + (int64_t)i * a.in_pitch + s0);
+            const float4 *row = reinterpret_cast<const float4 *>(img_in + (int64_t)i * a.in_pitch + s0);
 #pragma unroll
             for (int m = 0; m < MIT; ++m) {
                 const int t4 = ln + 64 * m;
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256) void k_band_pair(PairArgs a) {
             float acc = 0.f;
 #pragma unroll 4
             for (int k = 0; k < lim; ++k) acc = fmaf(wr[k], col[k * 256], acc);
-            if (live) a.out[(int64_t)r * a.out_pitch + c] = acc;
+            if (live) img_out[(int64_t)r * a.out_pitch + c] = acc;
         }
     }
 }
@@ -823,7 +826,7 @@ int psx_detector_plan_create(int Nx, int Ny, int ov, int nx, int ny, int margin,
     if (!rc) rc = pair(p->front, p->fy, p->fx);
     if (!rc && psf) rc = pair(p->back, p->by, p->bx);
     p->pitch2 = (p->fy.n_out + 3) / 4 * 4;
-    if (!rc && psf && p->back.ok) rc = scratch(&p->t2p, (size_t)p->fx.n_out * (size_t)p->pitch2);
+    if (!rc && psf && p->back.ok) rc = scratch(&p->t2p, (size_t)PSX_MAX_DETECT * (size_t)p->fx.n_out * (size_t)p->pitch2);
     if (rc) {
         psx_detector_plan_destroy(p);
         return rc;
@@ -935,18 +938,23 @@ int band_rows(const BandOp &op, const float *in, float *out, int C, hipStream_t 
 
 namespace {
 
-int band_pair(const BandPair &pr, const BandOp &C, const BandOp &R, const float *in, int in_pitch, float *out, int out_pitch,
-              hipStream_t st) {
+int band_pair(const BandPair &pr, const BandOp &C, const BandOp &R, const float *const *in, int in_pitch, float *const *out,
+              int out_pitch, int nimg, hipStream_t st) {
     PairArgs a;
-    a.in = in; a.out = out; a.in_pitch = in_pitch; a.out_pitch = out_pitch;
+    for (int k = 0; k < PSX_MAX_DETECT; ++k) {
+        a.in[k] = in[std::min(k, nimg - 1)];
+        a.out[k] = out[std::min(k, nimg - 1)];
+    }
+    a.in_pitch = in_pitch; a.out_pitch = out_pitch;
     a.c_start = C.start; a.c_blk = C.blk; a.c_wT = C.wT; a.c_W = C.W; a.Cin = C.n_in; a.Cout = C.n_out;
     a.r_start = R.start; a.r_w = R.w; a.r_W = R.W; a.Rin = R.n_in; a.Rout = R.n_out;
     a.r_tile = pr.r_tile; a.RT = pr.RT; a.n_rtiles = pr.n_rtiles; a.span_ld = pr.span_ld; a.mid_rows = pr.mid_rows;
-    // column blocks x row strips; a workgroup walks the row tiles of its strip (its column set-up is done once)
+    // column blocks x row strips x images; a workgroup walks the row tiles of its strip (its column set-up is done once), and
+    // the launch as a whole fills the chip once whatever the number of images
     const int cb = (C.n_out + 255) / 256;
     const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / pr.lds);
-    const int strips = std::max(1, std::min(a.n_rtiles, current_cu_count() * std::max(1, per_cu) / cb));
-    const dim3 grid(cb, strips);
+    const int strips = std::max(1, std::min(a.n_rtiles, current_cu_count() * std::max(1, per_cu) / (cb * nimg)));
+    const dim3 grid(cb, strips, nimg);
     if (C.W <= 8) PSX_TIMED("k_band_pair", st, k_band_pair<8, PAIR_MIT><<<grid, 256, pr.lds, st>>>(a));
     else PSX_TIMED("k_band_pair", st, k_band_pair<16, PAIR_MIT><<<grid, 256, pr.lds, st>>>(a));
     return launch_check("k_band_pair");
@@ -956,31 +964,65 @@ bool four_pass_forced() { return debug_switch(DBG_DETECT_4PASS) != 0; }   // dia
 
 }  // namespace
 
-int psx_detect_f32(psx_detector_plan *p, const float *img, float *out, void *stream) {
-    PSX_REQUIRE(p && img && out, "psx_detect_f32: null pointer");
-    hipStream_t st = (hipStream_t)stream;
+// The detector operator on nimg images.  With both stages fused (k_band_pair) the images of the call share each launch
+// (grid.z): a 4096^2 -> 2048^2 detection is two launches of 20-25 us whose set-up, first fetch and tail are a good part of
+// them, and an energy bin always detects two to four images.  Image k is computed exactly as a call of its own would.
+static int detect_impl(psx_detector_plan *p, const float *const *imgs, float *const *outs, int nimg, hipStream_t st) {
     const bool psf = p->bx.n_out != 0;
     // Each stage as ONE fused pass (k_band_pair) where that moves fewer bytes: the front stage when the image rows are 16-byte
     // aligned, the bands fit its tiles and the tiles' halos are small (a wide source blur makes an 8-row tile re-read half
     // its rows: two passes are cheaper then); the PSF stage whenever its bands fit -- it reads the front stage's result at a
     // 16-byte row pitch, which the two-pass front can only write when the row length is a multiple of 4 anyway.
     const bool allowed = !four_pass_forced();
-    const bool front_f = allowed && p->front.ok && p->front.cheap && p->Ny % 4 == 0 && (uintptr_t)img % 16 == 0;
+    bool aligned = true;
+    for (int k = 0; k < nimg; ++k) aligned = aligned && (uintptr_t)imgs[k] % 16 == 0;
+    const bool front_f = allowed && p->front.ok && p->front.cheap && p->Ny % 4 == 0 && aligned;
     const bool back_f = allowed && psf && p->back.ok && p->t2p && (front_f || p->pitch2 == p->fy.n_out);
-    float *mid_img = back_f ? p->t2p : p->t2;
-    const int mid_pitch = back_f ? p->pitch2 : p->fy.n_out;
-    if (front_f) {
-        if (int rc = band_pair(p->front, p->fy, p->fx, img, p->Ny, psf ? mid_img : out, psf ? mid_pitch : p->fy.n_out, st)) return rc;
-    } else {
-        // contiguous axis first (the only pass over the full-resolution image), then axis 0
-        if (int rc = band_cols(p->fy, img, p->t1, p->Nx, st)) return rc;
-        if (int rc = band_rows(p->fx, p->t1, psf ? mid_img : out, p->fy.n_out, st)) return rc;
+    if (nimg > 1 && front_f && (back_f || !psf)) {
+        float *mids[PSX_MAX_DETECT];
+        for (int k = 0; k < nimg; ++k) mids[k] = p->t2p + (size_t)k * p->fx.n_out * p->pitch2;
+        if (!psf) return band_pair(p->front, p->fy, p->fx, imgs, p->Ny, outs, p->fy.n_out, nimg, st);
+        if (int rc = band_pair(p->front, p->fy, p->fx, imgs, p->Ny, mids, p->pitch2, nimg, st)) return rc;
+        return band_pair(p->back, p->by, p->bx, mids, p->pitch2, outs, p->ny, nimg, st);
     }
-    if (!psf) return 0;
-    // back operator (PSF + crop) at detector resolution
-    if (back_f) return band_pair(p->back, p->by, p->bx, mid_img, mid_pitch, out, p->ny, st);
-    if (int rc = band_cols(p->by, p->t2, p->t3, p->fx.n_out, st)) return rc;
-    return band_rows(p->bx, p->t3, out, p->ny, st);
+    for (int k = 0; k < nimg; ++k) {
+        const float *img = imgs[k];
+        float *out = outs[k];
+        float *mid_img = back_f ? p->t2p : p->t2;
+        const int mid_pitch = back_f ? p->pitch2 : p->fy.n_out;
+        float *front_out = psf ? mid_img : out;
+        if (front_f) {
+            if (int rc = band_pair(p->front, p->fy, p->fx, &img, p->Ny, &front_out, psf ? mid_pitch : p->fy.n_out, 1, st)) return rc;
+        } else {
+            // contiguous axis first (the only pass over the full-resolution image), then axis 0
+            if (int rc = band_cols(p->fy, img, p->t1, p->Nx, st)) return rc;
+            if (int rc = band_rows(p->fx, p->t1, front_out, p->fy.n_out, st)) return rc;
+        }
+        if (!psf) continue;
+        // back operator (PSF + crop) at detector resolution
+        if (back_f) {
+            if (int rc = band_pair(p->back, p->by, p->bx, &mid_img, mid_pitch, &out, p->ny, 1, st)) return rc;
+            continue;
+        }
+        if (int rc = band_cols(p->by, p->t2, p->t3, p->fx.n_out, st)) return rc;
+        if (int rc = band_rows(p->bx, p->t3, out, p->ny, st)) return rc;
+    }
+    return 0;
+}
+
+int psx_detect_f32(psx_detector_plan *p, const float *img, float *out, void *stream) {
+    PSX_REQUIRE(p && img && out, "psx_detect_f32: null pointer");
+    return detect_impl(p, &img, &out, 1, (hipStream_t)stream);
+}
+
+int psx_detect_multi_f32(psx_detector_plan *p, const float *const *imgs, float *const *outs, int nimg, void *stream) {
+    PSX_REQUIRE(p && imgs && outs, "psx_detect_multi_f32: null pointer");
+    PSX_REQUIRE(nimg >= 1 && nimg <= PSX_MAX_DETECT, "psx_detect_multi_f32: %d images (1..%d)", nimg, PSX_MAX_DETECT);
+    for (int k = 0; k < nimg; ++k) {
+        PSX_REQUIRE(imgs[k] && outs[k], "psx_detect_multi_f32: null image %d", k);
+        for (int j = 0; j < k; ++j) PSX_REQUIRE(outs[j] != outs[k], "psx_detect_multi_f32: outputs %d and %d are the same image", j, k);
+    }
+    return detect_impl(p, imgs, outs, nimg, (hipStream_t)stream);
 }
 
 int psx_resize_f32(const float *img, int Nx, int Ny, float *out, int sx, int sy, void *stream) {

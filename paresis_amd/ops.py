@@ -698,6 +698,22 @@ class DetectorPlan:
         check(lib().psx_detect_f32(self._h, _ptr(img), _ptr(out), _stream()), "psx_detect_f32")
         return out
 
+    def detect_many(self, imgs, outs=None):
+        """detect() of several images of this plan's shape -- the images of an energy bin -- PSX_MAX_DETECT per call: fused
+        stages take them in one launch each; every image comes out exactly as detect() of it alone would."""
+        outs = [None] * len(imgs) if outs is None else list(outs)
+        for k, img in enumerate(imgs):
+            _need(img, torch.float32, "imgs[%d]" % k, (self.Nx, self.Ny))
+            if outs[k] is None:
+                outs[k] = torch.empty((self.nx, self.ny), dtype=torch.float32, device=img.device)
+            _need(outs[k], torch.float32, "outs[%d]" % k, (self.nx, self.ny))
+        for k0 in range(0, len(imgs), _lib.PSX_MAX_DETECT):
+            part_in, part_out = imgs[k0:k0 + _lib.PSX_MAX_DETECT], outs[k0:k0 + _lib.PSX_MAX_DETECT]
+            pin = (c_void_p * len(part_in))(*[t.data_ptr() for t in part_in])
+            pout = (c_void_p * len(part_out))(*[t.data_ptr() for t in part_out])
+            check(lib().psx_detect_multi_f32(self._h, pin, pout, len(part_in), _stream()), "psx_detect_multi_f32")
+        return outs
+
 
 def detector_operator_host(N, ov, n, sigma_src, sigma_psf, margin=MARGIN_DETECTOR):
     """One axis of the composed detector operator, built on the host (no GPU): (start[n], weights[n][W])."""

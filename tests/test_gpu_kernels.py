@@ -386,6 +386,37 @@ def test_detector_multi_block_grids(ops, case):
     assert relmax(out.cpu().numpy(), ref) < 2e-6, case
 
 
+@pytest.mark.parametrize("case", [(1100, 1204, 2, 1.3, 1.2), (1600, 2052, 4, 2.6, 0.0), (1101, 1203, 3, 0.0, 0.8),
+                                  (2048, 2048, 2, 0.036, 1.2), (2400, 600, 2, 9.0, 3.1)])
+def test_detector_images_of_a_bin_in_one_call(ops, case):
+    """psx_detect_multi_f32 (the two to four images of an energy bin, EXP:388-394): with both stages fused the images share
+    each launch; in every geometry -- fused front + PSF, fused front alone, the four-pass form (unaligned rows, wide blur) --
+    and for 2 ... 5 images (5: two calls) image k is bit for bit what detect() of it alone writes, misaligned inputs and
+    reused outputs included."""
+    Nx, Ny, ov, sig_src, sig_psf = case
+    nx, ny = Nx // ov, Ny // ov
+    g = torch.Generator(device="cuda").manual_seed(Nx * 7 + Ny)
+    plan = ops.DetectorPlan(Nx, Ny, ov, nx, ny, sig_src, sig_psf)
+    imgs = [torch.rand((Nx, Ny), generator=g, device="cuda") * (3.0 + k) for k in range(5)]
+    single = [plan.detect(im).clone() for im in imgs]
+    for n in (2, 3, 4, 5):
+        outs = plan.detect_many(imgs[:n])
+        for k in range(n):
+            assert torch.equal(outs[k], single[k]), (case, n, k)
+    # one image that is not 16-byte aligned sends the call down the one-by-one path; outputs handed in are filled in place
+    buf = torch.empty(Nx * Ny + 4, dtype=torch.float32, device="cuda")
+    mis = buf[1:1 + Nx * Ny].view(Nx, Ny)
+    mis.copy_(imgs[1])
+    outs = [torch.full((nx, ny), -1.0, device="cuda") for _ in range(3)]
+    res = plan.detect_many([imgs[0], mis, imgs[2]], outs)
+    for k in range(3):
+        assert res[k] is outs[k] and torch.equal(outs[k], single[k]), (case, k)
+    with pytest.raises(Exception, match="same image"):
+        plan.detect_many([imgs[0], imgs[1]], [outs[0], outs[0]])
+    plan.close()
+    ops.check_status(imgs[0].device, "detector")
+
+
 def test_resize_golden(ops):
     g = load("scalars.npz")
     for k in range(int(g["resize/n"])):
