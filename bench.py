@@ -931,9 +931,8 @@ def run_configs(a, dev):
         def step():
             plan.propagate(aa, gp, du, amp=amp, mats=wave_mats, want_wave=[False] * len(zs), inten_out=fres)
             ops.refract_multi((N, N), rt_mats, dsc, (N, N), I0=I0, outs=refr)
-            if det is not None:
-                for i, img in enumerate(fres + refr):
-                    det.detect(img, out=dets[i])
+            if det is not None:                    # up to four images per launch, each bit for bit what its own call would write
+                det.detect_many(fres + refr, dets)
 
         step()
         torch.cuda.synchronize()

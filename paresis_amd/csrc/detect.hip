@@ -955,7 +955,11 @@ int band_pair(const BandPair &pr, const BandOp &C, const BandOp &R, const float 
     const int per_cu = (int)std::min<size_t>(8, (160 * 1024) / pr.lds);
     const int strips = std::max(1, std::min(a.n_rtiles, current_cu_count() * std::max(1, per_cu) / (cb * nimg)));
     const dim3 grid(cb, strips, nimg);
-    if (C.W <= 8) PSX_TIMED("k_band_pair", st, k_band_pair<8, PAIR_MIT><<<grid, 256, pr.lds, st>>>(a));
+    // the column operator's taps sit in registers, a float4 of them per aligned LDS read: as few as the band needs (a plain
+    // ov = 2 binning has 2 taps, the usual PSF 9: two reads instead of three, four instead of five)
+    if (C.W <= 4) PSX_TIMED("k_band_pair", st, k_band_pair<4, PAIR_MIT><<<grid, 256, pr.lds, st>>>(a));
+    else if (C.W <= 8) PSX_TIMED("k_band_pair", st, k_band_pair<8, PAIR_MIT><<<grid, 256, pr.lds, st>>>(a));
+    else if (C.W <= 12) PSX_TIMED("k_band_pair", st, k_band_pair<12, PAIR_MIT><<<grid, 256, pr.lds, st>>>(a));
     else PSX_TIMED("k_band_pair", st, k_band_pair<16, PAIR_MIT><<<grid, 256, pr.lds, st>>>(a));
     return launch_check("k_band_pair");
 }
