@@ -111,6 +111,7 @@ enum DebugSwitch {
     DBG_STAMP_ROUND,       // which round of a unit the stamps are taken in
     DBG_DETECT_4PASS,      // detector stages as four passes instead of fused pairs
     DBG_FAR_STRIDE,        // far-ray replay: lists handed to the waves in a strided order (value = stride; 0: tile order)
+    DBG_NEAR_LDS_PAD,      // refraction tile kernel: KiB of LDS added to the launch (occupancy probe: beyond ~2 KiB one workgroup per CU)
     DBG_COUNT
 };
 int debug_switch(DebugSwitch s);

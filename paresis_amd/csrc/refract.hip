@@ -963,9 +963,11 @@ int launch_refract(RefractArgs &a, const float *I_in, const double *phi_in, int 
             static std::atomic<unsigned long long> attr_mask{0};
             if (first_on_device(attr_mask))
                 PSX_HIP(hipFuncSetAttribute((const void *)k_refract_near<G, NM, HI, HP>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            // diagnostics (psx_debug_switch "near_lds_pad"): more LDS than the tile needs, i.e. one workgroup per CU
+            const size_t lds = std::min<size_t>(160 * 1024, G::LDS + 1024 * (size_t)std::max(0, debug_switch(DBG_NEAR_LDS_PAD)));
             PSX_TIMED("k_refract_near", st,
-                      k_refract_near<G, NM, HI, HP><<<a.tiles_x * a.tiles_y, G::NT, G::LDS, st>>>(a));
+                      k_refract_near<G, NM, HI, HP><<<a.tiles_x * a.tiles_y, G::NT, lds, st>>>(a));
         }
         if (int rc = launch_check("k_refract_near")) return rc;
         const int nlists = a.tiles_x * a.tiles_y * a.ndist;

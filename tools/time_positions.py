@@ -16,6 +16,8 @@ import numpy as np
 import torch
 
 from paresis_amd import _lib, ops, synth
+import _switches                      # PSX_SWITCHES="near_lds_pad=8" -> psx_debug_switch
+_switches.apply()
 
 def _opt(name, default=None):
     return sys.argv[sys.argv.index(name) + 1] if name in sys.argv else default
