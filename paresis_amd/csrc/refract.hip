@@ -238,6 +238,7 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
                 const int sr = idx / SC, sc = idx - sr * SC;
                 // the phase needs float64 (it is differenced); the attenuation exponent, at most a few units, does not:
                 // exp(sum catt T) = exp2(sum (catt log2 e) T) in float32 is three instructions and good to 1e-7
+                // (a transmission below 2^-126 comes out as zero)
                 double ph = phin[u];
                 float la2 = 0.f;
 #pragma unroll
@@ -246,7 +247,7 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
                     la2 = fmaf((float)(a.m.catt[m] * 1.4426950408889634), t[u][m], la2);
                 }
                 float I = a.I0 * Iin[u];
-                if (NM > 0) I *= exp2f(la2);
+                if (NM > 0) I *= __builtin_amdgcn_exp2f(la2);   // v_exp_f32 itself: exp2f() wraps it in five instructions for results below 2^-126
                 const unsigned side = (sides >> u) & 1u;
                 sphi[idx] = with_side(ok[u] ? ph : 0.0, side, SPLITC);
                 if (sr >= 1 && sr <= GR && sc >= 1 && sc <= GC) {
@@ -298,7 +299,7 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
             }
             if (u < NP) {
                 float I = a.I0 * Iin[u];
-                if (NM > 0) I *= exp2f(la2);
+                if (NM > 0) I *= __builtin_amdgcn_exp2f(la2);   // v_exp_f32 itself: exp2f() wraps it in five instructions for results below 2^-126
                 const unsigned side = (sides >> u) & 1u;
                 sphi[(1 + idx / GC) * SC + 1 + (idx & (GC - 1))] = with_side(ph, side, SPLITC);
                 sI[idx] = I;
