@@ -94,8 +94,28 @@ struct CellSphere {
 // compacts the spheres of one job whose window meets the tile, eight jobs per round -- both layers of the usual two-layer
 // membrane in one round -- into one flat list.  The layers of a position (same list, one integer offset each,
 // getMembraneFromFile.py:139-142) are summed before the single store, and the uniform support map is written by the same launch.
+#ifndef PSX_ML_OFF
+#define PSX_ML_OFF 0          // timing experiments: 1 no splat, 2 no stores, 4 no search for spheres at all
+#endif
+// Tile (rows x columns) and workgroup size of the layers kernel -- build-time A/B, tools/ab_membrane_tile.sh.  Timing experiments
+// on the 32 x 32 x 256 form (PSX_ML_OFF; gpurun_out/r5s63, kernel by event pairs, 4096^2, two layers of 15 um spheres): whole kernel
+// 0.0733 ms; without the splat 0.0310; without the stores 0.0685; launch + zeroing alone 0.0142 -- the splat is 58 % of it, and a
+// sphere whose window straddles a tile border is splatted once per tile it touches (2.07 tiles per sphere at 32 x 32, 1.75 at
+// 32 x 64).  Measured (gpurun_out/r5s64): 32x32x256 0.0733, 32x64x256 **0.0596**, 64x64x512 0.0610, 32x128x512 0.0656, 32x64x512
+// 0.0777, 64x32x512 0.0796, 64x64x256 0.0738 (three workgroups per CU), 128x32x256 0.0912.
+#ifndef PSX_ML_TX
+#define PSX_ML_TX 32
+#endif
+#ifndef PSX_ML_TY
+#define PSX_ML_TY 64
+#endif
+constexpr int MLX = PSX_ML_TX, MLY = PSX_ML_TY;   // rows (axis 0) x columns
 constexpr int ML_MAX = 8;        // layers per launch
-constexpr int ML_SEGS = 8;       // jobs staged per round
+#ifndef PSX_ML_THREADS
+#define PSX_ML_THREADS 256
+#endif
+constexpr int MLT = PSX_ML_THREADS;           // threads per workgroup
+constexpr int ML_SEGS = MLT / 32;             // jobs staged per round: one per half-wave
 constexpr int ML_CAP = 32;       // spheres per job and batch
 constexpr int ML_FRAC = 36;      // fractional bits of the accumulators: chords below 2^14 pixels, sums below 2^27
 
@@ -111,39 +131,40 @@ struct StagedSphere {
 
 // sqrt of a positive float64 from the float32 reciprocal square root and one Newton step in float64 (relative error
 // ~2e-14; the library's correctly rounded sqrt costs three times the instructions and the result is stored as float32)
+template <bool CLAMP>
 __device__ __forceinline__ double chord_sqrt(double t) {
-    const float tf = fmaxf((float)t, 1e-30f);
+    const float tf = CLAMP ? fmaxf((float)t, 1e-30f) : (float)t;
     const double y = (double)__builtin_amdgcn_rsqf(tf);
     const double s0 = t * y, h0 = 0.5 * y;
     const double r = fma(-s0, h0, 0.5);
     return fma(s0, r, s0);
 }
 
-__global__ __launch_bounds__(256) void k_membrane_layers(const CellSphere *__restrict__ spheres,
+__global__ __launch_bounds__(MLT) void k_membrane_layers(const CellSphere *__restrict__ spheres,
                                                          const int *__restrict__ cell_off, int ncx, int ncy, double x0,
                                                          double y0, int rmax_int, LayerArgs la, float *__restrict__ out,
                                                          float *__restrict__ support, float support_value, int dimX,
                                                          int dimY, int margin, int margin2, int tiles_y, double scale,
                                                          int accumulate) {
-    __shared__ unsigned long long acc[MT * MT];
+    __shared__ unsigned long long acc[MLX * MLY];
     __shared__ StagedSphere flat[ML_SEGS * ML_CAP];
     __shared__ int shcnt[ML_SEGS], shrem[ML_SEGS];
-    const int tile = blockIdx.x, t0 = (tile / tiles_y) * MT, c0 = (tile % tiles_y) * MT;
+    const int tile = blockIdx.x, t0 = (tile / tiles_y) * MLX, c0 = (tile % tiles_y) * MLY;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, hl = lane & 31;
     const int seg = 2 * wave + half;                 // the job slot this half-wave stages
     const int grp = tid >> 4, col = tid & 15;        // splat: 16 lanes per sphere
     const int njobs = la.nlayers * la.rows;
     const int tx0 = t0 + margin, ty0 = c0 + margin;  // the tile on the margin-extended grid
-    for (int k = tid; k < MT * MT; k += 256) acc[k] = 0ull;
-    for (int j0 = 0; j0 < njobs; j0 += ML_SEGS) {
+    for (int k = tid; k < MLX * MLY; k += MLT) acc[k] = 0ull;
+    for (int j0 = 0; j0 < ((PSX_ML_OFF & 4) ? 0 : njobs); j0 += ML_SEGS) {
         // this half-wave's job: layer l, cell row cx0(l) + g, the spheres of cells [cy0, cy1] of that row
         const int job = j0 + seg, l = min(job / la.rows, ML_MAX - 1), g = job % la.rows;
         const int offx = la.offx[l], offy = la.offy[l];
         int beg = 0, end = 0;
         if (job < njobs) {
             // cells whose spheres can reach this tile: |centre - pixel| <= radInt + 1/2 on each axis
-            const double xlo = (double)(offx + tx0 - rmax_int - 1) - x0, xhi = (double)(offx + tx0 + MT + rmax_int + 1) - x0;
-            const double ylo = (double)(offy + ty0 - rmax_int - 1) - y0, yhi = (double)(offy + ty0 + MT + rmax_int + 1) - y0;
+            const double xlo = (double)(offx + tx0 - rmax_int - 1) - x0, xhi = (double)(offx + tx0 + MLX + rmax_int + 1) - x0;
+            const double ylo = (double)(offy + ty0 - rmax_int - 1) - y0, yhi = (double)(offy + ty0 + MLY + rmax_int + 1) - y0;
             const int cx = max(0, (int)floor(xlo / MC)) + g, cx1 = min(ncx - 1, (int)floor(xhi / MC));
             const int cy0 = max(0, (int)floor(ylo / MC)), cy1 = min(ncy - 1, (int)floor(yhi / MC));
             if (cx <= cx1 && cy0 <= cy1) {
@@ -165,9 +186,9 @@ __global__ __launch_bounds__(256) void k_membrane_layers(const CellSphere *__res
                 const bool ok = cs.r > 0.0 && margin2 < sp.xi && sp.xi < dimX + margin + margin2 && margin2 < sp.yi &&
                                 sp.yi < dimY + margin + margin2;                   // :152
                 sp.radInt = (int)floor(cs.r) + 1;
-                // window [xi - radInt, xi + radInt) against the tile's pixels [tx0, tx0 + MT)
-                hit = ok && sp.xi + sp.radInt > tx0 && sp.xi - sp.radInt < tx0 + MT && sp.yi + sp.radInt > ty0 &&
-                      sp.yi - sp.radInt < ty0 + MT;
+                // window [xi - radInt, xi + radInt) against the tile's pixels [tx0, tx0 + MLX)
+                hit = ok && sp.xi + sp.radInt > tx0 && sp.xi - sp.radInt < tx0 + MLX && sp.yi + sp.radInt > ty0 &&
+                      sp.yi - sp.radInt < ty0 + MLY;
             }
             const unsigned mh = (unsigned)(__ballot(hit) >> (32 * half));
             __syncthreads();                         // the previous batch has been splatted (and acc is zeroed)
@@ -187,25 +208,38 @@ __global__ __launch_bounds__(256) void k_membrane_layers(const CellSphere *__res
             }
             if (hit) flat[base + __popc(mh & ((1u << hl) - 1u))] = sp;
             __syncthreads();
-            for (int s = grp; s < total; s += 16) {
+            for (int s = grp; s < ((PSX_ML_OFF & 1) ? 0 : total); s += MLT / 16) {     // (PSX_ML_OFF: timing experiments, wrong images)
                 const StagedSphere c = flat[s];
                 // window rows clipped to the tile; columns: one per lane of the group, 16 at a time
-                const int i_lo = max(c.xi - c.radInt, tx0), i_hi = min(c.xi + c.radInt, tx0 + MT);
+                const int i_lo = max(c.xi - c.radInt, tx0), i_hi = min(c.xi + c.radInt, tx0 + MLX);
                 for (int pyc = c.yi - c.radInt + col; pyc < c.yi + c.radInt; pyc += 16) {
                     const int j = pyc - ty0;
-                    if (j < 0 || j >= MT) continue;
+                    if (j < 0 || j >= MLY) continue;
                     // getMembraneFromFile.py:157-159 takes dist = sqrt(dx^2 + dy^2), tests dist < r and adds
                     // 2 sqrt(r^2 - dist^2); comparing the squares saves one of the two square roots and moves the chord by
                     // one rounding of dist^2 (below 1e-9 of the membrane thickness, also at a sphere's rim)
-                    const double dy = (double)pyc - c.yf;
+                    // Build-time A/B (tools/ab_membrane_inc.sh): PSX_MEMBRANE_SPLAT 0 = the row offset converted per row, lengths in
+                    // pixels; 1 = the row offset by repeated addition (exact: both operands sit on one grid); 2 = also every length
+                    // in the accumulator's unit of 2^-ML_FRAC pixel (powers of two: the same bits), so that the chord leaves the
+                    // square root already in fixed point: doubling and rounding are one fma with an inline constant.
+#ifndef PSX_MEMBRANE_SPLAT
+#define PSX_MEMBRANE_SPLAT 2
+#endif
+                    constexpr double U = PSX_MEMBRANE_SPLAT == 2 ? (double)(1ull << ML_FRAC) : 1.0;
+                    const double dy = ((double)pyc - c.yf) * U;
                     const double dy2 = dy * dy;
-                    for (int pxr = i_lo; pxr < i_hi; ++pxr) {
-                        const double dx = (double)pxr - c.xf;
+                    const double r2 = c.r2 * (U * U);
+                    double dxr = ((double)i_lo - c.xf) * U;
+                    for (int pxr = i_lo; pxr < i_hi; ++pxr, dxr += U) {
+                        const double dx = PSX_MEMBRANE_SPLAT ? dxr : (double)pxr - c.xf;
                         const double d2 = fma(dx, dx, dy2);
-                        if (d2 < c.r2) {
+                        if (d2 < r2) {
                             // 2 sqrt(.) in units of 2^-ML_FRAC pixel, rounded to nearest through the 2^52 + 2^51 offset
-                            const double v = fma(chord_sqrt(c.r2 - d2), (double)(2ull << ML_FRAC), 6755399441055744.0);
-                            atomicAdd(&acc[(pxr - tx0) * MT + j], (unsigned long long)(__double_as_longlong(v) - 0x4338000000000000ll));
+                            // (scaled: r2 - d2 > 0 is at least an ulp of r2, far above the float32 range's floor: no clamp)
+                            const double v = PSX_MEMBRANE_SPLAT == 2
+                                                 ? fma(chord_sqrt<false>(r2 - d2), 2.0, 6755399441055744.0)
+                                                 : fma(chord_sqrt<true>(r2 - d2), (double)(2ull << ML_FRAC), 6755399441055744.0);
+                            atomicAdd(&acc[(pxr - tx0) * MLY + j], (unsigned long long)(__double_as_longlong(v) - 0x4338000000000000ll));
                         }
                     }
                 }
@@ -214,11 +248,12 @@ __global__ __launch_bounds__(256) void k_membrane_layers(const CellSphere *__res
     }
     __syncthreads();
     const double unit = scale / (double)(1ull << ML_FRAC);
-    for (int k = tid; k < MT * MT; k += 256) {
-        const int i = t0 + k / MT, j = c0 + k % MT;
+    for (int k = tid; k < MLX * MLY; k += MLT) {
+        const int i = t0 + k / MLY, j = c0 + k % MLY;
         if (i < dimX && j < dimY) {
             const float v = (float)((double)acc[k] * unit);
             const int64_t p = (int64_t)i * dimY + j;
+            if ((PSX_ML_OFF & 2) && v >= 0.f) continue;
             out[p] = accumulate ? out[p] + v : v;
             if (support) support[p] = support_value;
         }
@@ -300,17 +335,17 @@ int psx_membrane_layers_f32(psx_membrane_plan *p, int nlayers, const int *offx, 
     PSX_REQUIRE(p != nullptr && out != nullptr && dimX > 0 && dimY > 0 && margin >= 0, "psx_membrane_layers_f32: bad argument");
     PSX_REQUIRE(nlayers >= 0 && (nlayers == 0 || (offx && offy)), "psx_membrane_layers_f32: null offsets");
     hipStream_t st = (hipStream_t)stream;
-    const int tiles_x = (int)cdiv(dimX, MT), tiles_y = (int)cdiv(dimY, MT);
+    const int tiles_x = (int)cdiv(dimX, MLX), tiles_y = (int)cdiv(dimY, MLY);
     // ML_MAX layers per launch; later launches add to the map (and leave the support alone)
     for (int l0 = 0; l0 == 0 || l0 < nlayers; l0 += ML_MAX) {
         LayerArgs la = {};
         la.nlayers = std::min(ML_MAX, nlayers - l0);
-        la.rows = (MT + 2 * (p->rmax_int + 1)) / MC + 2;       // a window of that many pixels meets at most this many cells
+        la.rows = (MLX + 2 * (p->rmax_int + 1)) / MC + 2;      // a window of that many pixels meets at most this many cells
         for (int l = 0; l < la.nlayers; ++l) {
             la.offx[l] = offx[l0 + l];
             la.offy[l] = offy[l0 + l];
         }
-        PSX_TIMED("k_membrane", st, k_membrane_layers<<<tiles_x * tiles_y, 256, 0, st>>>(
+        PSX_TIMED("k_membrane", st, k_membrane_layers<<<tiles_x * tiles_y, MLT, 0, st>>>(
                       p->spheres, p->cell_off, p->ncx, p->ncy, p->x0, p->y0, p->rmax_int, la, out, l0 == 0 ? support : nullptr,
                       support_value, dimX, dimY, margin, margin2, tiles_y, scale, (accumulate || l0 > 0) ? 1 : 0));
         if (int rc = launch_check("k_membrane")) return rc;

@@ -1,20 +1,27 @@
 #!/usr/bin/env python3
-"""Diagnostic: wall time of one membrane synthesis (getMembraneSegmentedFromFile: host binning + k_membrane) at 4096^2."""
-import os, sys, time, ctypes
+"""Diagnostic: the membrane synthesis of a position (seeded offsets + k_membrane_layers) alone: the kernel by the library's own
+event pairs (psx_profile_*), and the loop's cadence -- which is the HOST's (about 0.067 ms of Python per call, gpurun_out/r5s62: it
+does not change when the kernel does nothing), not the kernel's.
+    python tools/time_membrane.py [N] [NPOS]"""
+import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from paresis_amd import _lib, synth
-from paresis_amd.Samples.getMembraneFromFile import getMembraneSegmentedFromFile
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+NPOS = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 lib = _lib.lib()
-class S: pass
-for N, pix, rad, layers in ((4096, 2.9252, 15.0, 2), (4096, 2.9252, 50.0, 3), (16384, 1.46, 15.0, 2)):
-    s = S(); s.myMeanSphereRadius = rad; s.myNbOfLayers = layers
-    getMembraneSegmentedFromFile(s, N, N, pix, 0, 6000.0); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for p in range(1, 4): getMembraneSegmentedFromFile(s, N, N, pix, p, 6000.0)
-    torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / 3 * 1e3
-    lib.psx_profile_enable(1)
-    getMembraneSegmentedFromFile(s, N, N, pix, 5, 6000.0); torch.cuda.synchronize()
-    buf = ctypes.create_string_buffer(1 << 16); lib.psx_profile_summary(buf, len(buf)); lib.psx_profile_enable(0)
-    print("N=%d pix=%.2f um radius %.0f um x %d layers: %.1f ms wall per position; kernels: %s" % (N, pix, rad, layers, wall, buf.value.decode().replace("\n", "; ")))
+exp, place = synth.bench_experiment(N, "RT", noise=False, seed=3)
+for p in range(8): place(p)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for p in range(NPOS): place(p)
+torch.cuda.synchronize()
+cadence = (time.perf_counter() - t0) / NPOS * 1e3
+lib.psx_profile_enable(1)
+for p in range(NPOS): place(p)
+torch.cuda.synchronize()
+buf = ctypes.create_string_buffer(1 << 14); lib.psx_profile_summary(buf, len(buf)); lib.psx_profile_enable(0)
+ks = {l.split()[0]: float(l.split()[2]) / int(l.split()[1]) for l in buf.value.decode().splitlines()}
+print("membrane synthesis %dx%d: kernel %.4f ms (event pairs around each launch, %d positions); loop cadence %.4f ms per position (host)"
+      % (N, N, ks.get("k_membrane", float("nan")), NPOS, cadence))
