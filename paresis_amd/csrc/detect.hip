@@ -546,6 +546,14 @@ struct Philox {
     }
 };
 
+// The hardware's own reciprocal, square root and logarithm (one instruction each, about 1 ulp): the IEEE forms of x / y and
+// sqrtf cost ten more instructions apiece, and k_poisson is bound by its instruction count (34 M vector instructions per launch
+// of two 2048^2 images, the vector pipe busy throughout: gpurun_out/r5s58).  PTRS's constants are fits to four digits; an ulp in
+// b or vr is far inside their margin, and the acceptance test's two sides (below) are compared at 1e-4.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718f; }     // x normal: v_log_f32 is log2
+
 // log of the Poisson probability  -L + k log L - log k!  for PTRS's acceptance test.  The three terms are of order
 // L log L and cancel to order 1, so a direct float32 evaluation is useless for large means.  With x = (k - L)/L and Stirling's series for log k!
 //     log pmf = -L g(x) - log(2 pi k)/2 - 1/(12 k) + 1/(360 k^3),      g(x) = (1 + x) log(1 + x) - x = x^2/2 - x^3/6 + ...
@@ -553,7 +561,7 @@ struct Philox {
 // two sides are that close); small k or L keep the float64 form.
 __device__ __forceinline__ float log_pmf(float k, float L) {
     if (k >= 64.f && L >= 64.f) {
-        const float x = (k - L) / L;                           // k - L is exact (Sterbenz) or far in the tail
+        const float x = (k - L) * fast_rcp(L);                 // k - L is exact (Sterbenz) or far in the tail
         float g;
         if (fabsf(x) < 0.125f) {                               // sum_{n>=2} (-1)^n x^n / (n (n-1)), 9 terms: < 1e-9 relative
             g = 1.f / 90.f;
@@ -569,8 +577,8 @@ __device__ __forceinline__ float log_pmf(float k, float L) {
         } else {
             g = (1.f + x) * log1pf(x) - x;
         }
-        const float ik = 1.f / k;
-        return -L * g - 0.5f * logf(6.2831853f * k) - ik * (1.f / 12.f) + ik * ik * ik * (1.f / 360.f);
+        const float ik = fast_rcp(k);
+        return -L * g - 0.5f * fast_log(6.2831853f * k) - ik * (1.f / 12.f) + ik * ik * ik * (1.f / 360.f);
     }
     // small k or L (10 <= L < 64): the terms are at most a few hundred, float32 leaves an absolute error ~2e-5 in a quantity
     // that is compared with the log of a uniform -- a decision changes with probability ~1e-5
@@ -618,19 +626,20 @@ __device__ __forceinline__ float poisson_finish(float L, float U0, float V0, uin
         }
         return (float)k;
     }
-    const float slam = sqrtf(L);
+    const float slam = fast_sqrt(L);
     const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
-    const float invalpha = 1.1239f + 1.1328f / (b - 3.4f), vr = 0.9277f - 3.6224f / (b - 2.f);
+    const float invalpha = 1.1239f + 1.1328f * fast_rcp(b - 3.4f), vr = 0.9277f - 3.6224f * fast_rcp(b - 2.f);
     float U = U0, V = V0, U2 = 0.f, V2 = 0.f;
     uint32_t sub = 1;
     bool have = false;
     float res = floorf(L);
     for (int it = 0; it < 128; ++it) {
         const float us = 0.5f - fabsf(U);
-        const float k = floorf((2.f * a / us + b) * U + L + 0.43f);
+        const float ius = fast_rcp(us);
+        const float k = floorf((2.f * a * ius + b) * U + L + 0.43f);
         if (us >= 0.07f && V <= vr) { res = k; break; }
         if (!(k < 0.f || (us < 0.013f && V > us))) {
-            const float lhs = logf(V) + logf(invalpha) - logf(a / (us * us) + b);
+            const float lhs = fast_log(V * invalpha * fast_rcp(a * ius * ius + b));
             if (lhs <= log_pmf(k, L)) { res = k; break; }
         }
         if (have) {
@@ -667,11 +676,11 @@ __global__ __launch_bounds__(256) void k_poisson(PoissonImgs im, const float *__
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float Li = L[i];
-            const float slam = sqrtf(Li);
+            const float slam = fast_sqrt(Li);
             const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
-            const float vr = 0.9277f - 3.6224f / (b - 2.f);
+            const float vr = 0.9277f - 3.6224f * fast_rcp(b - 2.f);
             const float us = 0.5f - fabsf(U[i]);
-            const float k = floorf((2.f * a / us + b) * U[i] + Li + 0.43f);
+            const float k = floorf((2.f * a * fast_rcp(us) + b) * U[i] + Li + 0.43f);
             const bool fast = Li >= 10.f && us >= 0.07f && V[i] <= vr;
             res[i] = fast ? k : 0.f;
             if (!fast && Li > 0.f) pending |= 1u << i;
