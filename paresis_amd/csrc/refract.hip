@@ -507,10 +507,26 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
 #define PSX_SKIP_MISS 1
 #endif
             if (!(PSX_SKIP_MISS && H >= 8) || __any(hit)) {
+#ifndef PSX_PK_WEIGHTS
+#define PSX_PK_WEIGHTS 1
+#endif
+            if (PSX_PK_WEIGHTS) {
+                // the same eight products, two per instruction (v_pk_mul_f32): bit for bit the scalar form's
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                const v2f ax = {1.f - wx, wx};
+                const float omy = 1.f - wy;
+                const v2f s0 = (ax * (v2f){omy, omy}) * (v2f){Is_, Is_};      // {(1-wx)(1-wy), wx(1-wy)} * I
+                const v2f s1 = (ax * (v2f){wy, wy}) * (v2f){Is_, Is_};        // {(1-wx)wy, wx wy} * I
+                dep(0, s0.x);
+                dep(AW, s0.y);
+                dep(1, s1.x);
+                dep(AW + 1, s1.y);
+            } else {
             dep(0, Is_ * ((1.f - wx) * (1.f - wy)));
             dep(AW, Is_ * (wx * (1.f - wy)));
             dep(1, Is_ * ((1.f - wx) * wy));
             dep(AW + 1, Is_ * (wx * wy));
+            }
             }
             // (kept as the reference's products I * (wx-part * wy-part), RF2:241-262: regrouping them as (I * wy-part) * wx-part
             // would save two multiplies but round differently)
