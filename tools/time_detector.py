@@ -1,39 +1,30 @@
 #!/usr/bin/env python3
-"""Diagnostic: the detector operator alone (Detector.detection without noise) at the bench size; kernels by name under
-rocprofv3 --kernel-trace --stats.    python tools/time_detector.py [N] [ov] [sigma_src, study pixels; bench: 0.036]"""
-import os
-import sys
-import time
-
+"""Diagnostic: the detector operator on the two images of a position (4096^2 -> 2048^2, the bench's geometry), by the library's
+event pairs: front stage alone (a plan without PSF) and both stages.     python tools/time_detector.py [N] [ov] [nimg]"""
+import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-
-import ctypes
 from paresis_amd import _lib, ops
-import _switches                      # PSX_SWITCHES="no_dif=1 ..." -> psx_debug_switch (the library reads no environment)
-_switches.apply()
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 ov = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-sig = float(sys.argv[3]) if len(sys.argv) > 3 else 1.3
-img = torch.rand((N, N), device="cuda") + 0.5
-plan = ops.DetectorPlan(N, N, ov, N // ov, N // ov, sig, 1.2, device=img.device)
-out = torch.empty((N // ov, N // ov), device="cuda")
-for _ in range(3):
-    plan.detect(img, out=out)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(50):
-    plan.detect(img, out=out)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 50
-print("detector %dx%d -> %dx%d: %.1f us per image (%.2f TB/s of the %d MB that must move)"
-      % (N, N, N // ov, N // ov, dt * 1e6, (img.numel() + out.numel()) * 4 / dt / 1e12, (img.numel() + out.numel()) * 4 >> 20))
+nimg = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+n = N // ov
 lib = _lib.lib()
-lib.psx_profile_enable(1)
-for _ in range(10):
-    plan.detect(img, out=out)
-torch.cuda.synchronize()
-buf = ctypes.create_string_buffer(1 << 16); lib.psx_profile_summary(buf, len(buf)); lib.psx_profile_enable(0)
-print("   library kernels per image (us):", ", ".join("%s x%d %.1f" % (l.split()[0], int(l.split()[1]) // 10, float(l.split()[2]) * 100 / 1)
-                                                      for l in buf.value.decode().splitlines()))
+g = torch.Generator(device="cuda").manual_seed(1)
+imgs = [torch.rand((N, N), generator=g, device="cuda") * 7500.0 for _ in range(nimg)]
+outs = [torch.empty((n, n), device="cuda") for _ in range(nimg)]
+res = {}
+for name, psf in (("front", 0.0), ("both", 1.2)):
+    plan = ops.DetectorPlan(N, N, ov, n, n, 0.036, psf)
+    for _ in range(5): plan.detect_many(imgs, outs)
+    torch.cuda.synchronize()
+    lib.psx_profile_enable(1)
+    for _ in range(200): plan.detect_many(imgs, outs)
+    torch.cuda.synchronize()
+    buf = ctypes.create_string_buffer(1 << 14); lib.psx_profile_summary(buf, len(buf)); lib.psx_profile_enable(0)
+    ks = {l.split()[0]: float(l.split()[2]) / 200 for l in buf.value.decode().splitlines()}
+    res[name] = ks.get("k_band_pair", float("nan"))
+    plan.close()
+print("detector %dx%d -> %dx%d, %d images per call: front stage %.4f ms, PSF stage %.4f ms (event pairs, 200 calls)"
+      % (N, N, n, n, nimg, res["front"], res["both"] - res["front"]))
