@@ -29,6 +29,8 @@ struct BandOp {
     float *w = nullptr;    // [n_out][W] device (row-major: the axis-0 pass reads a row with scalar loads)
     float *wT = nullptr;   // [W][n_out] device (transposed: the contiguous pass reads it coalesced)
     std::vector<int> h_start;   // host copy of start[] (row tiles of the fused pair are laid out from it)
+    bool stencil = false;       // every output reads start[0] + o .. with the SAME weights (a plain convolution: k_psf_tile)
+    std::vector<float> h_w0;    // those weights
 };
 
 // A contiguous-axis operator followed by an axis-0 operator in ONE pass (k_band_pair): per tile of RT output rows the
@@ -448,6 +450,99 @@ __global__ __launch_bounds__(256) void k_band_pair(PairArgs a) {
     }
 }
 
+// ---- the PSF stage as a register-tiled stencil -----------------------------------------------------------------------------
+// When both operators of the back stage are plain convolutions (every output reads the same W taps at start[0] + its index:
+// PSF radius <= the cropped margin, the usual case) the stage is out[r][c] = sum_k sum_l gx[k] gy[l] in[ox + r + k][oy + c + l].
+// A workgroup owns 32 x 128 outputs: the (32 + WT - 1) x (128 + WT - 1) inputs are staged in LDS with all loads in flight at
+// once; the contiguous pass gives every thread 4 adjacent outputs from 4 + WT - 1 consecutive samples (three 16-byte LDS reads
+// for 36 multiply-adds at WT = 9), the axis-0 pass 4 x 4 outputs from 4 + WT - 1 rows of 4 (twelve reads for 144), the
+// weights are scalars of the launch.  Same sums in the same order as k_band_pair's (whose aligned tap reads fetched 16 taps for
+// 9, at 1.5x halo rows: timing experiments in gpurun_out/r5s68): bit-identical images.  WT = 4 WQ - 3 taps, zero-padded.
+struct PsfArgs {
+    const float *in[PSX_MAX_DETECT];
+    float *out[PSX_MAX_DETECT];
+    int in_pitch, out_pitch, Rin, Cin, Rout, Cout, ox, oy;
+    float gx[20], gy[20];
+};
+
+template <int WQ>
+__global__ __launch_bounds__(256) void k_psf_tile(PsfArgs a) {
+    constexpr int WT = 4 * WQ - 3, TR = 32, TC = 128, SR = TR + WT - 1, SC = TC + 4 * WQ - 4;   // SC: TC + WT - 1, a multiple of 4
+    __shared__ __attribute__((aligned(16))) float sin_[SR * SC];
+    __shared__ __attribute__((aligned(16))) float mid[SR * TC];
+    const float *const in = a.in[blockIdx.z];
+    float *const out = a.out[blockIdx.z];
+    const int r0 = blockIdx.y * TR, c0 = blockIdx.x * TC;
+    const int tid = threadIdx.x;
+    // stage: clamped addresses (only outputs beyond the image read clamped samples, and they are not stored)
+    constexpr int NS = (SR * SC + 255) / 256;
+    float x[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int e = min(tid + 256 * j, SR * SC - 1);
+        const int i = e / SC, l = e - i * SC;
+        x[j] = in[(int64_t)min(a.ox + r0 + i, a.Rin - 1) * a.in_pitch + min(a.oy + c0 + l, a.Cin - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int e = tid + 256 * j;
+        if (e < SR * SC) sin_[e] = x[j];
+    }
+    __syncthreads();
+    // contiguous pass: SR rows x 32 quads of 4 outputs
+    for (int q = tid; q < SR * (TC / 4); q += 256) {
+        const int i = q >> 5, c4 = (q & 31) * 4;
+        const float4 *src = reinterpret_cast<const float4 *>(sin_ + i * SC + c4);
+        float v[4 * WQ];
+#pragma unroll
+        for (int m = 0; m < WQ; ++m) {
+            const float4 t = src[m];
+            v[4 * m] = t.x; v[4 * m + 1] = t.y; v[4 * m + 2] = t.z; v[4 * m + 3] = t.w;
+        }
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l = 0; l < WT; ++l)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = fmaf(a.gy[l], v[l + u], o[u]);
+        *reinterpret_cast<float4 *>(mid + i * TC + c4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+    // axis-0 pass: thread = 4 rows x 4 columns
+    const int c4 = (tid & 31) * 4, rq = (tid >> 5) * 4;
+    float4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < WT + 3; ++k) {
+        const float4 m = *reinterpret_cast<const float4 *>(mid + (rq + k) * TC + c4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = k - u;                                   // output row rq + u takes this row with tap t
+            if (t >= 0 && t < WT) {
+                acc[u].x = fmaf(a.gx[t], m.x, acc[u].x);
+                acc[u].y = fmaf(a.gx[t], m.y, acc[u].y);
+                acc[u].z = fmaf(a.gx[t], m.z, acc[u].z);
+                acc[u].w = fmaf(a.gx[t], m.w, acc[u].w);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = r0 + rq + u, c = c0 + c4;
+        if (r < a.Rout) {
+            float *dst = out + (int64_t)r * a.out_pitch + c;
+            if (c + 3 < a.Cout && (a.out_pitch & 3) == 0 && ((uintptr_t)out & 15) == 0) {
+                *reinterpret_cast<float4 *>(dst) = acc[u];
+            } else {
+                if (c < a.Cout) dst[0] = acc[u].x;
+                if (c + 1 < a.Cout) dst[1] = acc[u].y;
+                if (c + 2 < a.Cout) dst[2] = acc[u].z;
+                if (c + 3 < a.Cout) dst[3] = acc[u].w;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_resize(const float *__restrict__ img, int Nx, int Ny, float *__restrict__ out,
                                                 int sx, int sy, int s) {
     const int64_t n = (int64_t)sx * sy;
@@ -767,6 +862,12 @@ int psx_detector_plan_create(int Nx, int Ny, int ov, int nx, int ny, int margin,
         op.n_out = (int)st.size();
         op.n_in = stage == STAGE_BACK ? n + 2 * margin : N;
         op.h_start = st;
+        op.stencil = op.W >= 1;
+        for (int o = 0; o < op.n_out && op.stencil; ++o) {
+            op.stencil = st[o] == st[0] + o;
+            for (int k = 0; k < op.W && op.stencil; ++k) op.stencil = w[(size_t)o * op.W + k] == w[k];
+        }
+        op.h_w0.assign(w.begin(), w.begin() + std::min<size_t>(w.size(), (size_t)op.W));
         std::vector<float> wT((size_t)op.W * op.n_out);
         for (int o = 0; o < op.n_out; ++o)
             for (int k = 0; k < op.W; ++k) wT[(size_t)k * op.n_out + o] = w[(size_t)o * op.W + k];
@@ -973,6 +1074,28 @@ int band_pair(const BandPair &pr, const BandOp &C, const BandOp &R, const float 
     return launch_check("k_band_pair");
 }
 
+// the PSF stage as a stencil (k_psf_tile): both back operators plain convolutions of at most 17 taps
+bool psf_stencil_ok(const BandOp &C, const BandOp &R) { return C.stencil && R.stencil && C.W <= 17 && R.W <= 17; }
+
+int psf_tile(const BandOp &C, const BandOp &R, const float *const *in, int in_pitch, float *const *out, int out_pitch, int nimg,
+             hipStream_t st) {
+    PsfArgs a = {};
+    for (int k = 0; k < PSX_MAX_DETECT; ++k) {
+        a.in[k] = in[std::min(k, nimg - 1)];
+        a.out[k] = out[std::min(k, nimg - 1)];
+    }
+    a.in_pitch = in_pitch; a.out_pitch = out_pitch;
+    a.Rin = R.n_in; a.Cin = C.n_in; a.Rout = R.n_out; a.Cout = C.n_out; a.ox = R.h_start[0]; a.oy = C.h_start[0];
+    for (int k = 0; k < R.W; ++k) a.gx[k] = R.h_w0[k];
+    for (int l = 0; l < C.W; ++l) a.gy[l] = C.h_w0[l];
+    const dim3 grid((C.n_out + 127) / 128, (R.n_out + 31) / 32, nimg);
+    const int W = std::max(C.W, R.W);
+    if (W <= 9) PSX_TIMED("k_psf_tile", st, k_psf_tile<3><<<grid, 256, 0, st>>>(a));
+    else if (W <= 13) PSX_TIMED("k_psf_tile", st, k_psf_tile<4><<<grid, 256, 0, st>>>(a));
+    else PSX_TIMED("k_psf_tile", st, k_psf_tile<5><<<grid, 256, 0, st>>>(a));
+    return launch_check("k_psf_tile");
+}
+
 bool four_pass_forced() { return debug_switch(DBG_DETECT_4PASS) != 0; }   // diagnostics (psx_debug_switch "detect_4pass")
 
 }  // namespace
@@ -996,6 +1119,7 @@ static int detect_impl(psx_detector_plan *p, const float *const *imgs, float *co
         for (int k = 0; k < nimg; ++k) mids[k] = p->t2p + (size_t)k * p->fx.n_out * p->pitch2;
         if (!psf) return band_pair(p->front, p->fy, p->fx, imgs, p->Ny, outs, p->fy.n_out, nimg, st);
         if (int rc = band_pair(p->front, p->fy, p->fx, imgs, p->Ny, mids, p->pitch2, nimg, st)) return rc;
+        if (psf_stencil_ok(p->by, p->bx)) return psf_tile(p->by, p->bx, mids, p->pitch2, outs, p->ny, nimg, st);
         return band_pair(p->back, p->by, p->bx, mids, p->pitch2, outs, p->ny, nimg, st);
     }
     for (int k = 0; k < nimg; ++k) {
@@ -1014,7 +1138,11 @@ static int detect_impl(psx_detector_plan *p, const float *const *imgs, float *co
         if (!psf) continue;
         // back operator (PSF + crop) at detector resolution
         if (back_f) {
-            if (int rc = band_pair(p->back, p->by, p->bx, &mid_img, mid_pitch, &out, p->ny, 1, st)) return rc;
+            if (psf_stencil_ok(p->by, p->bx)) {
+                if (int rc = psf_tile(p->by, p->bx, &mid_img, mid_pitch, &out, p->ny, 1, st)) return rc;
+            } else if (int rc = band_pair(p->back, p->by, p->bx, &mid_img, mid_pitch, &out, p->ny, 1, st)) {
+                return rc;
+            }
             continue;
         }
         if (int rc = band_cols(p->by, p->t2, p->t3, p->fx.n_out, st)) return rc;

@@ -24,7 +24,7 @@ for name, psf in (("front", 0.0), ("both", 1.2)):
     torch.cuda.synchronize()
     buf = ctypes.create_string_buffer(1 << 14); lib.psx_profile_summary(buf, len(buf)); lib.psx_profile_enable(0)
     ks = {l.split()[0]: float(l.split()[2]) / 200 for l in buf.value.decode().splitlines()}
-    res[name] = ks.get("k_band_pair", float("nan"))
+    res[name] = ks.get("k_band_pair", 0.0) + ks.get("k_psf_tile", 0.0)
     plan.close()
 print("detector %dx%d -> %dx%d, %d images per call: front stage %.4f ms, PSF stage %.4f ms (event pairs, 200 calls)"
       % (N, N, n, n, nimg, res["front"], res["both"] - res["front"]))
