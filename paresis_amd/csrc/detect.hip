@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void k_band_pair(PairArgs a) {
 // ---- the PSF stage as a register-tiled stencil -----------------------------------------------------------------------------
 // When both operators of the back stage are plain convolutions (every output reads the same W taps at start[0] + its index:
 // PSF radius <= the cropped margin, the usual case) the stage is out[r][c] = sum_k sum_l gx[k] gy[l] in[ox + r + k][oy + c + l].
-// A workgroup owns 32 x 128 outputs: the (32 + WT - 1) x (128 + WT - 1) inputs are staged in LDS with all loads in flight at
+// A workgroup owns 16 x 128 outputs: the (16 + WT - 1) x (128 + WT - 1) inputs are staged in LDS with all loads in flight at
 // once; the contiguous pass gives every thread 4 adjacent outputs from 4 + WT - 1 consecutive samples (three 16-byte LDS reads
 // for 36 multiply-adds at WT = 9), the axis-0 pass 4 x 4 outputs from 4 + WT - 1 rows of 4 (twelve reads for 144), the
 // weights are scalars of the launch.  Same sums in the same order as k_band_pair's (whose aligned tap reads fetched 16 taps for
@@ -465,9 +465,12 @@ struct PsfArgs {
     float gx[20], gy[20];
 };
 
+#ifndef PSX_PSF_TR
+#define PSX_PSF_TR 16        // output rows per workgroup (build-time A/B, gpurun_out/r5s71: 16 -> 25 KB of LDS, six workgroups per CU: 0.0270 against 0.0287 ms with 32)
+#endif
 template <int WQ>
 __global__ __launch_bounds__(256) void k_psf_tile(PsfArgs a) {
-    constexpr int WT = 4 * WQ - 3, TR = 32, TC = 128, SR = TR + WT - 1, SC = TC + 4 * WQ - 4;   // SC: TC + WT - 1, a multiple of 4
+    constexpr int WT = 4 * WQ - 3, TR = PSX_PSF_TR, TC = 128, SR = TR + WT - 1, SC = TC + 4 * WQ - 4;   // SC: TC + WT - 1, a multiple of 4
     __shared__ __attribute__((aligned(16))) float sin_[SR * SC];
     __shared__ __attribute__((aligned(16))) float mid[SR * TC];
     const float *const in = a.in[blockIdx.z];
@@ -509,6 +512,7 @@ __global__ __launch_bounds__(256) void k_psf_tile(PsfArgs a) {
     __syncthreads();
     // axis-0 pass: thread = 4 rows x 4 columns
     const int c4 = (tid & 31) * 4, rq = (tid >> 5) * 4;
+    if (rq >= TR) return;
     float4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1088,7 +1092,7 @@ int psf_tile(const BandOp &C, const BandOp &R, const float *const *in, int in_pi
     a.Rin = R.n_in; a.Cin = C.n_in; a.Rout = R.n_out; a.Cout = C.n_out; a.ox = R.h_start[0]; a.oy = C.h_start[0];
     for (int k = 0; k < R.W; ++k) a.gx[k] = R.h_w0[k];
     for (int l = 0; l < C.W; ++l) a.gy[l] = C.h_w0[l];
-    const dim3 grid((C.n_out + 127) / 128, (R.n_out + 31) / 32, nimg);
+    const dim3 grid((C.n_out + 127) / 128, (R.n_out + PSX_PSF_TR - 1) / PSX_PSF_TR, nimg);
     const int W = std::max(C.W, R.W);
     if (W <= 9) PSX_TIMED("k_psf_tile", st, k_psf_tile<3><<<grid, 256, 0, st>>>(a));
     else if (W <= 13) PSX_TIMED("k_psf_tile", st, k_psf_tile<4><<<grid, 256, 0, st>>>(a));
