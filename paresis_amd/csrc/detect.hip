@@ -687,7 +687,7 @@ __device__ __forceinline__ float log_pmf(float k, float L) {
 // Poisson draw: product-of-uniforms for lam < 10, Hormann's PTRS transformed rejection otherwise (both exact samplers).
 // The draw of pixel p is a pure function of (seed, p):
 //   * its FIRST PTRS candidate takes two words of the Philox block (counter p >> 1, tag 0x5058): one block serves the
-//     first candidates of two neighbouring pixels (86 % of the pixels accept it through the squeeze, no logarithm);
+//     first candidates of two neighbouring pixels (78 % of the pixels accept it through the squeeze -- P(|U| <= 0.43) x vr = 0.86 x 0.91 at a mean of 7500 --, no logarithm);
 //   * everything else -- later candidates, the product of uniforms of small means -- comes from the pixel's own stream
 //     (counter p, sub-counter 1, 2, ..., tag 0x5059).
 struct PoissonImgs {
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256) void k_poisson(PoissonImgs im, const float *__
             res[i] = fast ? k : 0.f;
             if (!fast && Li > 0.f) pending |= 1u << i;
         }
-        // The pixels the squeeze did not settle (~14 %) are dealt out again over the wave: left with their owners, a wave
+        // The pixels the squeeze did not settle (~22 %) are dealt out again over the wave: left with their owners, a wave
         // would run the exact test as often as its unluckiest lane has pending pixels (3-4 times, a sixth of the lanes
         // alive); packed through LDS it runs it once or twice with the lanes full.  A draw is a function of (pixel, key)
         // alone, so who computes it changes nothing.
