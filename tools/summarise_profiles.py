@@ -24,7 +24,7 @@ def agg(d):
 fetch, write, sq = agg("fin_fetch"), agg("fin_write"), agg("fin_sq")
 summary = {}
 for k in sorted(set(fetch) | set(write) | set(sq)):
-    if not (k.startswith("k_fresnel") or k.startswith("k_refract") or k.startswith("k_source") or k.startswith("k_band")):
+    if not (k.startswith("k_fresnel") or k.startswith("k_refract") or k.startswith("k_source") or k.startswith("k_band") or k.startswith("k_psf")):
         continue
     e = {}
     if k in fetch:
