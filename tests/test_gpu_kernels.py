@@ -359,11 +359,13 @@ def test_detector_golden(ops):
 
 @pytest.mark.parametrize("case", [(1100, 1204, 2, 1.3, 1.2), (1101, 1203, 3, 0.0, 0.8), (1600, 2052, 4, 2.6, 0.0),
                                   (700, 520, 1, 0.9, 1.7), (2400, 600, 2, 9.0, 3.1), (1024, 1536, 2, 0.5, 0.0),
-                                  (520, 2052, 4, 0.3, 2.0), (2048, 2048, 2, 0.036, 1.2)])
+                                  (520, 2052, 4, 0.3, 2.0), (2048, 2048, 2, 0.036, 1.2), (1500, 1300, 2, 0.7, 2.4),
+                                  (1028, 772, 4, 0.0, 1.7)])
 def test_detector_multi_block_grids(ops, case):
     """The banded detector kernels on grids of several 256-output blocks: the fused (contiguous axis, axis 0) pairs where
     the rows are 16-byte aligned and the bands fit (front only, front + PSF, the bench geometry) and the four-pass form
-    elsewhere (unaligned rows, wide source blur), with and without each blur: against the dense composite operator of the
+    elsewhere (unaligned rows, wide source blur), with and without each blur; the PSF stage as a stencil (k_psf_tile: 5, 9, 11, 13
+    and 15 taps, its three instantiations) and as a banded pair (19 taps): against the dense composite operator of the
     host builder (the one the CPU suite holds to the oracle), applied in float64."""
     Nx, Ny, ov, sig_src, sig_psf = case
     nx, ny = Nx // ov, Ny // ov
@@ -387,7 +389,7 @@ def test_detector_multi_block_grids(ops, case):
 
 
 @pytest.mark.parametrize("case", [(1100, 1204, 2, 1.3, 1.2), (1600, 2052, 4, 2.6, 0.0), (1101, 1203, 3, 0.0, 0.8),
-                                  (2048, 2048, 2, 0.036, 1.2), (2400, 600, 2, 9.0, 3.1)])
+                                  (2048, 2048, 2, 0.036, 1.2), (2400, 600, 2, 9.0, 3.1), (1500, 1300, 2, 0.7, 2.4)])
 def test_detector_images_of_a_bin_in_one_call(ops, case):
     """psx_detect_multi_f32 (the two to four images of an energy bin, EXP:388-394): with both stages fused the images share
     each launch; in every geometry -- fused front + PSF, fused front alone, the four-pass form (unaligned rows, wide blur) --
