@@ -329,7 +329,8 @@ int psx_debug_stamps(void *buf);
 
 /* Diagnostic A/B switches, process-wide, all off by default; the library reads NOTHING from the environment.  Names:
  *   "no_dif", "no_pair" (read when a Fresnel plan is created), "no_dual", "no_dist_inner", "stamp_pass1", "stamp_round"
- *   (default 1), "detect_4pass", "far_stride" (the far-ray replay walks its lists in that stride instead of tile order), "near_lds_pad" (KiB of LDS added to the refraction tile launch: an occupancy probe).  tools/ and tests/ set them; timed product runs never do.  psx_debug_switches_active writes
+ *   (default 1), "detect_4pass", "far_stride" (the far-ray replay walks its lists in that stride instead of tile order), "near_lds_pad" (KiB of LDS added to the refraction tile launch: an occupancy probe), "no_p2" (read when a Fresnel plan is created: the
+ *   576*R3-point line transforms of round 5 instead of the power-of-two ones).  tools/ and tests/ set them; timed product runs never do.  psx_debug_switches_active writes
  *   "name=value ..." of every switch that is not at its default (empty string: none) -- bench.py echoes it in its JSON line. */
 int psx_debug_switch(const char *name, int value);
 int psx_debug_switches_active(char *buf, size_t cap);

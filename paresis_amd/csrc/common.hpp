@@ -112,6 +112,7 @@ enum DebugSwitch {
     DBG_DETECT_4PASS,      // detector stages as four passes instead of fused pairs
     DBG_FAR_STRIDE,        // far-ray replay: lists handed to the waves in a strided order (value = stride; 0: tile order)
     DBG_NEAR_LDS_PAD,      // refraction tile kernel: KiB of LDS added to the launch (occupancy probe: beyond ~2 KiB one workgroup per CU)
+    DBG_NO_P2,             // Fresnel LDS engine: lines through the 576 R3-point transforms even where a power of two serves (read when a plan is created)
     DBG_COUNT
 };
 int debug_switch(DebugSwitch s);

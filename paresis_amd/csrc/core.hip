@@ -67,9 +67,9 @@ unsigned long long *g_stamps = nullptr;
 
 namespace {
 const char *const g_dbg_names[DBG_COUNT] = {"no_dif", "no_pair", "no_dual", "no_dist_inner", "stamp_pass1", "stamp_round",
-                                            "detect_4pass", "far_stride", "near_lds_pad"};
-const int g_dbg_default[DBG_COUNT] = {0, 0, 0, 0, 0, 1, 0, 0, 0};
-std::atomic<int> g_dbg[DBG_COUNT] = {{0}, {0}, {0}, {0}, {0}, {1}, {0}, {0}, {0}};
+                                            "detect_4pass", "far_stride", "near_lds_pad", "no_p2"};
+const int g_dbg_default[DBG_COUNT] = {0, 0, 0, 0, 0, 1, 0, 0, 0, 0};
+std::atomic<int> g_dbg[DBG_COUNT] = {{0}, {0}, {0}, {0}, {0}, {1}, {0}, {0}, {0}, {0}};
 }  // namespace
 
 int debug_switch(DebugSwitch s) { return g_dbg[s].load(std::memory_order_relaxed); }

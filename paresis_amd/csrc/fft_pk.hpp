@@ -215,5 +215,9 @@ template <bool INV>
 struct DftPk<24, INV> {
     static __device__ __forceinline__ void run(v2f (&v)[24]) { dft_pk_split<3, 8, INV>(v); }
 };
+template <bool INV>
+struct DftPk<32, INV> {
+    static __device__ __forceinline__ void run(v2f (&v)[32]) { dft_pk_split<4, 8, INV>(v); }
+};
 
 }  // namespace psx

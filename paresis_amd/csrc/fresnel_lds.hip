@@ -33,6 +33,7 @@
 #include <tuple>
 #include <vector>
 
+#include "fresnel_p2.hpp"
 #include "fresnel_plan.hpp"
 #include "fresnel_stages.hpp"
 
@@ -1516,6 +1517,7 @@ namespace psx {
 
 struct AxisTables {
     int N = 0, R3 = 0, M = 0;
+    int p2 = 0;                                     // radix R1 of the power-of-two line kernels (fresnel_p2.hip; M = 256 R1), 0: the 576 R3-point ones
     int part = 0, B = 0, Lh = 0, S = 1, NB = 1;     // partitioned convolution (lines that do not fit one transform)
     int pair = 0, Mconv = 0;                        // part: the two LDS lines coupled into one transform of Mconv = 2M points
     int dif = 0;                                    // pair: one 2*Mconv-point convolution per line in two rounds (radix-2 DIF split)
@@ -1530,8 +1532,9 @@ struct AxisTables {
 };
 
 struct KernEntry {
-    float2 *H;          // S spectra of M points
+    float2 *H;          // S spectra of M points (power-of-two lines: M points + the first taps, p2::spectrum_elems)
     int M, S;
+    size_t elems;       // float2 elements allocated
     unsigned long long stamp;
 };
 
@@ -1586,6 +1589,8 @@ bool lds_engine_supported(int Nx, int Ny, int margin) {
 static int make_axis(AxisTables &t, int N, int margin, size_t &bytes) {
     t.N = N;
     t.R3 = pick_r3(N, margin);
+    // a power of two just below N + P - 1 with the wrapped outputs put right (fresnel_p2.hip) wherever it is the shorter transform
+    if (const int r1 = debug_switch(DBG_NO_P2) ? 0 : p2::pick_r1(N, margin); r1 && t.R3 && 256 * r1 < 576 * t.R3) t.p2 = r1;
     const bool no_pair = debug_switch(DBG_NO_PAIR) != 0;     // diagnostics: the round-1 partition (M-point products)
     if (!t.R3) {
         t.R3 = 16;
@@ -1602,14 +1607,21 @@ static int make_axis(AxisTables &t, int N, int margin, size_t &bytes) {
             t.Lh = N + 2 * margin;
         }
     }
-    t.M = 576 * t.R3;
+    t.M = t.p2 ? 256 * t.p2 : 576 * t.R3;
     t.Mconv = t.pair ? 2 * t.M : t.M;
     const int S1 = t.M / RAD;
-    PSX_HIP(hipMalloc((void **)&t.twA, sizeof(float2) * RAD * S1));
-    PSX_HIP(hipMalloc((void **)&t.twB, sizeof(float2) * RAD * t.R3));
-    bytes += sizeof(float2) * RAD * (S1 + t.R3);
-    k_stage_twiddles<<<(int)cdiv(RAD * S1, 256), 256>>>(t.twA, t.twB, t.M, t.R3);
-    if (int rc = launch_check("k_stage_twiddles")) return rc;
+    if (t.p2) {
+        PSX_HIP(hipMalloc((void **)&t.twA, sizeof(float2) * p2::twA_elems(t.p2)));
+        PSX_HIP(hipMalloc((void **)&t.twB, sizeof(float2) * p2::twB_elems()));
+        bytes += sizeof(float2) * (p2::twA_elems(t.p2) + p2::twB_elems());
+        if (int rc = p2::build_tables(t.twA, t.twB, t.p2, nullptr)) return rc;
+    } else {
+        PSX_HIP(hipMalloc((void **)&t.twA, sizeof(float2) * RAD * S1));
+        PSX_HIP(hipMalloc((void **)&t.twB, sizeof(float2) * RAD * t.R3));
+        bytes += sizeof(float2) * RAD * (S1 + t.R3);
+        k_stage_twiddles<<<(int)cdiv(RAD * S1, 256), 256>>>(t.twA, t.twB, t.M, t.R3);
+        if (int rc = launch_check("k_stage_twiddles")) return rc;
+    }
     // float64 transforms of the kernel-spectrum build
     if (int rc = rocfft_ensure_setup()) return rc;
     if (t.pair) {
@@ -1723,18 +1735,19 @@ static int kernel_spectrum(psx_fresnel_plan *p, AxisTables &t, double a, double 
     if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
         return fail(PSX_E_STATE, "psx_fresnel_propagate: kernel spectrum (a=%g, du=%g) is not cached and cannot be built while "
                                  "the stream is being captured: run the call once outside the capture first", a, du);
-    KernEntry k{nullptr, t.Mconv, t.S, ++e->clock};
-    const size_t bytes = sizeof(float2) * (size_t)t.Mconv * t.S;
+    const size_t elems = t.p2 ? p2::spectrum_elems(t.p2) : (size_t)t.Mconv * t.S;
+    KernEntry k{nullptr, t.Mconv, t.S, elems, ++e->clock};
+    const size_t bytes = sizeof(float2) * elems;
     if (e->cache_bytes + bytes > CACHE_CAP_BYTES && !e->cache.empty()) {   // evict the least recently used table
         auto lru = e->cache.begin();
         for (auto jt = e->cache.begin(); jt != e->cache.end(); ++jt)
             if (jt->second.stamp < lru->second.stamp) lru = jt;
         PSX_HIP(hipStreamSynchronize(st));       // its last readers are done
-        if (lru->second.M == t.Mconv && lru->second.S == t.S) {
+        if (lru->second.elems == elems) {
             k.H = lru->second.H;
         } else {
             (void)hipFree(lru->second.H);
-            e->cache_bytes -= sizeof(float2) * (size_t)lru->second.M * lru->second.S;
+            e->cache_bytes -= sizeof(float2) * lru->second.elems;
         }
         e->cache.erase(lru);
     }
@@ -1758,7 +1771,13 @@ static int kernel_spectrum(psx_fresnel_plan *p, AxisTables &t, double a, double 
         void *buf = t.bufM;
         PSX_ROCFFT(rocfft_execute(t.planM, &buf, nullptr, t.infoM));
     }
-    if (t.pair)
+    if (t.p2) {
+        if (int rc = p2::perm_spectrum(t.bufM, t.bufP, k.H, t.p2, P, st)) {
+            (void)hipFree(k.H);
+            e->cache_bytes -= bytes;
+            return rc;
+        }
+    } else if (t.pair)
         PSX_TIMED("k_kern_perm", st, k_kern_perm_pair<<<(int)cdiv((int64_t)t.M * t.S, 256), 256, 0, st>>>(t.bufM, reinterpret_cast<float4 *>(k.H), t.M, t.R3, t.S, t.dif ? 0.5 : 1.0));
     else
         PSX_TIMED("k_kern_perm", st, k_kern_perm<<<(int)cdiv((int64_t)t.M * t.S, 256), 256, 0, st>>>(t.bufM, k.H, t.M, t.R3, t.S));
@@ -1887,7 +1906,7 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         // one source for all distances: a workgroup takes the distances of a line group in consecutive rounds and fetches the
         // group once -- but only when there are enough line groups to occupy every CU that way (small grids: 32 groups of 16
         // lines at 512^2 would leave 224 CUs idle; there every (distance, group) pair is its own work item)
-        const int lds_lines = TOT / (576 * e->ax[0].R3);
+        const int lds_lines = e->ax[0].p2 ? p2::lines_per_round(e->ax[0].p2, false) : TOT / (576 * e->ax[0].R3);
         const int lines_per_group = (nnz >= 2 && !e->ax[0].part) ? lds_lines / 2 : lds_lines;   // shared-forward rounds take half the LDS lines
         const int ngroups0 = (p->Ny + lines_per_group - 1) / lines_per_group;
         la.dist_inner = (no_inner || e->ax[0].part || ngroups0 < current_cu_count()) ? 0 : 1;
@@ -1920,12 +1939,15 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
                 la.wave_out[nnz] = nullptr;       // odd count: the last pair's second result is computed and dropped
             }
             int rc = 0;
-            switch (e->ax[0].R3) {
+            if (e->ax[0].p2) rc = p2::launch(e->ax[0].p2, true, true, la, st, "k_fresnel_cols");
+            else switch (e->ax[0].R3) {
                 case 4: rc = launch_lines<4, true, true>(la, st, "k_fresnel_cols"); break;
                 case 8: rc = launch_lines<8, true, true>(la, st, "k_fresnel_cols"); break;
                 default: rc = launch_lines<16, true, true>(la, st, "k_fresnel_cols"); break;
             }
             if (rc) return rc;
+        } else if (e->ax[0].p2) {
+            if (int rc = p2::launch(e->ax[0].p2, true, false, la, st, "k_fresnel_cols")) return rc;
         } else if (int rc = launch_lines_r3<true>(e->ax[0].R3, la, st, "k_fresnel_cols", e->ax[0].part, e->ax[0].pair, e->ax[0].dif)) return rc;
     }
 
@@ -1959,7 +1981,9 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         lb.w2 = e->ax[1].w2;
         lb.w4 = e->ax[1].w4; lb.wgpart = e->wgpart; lb.wg_groups = e->wgpart_groups;
         lb.dsh = 2 * PART_M - p->Py; lb.thr = p->Ny + p->Py - 1 - 2 * PART_M;
-        if (int rc2 = launch_lines_r3<false>(e->ax[1].R3, lb, st, "k_fresnel_rows", e->ax[1].part, e->ax[1].pair, e->ax[1].dif)) return rc2;
+        if (e->ax[1].p2) {
+            if (int rc2 = p2::launch(e->ax[1].p2, false, false, lb, st, "k_fresnel_rows")) return rc2;
+        } else if (int rc2 = launch_lines_r3<false>(e->ax[1].R3, lb, st, "k_fresnel_rows", e->ax[1].part, e->ax[1].pair, e->ax[1].dif)) return rc2;
     }
     return 0;
 }
@@ -1978,7 +2002,7 @@ int lds_engine_propagate_sources(psx_fresnel_plan *p, const SourcesArgs &a) {
     const int V = a.n_src * a.n_dist;
     const size_t npix = (size_t)p->Nx * p->Ny;
     // one launch per pass only pays where a launch is mostly overhead and the generic (pair, group) work order applies
-    const int lds_lines = TOT / (576 * e->ax[0].R3);
+    const int lds_lines = e->ax[0].p2 ? p2::lines_per_round(e->ax[0].p2, false) : TOT / (576 * e->ax[0].R3);
     const int ngroups0 = (p->Ny + lds_lines - 1) / lds_lines;
     bool batched = a.n_src > 1 && !e->ax[0].part && !e->ax[1].part && ngroups0 < current_cu_count() && V <= MAX_LINE &&
                    a.n_src <= PSX_MAX_SRC;
@@ -2073,8 +2097,10 @@ int lds_engine_propagate_sources(psx_fresnel_plan *p, const SourcesArgs &a) {
             lb.H[i] = lb.H[0];
         }
     }
-    if (int rc = launch_lines_r3<true>(e->ax[0].R3, la, st, "k_fresnel_cols")) return rc;
-    return launch_lines_r3<false>(e->ax[1].R3, lb, st, "k_fresnel_rows");
+    if (int rc = e->ax[0].p2 ? p2::launch(e->ax[0].p2, true, false, la, st, "k_fresnel_cols")
+                             : launch_lines_r3<true>(e->ax[0].R3, la, st, "k_fresnel_cols")) return rc;
+    return e->ax[1].p2 ? p2::launch(e->ax[1].p2, false, false, lb, st, "k_fresnel_rows")
+                       : launch_lines_r3<false>(e->ax[1].R3, lb, st, "k_fresnel_rows");
 }
 
 }  // namespace psx

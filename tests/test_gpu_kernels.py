@@ -132,6 +132,44 @@ def test_fresnel_lds_engine_edge_geometries(ops, shape):
     plan.close()
 
 
+@pytest.mark.parametrize("shape,nd", [((512, 40), 1), ((40, 512), 2), ((1024, 500), 3), ((498, 2048), 1), ((2048, 505), 2), ((4096, 36), 1),
+                                      ((36, 4096), 2), ((4090, 1021), 3), ((1100, 33), 1), ((2200, 20), 2), ((300, 4081), 1)])
+def test_fresnel_power_of_two_lines_and_wrapped_outputs(ops, shape, nd):
+    """Lines of N samples through ONE M = 256 R1-point transform with M just below N + P - 1 (fresnel_p2.hip): every radix
+    (M = 1024 ... 8192), on either axis, with 29 / 5 / 1 / 0 wrapped outputs put right by the taps they missed, one distance
+    and the shared-forward rounds of several; and the line lengths that stay on the 576 R3-point transforms (1100, 2200).
+    Whole complex fields against the float64 oracle; the same plan with the switch "no_p2" must agree as well."""
+    from paresis_amd._lib import lib
+    Nx, Ny = shape
+    rng = np.random.default_rng(11 + Nx + 3 * Ny)
+    E, pix, M = 52.0, 2.9, 1.03
+    zs = (2.3, 7.2, 0.4)[:nd]
+    T64 = rng.uniform(0.0, 3e-5, size=(2, Nx, Ny))
+    dl, bl = np.array([6.2e-7, 9.9e-8]), np.array([4e-9, 4.5e-11])
+    w_in = rng.normal(size=(Nx, Ny)) + 1j * rng.normal(size=(Nx, Ny))
+    k = orc.k_sample(E)
+    m = ops.MaterialStack(dev(T64, torch.float32), cphase=-k * dl, catt=-k * bl)
+    T32 = T64.astype(np.float32).astype(np.float64)
+    w0 = orc.set_wave(1.25 * w_in.astype(np.complex64).astype(np.complex128), T32, dl, bl, E)
+    kk = orc.getk(E * 1000)
+    du = (2 * np.pi / (Nx * pix * 1e-6), 2 * np.pi / (Ny * pix * 1e-6))
+    refs = [orc.wave_propagation(w0, z, E, M, (Nx, Ny), pix) for z in zs]
+    for no_p2 in (0, 1):
+        assert lib().psx_debug_switch(b"no_p2", no_p2) == 0
+        try:
+            plan = ops.FresnelPlan(Nx, Ny, max_dist=nd, engine=2)
+        finally:
+            lib().psx_debug_switch(b"no_p2", 0)
+        assert plan.engine == 2
+        inten = [torch.zeros((Nx, Ny), dtype=torch.float32, device="cuda") for _ in zs]
+        outs = plan.propagate([z / (2 * kk * M) for z in zs], [kk * z / M for z in zs], du, wave_in=dev(w_in, torch.complex64),
+                              amp=1.25, mats=m, inten_out=inten)
+        for z, o, it, ref in zip(zs, outs, inten, refs):
+            assert relmax(o.cpu().numpy(), ref) < TOL, (shape, z, no_p2)
+            assert relmax(it.cpu().numpy(), np.abs(ref) ** 2) < TOL, (shape, z, no_p2)
+        plan.close()
+
+
 def test_fresnel_known_answers(ops):
     # uniform wave keeps its modulus (reflect pad of a constant is constant: only the DC bin, chirp(0)=1)
     plan = ops.FresnelPlan(40, 44)
