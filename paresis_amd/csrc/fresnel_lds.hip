@@ -2005,6 +2005,7 @@ int lds_engine_propagate_sources(psx_fresnel_plan *p, const SourcesArgs &a) {
     const int lds_lines = e->ax[0].p2 ? p2::lines_per_round(e->ax[0].p2, false) : TOT / (576 * e->ax[0].R3);
     const int ngroups0 = (p->Ny + lds_lines - 1) / lds_lines;
     bool batched = a.n_src > 1 && !e->ax[0].part && !e->ax[1].part && ngroups0 < current_cu_count() && V <= MAX_LINE &&
+                   (!e->ax[0].p2 || V <= p2::max_distances(e->ax[0].p2)) && (!e->ax[1].p2 || V <= p2::max_distances(e->ax[1].p2)) &&
                    a.n_src <= PSX_MAX_SRC;
     for (int v = 0; v < V && batched; ++v) batched = a.a[v] != 0.0;         // z == 0 pairs take the one-source path
     if (!batched) {

@@ -45,43 +45,54 @@ struct G2 {
     static constexpr int R1 = R1_, M = 256 * R1, LINES = TOT2 / M, LH = DUAL_ ? LINES / 2 : LINES;
     // a line buffer: M points + pad slots + the LXM dropped samples e[M + j] behind them (the loaders write every sample at its
     // position of the extension; positions >= M are not part of the transform and keep what the fix-up needs)
-    static constexpr int MP = M + M / 32 + LXM + 2;
+    static constexpr int MP = M + M / 32 + LXM;
     static constexpr int NBA = 32 / R1;          // stage-A butterflies per engine thread
     static constexpr int SPL = M / 16;           // slabs per line
-    static constexpr int LDA = R1 + 1, LDB = 17; // padded rows of the twiddle tables
+    static constexpr int LB = R1 == 32 ? 5 : (R1 == 16 ? 4 : (R1 == 8 ? 3 : 2));   // log2(R1): powers w^(n 2^b) per stage-A row
+    static constexpr int LDP = LB | 1, LDB = 17; // padded rows of the twiddle tables (odd: consecutive rows on different banks)
+    // fix-up: TPL loader threads per LDS line, the taps of an output in NCH chunks of CL (one partial sum per chunk)
+    static constexpr int TPL = TLD / LINES, NCH = TPL >= 2 * LXM ? TPL / LXM : 1, CL = LXM / NCH;
     // LDS map, in float2 elements
-    static constexpr int O_TA1 = LINES * MP, O_TA0 = O_TA1 + 16 * LDA, O_TB = O_TA0 + 16 * LDA, O_SA = O_TB + 16 * LDB,
-                         O_C = O_SA + LH * LXM, O_UQ = O_C + LINES * LXM, O_HT = O_UQ + 2;
+    static constexpr int O_TP = LINES * MP, O_TB = O_TP + 256 * LDP, O_SA = O_TB + 16 * LDB, O_C = O_SA + LH * LXM,
+                         O_UQ = O_C + NCH * LINES * LXM, O_HT = O_UQ + 2;
     static constexpr size_t lds_bytes(int ntap) { return sizeof(float2) * (size_t)(O_HT + ntap * LXM); }
-    static_assert(LINES >= 2 && NBA >= 1 && sizeof(float2) * (size_t)(O_HT + MAX_LINE * LXM) <= 160 * 1024, "LDS budget");
+    static constexpr int max_taps = (160 * 1024 / (int)sizeof(float2) - O_HT) / LXM < MAX_LINE ? (160 * 1024 / (int)sizeof(float2) - O_HT) / LXM : MAX_LINE;
+    static_assert(LINES >= 2 && NBA >= 1 && max_taps >= 16, "LDS budget");
 };
 
-template <int Q0, int Q1, int R, bool CONJ>
-__device__ __forceinline__ void twiddle_chunk(v2f (&v)[R], const v2f *row1, const v2f *row0) {
-    v2f w1[Q1 - Q0], w0[Q1 - Q0];
-#pragma unroll
-    for (int q = Q0; q < Q1; ++q) {
-        w1[q - Q0] = lds_read(row1 + q);
-        w0[q - Q0] = lds_read(row0 + q);
-    }
-#pragma unroll
-    for (int q = Q0; q < Q1; ++q) {
-        const v2f w = pk_cmul(w1[q - Q0], w0[q - Q0]);
-        v[q] = CONJ ? pk_cmulc(v[q], w) : pk_cmul(v[q], w);
-    }
-}
-// v[q] *= (or conj-*=) row1[q] * row0[q], q = 1 .. R-1, eight legs at a time
+// Stage A's twiddles w_M^{n q}, q < R, from the LB = log2(R) powers w^(n 2^b) of the thread's row: w^(n q) is the product of the
+// powers of q's set bits, at most four multiplications deep -- 26 products for R = 32 where two factor tables cost 31 and 62 LDS
+// reads (fresnel_lds.hip, twiddle_A); 5 reads here.  The lower half is applied as it is built, the upper half takes w^(16 n) first.
 template <int R, bool CONJ>
-__device__ __forceinline__ void twiddle_A2(v2f (&v)[R], const v2f *row1, const v2f *row0) {
-    if constexpr (R <= 8) {
-        twiddle_chunk<1, R, R, CONJ>(v, row1, row0);
-    } else {
-        twiddle_chunk<1, 8, R, CONJ>(v, row1, row0);
-        twiddle_chunk<8, 16, R, CONJ>(v, row1, row0);
-        if constexpr (R > 16) {
-            twiddle_chunk<16, 24, R, CONJ>(v, row1, row0);
-            twiddle_chunk<24, 32, R, CONJ>(v, row1, row0);
-        }
+__device__ __forceinline__ v2f tw_apply(v2f x, v2f w) {
+    return CONJ ? pk_cmulc(x, w) : pk_cmul(x, w);
+}
+template <int R, bool CONJ>
+__device__ __forceinline__ void twiddle_A2(v2f (&v)[R], const v2f *row) {
+    constexpr int H = R >= 16 ? 16 : R;          // twiddles built explicitly: q < H
+    v2f t[H];
+    t[1] = lds_read(row);
+    if constexpr (R >= 4) t[2] = lds_read(row + 1);
+    if constexpr (R >= 8) t[4] = lds_read(row + 2);
+    if constexpr (R >= 16) t[8] = lds_read(row + 3);
+    v2f t16 = (v2f){1.f, 0.f};
+    if constexpr (R == 32) t16 = lds_read(row + 4);
+    if constexpr (R >= 4) t[3] = pk_cmul(t[1], t[2]);
+    if constexpr (R >= 8) {
+#pragma unroll
+        for (int r = 1; r < 4; ++r) t[4 + r] = pk_cmul(t[4], t[r]);
+    }
+    if constexpr (R >= 16) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) t[8 + r] = pk_cmul(t[8], t[r]);
+    }
+#pragma unroll
+    for (int q = 1; q < H; ++q) v[q] = tw_apply<R, CONJ>(v[q], t[q]);
+    if constexpr (R == 32) {
+#pragma unroll
+        for (int q = 16; q < 32; ++q) v[q] = tw_apply<R, CONJ>(v[q], t16);
+#pragma unroll
+        for (int q = 17; q < 32; ++q) v[q] = tw_apply<R, CONJ>(v[q], t[q - 16]);
     }
 }
 
@@ -144,15 +155,16 @@ __device__ __forceinline__ void store_legs(const v2f (&v)[R], v2f vw, v2f *wo, f
 template <int R1, bool CONTIG, bool DUAL, bool QUEUE>
 __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
     using GE = G2<R1, DUAL>;
-    constexpr int M = GE::M, LINES = GE::LINES, LH = GE::LH, MP = GE::MP, NBA = GE::NBA, SPL = GE::SPL, LDA = GE::LDA, LDB = GE::LDB;
+    constexpr int M = GE::M, LINES = GE::LINES, LH = GE::LH, MP = GE::MP, NBA = GE::NBA, SPL = GE::SPL, LDP = GE::LDP, LDB = GE::LDB;
+    constexpr int NCH = GE::NCH, CL = GE::CL, TPL = GE::TPL;
     constexpr int LPG = LH;          // image lines per round
     constexpr int LL = LH;           // LDS lines the loaders fill
     static_assert(!DUAL || CONTIG, "DUAL is pass 1");
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     v2f *const Lb = reinterpret_cast<v2f *>(lds);
-    v2f *const tA1 = Lb + GE::O_TA1, *const tA0 = Lb + GE::O_TA0, *const tB = Lb + GE::O_TB;
+    v2f *const tP = Lb + GE::O_TP, *const tB = Lb + GE::O_TB;
     v2f *const SA = Lb + GE::O_SA;         // [LH][LXM]: e[j], j < LXM, of every image line of the round (the transform overwrites them)
-    v2f *const CF = Lb + GE::O_C;          // [LINES][LXM]: fix-up of the wrapped outputs of every LDS line
+    v2f *const CF = Lb + GE::O_C;          // [NCH][LINES][LXM]: fix-up of the wrapped outputs of every LDS line, one partial sum per tap chunk
     v2f *const HT = Lb + GE::O_HT;         // [distances][LXM]: the first taps of every distance of the launch
     int *const uq = reinterpret_cast<int *>(Lb + GE::O_UQ);
     const int tid = threadIdx.x;
@@ -211,10 +223,9 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
     unsigned first2 = 0u;
     if (DYN && tid == TE) first2 = atomicAdd(qcount(slot), 2u);
     // ---- stage twiddles and the first taps of every distance into LDS
-    for (int idx = tid; idx < 16 * R1; idx += TT) {
-        const float2 w1 = a.twA[idx], w0 = a.twA[16 * R1 + idx];
-        tA1[(idx / R1) * LDA + idx % R1] = (v2f){w1.x, w1.y};
-        tA0[(idx / R1) * LDA + idx % R1] = (v2f){w0.x, w0.y};
+    for (int idx = tid; idx < 256 * GE::LB; idx += TT) {
+        const float2 wv = a.twA[idx];
+        tP[(idx / GE::LB) * LDP + idx % GE::LB] = (v2f){wv.x, wv.y};
     }
     for (int idx = tid; idx < 256; idx += TT) {
         const float2 w = a.twB[idx];
@@ -256,7 +267,20 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
         const int64_t pstep = (int64_t)STEP * (a.in_blocked ? (int64_t)IB : a.in_si);
         float2 *sa_line = lds + GE::O_SA + line * LXM;
 
-        float2 xs[NLD], xm = make_float2(0.f, 0.f);
+        // Pass 2 (!CONTIG) reads the blocked intermediate, where sample i of the lines 8b .. 8b+7 is one 64-byte piece: a thread
+        // moves sample i of TWO adjacent lines (2 c2, 2 c2 + 1 of the group) with one 16-byte load -- half the lanes and half the
+        // wave-instructions of a load per (line, sample).  (First form of this kernel, 8-byte loads: the loaders needed 5.35 us to
+        // issue a round's fetch at 4096^2, the engine reached barrier (2) after 5.1: gpurun_out/r6s1.)
+        constexpr int CH = LL / 2 > 0 ? LL / 2 : 1, STEPV = TLD / CH, NLV = M / (2 * STEPV), PSTEPV = STEPV + STEPV / 32;
+        static_assert(CONTIG || (LL % 2 == 0 && IB % 2 == 0 && STEPV % 32 == 0 && NLV * STEPV == M / 2), "16-byte loads of the blocked intermediate");
+        const int c2 = lt % CH, i0v = lt / CH;
+        float2 *base_v = lds + 2 * c2 * MP;
+        const int jav = i0v + N + 2 * mg - 1, jbv = i0v - 1;
+        const int oav = phys(jav), obv = phys(jbv);
+        float2 *sa_v = lds + GE::O_SA + 2 * c2 * LXM;
+
+        float2 xs[CONTIG ? NLD : 1], xm = make_float2(0.f, 0.f);
+        float4 xv[CONTIG ? 1 : NLV];
         auto fetch = [&](int j) __attribute__((always_inline)) {
             int d, g;
             item(j, d, g);
@@ -264,6 +288,19 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
             const float2 *src = a.src[d];
             const int l0 = g * LPG;
             const bool line_ok = l0 + line < a.nlines;
+            if constexpr (!CONTIG) {
+                const int l = l0 + 2 * c2;                           // even: the pair (l, l + 1) is 16 bytes of one 64-byte piece
+                const bool pair_ok = l < a.nlines;                   // l + 1 may lie past the image: inside the block's padding, dropped at the spread
+                const int64_t pix0 = ((int64_t)(l / IB) * N + i0v) * IB + l % IB;
+#pragma unroll
+                for (int k = 0; k < NLV; ++k) {
+                    const bool ok = pair_ok && i0v + STEPV * k < N;
+                    xv[k] = *reinterpret_cast<const float4 *>(src + (ok ? pix0 + (int64_t)STEPV * k * IB : (int64_t)0));
+                }
+                const int64_t pixm = ((int64_t)((l0 + lm) / IB) * N + im) * IB + (l0 + lm) % IB;
+                xm = src[(im >= 0 && l0 + lm < a.nlines) ? pixm : (int64_t)0];
+                return;
+            }
             const int64_t pix0 = a.in_blocked ? ((int64_t)((l0 + line) / IB) * N + i0) * IB + (l0 + line) % IB
                                               : (int64_t)i0 * a.in_si + (int64_t)(l0 + line) * a.in_sl;
 #pragma unroll
@@ -285,8 +322,31 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
 #pragma unroll
                 for (int ln = 0; ln < LL; ++ln) lds[ln * MP + pz] = make_float2(0.f, 0.f);
             }
+            if constexpr (!CONTIG) {
+                const bool ok0 = l0 + 2 * c2 < a.nlines, ok1 = l0 + 2 * c2 + 1 < a.nlines;
 #pragma unroll
-            for (int k = 0; k < NLD; ++k) {
+                for (int k = 0; k < NLV; ++k) {
+                    if (i0v + STEPV * k < N) {
+                        const float2 x0 = ok0 ? make_float2(xv[k].x, xv[k].y) : make_float2(0.f, 0.f);
+                        const float2 x1 = ok1 ? make_float2(xv[k].z, xv[k].w) : make_float2(0.f, 0.f);
+                        base_v[oav + k * PSTEPV] = x0;
+                        base_v[MP + oav + k * PSTEPV] = x1;
+                        if (k > 0 || jbv >= 0) {
+                            base_v[obv + k * PSTEPV] = x0;
+                            base_v[MP + obv + k * PSTEPV] = x1;
+                        }
+                        if (STEPV * k <= LXM) {
+                            const int js = jbv + STEPV * k;
+                            if ((unsigned)js < (unsigned)LXM) {
+                                sa_v[js] = x0;
+                                sa_v[LXM + js] = x1;
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < (CONTIG ? NLD : 0); ++k) {
                 if (i0 + STEP * k < N) {
                     const float2 x = line_ok ? xs[k] : make_float2(0.f, 0.f);
                     // first image: position i + P - 1 (the last Lx samples land behind the M points of the transform: they are
@@ -315,26 +375,31 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
                 lds[ln * MP + phys(j2)] = x2;
             }
         };
-        // fix-up of the wrapped outputs of round j: CF[lb][m'] = sum_{t <= m'} h_dd[t] * (e[M + m' - t] - e[m' - t]); LDS traffic
-        // only (the loads of the next group are in flight meanwhile and their counter is not waited on)
+        // fix-up of the wrapped outputs of round j: CF[c][lb][m'] = sum over the taps t of chunk c, t <= m', of
+        // h_dd[t] * (e[M + m' - t] - e[m' - t]).  LDS traffic only (the loads of the next group are in flight meanwhile and their
+        // counter is not waited on); every term of a thread is independent, so its reads travel together.
         auto fixup = [&](int j) __attribute__((always_inline)) {
             if (Lx <= 0) return;
             int d, g;
             item(j, d, g);
-            constexpr int TPL = TLD / LINES;                         // loader threads per LDS line
             const int lb = lt / TPL, r = lt % TPL;
             const int lbi = DUAL ? lb % LH : lb;                     // LDS line that holds the image line's samples
             const int dd = DUAL ? 2 * d + lb / LH : d;
             const v2f *ht = HT + dd * LXM;
             const v2f *sa = SA + lbi * LXM;
             const v2f *sb = Lb + lbi * MP + M + M / 32;              // phys(M + j) = M + M/32 + j for j < 32
-            for (int mp = r; mp < Lx; mp += TPL) {
+            const int c = NCH > 1 ? r / LXM : 0;
+            for (int mp = NCH > 1 ? r % LXM : r; mp < LXM; mp += (NCH > 1 ? LXM : TPL)) {
                 v2f acc = (v2f){0.f, 0.f};
-                for (int t = 0; t <= mp; ++t) {
-                    const v2f dl = sb[mp - t] - sa[mp - t];
-                    acc += pk_cmul(dl, ht[t]);
+#pragma unroll
+                for (int tt = 0; tt < CL; ++tt) {
+                    const int t = c * CL + tt;
+                    const int jx = mp >= t ? mp - t : 0;             // clamped: the reads stay unconditional
+                    const v2f dl = lds_read(sb + jx) - lds_read(sa + jx);
+                    const v2f term = pk_cmul(dl, lds_read(ht + t));
+                    acc += mp >= t ? term : (v2f){0.f, 0.f};
                 }
-                CF[lb * LXM + mp] = acc;
+                CF[(c * LINES + lb) * LXM + mp] = acc;
             }
         };
 
@@ -446,7 +511,7 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
                 v2f *p = Lb + (b >> 8) * MP + n + (n >> 5);
                 DftPk<R1, false>::run(v[i]);
                 __builtin_amdgcn_sched_barrier(0);
-                twiddle_A2<R1, false>(v[i], tA1 + (n >> 4) * LDA, tA0 + (n & 15) * LDA);
+                twiddle_A2<R1, false>(v[i], tP + n * LDP);
 #pragma unroll
                 for (int q = 0; q < R1; ++q) p[q * BSTR] = v[i][q];
             }
@@ -597,6 +662,8 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
 #pragma unroll
                 for (int q = 0; q < R1; ++q) v[i][q] = p[q * BSTR];
                 cf[i] = CF[(b >> 8) * LXM + (n & (LXM - 1))];
+#pragma unroll
+                for (int c = 1; c < NCH; ++c) cf[i] += CF[(c * LINES + (b >> 8)) * LXM + (n & (LXM - 1))];
             }
             lds_barrier();                           // (3)
             PSX_STAMP(11);
@@ -605,7 +672,7 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
                 int bo = tid + TE * i;
                 asm volatile("" : "+v"(bo));         // opaque: the per-leg addresses are formed here, not hoisted out of the round loop
                 const int n = bo & 255, lb = bo >> 8;
-                twiddle_A2<R1, true>(v[i], tA1 + (n >> 4) * LDA, tA0 + (n & 15) * LDA);
+                twiddle_A2<R1, true>(v[i], tP + n * LDP);
                 __builtin_amdgcn_sched_barrier(0);
                 DftPk<R1, true>::run(v[i]);
                 // leg q holds y_c[n + 256 q] = output sample n + 256 q - (P - 1); leg 0 is also the wrapped output n + M - (P - 1)
@@ -630,16 +697,14 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
     }
 }
 
-__global__ void k_p2_twiddles(float2 *twA, float2 *twB, int R1) {
+__global__ void k_p2_twiddles(float2 *twA, float2 *twB, int R1, int LB) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int M = 256 * R1;
-    if (idx < 16 * R1) {
-        const int r = idx / R1, q = idx % R1;
+    if (idx < 256 * LB) {
+        const int n = idx / LB, b = idx % LB;
         double s, c;
-        sincospi(-2.0 * (double)((16 * r * q) % M) / (double)M, &s, &c);      // w_M^{16 nh q}
+        sincospi(-2.0 * (double)((n << b) % M) / (double)M, &s, &c);          // w_M^(n 2^b)
         twA[idx] = make_float2((float)c, (float)s);
-        sincospi(-2.0 * (double)((r * q) % M) / (double)M, &s, &c);           // w_M^{nl q}
-        twA[16 * R1 + idx] = make_float2((float)c, (float)s);
     }
     if (idx < 256) {
         const int n = idx >> 4, k = idx & 15;
@@ -679,10 +744,11 @@ int launch_t(const LineArgs &la, hipStream_t st, const char *name) {
     static std::atomic<unsigned long long> attr_mask{0};
     if (first_on_device(attr_mask))
         PSX_HIP(hipFuncSetAttribute((const void *)k_fresnel_p2<R1, CONTIG, DUAL, QUEUE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)GE::lds_bytes(MAX_LINE)));
+                                    (int)GE::lds_bytes(GE::max_taps)));
     if (la.n_dist < 1 || la.n_dist > MAX_LINE || (DUAL && !la.dist_inner))
         return fail(PSX_E_STATE, "LDS engine (power-of-two lines): %d distances, dist_inner %d", la.n_dist, la.dist_inner);
     const int ntap = DUAL ? 2 * ((la.n_dist + 1) / 2) : la.n_dist;
+    if (ntap > GE::max_taps) return fail(PSX_E_STATE, "LDS engine (power-of-two lines): %d distances in one launch, %d fit", ntap, GE::max_taps);
     const int nwork = ((la.nlines + GE::LH - 1) / GE::LH) * (la.dist_inner ? 1 : la.n_dist);
     const int nslot = line_grid_slots(nwork, QUEUE ? 32 : 0);
     PSX_TIMED(name, st, k_fresnel_p2<R1, CONTIG, DUAL, QUEUE><<<8 * nslot, TT, GE::lds_bytes(ntap), st>>>(la));
@@ -715,13 +781,22 @@ int pick_r1(int N, int margin) {
     return 0;
 }
 
-size_t twA_elems(int R1) { return (size_t)2 * 16 * R1; }
+static int log2_r1(int R1) { return R1 == 32 ? 5 : (R1 == 16 ? 4 : (R1 == 8 ? 3 : 2)); }
+size_t twA_elems(int R1) { return (size_t)256 * log2_r1(R1); }
+int max_distances(int R1) {
+    switch (R1) {
+        case 4: return G2<4, false>::max_taps;
+        case 8: return G2<8, false>::max_taps;
+        case 16: return G2<16, false>::max_taps;
+    }
+    return G2<32, false>::max_taps;
+}
 size_t twB_elems() { return 256; }
 size_t spectrum_elems(int R1) { return (size_t)256 * R1 + LXMAX; }
 int lines_per_round(int R1, bool dual) { return (TOT2 / (256 * R1)) / (dual ? 2 : 1); }
 
 int build_tables(float2 *twA, float2 *twB, int R1, hipStream_t st) {
-    k_p2_twiddles<<<(16 * R1 + 255) / 256 > 1 ? (16 * R1 + 255) / 256 : 1, 256, 0, st>>>(twA, twB, R1);
+    k_p2_twiddles<<<(256 * log2_r1(R1) + 255) / 256, 256, 0, st>>>(twA, twB, R1, log2_r1(R1));
     return launch_check("k_p2_twiddles");
 }
 

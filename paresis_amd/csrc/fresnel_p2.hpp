@@ -15,7 +15,7 @@ constexpr int LXMAX = 32;     // wrapped outputs a line may have (margin 15 on a
 // radix of the first stage (M = 256 * R1, R1 in {4, 8, 16, 32}) if lines of N samples with this margin run on these kernels, else 0
 int pick_r1(int N, int margin);
 
-// stage twiddles in global memory: twA = [16][R1] w_M^{16 nh q} followed by [16][R1] w_M^{nl q}; twB = [16][16] w_256^{n3 k2}
+// stage twiddles in global memory: twA = [256][log2 R1] powers w_M^(n 2^b) of stage A's row n; twB = [16][16] w_256^{n3 k2}
 size_t twA_elems(int R1);
 size_t twB_elems();
 int build_tables(float2 *twA, float2 *twB, int R1, hipStream_t st);
@@ -28,6 +28,9 @@ int perm_spectrum(const double2 *Hh, const double2 *hP, float2 *out, int R1, int
 // one pass over the lines of an image: la as for k_fresnel_lines, with twA / twB from build_tables and H[d] from perm_spectrum.
 // dual: pass 1 of a call with several distances (one line x two distances per round; la.dist_inner must be 1).
 int launch(int R1, bool contig, bool dual, const lines::LineArgs &la, hipStream_t st, const char *name);
+
+// (source, distance) pairs one launch can carry (their first taps live in LDS): MAX_LINE, or a few less at R1 = 4
+int max_distances(int R1);
 
 // image lines per round of a launch (the host's choice of the work order needs it)
 int lines_per_round(int R1, bool dual);
