@@ -264,7 +264,6 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
         float2 *base = lds + line * MP;
         const int ja = i0 + N + 2 * mg - 1, jb = i0 - 1;
         const int oa = phys(ja), ob = phys(jb);
-        const int64_t pstep = (int64_t)STEP * (a.in_blocked ? (int64_t)IB : a.in_si);
         float2 *sa_line = lds + GE::O_SA + line * LXM;
 
         // Pass 2 (!CONTIG) reads the blocked intermediate, where sample i of the lines 8b .. 8b+7 is one 64-byte piece: a thread
@@ -278,6 +277,8 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
         const int jav = i0v + N + 2 * mg - 1, jbv = i0v - 1;
         const int oav = phys(jav), obv = phys(jbv);
         float2 *sa_v = lds + GE::O_SA + 2 * c2 * LXM;
+        // byte offset of (sample i0v, line pair c2) from sample 0 of the group's first line, in the blocked intermediate
+        const int voff_v = ((((2 * c2) / IB) * N + i0v) * IB + (2 * c2) % IB) * (int)sizeof(float2);
 
         float2 xs[CONTIG ? NLD : 1], xm = make_float2(0.f, 0.f);
         float4 xv[CONTIG ? 1 : NLV];
@@ -287,30 +288,40 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
             if (a.dist_inner && d != 0) return;
             const float2 *src = a.src[d];
             const int l0 = g * LPG;
-            const bool line_ok = l0 + line < a.nlines;
             if constexpr (!CONTIG) {
-                const int l = l0 + 2 * c2;                           // even: the pair (l, l + 1) is 16 bytes of one 64-byte piece
-                const bool pair_ok = l < a.nlines;                   // l + 1 may lie past the image: inside the block's padding, dropped at the spread
-                const int64_t pix0 = ((int64_t)(l / IB) * N + i0v) * IB + l % IB;
+                // The group's lines l0 .. l0 + LL - 1 lie in one block of IB lines (two at LL = 16): the descriptor starts at
+                // sample 0 of line l0 and ends with the last block that holds a line of the image, so a sample index >= N and a
+                // block past the image fall outside its range and read zeros -- one address add per load, no compare, no select
+                // (the loader waves are the youngest of their SIMDs: with eight vector instructions per load a round's fetch took
+                // 4.9 us to ISSUE, gpurun_out/r6s2).  A pair (l, l + 1) whose second line lies past the image reads the block's
+                // padding; the spread drops it.
+                constexpr int LLB = LL > IB ? LL / IB : 1;
+                const int nblk = min(LLB, (a.nlines - l0 + IB - 1) / IB);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float2 *>(src) + ((int64_t)(l0 / IB) * N) * IB + l0 % IB, 0,
+                    nblk * N * IB * (int)sizeof(float2) - (l0 % IB) * (int)sizeof(float2), 0x00020000);
 #pragma unroll
                 for (int k = 0; k < NLV; ++k) {
-                    const bool ok = pair_ok && i0v + STEPV * k < N;
-                    xv[k] = *reinterpret_cast<const float4 *>(src + (ok ? pix0 + (int64_t)STEPV * k * IB : (int64_t)0));
+                    const v4u r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_v + k * (STEPV * IB * (int)sizeof(float2)), 0, 0);
+                    xv[k] = __builtin_bit_cast(float4, r);
                 }
                 const int64_t pixm = ((int64_t)((l0 + lm) / IB) * N + im) * IB + (l0 + lm) % IB;
                 xm = src[(im >= 0 && l0 + lm < a.nlines) ? pixm : (int64_t)0];
                 return;
-            }
-            const int64_t pix0 = a.in_blocked ? ((int64_t)((l0 + line) / IB) * N + i0) * IB + (l0 + line) % IB
-                                              : (int64_t)i0 * a.in_si + (int64_t)(l0 + line) * a.in_sl;
+            } else {
+                // rows of the transposed source, in_si == 1: the descriptor covers the group's lines inside the image
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float2 *>(src) + (int64_t)l0 * a.in_sl, 0, min(LL, a.nlines - l0) * (int)a.in_sl * (int)sizeof(float2), 0x00020000);
+                const int voff = (line * (int)a.in_sl + i0) * (int)sizeof(float2);
 #pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const bool ok = line_ok && i0 + STEP * k < N;
-                xs[k] = src[ok ? pix0 + pstep * k : (int64_t)0];
+                for (int k = 0; k < NLD; ++k) {
+                    const v2u r = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + k * (STEP * (int)sizeof(float2)), 0, 0);
+                    xs[k] = __builtin_bit_cast(float2, r);
+                }
+                const int64_t pixm = (int64_t)im + (int64_t)(l0 + lm) * a.in_sl;
+                xm = src[(im >= 0 && l0 + lm < a.nlines) ? pixm : (int64_t)0];
+                return;
             }
-            const int64_t pixm = a.in_blocked ? ((int64_t)((l0 + lm) / IB) * N + im) * IB + (l0 + lm) % IB
-                                              : (int64_t)im * a.in_si + (int64_t)(l0 + lm) * a.in_sl;
-            xm = src[(im >= 0 && l0 + lm < a.nlines) ? pixm : (int64_t)0];
         };
         auto spread = [&](int j) __attribute__((always_inline)) {
             int d, g;
@@ -472,6 +483,13 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
     // TWO slabs: 16 different bank pairs per ds_write_b64 group)
     const int slabw = (ln & 32) + ((ln & 31) < 16 ? 2 * (ln & 31) : 2 * ((ln & 31) - 16) + 1);
     const v2f *rowB = tB + n3 * LDB;
+    // What a wave owns between the barriers after forward stage A and before inverse stage A: the same 1024 points (4 blocks of 256
+    // = 64 slabs) of TWO LDS lines -- lines 2p and 2p + 1 of the round (DUAL: an image line's buffer and the buffer of its second
+    // distance, LH lines further) -- so that one slab of the kernel spectrum, fetched once, meets both lines: half the spectrum
+    // loads of a one-line range, and the engine's loads share the CU's memory pipeline with the loaders' fetch.
+    constexpr int RPL = R1 / 4;                        // ranges of 1024 points per line
+    const int G0 = DUAL ? 4 * w + blk : 2 * (w / RPL) * R1 + 4 * (w % RPL) + blk, G1 = G0 + (DUAL ? 32 : R1);      // this lane's two blocks
+    const int S0 = DUAL ? 64 * w + slabw : 2 * (w / RPL) * SPL + 64 * (w % RPL) + slabw, S1 = S0 + (DUAL ? LH * SPL : SPL);   // ... and slabs
     auto block_ptr = [&](int G) __attribute__((always_inline)) { return Lb + (G / R1) * MP + (G % R1) * BSTR + n3; };
     auto slab_ptr = [&](int S) __attribute__((always_inline)) {
         const int sl = S % SPL;
@@ -516,10 +534,10 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
                 for (int q = 0; q < R1; ++q) p[q * BSTR] = v[i][q];
             }
         }
-        // the kernel spectrum of the first slab travels ahead of its use
-        float4 hh[8];
+        // The kernel spectrum (the engine's only global loads) travels well ahead of its use: the slab's 128 bytes are requested
+        // here, before barrier (1) and before the loaders' fetch (DUAL: the second distance's in forward stage B, behind its reads).
+        float4 hh[8], hh1[DUAL ? 8 : 1];
         {
-            const int S0 = DUAL ? 64 * w + slabw : 128 * w + slabw;
             const float4 *h4 = reinterpret_cast<const float4 *>(a.H[DUAL ? 2 * d : d] + 16 * (S0 % SPL));
 #pragma unroll
             for (int q = 0; q < 8; ++q) hh[q] = h4[q];
@@ -528,31 +546,30 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
         lds_barrier();                               // (1)
         PSX_STAMP(4);
 
-        // ---- forward stage B: radix 16 inside each block of 256, stride 16.  The wave's own 8 blocks (DUAL: its 4 blocks of the
-        // first half of the LDS lines -- the slabs its middle stage reads)
+        // ---- forward stage B: radix 16 inside each block of 256, stride 16 (DUAL: the first distance's buffer only)
         {
             v2f wt[16];
 #pragma unroll
             for (int q = 1; q < 16; ++q) wt[q] = lds_read(rowB + q);
             wt[0] = (v2f){1.f, 0.f};
+            v2f *p0 = block_ptr(G0), *p1 = block_ptr(G1);
+            v2f v0[16], v1[DUAL ? 1 : 16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v0[q] = lds_read(p0 + offB(q));
             if constexpr (DUAL) {
-                v2f *p0 = block_ptr(4 * w + blk);
-                v2f v0[16];
+                const float4 *h4b = reinterpret_cast<const float4 *>(a.H[2 * d + 1] + 16 * (S0 % SPL));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < 16; ++q) v0[q] = lds_read(p0 + offB(q));
-                fwdB_regs(v0, wt);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) p0[offB(q)] = v0[q];
+                for (int q = 0; q < 8; ++q) hh1[q] = h4b[q];
+                __builtin_amdgcn_sched_barrier(0);
             } else {
-                v2f *p0 = block_ptr(8 * w + blk), *p1 = block_ptr(8 * w + 4 + blk);
-                v2f v0[16], v1[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) v0[q] = lds_read(p0 + offB(q));
 #pragma unroll
                 for (int q = 0; q < 16; ++q) v1[q] = lds_read(p1 + offB(q));
-                fwdB_regs(v0, wt);
+            }
+            fwdB_regs(v0, wt);
 #pragma unroll
-                for (int q = 0; q < 16; ++q) p0[offB(q)] = v0[q];
+            for (int q = 0; q < 16; ++q) p0[offB(q)] = v0[q];
+            if constexpr (!DUAL) {
                 fwdB_regs(v1, wt);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) p1[offB(q)] = v1[q];
@@ -563,66 +580,54 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
         PSX_STAMP(6);
 
         // ---- middle stage, slab by slab: forward radix 16 on contiguous points, x FFT_M(h_d), inverse radix 16, back to LDS
-        if constexpr (DUAL) {
-            v2f *b0 = slab_ptr(64 * w + slabw), *b1 = b0 + LH * MP;
-            const int sl = (64 * w + slabw) % SPL;
+        {
+            v2f *b0 = slab_ptr(S0), *b1 = slab_ptr(S1);
             v2f x[16], y[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) x[q] = lds_read(b0 + q);
-            DftPk<16, false>::run(x);                                   // the spectrum slab, shared by the two distances
+            if constexpr (!DUAL) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                y[2 * q] = pk_cmul(x[2 * q], (v2f){hh[q].x, hh[q].y});
-                y[2 * q + 1] = pk_cmul(x[2 * q + 1], (v2f){hh[q].z, hh[q].w});
+                for (int q = 0; q < 16; ++q) y[q] = lds_read(b1 + q);
             }
-            const float4 *h4b = reinterpret_cast<const float4 *>(a.H[2 * d + 1] + 16 * sl);
-            __builtin_amdgcn_sched_barrier(0);
+            DftPk<16, false>::run(x);
+            if constexpr (DUAL) {
+                // the spectrum slab is shared by the two distances: y = x * H_first, then x *= H_second
 #pragma unroll
-            for (int q = 0; q < 8; ++q) hh[q] = h4b[q];
-            __builtin_amdgcn_sched_barrier(0);
-            DftPk<16, true>::run(y);
+                for (int q = 0; q < 8; ++q) {
+                    y[2 * q] = pk_cmul(x[2 * q], (v2f){hh[q].x, hh[q].y});
+                    y[2 * q + 1] = pk_cmul(x[2 * q + 1], (v2f){hh[q].z, hh[q].w});
+                }
+                DftPk<16, true>::run(y);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) b0[q] = y[q];
+                for (int q = 0; q < 16; ++q) b0[q] = y[q];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                x[2 * q] = pk_cmul(x[2 * q], (v2f){hh[q].x, hh[q].y});
-                x[2 * q + 1] = pk_cmul(x[2 * q + 1], (v2f){hh[q].z, hh[q].w});
+                for (int q = 0; q < 8; ++q) {
+                    x[2 * q] = pk_cmul(x[2 * q], (v2f){hh1[q].x, hh1[q].y});
+                    x[2 * q + 1] = pk_cmul(x[2 * q + 1], (v2f){hh1[q].z, hh1[q].w});
+                }
+                DftPk<16, true>::run(x);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) b1[q] = x[q];
+            } else {
+                // two lines, one spectrum slab
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    x[2 * q] = pk_cmul(x[2 * q], (v2f){hh[q].x, hh[q].y});
+                    x[2 * q + 1] = pk_cmul(x[2 * q + 1], (v2f){hh[q].z, hh[q].w});
+                }
+                DftPk<16, true>::run(x);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) b0[q] = x[q];
+                DftPk<16, false>::run(y);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    y[2 * q] = pk_cmul(y[2 * q], (v2f){hh[q].x, hh[q].y});
+                    y[2 * q + 1] = pk_cmul(y[2 * q + 1], (v2f){hh[q].z, hh[q].w});
+                }
+                DftPk<16, true>::run(y);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) b1[q] = y[q];
             }
-            DftPk<16, true>::run(x);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) b1[q] = x[q];
-        } else {
-            v2f *b0 = slab_ptr(128 * w + slabw), *b1 = slab_ptr(128 * w + 64 + slabw);
-            v2f f0[16], f1[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) f0[q] = lds_read(b0 + q);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) f1[q] = lds_read(b1 + q);
-            DftPk<16, false>::run(f0);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                f0[2 * q] = pk_cmul(f0[2 * q], (v2f){hh[q].x, hh[q].y});
-                f0[2 * q + 1] = pk_cmul(f0[2 * q + 1], (v2f){hh[q].z, hh[q].w});
-            }
-            {
-                const float4 *h4 = reinterpret_cast<const float4 *>(a.H[d] + 16 * ((128 * w + 64 + slabw) % SPL));
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) hh[q] = h4[q];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            DftPk<16, true>::run(f0);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) b0[q] = f0[q];
-            DftPk<16, false>::run(f1);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                f1[2 * q] = pk_cmul(f1[2 * q], (v2f){hh[q].x, hh[q].y});
-                f1[2 * q + 1] = pk_cmul(f1[2 * q + 1], (v2f){hh[q].z, hh[q].w});
-            }
-            DftPk<16, true>::run(f1);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) b1[q] = f1[q];
         }
         PSX_STAMP(7);
         wave_sync();
@@ -634,7 +639,7 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
 #pragma unroll
             for (int q = 1; q < 16; ++q) wt[q] = lds_read(rowB + q);
             wt[0] = (v2f){1.f, 0.f};
-            v2f *p0 = block_ptr(DUAL ? 4 * w + blk : 8 * w + blk), *p1 = block_ptr(DUAL ? 32 + 4 * w + blk : 8 * w + 4 + blk);
+            v2f *p0 = block_ptr(G0), *p1 = block_ptr(G1);
             v2f v0[16], v1[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) v0[q] = lds_read(p0 + offB(q));
