@@ -558,6 +558,7 @@ def positions_batch(a, sim, N, rank, world, dev, reproducible=False):
     # 8 (float atomics let a last bit flip a Poisson draw); the Fresnel chain has no float atomics anywhere
     det_mode = sim == "RayT" and reproducible
     exp.exp_dict['reproducible'] = bool(reproducible)     # the Experiment sets the library's mode around its ray-tracing chain
+    exp.exp_dict['sharedZeroStacks'] = True               # as main.run: the loop only reads (packs) what a position returns
     cpu_dev = dev if (world == 1 or a.backend == "nccl") else torch.device("cpu")
 
     def position(p):
@@ -761,6 +762,7 @@ def emulated_rank_share(a, sim, N, r, W, dev):
 
     P = a.positions
     exp, place = synth.bench_experiment(N, sim, noise=True, seed=7)
+    exp.exp_dict['sharedZeroStacks'] = True               # as positions_batch
     mine = dist.my_positions(P, r, W)
 
     def position(p):

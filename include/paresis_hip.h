@@ -167,11 +167,13 @@ int psx_refract_batch_f32(int n, const float *const *I_in, const float *I0, cons
 int psx_set_deterministic(int on);
 int psx_get_deterministic(void);
 /* Optional: the fixed-point unit of the order-independent replay from the CALLER's intensity scale instead of the call's measured
- * maximum -- scale > 0: one unit = 2^-30 of the power of two above 64 * scale (shares up to 2^20 times that still fit; beyond,
- * PSX_STATUS_NONFINITE is raised); the tile kernels then send no maximum and the call needs no memset node (4.7 us per call at
+ * maximum -- scale > 0: one unit = 2^-30 of the power of two above 64 * scale (a share up to 2^10 times that is taken -- 2^11 of them
+ * fit a pixel's sum --; beyond, PSX_STATUS_NONFINITE is raised); the tile kernels then send no maximum and the call needs no memset node (4.7 us per call at
  * 4096^2).  The sums are quantised to the unit whatever the image holds, so the scale should be the image's order of magnitude
  * (the Experiment class passes the incident intensity per study pixel).  0 (default): measure.  A setting of the calling thread. */
 int psx_set_deterministic_scale(float scale);
+/* the calling thread's setting (callers that restore it: a nested scope must not lose the outer scope's scale) */
+float psx_get_deterministic_scale(void);
 
 /* The raw scatter loop on explicit displacement fields: fastloopNumba (refractionFileNumba2.py:198-263).
  * I, Dx, Dy, I2 are [Nx][Ny]; I2 is accumulated into (float atomics; order-dependent in the last bits). */

@@ -216,7 +216,7 @@ class Experiment:
         """Experiment.py:255-277.  (_mutate=False: the chain's own calls, whose input is a temporary, skip the in-place zeroing
         of clamped rays in the dark-field variant.)"""
         from .refractionFileNumba2 import fastRefraction, fastRefractionDF
-        with ops.deterministic(self._reproducible()):
+        with ops.deterministic(self._reproducible(), scale=None):     # the caller's unit: the chain's own scope, or the user's setting
             if type(darkField) == int or type(darkField) == float:
                 return fastRefraction(intensityRefracted, phi, propagationDistance, Energy, magnification,
                                       self.exp_dict["studyPixelSize"])
@@ -253,14 +253,20 @@ class Experiment:
         n0, n1 = int(dp['myDimensions'][0]), int(dp['myDimensions'][1])
         # one allocation for the stacks; every slot of Sample/Reference is written by its bin's detection, Propag only at
         # position 0 and White is zero elsewhere (the reference detects an all-zero white there: Poisson(0) = 0).  Away from
-        # position 0 Propag and White are ONE zero stack per experiment, shared by every position's result (read-only by
-        # convention: the reference returns fresh zero arrays) -- not 33 MB filled per position (10 us at 2048^2 detectors, the
-        # kernel trace of gpurun_out/r5s36) and half the memory a caller keeps per position.
-        if pointNum != 0:
+        # position 0 the reference returns fresh zero arrays (EXP:363-375, 488-498), and so does this class: two zeroed stacks of
+        # the position's own (a caller may write into them: `White[White == 0] = 1`).  A caller that only READS what it is
+        # handed -- main.run, which saves or packs every stack, the bench's position loop -- sets exp_dict['sharedZeroStacks']:
+        # Propag and White of every position but 0 are then ONE zero stack per experiment, not 33 MB filled per position (10 us
+        # at 2048^2 detectors, the kernel trace of gpurun_out/r5s36) and half the memory kept per position.
+        if pointNum != 0 and self.exp_dict.get('sharedZeroStacks', False):
             if self._zero_stack is None or tuple(self._zero_stack.shape) != (nbins, n0, n1) or self._zero_stack.device != dev:
                 self._zero_stack = ops.fill(torch.empty((nbins, n0, n1), dtype=torch.float32, device=dev), 0.0)
             two = torch.empty((2, nbins, n0, n1), dtype=torch.float32, device=dev)
             out = [two[0], two[1], self._zero_stack, self._zero_stack]
+        elif pointNum != 0:
+            four = torch.empty((4, nbins, n0, n1), dtype=torch.float32, device=dev)
+            ops.fill(four[2:], 0.0)
+            out = [four[0], four[1], four[2], four[3]]
         else:
             four = torch.empty((4, nbins, n0, n1), dtype=torch.float32, device=dev)
             out = [four[0], four[1], four[2], four[3]]
@@ -289,8 +295,10 @@ class Experiment:
         dp = self.myDetector.det_param
         nbins = self._close_bins()
         n0, n1 = int(dp['myDimensions'][0]), int(dp['myDimensions'][1])
-        # position 0 returns four stacks, every other position two (+ the experiment's shared zero stack)
-        blocks = [torch.empty((2, nbins, n0, n1), dtype=torch.float32, device=device()) for _ in range(int(n_positions))]
+        # position 0 returns four stacks, every other position four of its own or, with exp_dict['sharedZeroStacks'], two (+ the
+        # experiment's shared zero stack)
+        per = 2 if self.exp_dict.get('sharedZeroStacks', False) else 4
+        blocks = [torch.empty((per, nbins, n0, n1), dtype=torch.float32, device=device()) for _ in range(int(n_positions))]
         blocks.append(torch.empty((4, nbins, n0, n1), dtype=torch.float32, device=device()))
         if extras and self.exp_dict.get('simulation_type') == "RayT":
             # position 0 of the ray-tracing chain also returns two padded displacement maps and a dark-field map (EXP:488-498)

@@ -18,7 +18,7 @@ PSX_MAX_SRC = 16
 PSX_SUM_SLOTS, PSX_SUM_STRIDE = 32, 16
 ENGINE_AUTO, ENGINE_ROCFFT, ENGINE_LDS = 0, 1, 2
 STATUS_NONFINITE = 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class PsxError(RuntimeError):
@@ -45,6 +45,7 @@ PROTOTYPES = {
     "psx_set_deterministic": (c_int, [c_int]),
     "psx_get_deterministic": (c_int, []),
     "psx_set_deterministic_scale": (c_int, [c_float]),
+    "psx_get_deterministic_scale": (c_float, []),
     "psx_refract_f32": (c_int, [_vp, c_float, _vpp, _dp, _dp, c_int, _vp, _vp, c_float, c_int, _vp, _vp, _vp, c_int,
                                 c_int, c_int, c_double, c_double, c_double, _vp, _vp, _vp]),
     "psx_refract_split_f32": (c_int, [_vp, _vp, c_float, _vpp, _dp, _dp, c_int, _vp, _vp, _vp, c_float, c_int, c_int, c_int,

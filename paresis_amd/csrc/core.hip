@@ -98,7 +98,7 @@ __global__ void psx_probe_kernel(int *out) { *out = 950; }
 
 extern "C" {
 
-int psx_abi_version(void) { return 8; }   // 3: psx_debug_switch(es_active), psx_set_deterministic(1) allocation-free; 4: psx_darkfield_split_f32(num, den); 5: psx_get_deterministic; 6: psx_refract_split_f32, psx_darkfield_blur_prepared_f32(accumulate); 7: psx_set_deterministic_scale; 8: psx_detect_multi_f32
+int psx_abi_version(void) { return 9; }   // 3: psx_debug_switch(es_active), psx_set_deterministic(1) allocation-free; 4: psx_darkfield_split_f32(num, den); 5: psx_get_deterministic; 6: psx_refract_split_f32, psx_darkfield_blur_prepared_f32(accumulate); 7: psx_set_deterministic_scale; 8: psx_detect_multi_f32; 9: psx_get_deterministic_scale
 
 const char *psx_last_error(void) { return psx::err_buf(); }
 

@@ -774,7 +774,12 @@ __device__ __forceinline__ void refract_far_body(const RefractArgs &a) {
                             return;
                         }
                         const float xq = v * unit;                              // |xq| <= 2^30 when the unit comes from the call's maximum
-                        if (!(fabsf(xq) < 1.1258999e15f)) {                     // a caller's scale 2^20 times too small: an "insane value"
+                        // a caller's scale 2^10 times too small is an "insane value": one share stays below 2^40 units, so the 2^11
+                        // shares a pixel's 52-bit signed sum is then sure to hold outnumber what the 12-bit deposit counter admits of
+                        // such extremes only by a factor of two -- and a share of the class's own chain (an intensity times weights
+                        // <= 1, the scale being the incident intensity) is below 2^36 (the bound was 2^50, where two
+                        // shares on one pixel wrapped into the counter unnoticed)
+                        if (!(fabsf(xq) < 1.0995116e12f)) {
                             if (a.status) atomicOr(a.status, PSX_STATUS_NONFINITE);
                             return;
                         }
@@ -1169,6 +1174,8 @@ int psx_set_deterministic_scale(float scale) {
     g_det_scale = scale;
     return 0;
 }
+
+float psx_get_deterministic_scale(void) { return g_det_scale; }
 
 size_t psx_refract_batch_workspace_bytes(int Nx, int Ny, int n) {
     if (Nx <= 0 || Ny <= 0) return 16;

@@ -249,11 +249,17 @@ class PackedPositions(dict):
     ends with 2 x 64 widening launches on the sink that nobody may ever look at (0.8 ms of rank 0's 10 ms share: bench.py
     rank_share, round 5); main.run's host copies are widened on the host in either case."""
 
-    def __init__(self, packed, per_img, shape, ready):
+    def __init__(self, packed, per_img, shape, ready, owner=None):
         super().__init__(ready)
         self._packed, self._per_img, self._shape = dict(packed), per_img, tuple(shape)
+        # the packed bytes live in the gatherer's pooled receive buckets, which its next run overwrites: a position still packed
+        # when PositionGatherer.reset() is called can no longer be read -- and says so instead of widening the next run's data
+        self._owner, self._generation = owner, getattr(owner, "generation", 0)
 
     def _widen(self, p):
+        if self._owner is not None and self._owner.generation != self._generation:
+            raise RuntimeError("PackedPositions: position %d was still packed when its gatherer was reset for another run; its "
+                               "receive buffer has been reused (read, or copy(), a result before PositionGatherer.reset())" % p)
         b = self._packed.pop(p)
         img = _CountsWire(2 * self._per_img, b.device, like=b).unpack().view((2,) + self._shape)
         super().__setitem__(p, (img[0], img[1]))
@@ -262,6 +268,17 @@ class PackedPositions(dict):
         if p in self._packed and not super().__contains__(p):
             self._widen(p)
         return super().__getitem__(p)
+
+    def __setitem__(self, p, v):
+        self._packed.pop(p, None)
+        super().__setitem__(p, v)
+
+    def __delitem__(self, p):
+        if p in self._packed and not super().__contains__(p):
+            del self._packed[p]
+        else:
+            self._packed.pop(p, None)
+            super().__delitem__(p)
 
     def __contains__(self, p):
         return super().__contains__(p) or p in self._packed
@@ -283,6 +300,39 @@ class PackedPositions(dict):
 
     def get(self, p, default=None):
         return self[p] if p in self else default
+
+    _missing = object()
+
+    def pop(self, p, default=_missing):
+        if p in self:
+            v = self[p]
+            del self[p]
+            return v
+        if default is PackedPositions._missing:
+            raise KeyError(p)
+        return default
+
+    def setdefault(self, p, default=None):
+        if p not in self:
+            self[p] = default
+        return self[p]
+
+    def update(self, *args, **kw):
+        for p, v in dict(*args, **kw).items():
+            self[p] = v
+
+    def copy(self):
+        """A plain dict of float32 stacks (every position widened): what to keep across PositionGatherer.reset()."""
+        return {p: self[p] for p in self}
+
+    def clear(self):
+        self._packed.clear()
+        super().clear()
+
+    def popitem(self):
+        for p in reversed(self.keys()):
+            return p, self.pop(p)
+        raise KeyError("popitem(): PackedPositions is empty")
 
     def __repr__(self):
         return "PackedPositions(%d positions, %d still packed)" % (len(self), len(self._packed))
@@ -316,6 +366,7 @@ class PositionGatherer:
         self.next_round = 0
         self.pool = None               # (wires, buckets) of every round, allocated by prepare()
         self.issued = 0                # collectives issued so far: an exception after the first one is not recoverable
+        self.generation = 0            # runs started on these buffers: a PackedPositions of an earlier run refuses to widen
 
     def prepare(self):
         """Allocates the wire buffer of every round and, on dst, the `world` receive buckets per round (~2 GiB for 64
@@ -336,7 +387,9 @@ class PositionGatherer:
     def reset(self):
         """Ready for another run over the same positions with the buffers of prepare() (the bench: an untimed run first).
         The receive buckets are reused: positions of the PREVIOUS run's result that were never read (dist.PackedPositions
-        widens on first access) must not be read after the next run has started."""
+        widens on first access) can no longer be read -- the result raises instead of widening the next run's bytes; keep
+        `result.copy()` if it is wanted."""
+        self.generation += 1
         self.results, self.work, self.wires, self.buckets = {}, [], [], []
         self.next_round = 0
         self.issued = 0
@@ -448,7 +501,7 @@ class PositionGatherer:
                     img = _CountsWire(2 * per_img, b.device, like=b).unpack().view((2,) + self.shape)
                     out[q] = (img[0], img[1])
             if lazy:
-                out = PackedPositions(lazy, per_img, self.shape, out)
+                out = PackedPositions(lazy, per_img, self.shape, out, owner=self)
             if extras is not None:                                       # Propag / White / Dx,Dy exist for position 0 only
                 out[0] = extras
         last_gather.update(packed=True, wire_bytes=wire_bytes, overlapped=True, lazy=bool(lazy))

@@ -27,6 +27,9 @@ def run(exp_dict, save=True, saving_format=".tif", backend=None):
     # one experiment ID for all ranks (the reference takes the wall clock, main.py:30; ranks would disagree by a second)
     exp_dict['expID'] = dist.broadcast_object(datetime.datetime.now().strftime("%Y%m%d-%H%M%S"), rank, world)
     exp_dict.setdefault('deferMeanEnergy', True)       # no host synchronisation per position (resolved before the dump)
+    # this loop only reads the stacks a position returns (packs, copies to the host, saves): the all-zero Propag / White of the
+    # positions after the first may be ONE stack of the experiment (Experiment._begin)
+    exp_dict.setdefault('sharedZeroStacks', True)
     # exp_dict['reproducible'] (default True; --float-atomics turns it off): the ray-tracing chain's far rays go through the
     # order-independent replay (the Experiment class sets psx_set_deterministic around its chain and restores the caller's
     # mode): every image is then the same bits on 1 GPU and on 8; the Fresnel chain has no float atomics and is reproducible

@@ -526,22 +526,30 @@ def set_deterministic_scale(scale=0.0):
     check(lib().psx_set_deterministic_scale(c_float(float(scale))), "psx_set_deterministic_scale")
 
 
+def get_deterministic_scale():
+    """The calling thread's replay scale (psx_get_deterministic_scale; 0 = the unit comes from each call's measured maximum)."""
+    return float(lib().psx_get_deterministic_scale())
+
+
 class deterministic:
-    """with ops.deterministic(on[, scale]): ... -- sets the mode (and the unit's scale) and puts back what the caller had
-    (the scale goes back to 0 = measured: the library has no getter for it and nothing else sets it)."""
+    """with ops.deterministic(on[, scale]): ... -- sets the mode (and the unit's scale) and puts back what the caller had, mode AND
+    scale: scopes nest (Experiment.refraction inside the ray-tracing chain's scope keeps the chain's fixed unit; a user's own
+    psx_set_deterministic_scale survives a call of the class).  scale=None keeps the caller's scale."""
 
     def __init__(self, on=True, scale=0.0):
-        self.on, self.scale = bool(on), float(scale) if on else 0.0
+        self.on = bool(on)
+        self.scale = None if scale is None else (float(scale) if on else 0.0)
 
     def __enter__(self):
-        self.prev = get_deterministic()
+        self.prev, self.prev_scale = get_deterministic(), get_deterministic_scale()
         set_deterministic(self.on)
-        set_deterministic_scale(self.scale)
+        if self.scale is not None:
+            set_deterministic_scale(self.scale)
         return self
 
     def __exit__(self, *exc):
         set_deterministic(self.prev)
-        set_deterministic_scale(0.0)
+        set_deterministic_scale(self.prev_scale)
         return False
 
 

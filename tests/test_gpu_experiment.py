@@ -281,6 +281,26 @@ def test_darkfield_chain_is_bitwise_repeatable_and_restores_the_callers_mode():
         assert float((a - b).abs().max() / b.abs().max()) < 2e-6
 
 
+def test_replay_scopes_nest_and_keep_the_callers_scale():
+    """ops.deterministic restores mode AND scale, so a nested scope (Experiment.refraction inside the chain's
+    own scope, the zero-width dark-field branch) neither loses the chain's fixed unit nor clobbers a user's own setting."""
+    from paresis_amd import ops
+    assert ops.get_deterministic_scale() == 0.0
+    ops.set_deterministic_scale(123.0)
+    try:
+        with ops.deterministic(True, scale=7500.0):
+            assert ops.get_deterministic() and ops.get_deterministic_scale() == 7500.0
+            with ops.deterministic(True, scale=None):                # Experiment.refraction's scope: the caller's unit stays
+                assert ops.get_deterministic_scale() == 7500.0
+            assert ops.get_deterministic_scale() == 7500.0
+            with ops.deterministic(False):
+                assert not ops.get_deterministic() and ops.get_deterministic_scale() == 0.0
+            assert ops.get_deterministic() and ops.get_deterministic_scale() == 7500.0
+        assert ops.get_deterministic_scale() == 123.0 and not ops.get_deterministic()
+    finally:
+        ops.set_deterministic_scale(0.0)
+
+
 @pytest.mark.parametrize("sim", ["RT", "Fresnel"])
 def test_polychromatic_frontend_chain(sim):
     """the energy loop as a reduced axis -- 5 energies from the re-binned tabulated spectrum, table-walk

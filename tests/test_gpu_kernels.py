@@ -982,8 +982,8 @@ def test_refract_split_equals_two_masked_refractions(ops, halo, det):
 def test_replay_unit_from_the_callers_scale(ops):
     """psx_set_deterministic_scale (round 5): the order-independent replay takes its fixed-point unit from the caller's
     intensity scale instead of measuring the call's maximum (no memset node, no atomicMax).  Bitwise repeatable, within float
-    rounding of the measured-unit result and of the oracle; a scale 2^20 times too small raises the status word instead of
-    overflowing a sum."""
+    rounding of the measured-unit result and of the oracle; a scale far too small (a share beyond 2^40 units) raises the status
+    word instead of overflowing a sum."""
     from paresis_amd._lib import PsxError
     rng = np.random.default_rng(31)
     Nx, Ny = 240, 199
@@ -1004,7 +1004,7 @@ def test_replay_unit_from_the_callers_scale(ops):
     assert relmax(a.cpu().numpy(), ref) < TOL
     assert float((a - measured).abs().max() / measured.abs().max()) < 1e-6
     assert not ops.get_deterministic()
-    with ops.deterministic(True, scale=1e-4):                 # shares 1.5e6 times the scale: still inside the 2^20 x 64 of room
+    with ops.deterministic(True, scale=0.05):                 # shares 3000 times the scale: still inside the 2^10 x 64 of room
         c = run()
         ops.check_status(It.device)
     assert float((c - measured).abs().max() / measured.abs().max()) < 1e-6

@@ -178,6 +178,36 @@ def test_fresh_experiment_starts_at_any_position():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("sim", ["Fresnel", "RayT"])
+def test_zero_stacks_of_later_positions_belong_to_the_caller(sim):
+    """the reference returns FRESH zero arrays for Propag and White away from position 0 (EXP:363-375,
+    488-498); a caller doing flat-field housekeeping in place (`White[White == 0] = 1`) must not change Propag, nor any other
+    position's stacks.  The one-stack-per-experiment saving is an opt-in for callers that only read (main.run, the bench)."""
+    from paresis_amd.Experiment import Experiment
+    ed = {"experimentName": "Fil_Nylon_ID17", "filepath": "/tmp/", "overSampling": 2, "nbExpPoints": 3,
+          "simulation_type": sim, "noise": False}
+    exp = Experiment(ed)
+    outs = []
+    for point in (1, 2):
+        exp.myMembrane.myGeometry = []
+        exp.myMembrane.getMyGeometry(ed["studyDimensions"], exp.myMembrane.membranePixelSize, 2, point, 3)
+        out = exp.computeSampleAndReferenceImages(point)
+        S, R, Pg, W = out[:4]
+        assert float(Pg.abs().max()) == 0.0 and float(W.abs().max()) == 0.0
+        assert Pg.data_ptr() != W.data_ptr()
+        W[W == 0] = 1.0                                   # the caller's housekeeping
+        assert float(Pg.abs().max()) == 0.0
+        outs.append((Pg, W))
+    assert float(outs[0][1].min()) == 1.0 and float(outs[0][0].abs().max()) == 0.0     # position 1's stacks untouched by position 2
+    # the opt-in: one shared stack, read-only by contract
+    ed2 = dict(ed, sharedZeroStacks=True)
+    exp2 = Experiment(ed2)
+    exp2.myMembrane.myGeometry = []
+    exp2.myMembrane.getMyGeometry(ed2["studyDimensions"], exp2.myMembrane.membranePixelSize, 2, 1, 3)
+    o2 = exp2.computeSampleAndReferenceImages(1)
+    assert o2[2].data_ptr() == o2[3].data_ptr() and float(o2[2].abs().max()) == 0.0
+
+
 def test_noise_keys_differ_between_positions_bins_and_kinds():
     from paresis_amd import ops
     keys = {ops.poisson_key(5, p, b, k) for p in range(8) for b in range(3) for k in range(4)}

@@ -537,6 +537,49 @@ def test_packed_positions_widen_on_first_read():
     assert out.get(9) is None and out.get(2) is out[2] and "0 still packed" in repr(out)
 
 
+def test_packed_positions_dict_methods_and_stale_results():
+    """every dict method sees the packed entries (pop, del, setdefault, update, copy, popitem, clear), and a
+    result whose gatherer has been reset for another run refuses to widen what is now the NEXT run's bytes."""
+    import types
+    import torch
+    from paresis_amd import dist
+    shape, per_img = (1, 2, 4), 8
+    flag = torch.zeros(1, dtype=torch.int32)
+
+    def wire(v):
+        w = dist._CountsWire(2 * per_img, torch.device("cpu"))
+        w.head.zero_()
+        w.pack(torch.full(shape, float(v)), 0, flag)
+        w.pack(torch.full(shape, float(v) + 1), per_img, flag)
+        return w.bytes
+
+    owner = types.SimpleNamespace(generation=3)
+    out = dist.PackedPositions({p: wire(10 * p) for p in (1, 2, 3, 4, 5)}, per_img, shape, {0: ("S0", "R0")}, owner=owner)
+    assert float(out.pop(2)[0].max()) == 20.0 and 2 not in out and len(out) == 5
+    assert out.pop(9, "none") == "none"
+    with pytest.raises(KeyError):
+        out.pop(9)
+    del out[3]
+    assert sorted(out) == [0, 1, 4, 5] and 3 not in out._packed
+    assert out.setdefault(1, "x") is out[1] and float(out[1][1].max()) == 11.0        # packed entry wins over the default
+    assert out.setdefault(7, "seven") == "seven"
+    out.update({4: ("a", "b")})
+    assert out[4] == ("a", "b") and 4 not in out._packed                              # the packed bytes of 4 are gone with it
+    plain = out.copy()
+    assert type(plain) is dict and sorted(plain) == [0, 1, 4, 5, 7] and float(plain[5][0].max()) == 50.0
+    # a second result on the same buffers, read after the gatherer moved on
+    stale = dist.PackedPositions({1: wire(1), 2: wire(2)}, per_img, shape, {}, owner=owner)
+    assert float(stale[1][0].max()) == 1.0                 # read in time: fine, and stays readable
+    owner.generation += 1                                  # PositionGatherer.reset()
+    assert float(stale[1][0].max()) == 1.0
+    with pytest.raises(RuntimeError, match="reset"):
+        stale[2]
+    del stale[2]                                           # dropping a stale entry is allowed; reading it is not
+    assert stale.popitem()[0] == 1
+    stale.clear()
+    assert len(stale) == 0 and not stale._packed
+
+
 def test_bench_rank_share_prediction_arithmetic(monkeypatch):
     """bench.emulate_world (positions_batch.<sim>.rank_share): the predicted 8-GPU speed-up is the one-GPU time over the SLOWER of
     the two emulated shares plus the exposed part of the gather, priced per point-to-point link; the children are fresh
