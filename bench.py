@@ -845,7 +845,10 @@ def emulate_world(a, sim, one_gpu):
     point-to-point link per peer, ~153 GB/s each, all 7 into the sink at once)."""
     import subprocess
     W = a.emulate_world
-    out = {"world": W, "note": "prediction, not a measurement: each share run alone on one GPU in a fresh process; no collective issued"}
+    out = {"world": W, "note": "prediction, not a measurement: each share run alone on one GPU in a fresh process; no collective issued",
+           "context": "the children are started by this process AFTER its own positions batch: the parent still holds its HIP context "
+                      "and HBM, and the card's clocks may be warm from the batch just finished (ADVICE r5) -- `cold_ms` is cold for the "
+                      "child's caches and allocator, not necessarily for the clocks; every predicted_* figure is a model built on them"}
     if any(k.startswith("ROCPROFILER_") or k.startswith("ROCPROF_") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
         out["skipped"] = "under rocprofv3 (a child process would be profiled as well)"
         return out
@@ -1126,8 +1129,9 @@ def pmc_value(prof, kernel, field):
             continue
         if kernel in ("k_fresnel_rows", "k_fresnel_cols"):
             # pass 2 (k_fresnel_rows) is the CONTIG = false instance of a line kernel (strided reads), pass 1 CONTIG = true:
-            # k_fresnel_lines<R3, CONTIG, ...> (lines that fit one LDS transform), k_fresnel_part<CONTIG, PAIR, DIF> (longer lines)
-            if name.startswith("k_fresnel_lines<"):
+            # k_fresnel_p2<R1, CONTIG, DUAL, QUEUE> (power-of-two transforms), k_fresnel_lines<R3, CONTIG, ...> (576 R3 points),
+            # k_fresnel_part<CONTIG, PAIR, DIF> (longer lines)
+            if name.startswith("k_fresnel_lines<") or name.startswith("k_fresnel_p2<"):     # <R3 | R1, CONTIG, ...>
                 contig = name.split(",")[1].strip()
             elif name.startswith("k_fresnel_part<"):
                 contig = name.split("<")[1].split(",")[0].strip()

@@ -133,6 +133,114 @@ def test_xml_derived_scalars_match_the_reference_arithmetic():
     assert [int(v) for v in g["Config1_512/studyDimensions"]] == [512, 512]      # BASELINE.json config 1's grid
 
 
+XML_REF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fixtures", "xml_ref")
+
+
+XML_PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "paresis_amd", "xmlFiles")
+XML_SETS = {"reference": (XML_REF, "xml_ref_parsed.json", (4, 5, 13, 4)), "package": (XML_PKG, "xml_pkg_parsed.json", (2, 4, 5, 4))}
+
+
+def _ref_parsed(which="reference"):
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", XML_SETS[which][1])))
+
+
+@pytest.mark.parametrize("which", ["reference", "package"])
+def test_reference_xml_files_parse_like_the_reference(which):
+    """("package": the same for the re-authored files this package ships -- the experiments the GPU tests and the bench run --, so
+    that test_xml_experiment_matches_oracle's inputs are pinned by the reference's parsers too: spectrum, PSF, bins, source size.)
+    VERDICT r5 item 6: the reference's OWN four XML files (tests/fixtures/xml_ref: 4 experiments, 13 samples, 4 sources, 5
+    detectors, copied as shipped) through this package's loaders, against what the reference's own parsers read from them
+    (tests/golden/xml_ref_parsed.json, written by tests/golden/make_golden_xmlref.py running Source / Detector / Sample /
+    Experiment.defineCorrectValues of the reference): every numeric field, the optional tags (inVacuum, plateName,
+    myBinsThersholds, myScintillator*, photonCounting, sourceVoltage, filter*, myTargetMaterial, the xls spectrum keys) and the
+    bool("False") quirk (DET:66, SRC:62: any non-empty text is True)."""
+    from paresis_amd.Detector import Detector
+    from paresis_amd.Sample import AnalyticalSample
+    from paresis_amd.Source import Source
+    XML_REF = XML_SETS[which][0]
+    ref = _ref_parsed(which)
+    assert (len(ref["sources"]), len(ref["detectors"]), len(ref["samples"]), len(ref["experiments"])) == XML_SETS[which][2]
+    for name, want in ref["sources"].items():
+        s = Source(xml_directory=XML_REF)
+        s.myName = name
+        s.defineCorrectValuesSource()
+        for k, v in want["source_dict"].items():
+            assert s.source_dict.get(k) == v, (name, k, s.source_dict.get(k), v)
+        assert bool(s.spectrumFromXls) == want["spectrumFromXls"], name
+        if "mySpectrum" in want:
+            s.setMySpectrum()
+            assert [list(e) for e in s.mySpectrum] == want["mySpectrum"], name
+    for name, want in ref["detectors"].items():
+        d = Detector({}, xml_directory=XML_REF)
+        d.myName = name
+        d.defineCorrectValuesDetector()
+        for k, v in want["det_param"].items():
+            got = d.det_param.get(k)
+            got = [int(x) for x in got] if k == "myDimensions" else got
+            assert got == v, (name, k, got, v)
+        assert getattr(d, "myEnergyLimit", None) == want["myEnergyLimit"]
+    for name, want in ref["samples"].items():
+        a = AnalyticalSample(xml_directory=XML_REF)
+        a.myName = name
+        a.defineCorrectValuesSample()
+        for k, v in want.items():
+            assert getattr(a, k) == v, (name, k, getattr(a, k, None), v)
+    with pytest.raises(ValueError):
+        s = Source(xml_directory=XML_REF)
+        s.myName = "no such source"
+        s.defineCorrectValuesSource()
+
+
+@pytest.mark.parametrize("which", ["reference", "package"])
+def test_reference_xml_experiments_resolve_and_derive_like_the_reference(which):
+    """Every experiment of the reference's Experiment.xml (and of this package's): the four objects resolved by name, distances, shot count, inVacuum /
+    plateName, and the scalars the constructor derives (magnification EXP:81, study grid EXP:204-216, membrane pixel EXP:96)
+    and the detection step's effective source size (EXP:380), bit-equal to the reference's arithmetic at oversampling 2.  The two
+    experiments whose sample generator and materials are in scope build completely; the two contrast phantoms stop where
+    SURVEY section 2 draws the line -- at the material table (xraylib / xlrd absent), with the material named."""
+    from paresis_amd.Experiment import Experiment
+    XML_REF = XML_SETS[which][0]
+    ref = _ref_parsed(which)
+    for name, want in ref["experiments"].items():
+        ed = {"experimentName": name, "filepath": "/tmp/", "overSampling": 2, "nbExpPoints": 1, "simulation_type": "RayT",
+              "xmlDir": XML_REF, "inVacuum": False}
+        x = object.__new__(Experiment)                # the parse step alone (the constructor goes on to tables and geometry)
+        x.name, x.exp_dict, x._xml_directory = name, ed, XML_REF
+        x._init_state()
+        x.defineCorrectValues(ed)
+        assert (x.myMembrane.myName, x.mySampleofInterest.myName, x.myDetector.myName, x.mySource.myName) == (
+            want["membraneName"], want["sampleName"], want["detectorName"], want["sourceName"]), name
+        assert (x.myPlate.myName if x.myPlate is not None else None) == want["plateName"] and x.myAirVolume.myName == want["airName"]
+        for k in ("distSourceToMembrane", "distMembraneToObject", "distObjectToDetector", "meanShotCount", "inVacuum"):
+            assert ed[k] == want["exp_dict"][k], (name, k, ed[k], want["exp_dict"][k])
+        x.myDetector.defineCorrectValuesDetector()
+        x.mySource.defineCorrectValuesSource()
+        ed['magnification'] = (ed['distSourceToMembrane'] + ed['distObjectToDetector'] + ed['distMembraneToObject']) / (
+            ed['distSourceToMembrane'] + ed['distMembraneToObject'])
+        x.getStudyDimensions()
+        assert ed["magnification"] == want["exp_dict"]["magnification"], name
+        assert [int(v) for v in ed["studyDimensions"]] == want["exp_dict"]["studyDimensions"], name
+        assert ed["studyPixelSize"] == want["exp_dict"]["studyPixelSize"], name
+        assert x._effective_source() == want["effectiveSourceSize"], name
+    built = {}
+    for name in ref["experiments"]:
+        ed = {"experimentName": name, "filepath": "/tmp/", "overSampling": 2, "nbExpPoints": 1, "simulation_type": "RayT",
+              "xmlDir": XML_REF}
+        try:
+            built[name] = Experiment(ed)
+            assert built[name].myMembrane.membranePixelSize == ref["experiments"][name]["membranePixelSize"], name
+        except Exception as exc:                      # noqa: BLE001 -- the message is the assertion
+            built[name] = exc
+    if which == "package":
+        assert not any(isinstance(v, Exception) for v in built.values()), built
+        return
+    assert not isinstance(built["Fil_Nylon_ID17"], Exception), built["Fil_Nylon_ID17"]
+    assert not isinstance(built["SIMAP_SpheresInTube"], Exception), built["SIMAP_SpheresInTube"]
+    for name in ("id17_ContrastPhantom", "SpectralClinic_ContrastPhantom"):
+        assert isinstance(built[name], Exception) and "CorticalBoneCB250pct" in str(built[name]), (name, built[name])
+
+
 def test_xml_plate_and_psf_experiment():
     from paresis_amd.Experiment import Experiment
     ed = {"experimentName": "Sphere_PMMA_plate", "filepath": "/tmp/", "overSampling": 1, "nbExpPoints": 1,
