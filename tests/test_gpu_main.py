@@ -267,6 +267,65 @@ def test_main_two_ranks_match_one(tmp_path):
     assert len(glob.glob(out + "/Fresnel_*/membraneThickness/*.tif")) == 5
 
 
+def _rank_config4(rank, world, port, outdir, sim, q):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      PARESIS_ALLOW_SYNTHETIC_MATERIALS="1")
+    import torch as th
+    from paresis_amd import dist, main
+    ed = {"experimentName": "Bench_4096", "filepath": outdir + "/", "overSampling": 2, "nbExpPoints": 8,
+          "simulation_type": sim, "noise": True, "seed": 21}
+    res = main.run(ed, save=False, backend="gloo")                             # both ranks on the ONE GPU of the box
+    if rank == 0:
+        import zlib
+        q.put({"crc": {p: [zlib.crc32(t.numpy().tobytes()) for t in v[:2]] for p, v in res.items()},
+               "packed": bool(dist.last_gather.get("packed")), "overlapped": bool(dist.last_gather.get("overlapped")),
+               "wire_bytes": int(dist.last_gather.get("wire_bytes", 0))})
+    else:
+        q.put(res == {})
+    th.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("sim", ["Fresnel", "RayT"])
+def test_config4_workload_two_ranks_on_one_gpu(tmp_path, sim):
+    """BASELINE config 4's workload inside the GPU suite: the XML entry point over 8 membrane positions of the
+    4096^2 experiment (detector 2048^2, oversampling 2) -- membrane synthesis with seed(pointNum), chain, detection, shot noise
+    -- sharded over 2 ranks on this GPU (gloo control plane, the gather round by round behind the computation, 16-bit packed
+    counts on the wire), against the 1-process run: every Sample / Reference stack bit for bit, shot noise included; position 0
+    carries its Propag / White.  (64 positions over 8 GPUs is the driver's SCALE run; tests/test_dist_gloo.py rehearses its
+    indexing at world 8 x 64 on the CPU.)"""
+    import socket
+    import zlib
+    import torch.multiprocessing as mp
+    from paresis_amd import main
+    ed = {"experimentName": "Bench_4096", "filepath": str(tmp_path) + "/one/", "overSampling": 2, "nbExpPoints": 8,
+          "simulation_type": sim, "noise": True, "seed": 21}
+    os.makedirs(ed["filepath"])
+    one = main.run(ed, save=False)
+    assert sorted(one) == list(range(8)) and tuple(one[0][0].shape) == (1, 2048, 2048) and len(one[0]) >= 4
+    assert float(one[0][2].abs().max()) > 0 and float(one[3][0].mean()) > 1000          # Propag at position 0; photon counts
+    crc_one = {p: [zlib.crc32(t.numpy().tobytes()) for t in v[:2]] for p, v in one.items()}
+    assert len({c[0] for c in crc_one.values()}) == 8                                     # eight different membranes / noise keys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    out = str(tmp_path) + "/two"
+    os.makedirs(out)
+    procs = [ctx.Process(target=_rank_config4, args=(r, 2, port, out, sim, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    two = next(r for r in res if isinstance(r, dict))
+    assert two["crc"] == crc_one
+    assert two["packed"] and two["overlapped"] and 0 < two["wire_bytes"] < 8 * 2 * 2048 * 2048 * 4 * 0.6     # 16-bit counts crossed
+
+
 def test_reproducible_ray_tracing_run_is_bitwise_repeatable(tmp_path):
     """exp_dict['reproducible']: the ray-tracing chain with the order-independent far-ray replay -- two runs of the XML entry
     point give the same bits, shot noise included (with float atomics a last bit may flip a Poisson draw); the images stay
