@@ -47,7 +47,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--engine", default="auto", choices=["auto", "rocfft", "lds"])
-    ap.add_argument("--halo", type=int, default=4, choices=[4, 6, 8, 12, 16], help="refraction gather halo (speed knob)")
+    ap.add_argument("--halo", type=int, default=0, choices=[0, 4, 6, 8, 12, 16],
+                    help="refraction gather halo of the headline step (a speed knob; 0 = 6 with the order-independent replay, 4 with "
+                         "float atomics: the measured optima of this step, gpurun_out/r6s8)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     ap.add_argument("--overlap", action="store_true",
                     help="issue the step's refractions on a second stream (no gain since the Fresnel call became two long "
@@ -74,8 +76,13 @@ def parse():
                     help="A/B: the line kernels' work queue on the headline step itself (default: static shares)")
     ap.add_argument("--no-reproducible-batch", action="store_true",
                     help="positions batch: skip the third measurement (ray tracing with the order-independent far-ray replay)")
-    ap.add_argument("--deterministic-step", action="store_true",
-                    help="A/B: the headline step's refraction with the order-independent far-ray replay")
+    ap.add_argument("--deterministic-step", action="store_true", help="accepted and ignored: the default since round 6")
+    ap.add_argument("--float-atomics-step", action="store_true",
+                    help="the headline step's far rays through float atomics (the library's default mode) instead of the order-independent "
+                         "replay the Experiment class runs by default; `other_far_ray_mode` on the line is then the replay")
+    ap.add_argument("--no-replay-scale", action="store_true",
+                    help="with --deterministic-step: the replay's unit from each call's measured maximum (memset node + atomicMax) "
+                         "instead of the caller's intensity scale")
     ap.add_argument("--sink", type=int, default=0,
                     help="positions batch on several ranks: the rank that receives every position's images (default 0, which also "
                          "owns position 0 and its extra images: with another sink the straggler and the receiver are two GPUs)")
@@ -158,12 +165,17 @@ def main():
                               timeout=datetime.timedelta(seconds=pdist.timeout_s()), **kw)
     lib = _lib.lib()
     assert lib.psx_device_ok() == 1, lib.psx_last_error()
+    a.deterministic_step = not a.float_atomics_step
+    if a.halo == 0:
+        a.halo = 6 if a.deterministic_step else 4
     _lib.check(lib.psx_refract_set_halo(a.halo), "psx_refract_set_halo")
     for item in a.debug_switch:
         name, _, val = item.partition("=")
         ops.debug_switch(name, int(val) if val else 1)
     if a.deterministic_step:
         ops.set_deterministic(True)
+        if not a.no_replay_scale:
+            ops.set_deterministic_scale(30000.0 / 4)      # as Experiment._replay_scale: the incident intensity per study pixel
     if a.emulate_rank >= 0:
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):
@@ -312,6 +324,8 @@ def main():
         dt_other = time.perf_counter() - t2
         ops.check_status(dev, "bench (other far-ray mode)")
         ops.set_deterministic(not ops.get_deterministic())
+        step()                      # the images the parity leg checks are the headline mode's
+        barrier()
         other_mode.update(ms_per_step=round(dt_other / a.steps * 1e3, 4),
                           value=round(len(DISTANCES) * N * N * world / (dt_other / a.steps) / 1e6, 1),
                           vs_steady_pct=round((dt_other / dt_steady - 1.0) * 100.0, 2),
@@ -339,7 +353,7 @@ def main():
                                   "z={1.6,3.6,5.2,7.2} m: 4 x (Fresnel propagation + refraction) from the 2-material "
                                   "membrane thickness maps (transmission evaluated inside the step); 52 keV, "
                                   "dSM/dMO/dOD=140/1.6/3.6 m" % (N, N),
-                      "units_per_step": units, "fresnel_engine": {1: "rocfft", 2: "lds"}[plan.engine],
+                      "units_per_step": units, "fresnel_engine": {1: "rocfft", 2: "lds"}[plan.engine], "refraction_halo": a.halo,
                       "streams": 1 if side is None else 2,
                       "parallelism": "positions sharded, 1 per GPU" if world > 1 else "single GPU"},
            "ranks_seen": ranks_seen,
@@ -358,6 +372,10 @@ def main():
                       "note": "the same K un-instrumented steps timed a second time, after the per-kernel event pass: the device "
                               "needs ~40 ms of load to reach its steady step time (tools/step_ramp.py)"}}
 
+    # the library's own default (float atomics, measured unit) for what follows: the position batches set the mode through the
+    # Experiment class, the `configs` entries say which mode they ran in
+    ops.set_deterministic(False)
+    ops.set_deterministic_scale(0.0)
     # ---- BASELINE.json config 4: the membrane-position batch, its own timed region (all ranks take part)
     if a.positions > 0:
         import contextlib

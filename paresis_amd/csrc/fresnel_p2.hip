@@ -39,6 +39,19 @@ constexpr int TT = TE + TLD;
 constexpr int TOT2 = 16384;    // complex points resident in LDS per workgroup
 constexpr int LXM = psx::p2::LXMAX;
 constexpr int BSTR = 256 + 8;  // padded stride of a block of 256 points (one pad slot per 32)
+// build-time A/B switches (tools/ab_p2.sh builds one library per setting; both arms of a comparison run on ONE box)
+#ifndef PSX_P2_SKIP_LEGS
+#define PSX_P2_SKIP_LEGS 1     // inverse stage A: the legs that lie before sample 0 for every butterfly are not stored
+#endif
+#ifndef PSX_P2_PRIO
+#define PSX_P2_PRIO 0          // 1: static priority 1 for engine waves 4-7 (the younger wave of every SIMD)
+#endif
+#ifndef PSX_P2_TWEARLY
+#define PSX_P2_TWEARLY 0       // 1: stage A's twiddle powers are read together with the butterfly's inputs
+#endif
+#ifndef PSX_P2_LDPRIO
+#define PSX_P2_LDPRIO 0        // priority of the loader waves while they issue a round's fetch
+#endif
 
 template <int R1_, bool DUAL_>
 struct G2 {
@@ -67,16 +80,24 @@ template <int R, bool CONJ>
 __device__ __forceinline__ v2f tw_apply(v2f x, v2f w) {
     return CONJ ? pk_cmulc(x, w) : pk_cmul(x, w);
 }
+template <int R>
+__device__ __forceinline__ void tw_powers(v2f (&pw)[5], const v2f *row) {
+    pw[0] = lds_read(row);
+    if constexpr (R >= 4) pw[1] = lds_read(row + 1);
+    if constexpr (R >= 8) pw[2] = lds_read(row + 2);
+    if constexpr (R >= 16) pw[3] = lds_read(row + 3);
+    if constexpr (R == 32) pw[4] = lds_read(row + 4);
+}
 template <int R, bool CONJ>
-__device__ __forceinline__ void twiddle_A2(v2f (&v)[R], const v2f *row) {
+__device__ __forceinline__ void twiddle_A2(v2f (&v)[R], const v2f (&pw)[5]) {
     constexpr int H = R >= 16 ? 16 : R;          // twiddles built explicitly: q < H
     v2f t[H];
-    t[1] = lds_read(row);
-    if constexpr (R >= 4) t[2] = lds_read(row + 1);
-    if constexpr (R >= 8) t[4] = lds_read(row + 2);
-    if constexpr (R >= 16) t[8] = lds_read(row + 3);
+    t[1] = pw[0];
+    if constexpr (R >= 4) t[2] = pw[1];
+    if constexpr (R >= 8) t[4] = pw[2];
+    if constexpr (R >= 16) t[8] = pw[3];
     v2f t16 = (v2f){1.f, 0.f};
-    if constexpr (R == 32) t16 = lds_read(row + 4);
+    if constexpr (R == 32) t16 = pw[4];
     if constexpr (R >= 4) t[3] = pk_cmul(t[1], t[2]);
     if constexpr (R >= 8) {
 #pragma unroll
@@ -112,18 +133,22 @@ __device__ __forceinline__ void invB_regs(v2f (&v)[16], const v2f (&w)[16]) {
     DftPk<16, true>::run(v);
 }
 
-// R legs + the wrapped leg of one inverse stage-A butterfly through a buffer descriptor whose range is the window the line may
-// touch (fresnel_stages.hpp, store_window: the hardware drops what falls outside).  Leg q goes to element e0 + q * estep,
-// the wrapped leg vw (leg 0 + its fix-up) to e0 + R * estep.
-template <int R>
+// Legs Q0 .. R-1 + the wrapped leg of one inverse stage-A butterfly through a buffer descriptor whose range is the window the
+// line may touch (fresnel_stages.hpp, store_window: the hardware drops what falls outside).  Leg q goes to element e0 + q *
+// estep, the wrapped leg vw (leg 0 + its fix-up) to e0 + R * estep.
+// Q0 = R / 2: the caller knows that the lower half of the legs lies before sample 0 for EVERY butterfly of the line (leg q of
+// butterfly n is sample n + 256 q - (P - 1); so whenever P - 1 >= M / 2, i.e. on every power-of-two grid) -- their stores, and
+// the |.|^2 or global phase in front of them, are not issued at all.  (A per-leg uniform test instead of the two compiled forms
+// cost pass 2 what it saved: gpurun_out/r6s9.)
+template <int R, int Q0>
 __device__ __forceinline__ void store_legs(const v2f (&v)[R], v2f vw, v2f *wo, float *io, int64_t wbase, int welems, int e0, int estep,
                                            v2f gp, float sc, int accumulate) {
     if (wo) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wo + wbase, 0, welems * 8, 0x00020000);
-        int off = e0 * 8;
         const bool plain = gp.x == 1.f && gp.y == 0.f;     // pass 1: no global phase
+        int off = (e0 + Q0 * estep) * 8;
 #pragma unroll
-        for (int q = 0; q <= R; ++q) {
+        for (int q = Q0; q <= R; ++q) {
             const v2f x = q < R ? v[q < R ? q : 0] : vw;
             const v2f r = plain ? x : pk_cmul_s(x, gp);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, r), rs, off, 0, 0);
@@ -132,9 +157,9 @@ __device__ __forceinline__ void store_legs(const v2f (&v)[R], v2f vw, v2f *wo, f
     }
     if (io) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(io + wbase, 0, welems * 4, 0x00020000);
-        int off = e0 * 4;
+        int off = (e0 + Q0 * estep) * 4;
 #pragma unroll
-        for (int q = 0; q <= R; ++q) {
+        for (int q = Q0; q <= R; ++q) {
             const v2f x = q < R ? v[q < R ? q : 0] : vw;
             float I = sc * (x.x * x.x + x.y * x.y);
             if (accumulate) I += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
@@ -170,6 +195,7 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
     const int tid = threadIdx.x;
     const int N = a.N, mg = a.margin;
     const int Lx = a.L - M;                // outputs whose window wraps (<= 0: none)
+    const bool upper_half = PSX_P2_SKIP_LEGS && ((a.P - 1) >> 8) >= R1 / 2;   // the lower half of an inverse stage-A butterfly's legs lies before sample 0 (store_legs)
 
     // ---- work units: exactly k_fresnel_lines' order (XCD-contiguous chunks of line groups, static shares or queues)
     const int ngroups = (a.nlines + LPG - 1) / LPG;
@@ -430,7 +456,9 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
             const bool claiming = qround && ring_ok(ucur + 1);
             unsigned mine = 0xffffffffu;
             if (claiming && !own_dry && lt == 0) mine = atomicAdd(qcount(slot), 1u);
+            if (PSX_P2_LDPRIO) __builtin_amdgcn_s_setprio(PSX_P2_LDPRIO);
             if (more) fetch(j + 1);
+            if (PSX_P2_LDPRIO) __builtin_amdgcn_s_setprio(0);
             if (a.stamps && lt == 0 && j == a.stamp_j) a.stamps[(size_t)blockIdx.x * 32 + 17] = wall_clock64();
             fixup(j);
             lds_barrier();                               // (2) engine: wave-private stages done
@@ -499,6 +527,7 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
     // line = the butterflies of the first four waves; with smaller radices every thread has its share
     const bool fwdA_on = !(DUAL && R1 == 32) || tid < TE / 2;
     constexpr int NBAF = DUAL ? (R1 == 32 ? 1 : NBA / 2) : NBA;      // forward stage-A butterflies per thread
+    if (PSX_P2_PRIO && tid >= TE / 2) __builtin_amdgcn_s_setprio(1);
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 0] = wall_clock64();
     lds_barrier();                                       // (0) first group is in LDS
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 32 + 1] = wall_clock64();
@@ -515,7 +544,7 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
 
         // ---- forward stage A: radix R1 over stride 256, twiddle w_M^{n q} = w_M^{16 nh q} w_M^{nl q}
         if (fwdA_on) {
-            v2f v[NBAF][R1];
+            v2f v[NBAF][R1], pw[5];
 #pragma unroll
             for (int i = 0; i < NBAF; ++i) {
                 const int b = tid + TE * i, n = b & 255;
@@ -523,13 +552,15 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
 #pragma unroll
                 for (int q = 0; q < R1; ++q) v[i][q] = p[q * BSTR];
             }
+            if (PSX_P2_TWEARLY) tw_powers<R1>(pw, tP + (tid & 255) * LDP);      // n = b & 255 is the same for every butterfly of a thread
 #pragma unroll
             for (int i = 0; i < NBAF; ++i) {
-                const int b = tid + TE * i, n = b & 255;
-                v2f *p = Lb + (b >> 8) * MP + n + (n >> 5);
+                const int b = tid + TE * i;
+                v2f *p = Lb + (b >> 8) * MP + (b & 255) + ((b & 255) >> 5);
                 DftPk<R1, false>::run(v[i]);
                 __builtin_amdgcn_sched_barrier(0);
-                twiddle_A2<R1, false>(v[i], tP + n * LDP);
+                if (!PSX_P2_TWEARLY && i == 0) tw_powers<R1>(pw, tP + (tid & 255) * LDP);
+                twiddle_A2<R1, false>(v[i], pw);
 #pragma unroll
                 for (int q = 0; q < R1; ++q) p[q * BSTR] = v[i][q];
             }
@@ -659,7 +690,8 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
         // ---- inverse stage A; the wanted outputs leave for HBM straight from the registers.  Once every engine thread holds its
         // 32 points LDS is free: the loaders fill it with the next group meanwhile.
         {
-            v2f v[NBA][R1], cf[NBA];
+            v2f v[NBA][R1], cf[NBA], pw[5];
+            if (PSX_P2_TWEARLY) tw_powers<R1>(pw, tP + (tid & 255) * LDP);
 #pragma unroll
             for (int i = 0; i < NBA; ++i) {
                 const int b = tid + TE * i, n = b & 255;
@@ -677,8 +709,11 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
                 int bo = tid + TE * i;
                 asm volatile("" : "+v"(bo));         // opaque: the per-leg addresses are formed here, not hoisted out of the round loop
                 const int n = bo & 255, lb = bo >> 8;
-                twiddle_A2<R1, true>(v[i], tP + n * LDP);
+                if (!PSX_P2_TWEARLY && i == 0) tw_powers<R1>(pw, tP + n * LDP);
+                twiddle_A2<R1, true>(v[i], pw);
                 __builtin_amdgcn_sched_barrier(0);
+                // (computing only the upper half of the legs when the lower half is not stored -- 23 instead of 27 instructions per
+                // radix-8 block -- puts two butterflies behind the uniform branch and spills 28 registers: not done)
                 DftPk<R1, true>::run(v[i]);
                 // leg q holds y_c[n + 256 q] = output sample n + 256 q - (P - 1); leg 0 is also the wrapped output n + M - (P - 1)
                 const int ifirst = n - (a.P - 1);
@@ -692,8 +727,12 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
                 const int estep = a.out_blocked ? (256 / IB) * a.nlines * IB : 256;
                 const int64_t wbase = a.out_blocked ? 0 : (int64_t)l * a.out_ld;
                 const int welems = lok ? (a.out_blocked ? ((N + IB - 1) / IB) * IB * a.nlines : N) : 0;
-                store_legs<R1>(v[i], v[i][0] + cf[i], wo, io, wbase, welems, e0, estep, (v2f){a.gph[dd].x, a.gph[dd].y}, a.scale[dd],
-                               a.accumulate);
+                if (upper_half)
+                    store_legs<R1, R1 / 2>(v[i], v[i][0] + cf[i], wo, io, wbase, welems, e0, estep, (v2f){a.gph[dd].x, a.gph[dd].y},
+                                           a.scale[dd], a.accumulate);
+                else
+                    store_legs<R1, 0>(v[i], v[i][0] + cf[i], wo, io, wbase, welems, e0, estep, (v2f){a.gph[dd].x, a.gph[dd].y},
+                                      a.scale[dd], a.accumulate);
             }
         }
         PSX_STAMP(12);
