@@ -419,7 +419,9 @@ __global__ __launch_bounds__(TT) void k_fresnel_p2(LineArgs a) {
             if (Lx <= 0) return;
             int d, g;
             item(j, d, g);
-            const int lb = lt / TPL, r = lt % TPL;
+            int lo = lt;
+            asm volatile("" : "+v"(lo));                            // opaque copy: what follows is re-derived every round, not kept across the loop
+            const int lb = lo / TPL, r = lo % TPL;
             const int lbi = DUAL ? lb % LH : lb;                     // LDS line that holds the image line's samples
             const int dd = DUAL ? 2 * d + lb / LH : d;
             const v2f *ht = HT + dd * LXM;
