@@ -915,6 +915,10 @@ def run_configs(a, dev):
     from paresis_amd.Samples.getMembraneFromFile import getMembraneSegmentedFromFile
     from paresis_amd.getk import getk, k_refraction, k_sample
 
+    # the `configs` entries run the library's default far-ray mode (float atomics), as in every earlier round: their figures stay
+    # comparable; the headline carries both modes
+    ops.set_deterministic(False)
+    ops.set_deterministic_scale(0.0)
     E, I0 = 52.0, 7500.0
     db = [synth.DELTA_BETA_52KEV[m] for m in ("CuSn", "PMMA")]
     delta, beta = [d for d, _ in db], [b for _, b in db]

@@ -1518,6 +1518,7 @@ namespace psx {
 struct AxisTables {
     int N = 0, R3 = 0, M = 0;
     int p2 = 0;                                     // radix R1 of the power-of-two line kernels (fresnel_p2.hip; M = 256 R1), 0: the 576 R3-point ones
+    int p2x = 0;                                    // lines of ~16384 samples on the two-round power-of-two kernel (fresnel_p2x.hip)
     int part = 0, B = 0, Lh = 0, S = 1, NB = 1;     // partitioned convolution (lines that do not fit one transform)
     int pair = 0, Mconv = 0;                        // part: the two LDS lines coupled into one transform of Mconv = 2M points
     int dif = 0;                                    // pair: one 2*Mconv-point convolution per line in two rounds (radix-2 DIF split)
@@ -1592,6 +1593,14 @@ static int make_axis(AxisTables &t, int N, int margin, size_t &bytes) {
     // a power of two just below N + P - 1 with the wrapped outputs put right (fresnel_p2.hip) wherever it is the shorter transform
     if (const int r1 = debug_switch(DBG_NO_P2) ? 0 : p2::pick_r1(N, margin); r1 && t.R3 && 256 * r1 < 576 * t.R3) t.p2 = r1;
     const bool no_pair = debug_switch(DBG_NO_PAIR) != 0;     // diagnostics: the round-1 partition (M-point products)
+    if (!t.R3 && !debug_switch(DBG_NO_P2) && !debug_switch(DBG_NO_DIF) && !no_pair && p2::x_serves(N, margin)) {
+        t.p2x = 1;                                           // one 32768-point convolution per line, two rounds of 16384 points
+        t.R3 = 16;
+        t.S = 2;
+        t.NB = 1;
+        t.B = (N + BR - 1) / BR * BR;
+        t.Lh = N + 2 * margin;
+    }
     if (!t.R3) {
         t.R3 = 16;
         t.part = 1;
@@ -1607,10 +1616,18 @@ static int make_axis(AxisTables &t, int N, int margin, size_t &bytes) {
             t.Lh = N + 2 * margin;
         }
     }
-    t.M = t.p2 ? 256 * t.p2 : 576 * t.R3;
-    t.Mconv = t.pair ? 2 * t.M : t.M;
+    t.M = t.p2 ? 256 * t.p2 : (t.p2x ? p2::x_points() / 2 : 576 * t.R3);
+    t.Mconv = (t.pair || t.p2x) ? 2 * t.M : t.M;
     const int S1 = t.M / RAD;
-    if (t.p2) {
+    if (t.p2x) {
+        PSX_HIP(hipMalloc((void **)&t.twA, sizeof(float2) * p2::twA_elems(32)));
+        PSX_HIP(hipMalloc((void **)&t.twB, sizeof(float2) * p2::twB_elems()));
+        PSX_HIP(hipMalloc((void **)&t.w2, sizeof(float2) * 512));
+        PSX_HIP(hipMalloc((void **)&t.w4, sizeof(float2) * 512));
+        bytes += sizeof(float2) * (p2::twA_elems(32) + p2::twB_elems() + 1024);
+        if (int rc = p2::build_tables(t.twA, t.twB, 32, nullptr)) return rc;
+        if (int rc = p2::x_build_twiddles(t.w2, t.w4, nullptr)) return rc;
+    } else if (t.p2) {
         PSX_HIP(hipMalloc((void **)&t.twA, sizeof(float2) * p2::twA_elems(t.p2)));
         PSX_HIP(hipMalloc((void **)&t.twB, sizeof(float2) * p2::twB_elems()));
         bytes += sizeof(float2) * (p2::twA_elems(t.p2) + p2::twB_elems());
@@ -1676,7 +1693,7 @@ int lds_engine_create(psx_fresnel_plan *p) {
     p->bytes += sizeof(float2) * npix;
     PSX_HIP(hipMalloc((void **)&e->queue, sizeof(unsigned) * 2 * QUEUE_WORDS));
     PSX_HIP(hipMemset(e->queue, 0, sizeof(unsigned) * 2 * QUEUE_WORDS));
-    if (e->ax[0].dif || e->ax[1].dif) {
+    if (e->ax[0].dif || e->ax[1].dif || e->ax[0].p2x || e->ax[1].p2x) {
         e->wgpart_groups = current_cu_count();
         PSX_HIP(hipMalloc((void **)&e->wgpart, sizeof(float2) * 2 * PART_M * (size_t)e->wgpart_groups));
         p->bytes += sizeof(float2) * 2 * PART_M * (size_t)e->wgpart_groups;
@@ -1735,7 +1752,7 @@ static int kernel_spectrum(psx_fresnel_plan *p, AxisTables &t, double a, double 
     if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
         return fail(PSX_E_STATE, "psx_fresnel_propagate: kernel spectrum (a=%g, du=%g) is not cached and cannot be built while "
                                  "the stream is being captured: run the call once outside the capture first", a, du);
-    const size_t elems = t.p2 ? p2::spectrum_elems(t.p2) : (size_t)t.Mconv * t.S;
+    const size_t elems = t.p2x ? p2::x_spectrum_elems() : (t.p2 ? p2::spectrum_elems(t.p2) : (size_t)t.Mconv * t.S);
     KernEntry k{nullptr, t.Mconv, t.S, elems, ++e->clock};
     const size_t bytes = sizeof(float2) * elems;
     if (e->cache_bytes + bytes > CACHE_CAP_BYTES && !e->cache.empty()) {   // evict the least recently used table
@@ -1765,13 +1782,22 @@ static int kernel_spectrum(psx_fresnel_plan *p, AxisTables &t, double a, double 
         void *buf = t.bufP;
         PSX_ROCFFT(rocfft_execute(t.planP, &buf, nullptr, t.infoP));
     }
-    PSX_TIMED("k_kern_pad", st, k_kern_pad<<<(int)cdiv((int64_t)t.Mconv * t.S, 256), 256, 0, st>>>(t.bufP, t.bufM, P, t.Mconv, t.Lh, t.S, t.dif ? 2 : t.part));
+    if (t.p2x) {
+        if (int rc = p2::x_pad_taps(t.bufP, t.bufM, P, st)) return rc;
+    } else
+        PSX_TIMED("k_kern_pad", st, k_kern_pad<<<(int)cdiv((int64_t)t.Mconv * t.S, 256), 256, 0, st>>>(t.bufP, t.bufM, P, t.Mconv, t.Lh, t.S, t.dif ? 2 : t.part));
     {
         ProfScope ps("kern_fft_M", st);
         void *buf = t.bufM;
         PSX_ROCFFT(rocfft_execute(t.planM, &buf, nullptr, t.infoM));
     }
-    if (t.p2) {
+    if (t.p2x) {
+        if (int rc = p2::x_perm_spectrum(t.bufM, t.bufP, k.H, P, st)) {
+            (void)hipFree(k.H);
+            e->cache_bytes -= bytes;
+            return rc;
+        }
+    } else if (t.p2) {
         if (int rc = p2::perm_spectrum(t.bufM, t.bufP, k.H, t.p2, P, st)) {
             (void)hipFree(k.H);
             e->cache_bytes -= bytes;
@@ -1913,6 +1939,7 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         // DIF rounds: the distances of a line in consecutive units of one workgroup, whose loaders keep the line in registers
         // (k_fresnel_part) -- when the lines alone fill the chip
         if (e->ax[0].dif && !no_inner && nnz >= 2 && p->Ny >= current_cu_count()) la.dist_inner = 1;
+        if (e->ax[0].p2x) la.dist_inner = (!no_inner && p->Ny >= current_cu_count()) ? 1 : 0;     // a line fetched once for all its rounds
         la.B = e->ax[0].B; la.Lh = e->ax[0].Lh; la.S = e->ax[0].S; la.NB = e->ax[0].NB;
         for (int i = 0; i < PSX_MAX_DIST; ++i) {
             const int k = i < nnz ? i : 0;
@@ -1932,7 +1959,9 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         la.w4 = e->ax[0].w4; la.wgpart = e->wgpart; la.wg_groups = e->wgpart_groups;
         la.dsh = 2 * PART_M - p->Px; la.thr = p->Nx + p->Px - 1 - 2 * PART_M;
         const bool no_dual = debug_switch(DBG_NO_DUAL) != 0;        // diagnostics: A/B of the shared forward transform
-        if (!no_dual && la.dist_inner && nnz >= 2 && !e->ax[0].part) {
+        if (e->ax[0].p2x) {
+            if (int rc = p2::x_launch(true, la, st, "k_fresnel_cols")) return rc;
+        } else if (!no_dual && la.dist_inner && nnz >= 2 && !e->ax[0].part) {
             // one line x two distances per round: the forward transform of a line is shared by the pair
             if (nnz & 1) {
                 la.H[nnz] = la.H[nnz - 1];
@@ -1981,7 +2010,9 @@ int lds_engine_propagate(psx_fresnel_plan *p, const PropArgs &a) {
         lb.w2 = e->ax[1].w2;
         lb.w4 = e->ax[1].w4; lb.wgpart = e->wgpart; lb.wg_groups = e->wgpart_groups;
         lb.dsh = 2 * PART_M - p->Py; lb.thr = p->Ny + p->Py - 1 - 2 * PART_M;
-        if (e->ax[1].p2) {
+        if (e->ax[1].p2x) {
+            if (int rc2 = p2::x_launch(false, lb, st, "k_fresnel_rows")) return rc2;
+        } else if (e->ax[1].p2) {
             if (int rc2 = p2::launch(e->ax[1].p2, false, false, lb, st, "k_fresnel_rows")) return rc2;
         } else if (int rc2 = launch_lines_r3<false>(e->ax[1].R3, lb, st, "k_fresnel_rows", e->ax[1].part, e->ax[1].pair, e->ax[1].dif)) return rc2;
     }

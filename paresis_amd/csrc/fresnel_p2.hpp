@@ -35,5 +35,16 @@ int max_distances(int R1);
 // image lines per round of a launch (the host's choice of the work order needs it)
 int lines_per_round(int R1, bool dual);
 
+// ---- lines of about 16384 samples: one 32768-point circular convolution in two coupled rounds (fresnel_p2x.hip)
+bool x_serves(int N, int margin);                 // do lines of N samples with this margin run on that kernel?
+int x_points();                                   // points of one round's transform (the kernel spectrum is built from two of them)
+size_t x_spectrum_elems();                        // float2 elements of one distance's table (two rounds of pairs + the first taps)
+size_t x_line_buffer_elems();                     // float2 elements of a workgroup's private line buffer (LineArgs::wgpart)
+int x_build_twiddles(float2 *w2, float2 *w4, hipStream_t st);      // 512 entries each (LineArgs::w2, w4)
+int x_pad_taps(const double2 *hP, double2 *buf, int P, hipStream_t st);     // taps -> the two folded sequences of x_points()
+int x_perm_spectrum(const double2 *Hh, const double2 *hP, float2 *out, int P, hipStream_t st);
+// la as for fresnel_p2's launch at R1 = 32 (twA / twB from build_tables(.., 32, ..)), H[d] from x_perm_spectrum, w2 / w4 / wgpart set
+int x_launch(bool contig, const lines::LineArgs &la, hipStream_t st, const char *name);
+
 }  // namespace p2
 }  // namespace psx

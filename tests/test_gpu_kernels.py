@@ -133,11 +133,14 @@ def test_fresnel_lds_engine_edge_geometries(ops, shape):
 
 
 @pytest.mark.parametrize("shape,nd", [((512, 40), 1), ((40, 512), 2), ((1024, 500), 3), ((498, 2048), 1), ((2048, 505), 2), ((4096, 36), 1),
-                                      ((36, 4096), 2), ((4090, 1021), 3), ((1100, 33), 1), ((2200, 20), 2), ((300, 4081), 1)])
+                                      ((36, 4096), 2), ((4090, 1021), 3), ((1100, 33), 1), ((2200, 20), 2), ((300, 4081), 1),
+                                      ((16384, 36), 2), ((36, 16384), 1), ((16370, 20), 3), ((24, 16356), 2), ((16384, 520), 4)])
 def test_fresnel_power_of_two_lines_and_wrapped_outputs(ops, shape, nd):
     """Lines of N samples through ONE M = 256 R1-point transform with M just below N + P - 1 (fresnel_p2.hip): every radix
     (M = 1024 ... 8192), on either axis, with 29 / 5 / 1 / 0 wrapped outputs put right by the taps they missed, one distance
-    and the shared-forward rounds of several; and the line lengths that stay on the 576 R3-point transforms (1100, 2200).
+    and the shared-forward rounds of several; the line lengths that stay on the 576 R3-point transforms (1100, 2200); and lines
+    of about 16384 samples, one 32768-point convolution in two coupled rounds (fresnel_p2x.hip: 29 / 1 wrapped outputs, either
+    axis, a line fetched once for the rounds of all its distances).
     Whole complex fields against the float64 oracle; the same plan with the switch "no_p2" must agree as well."""
     from paresis_amd._lib import lib
     Nx, Ny = shape

@@ -95,3 +95,73 @@ if __name__ == "__main__":
         ref = reference_line(x, mg, h)
         out = engine_line(x, mg, h, R1)
         print("N %5d margin %2d M %5d Lx %4d  max err %.2e" % (N, mg, 256 * R1, N + P - 1 - 256 * R1, np.abs(out - ref).max() / np.abs(ref).max()))
+
+
+# ---- lines of about 4 x 8192 samples' worth of extension (N = 16384): ONE circular convolution of R = 32768 points, split by a
+# radix-2 decimation-in-frequency step over two rounds, each a Q = 16384-point transform whose even / odd samples live in the two
+# LDS lines (coupled by the radix-2 butterfly of the double-size transform in the middle stage) -- csrc/fresnel_p2x.hip
+def pair_fft(a, b, R1=32, inverse=False):
+    """The two LDS lines a (even samples) and b (odd samples) of one Q = 2M-point sequence -> the two lines of its spectrum in
+    digit order: line 0 position p holds bin k(p), line 1 position p holds bin k(p) + M."""
+    M = 256 * R1
+    p = np.arange(M)
+    k = p // 256 + R1 * ((p // 16) % 16) + 16 * R1 * (p % 16)
+    if not inverse:
+        A, B = dif3(a, R1), dif3(b, R1)
+        t = B * np.exp(-2j * np.pi * k / (2 * M))
+        return A + t, A - t
+    y0, y1 = a, b
+    return dif3(y0 + y1, R1, inverse=True), dif3((y0 - y1) * np.exp(+2j * np.pi * k / (2 * M)), R1, inverse=True)
+
+
+def engine_line_dif(x, mg, h, R1=32):
+    N = len(x)
+    P = N + 2 * mg
+    M = 256 * R1
+    Q, R = 2 * M, 4 * M
+    L = N + P - 1
+    Lx = L - R
+    assert Q < P <= Q + 64 and Lx <= 32 and P <= R
+    e = extension(x, mg, L)
+    # one copy in LDS: positions t < P (the slack behind the Q points of the transform holds t >= Q); the partner x[n + Q] of
+    # position n is e[n + Q] = e[(n + Q) mod P]: position n - (P - Q) for n >= P - Q, the slack position Q + n below
+    lds = e[:P].copy()
+    sa, sb = lds[:32].copy(), lds[R - P:R - P + 32].copy()        # e[j] and e[R + j] = e[R - P + j], j < 32: saved for the fix-up
+    n = np.arange(Q)
+    partner = lds[(n + Q) % P]
+    # kernel spectrum halves: H_R[2k] = FFT_Q(h folded), H_R[2k+1] = FFT_Q((h[d] - h[d + Q]) w_R^d); 1/Q (inverse) and 1/2 (recombination)
+    hp = np.concatenate([h, np.zeros(R - P)])
+    he = hp[:Q] + hp[Q:]
+    ho = (hp[:Q] - hp[Q:]) * np.exp(-2j * np.pi * n / R)
+    p = np.arange(M)
+    k = p // 256 + R1 * ((p // 16) % 16) + 16 * R1 * (p % 16)
+    outs = []
+    for rnd, hk in ((0, he), (1, ho)):
+        s = lds[:Q] + partner if rnd == 0 else (lds[:Q] - partner) * np.exp(-2j * np.pi * n / R)
+        G = np.fft.fft(hk) / (2 * Q)
+        S0, S1 = pair_fft(s[0::2], s[1::2], R1)
+        a2, b2 = pair_fft(S0 * G[k], S1 * G[k + M], R1, inverse=True)
+        y = np.empty(Q, complex)
+        y[0::2], y[1::2] = a2, b2
+        outs.append(y)
+    ye, yo = outs
+    z = yo * np.exp(+2j * np.pi * n / R)                      # w_R^-m' yo[m']
+    out = np.empty(N, complex)
+    i = n - (P - 1 - Q)                                       # y[m' + Q] = ye - z  ->  sample m' + Q - (P - 1)
+    ok = (i >= 0) & (i < N)
+    out[i[ok]] = (ye - z)[ok]
+    for mp in range(max(Lx, 0)):                              # y[m' + 2Q] = ye + z + fix-up  ->  sample m' + 2Q - (P - 1)
+        t = np.arange(mp + 1)
+        out[mp + R - (P - 1)] = ye[mp] + z[mp] + np.sum(h[t] * (sb[mp - t] - sa[mp - t]))
+    return out
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(1)
+    for N, mg in [(16384, 15), (16380, 15), (16384, 10), (16370, 15)]:
+        x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+        P = N + 2 * mg
+        h = taps(P, 1.3e-11, 2 * np.pi / (N * 1.46e-6))
+        ref = reference_line(x, mg, h)
+        out = engine_line_dif(x, mg, h)
+        print("DIF  N %5d margin %2d Lx %4d  max err %.2e" % (N, mg, N + P - 1 - 32768, np.abs(out - ref).max() / np.abs(ref).max()))
