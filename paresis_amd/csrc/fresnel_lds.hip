@@ -27,6 +27,7 @@
 // Each CU runs ONE persistent 16-wave workgroup: 12 engine waves own the butterflies (packed-fp32 arithmetic,
 // fft_pk.hpp), 4 loader waves fetch the next line group from HBM during the transform and spread it into LDS while the
 // engine finishes the last butterfly and its stores.
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <map>
@@ -1695,8 +1696,10 @@ int lds_engine_create(psx_fresnel_plan *p) {
     PSX_HIP(hipMemset(e->queue, 0, sizeof(unsigned) * 2 * QUEUE_WORDS));
     if (e->ax[0].dif || e->ax[1].dif || e->ax[0].p2x || e->ax[1].p2x) {
         e->wgpart_groups = current_cu_count();
-        PSX_HIP(hipMalloc((void **)&e->wgpart, sizeof(float2) * 2 * PART_M * (size_t)e->wgpart_groups));
-        p->bytes += sizeof(float2) * 2 * PART_M * (size_t)e->wgpart_groups;
+        // DIF rounds park 2 * PART_M points per workgroup, the two-round power-of-two kernel 2 * 16384 (ye and round O's input)
+        const size_t per_wg = std::max((size_t)2 * PART_M, (e->ax[0].p2x || e->ax[1].p2x) ? p2::x_line_buffer_elems() : (size_t)0);
+        PSX_HIP(hipMalloc((void **)&e->wgpart, sizeof(float2) * per_wg * (size_t)e->wgpart_groups));
+        p->bytes += sizeof(float2) * per_wg * (size_t)e->wgpart_groups;
     }
     if (e->ax[1].part && e->ax[1].S > 1 && !e->ax[1].dif) {      // complex partial sums of pass 2 when only |.|^2 leaves the pass
         PSX_HIP(hipMalloc((void **)&e->part, sizeof(float2) * npix * p->max_dist));

@@ -109,5 +109,34 @@ __device__ __forceinline__ void store_legs(const v2f (&v)[R], v2f vw, v2f *wo, f
     }
 }
 
+// CNT consecutive legs, the first of them leg q0, of a butterfly whose leg q goes to element e0 + q * estep of the window (the
+// two-round kernel stores a butterfly in two halves, each as soon as its data is there)
+template <int CNT>
+__device__ __forceinline__ void store_legs_range(const v2f (&v)[CNT], int q0, v2f *wo, float *io, int64_t wbase, int welems, int e0, int estep,
+                                                 v2f gp, float sc, int accumulate) {
+    if (wo) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(wo + wbase, 0, (int)((unsigned)welems * 8u), 0x00020000);
+        const bool plain = gp.x == 1.f && gp.y == 0.f;
+        unsigned off = ((unsigned)e0 + (unsigned)q0 * (unsigned)estep) * 8u;
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+            const v2f r = plain ? v[q] : pk_cmul_s(v[q], gp);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, r), rs, (int)off, 0, 0);
+            off += (unsigned)estep * 8u;
+        }
+    }
+    if (io) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(io + wbase, 0, (int)((unsigned)welems * 4u), 0x00020000);
+        unsigned off = ((unsigned)e0 + (unsigned)q0 * (unsigned)estep) * 4u;
+#pragma unroll
+        for (int q = 0; q < CNT; ++q) {
+            float I = sc * (v[q].x * v[q].x + v[q].y * v[q].y);
+            if (accumulate) I += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, I), rs, (int)off, 0, 0);
+            off += (unsigned)estep * 4u;
+        }
+    }
+}
+
 }  // namespace p2dev
 }  // namespace psx
