@@ -569,36 +569,82 @@ __global__ __launch_bounds__(256) void k_pack_u16(const float *__restrict__ src,
                                                   int64_t index0, int32_t *__restrict__ exc, int32_t *__restrict__ exc_count,
                                                   int cap, int *__restrict__ overflow) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool bad = false;
-    auto cvt = [&](float x, int64_t p) {
+    const int lane = threadIdx.x & 63;
+    // the escapes of a wave's pixels take their table slots with ONE atomic (an image behind a sphere membrane has caustics over
+    // 3 % of its pixels: an atomic each -- or one per wave and pixel slot, as the compiler aggregates them -- is 1e5 returning
+    // atomics on one word, about a millisecond): exclusive scan of the lanes' counts, the last lane draws the wave's block
+    auto slots = [&](int c) {
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            incl += lane >= o ? t : 0;
+        }
+        int base = 0;
+        if (lane == 63) base = atomicAdd(exc_count, incl);
+        return __shfl(base, 63) + incl - c;
+    };
+    auto cvt = [&](float x, unsigned &q) {           // q = the 16-bit code; returns the count itself
         const float c = fminf(fmaxf(x, 0.f), 16777216.f);
-        unsigned q = (unsigned)c;
-        bad |= !((float)q == x);                     // NaN, inf, negatives, fractions and counts above 2^24 all land here
-        if (q >= 65535u) {
-            const int e = atomicAdd(exc_count, 1);
+        const unsigned v = (unsigned)c;
+        bad |= !((float)v == x);                     // NaN, inf, negatives, fractions and counts above 2^24 all land here
+        q = min(v, 65535u);
+        return v;
+    };
+    auto escape = [&](int &e, unsigned v, int64_t p) {
+        if (v >= 65535u) {
             if (e < cap) {
                 exc[2 * e] = (int32_t)(index0 + p);
-                exc[2 * e + 1] = (int32_t)q;
+                exc[2 * e + 1] = (int32_t)v;
             } else {
                 bad = true;
             }
-            q = 65535u;
+            ++e;
         }
-        return q;
     };
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     const int64_t n8 = vec ? n / 8 : 0;
-    for (int64_t g = t0; g < n8; g += stride) {
-        const float4 a = reinterpret_cast<const float4 *>(src)[2 * g], b = reinterpret_cast<const float4 *>(src)[2 * g + 1];
-        uint4 o;
-        o.x = cvt(a.x, 8 * g) | (cvt(a.y, 8 * g + 1) << 16);
-        o.y = cvt(a.z, 8 * g + 2) | (cvt(a.w, 8 * g + 3) << 16);
-        o.z = cvt(b.x, 8 * g + 4) | (cvt(b.y, 8 * g + 5) << 16);
-        o.w = cvt(b.z, 8 * g + 6) | (cvt(b.w, 8 * g + 7) << 16);
-        reinterpret_cast<uint4 *>(dst)[g] = o;
+    for (int64_t g0 = (int64_t)blockIdx.x * blockDim.x; g0 < n8; g0 += stride) {     // whole waves: the scan holds shuffles
+        const int64_t g = g0 + threadIdx.x;
+        const bool live = g < n8;
+        float x[8];
+        unsigned q[8], v[8];
+        if (live) {
+            const float4 a = reinterpret_cast<const float4 *>(src)[2 * g], b = reinterpret_cast<const float4 *>(src)[2 * g + 1];
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+        }
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = live ? cvt(x[k], q[k]) : 0u;
+            c += v[k] >= 65535u ? 1 : 0;
+        }
+        if (__any(c > 0)) {
+            int e = slots(c);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) escape(e, v[k], 8 * g + k);
+        }
+        if (live) {
+            uint4 o;
+            o.x = q[0] | (q[1] << 16);
+            o.y = q[2] | (q[3] << 16);
+            o.z = q[4] | (q[5] << 16);
+            o.w = q[6] | (q[7] << 16);
+            reinterpret_cast<uint4 *>(dst)[g] = o;
+        }
     }
-    for (int64_t p = n8 * 8 + t0; p < n; p += stride) dst[p] = (uint16_t)cvt(src[p], p);
+    for (int64_t p0 = n8 * 8 + (int64_t)blockIdx.x * blockDim.x; p0 < n; p0 += stride) {
+        const int64_t p = p0 + threadIdx.x;
+        unsigned q = 0u, v = 0u;
+        if (p < n) v = cvt(src[p], q);
+        const int c = v >= 65535u ? 1 : 0;
+        if (__any(c > 0)) {
+            int e = slots(c);
+            escape(e, v, p);
+        }
+        if (p < n) dst[p] = (uint16_t)q;
+    }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(overflow, 1);
 }
 

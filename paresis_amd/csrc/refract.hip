@@ -403,7 +403,11 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
             // table) the compiler makes of plain loads -- it leaves volatile ones alone.  0.271 -> 0.262 ms at 4096^2 (r4s21)
             const volatile __attribute__((address_space(3))) double *vphi =
                 (const volatile __attribute__((address_space(3))) double *)sphi;
+#if defined(PSX_NEAR_EXP) && (PSX_NEAR_EXP & 2)
+            const double xp = 1e-3 * sidx, xm = 0.0, yp = -2e-3 * sidx, ym = 0.0;
+#else
             const double xp = vphi[sidx + SC], xm = vphi[sidx - SC], yp = vphi[sidx + 1], ym = vphi[sidx - 1];
+#endif
             gx = (xp - xm) * hscale;
             gy = (yp - ym) * hscale;
         } else if (inside) {                                         // image border: np.gradient(edge_order=2)
@@ -476,7 +480,12 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
         {
             const float wx = dx - fx, wy = dy - fy;                  // exact in float32
             // base target in ring coordinates (+1): the four shares land inside the accumulator iff 0 <= ti <= TH, 0 <= tj <= TW
-            const int ti = gr - H + ifx + 1, tj = gc - H + ify + 1;
+#ifndef PSX_NEAR_EXP
+#define PSX_NEAR_EXP 0
+#endif
+            // PSX_NEAR_EXP (tools/ab_refract4.sh, wrong images, timing only): 1 -> every ray deposits at its own pixel (no two lanes of
+            // a wave share an address or a bank), 2 -> no stencil reads (a constant displacement), 3 -> both
+            const int ti = gr - H + ((PSX_NEAR_EXP & 1) ? 0 : ifx) + 1, tj = gc - H + ((PSX_NEAR_EXP & 1) ? 0 : ify) + 1;
             // ANY ray of the window whose base pixel falls in the accumulator is deposited, however long it is: the
             // share of a ray at target pixel t is gathered exactly when the source lies in the window of t's tile, and
             // k_refract_far applies the same test to decide what is left for it
