@@ -567,6 +567,23 @@ def test_no_shipped_kernel_spills_registers():
     assert any("k_fresnel_lines" in k["symbol"] for k in ks) and any("k_refract_near" in k["symbol"] for k in ks)
 
 
+def test_no_wide_store_is_overwritten_behind_its_back():
+    """Disassembly of libparesis_hip.so (no GPU needed): no buffer store of more than 64 bits with a REGISTER scalar offset is
+    followed at once by a vector-ALU instruction that overwrites its data registers.  gfx950 reads the upper half of such a
+    store's data late (lanes 12-15 of every row of 16 get the NEW value), the compiler pads the hazard only when the scalar offset
+    is an immediate, and the result is silently wrong bytes in memory -- the cause of round 6's three failed forms of the
+    two-round kernel's parked input (gpurun_out/r6s31 - r6s34; tools/check_store_hazard.py finds 17 sites in that build)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_store_hazard
+    assert check_store_hazard.sites() == []
+    # the scanner itself, on the three shapes it must tell apart
+    assert check_store_hazard.STORE.match("\tbuffer_store_dwordx4 v[38:41], v138, s[20:23], s71 offen").groups()[1:] == ("38", "41", "v138", "s71")
+    assert check_store_hazard.STORE.match("\tbuffer_store_dwordx2 v[38:39], v138, s[20:23], s71 offen") is None
+    assert check_store_hazard.VDST.match("v_pk_mul_f32 v[40:41], v[6:7], s[50:51] op_sel:[1,1]").group(1) == "40"
+    assert check_store_hazard.VDST.match("v_mov_b32_e32 v7, v3").group(3) == "7"
+
+
 def test_dif_stage_a_partner_reads_stay_inside_the_lines():
     """k_fresnel_part's DIF stage A (csrc/fresnel_lds.hip, `if constexpr (DIF)`) reads, for each of a thread's 24 legs, the
     partner sample x[n + 2M] = L[n + D] from LDS -- also for legs that HAVE no partner (q >= qb), whose value it drops: their

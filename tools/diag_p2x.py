@@ -34,5 +34,18 @@ for rep in range(2):
             for i in list(bp[:10]) + [int(bp[0]) - 1, int(bp[7]) + 1]:
                 print("   i", i, "out", colo[i], "ref", colr[i], "ratio", colo[i] / colr[i])
             print("line 0 bad positions", [int(v) for v in bp[:16]], "\n n0 = i - 8163:", list(n0), "\n nA", list(n0 // 2), "lineA", list(n0 % 2))
+        if len(bad_pos):
+            # leg q x engine wave w of the stage-A butterfly that produced output i: m' = i + (P - 1 - 16384), q = m' // 512, w = (m' % 512) // 64
+            N = max(Nx, Ny)
+            shx = N + 30 - 1 - 16384
+            col = (err[:, :].max(axis=1) if long_axis == 0 else err[:, :].max(axis=0)) > 1e-5
+            mp = np.arange(N) + shx
+            tab = np.zeros((33, 8), int)
+            for i in np.nonzero(col)[0]:
+                tab[min(mp[i] // 512, 32), (mp[i] % 512) // 64] += 1
+            print("bad outputs by leg (rows) x wave (columns):")
+            for q in range(33):
+                if tab[q].any():
+                    print("  leg %2d " % q + " ".join("%3d" % v for v in tab[q]))
         print("rep", rep, "z", z, "max err %.2e" % err.max(), "bad lines", bad_lines[:12], len(bad_lines), "bad positions: n", len(bad_pos),
               "range", (bad_pos.min(), bad_pos.max()) if len(bad_pos) else None, "first", bad_pos[:8])

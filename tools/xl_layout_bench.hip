@@ -1,0 +1,61 @@
+// Microbenchmark (diagnostic): the transposition between the two passes of the 16384^2 Fresnel call.  A workgroup handles ONE
+// line of 16384 complex samples at a time (the line is the LDS); the intermediate image is blocked in pieces of 8 samples = 64 B.
+//   layout A (shipped)  [x/8][y][x%8]: pass 1 (line y) STORES whole 64-B pieces 1 MiB apart; pass 2 (line x) LOADS 8 B of every
+//                                       piece of a contiguous 1 MiB region
+//   layout B            [y/8][x][y%8]: pass 1 STORES 8 B into every piece of a contiguous 1 MiB region; pass 2 LOADS whole 64-B
+//                                       pieces 1 MiB apart
+// 256 persistent workgroups of 256 threads (the loader waves' shape), lines handed out as the line kernels do (XCD-contiguous
+// chunks, neighbouring lines on neighbouring CUs of one XCD at the same time).  Prints microseconds per line and workgroup.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+constexpr int N = 16384, IB = 8;
+__device__ __forceinline__ void share(int nwork, int &cstart, int &clen, int &slot, int &nslot) {
+    const int xcd = blockIdx.x & 7;
+    slot = blockIdx.x >> 3; nslot = gridDim.x >> 3;
+    const int cq = nwork >> 3, cr = nwork & 7;
+    cstart = xcd * cq + (xcd < cr ? xcd : cr); clen = cq + (xcd < cr ? 1 : 0);
+}
+// MODE 0: load 8 B of every piece (A pass 2); 1: load whole pieces 1 MiB apart (B pass 2); 2: store whole pieces 1 MiB apart (A pass 1);
+// 3: store 8 B into every piece (B pass 1)
+template <int MODE>
+__global__ __launch_bounds__(256) void k(float2 *img, float *sink, int nlines) {
+    int cstart, clen, slot, nslot;
+    share(nlines, cstart, clen, slot, nslot);
+    float acc = 0.f;
+    for (int u = slot; u < clen; u += nslot) {
+        const int l = cstart + u;
+        if (MODE == 0 || MODE == 3) {           // element s of line l: ((l / IB) * N + s) * IB + l % IB
+            float2 *base = img + ((size_t)(l / IB) * N) * IB + l % IB;
+            for (int s = threadIdx.x; s < N; s += 256) {
+                if (MODE == 0) { const float2 v = base[(size_t)s * IB]; acc += v.x + v.y; }
+                else base[(size_t)s * IB] = make_float2((float)s, (float)l);
+            }
+        } else {                                // samples 8 p .. 8 p + 7 of line l: piece ((p * N) + l) * IB
+            float4 *base = reinterpret_cast<float4 *>(img + (size_t)l * IB);
+            for (int q = threadIdx.x; q < N / 2; q += 256) {          // 16 bytes = 2 samples per thread and step
+                const int p = q >> 2, h = q & 3;
+                float4 *a = base + (size_t)p * N * IB / 2 + h;
+                if (MODE == 1) { const float4 v = *a; acc += v.x + v.y + v.z + v.w; }
+                else *a = make_float4((float)q, (float)l, 1.f, 2.f);
+            }
+        }
+    }
+    if (acc == 12345.678f) sink[blockIdx.x] = acc;
+}
+int main() {
+    float2 *img; float *o;
+    hipMalloc(&img, sizeof(float2) * (size_t)N * N); hipMalloc(&o, 1 << 16);
+    hipMemset(img, 0, sizeof(float2) * (size_t)N * N);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int nlines = N;
+    auto run = [&](const char *nm, auto f) {
+        f(); hipDeviceSynchronize(); hipEventRecord(e0); for (int r = 0; r < 3; ++r) f(); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+        printf("%-62s %7.3f ms per image  %6.2f us per line and workgroup  %5.2f TB/s of useful bytes\n", nm, ms, ms * 1e3 / (nlines / 256.0), 2.147 / ms);
+    };
+    run("A pass 2: loads, 8 B of every 64-B piece", [&] { k<0><<<256, 256>>>(img, o, nlines); });
+    run("B pass 2: loads, whole 64-B pieces 1 MiB apart", [&] { k<1><<<256, 256>>>(img, o, nlines); });
+    run("A pass 1: stores, whole 64-B pieces 1 MiB apart", [&] { k<2><<<256, 256>>>(img, o, nlines); });
+    run("B pass 1: stores, 8 B into every 64-B piece", [&] { k<3><<<256, 256>>>(img, o, nlines); });
+    return 0;
+}
