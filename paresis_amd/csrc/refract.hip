@@ -372,6 +372,28 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
     // accumulator and writes its own image.
     bool any_bad = false;
     constexpr int ITERS = (GR * GC + NTHREADS - 1) / NTHREADS;   // uniform trip count: the loop holds wave ballots
+    // Interior tiles of a distance batch: the float64 phase differences of a thread's ITERS sources are formed ONCE (16 registers)
+    // and every distance scales them -- the same products bit for bit, (xp - xm) * hscale, without the four LDS reads, their
+    // address and the two float64 subtractions per source and distance (PSX_NEAR_HOIST, tools/ab_src.sh)
+#ifndef PSX_NEAR_HOIST
+#define PSX_NEAR_HOIST 1
+#endif
+    constexpr bool HOIST = PSX_NEAR_HOIST && (GR * GC) % NTHREADS == 0;
+    double hgx[HOIST ? ITERS : 1], hgy[HOIST ? ITERS : 1];
+    const bool hoisted = HOIST && window_inside && a.ndist > 1;      // uniform
+    if constexpr (HOIST) {
+        if (hoisted) {
+            const volatile __attribute__((address_space(3))) double *vphi = (const volatile __attribute__((address_space(3))) double *)sphi;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int idx = it * NTHREADS + tid;
+                const int sidx = ((int)((unsigned)idx / (unsigned)GC) + 1) * SC + ((int)((unsigned)idx % (unsigned)GC) + 1);
+                const double xp = vphi[sidx + SC], xm = vphi[sidx - SC], yp = vphi[sidx + 1], ym = vphi[sidx - 1];
+                hgx[it] = xp - xm;
+                hgy[it] = yp - ym;
+            }
+        }
+    }
     for (int d = 0; d < a.ndist; ++d) {
     // the per-thread index arithmetic is recomputed per distance rather than kept live across the loop (opaque copy of
     // the thread index): hoisted, it costs 40 VGPRs and the second workgroup of the CU
@@ -394,9 +416,16 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
         continue;                                        // the accumulator and the list counter are untouched: no barrier owed
     }
     // D = gradient(phi) * dscale at staged pixel `sidx` (image pixel (i, j)), float64 differencing, float32 result
-    auto displacement = [&](auto inside_tag, int i, int j, int sidx, bool inside, float &dx, float &dy) __attribute__((always_inline)) {
+    auto displacement = [&](auto inside_tag, int it, int i, int j, int sidx, bool inside, float &dx, float &dy) __attribute__((always_inline)) {
         constexpr bool IN = decltype(inside_tag)::value && (GR * GC) % NTHREADS == 0;
         double gx, gy;
+        if constexpr (IN && HOIST) {
+            if (hoisted) {                                                // uniform
+                dx = (float)(hgx[it] * hscale);
+                dy = (float)(hgy[it] * hscale);
+                return;
+            }
+        }
         // gx, gy hold gradient * dscale.  (d * 0.5) * dscale == d * (0.5 * dscale) bit for bit: halving is exact.
         if (IN || (i > 0 && i < a.Nx - 1 && j > 0 && j < a.Ny - 1)) {   // interior: central differences (RF2:54)
             // four ds_read_b64 (2 LDS cycles per wave instruction), not the two ds_read2_b64 (8 each: MI355X_MICROARCH.md, LDS
@@ -447,7 +476,7 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
         if constexpr (SPLITC)                                        // split call: only the sources of side d
             I = (reinterpret_cast<const unsigned *>(sphi)[2 * sidx] & 1u) == (unsigned)d ? I : 0.f;
         float dx, dy;
-        displacement(inside_tag, i, j, sidx, inside, dx, dy);
+        displacement(inside_tag, it, i, j, sidx, inside, dx, dy);
         // RF2:59-60 zeroes |D| < 1e-12.  For the deposit that is a no-op in float32 -- such a ray puts weight 1.0f on its
         // own pixel and less than 2^-30 of a unit elsewhere either way -- so only the displacement maps apply it.
         const bool clx = fabsf(dx) > a.clamp_xf, cly = fabsf(dy) > a.clamp_yf;   // RF2:61-64
