@@ -513,7 +513,7 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
 #define PSX_NEAR_EXP 0
 #endif
             // PSX_NEAR_EXP (tools/ab_refract4.sh, wrong images, timing only): 1 -> every ray deposits at its own pixel (no two lanes of
-            // a wave share an address or a bank), 2 -> no stencil reads (a constant displacement), 3 -> both
+            // a wave share an address or a bank), 2 -> no stencil reads (a constant displacement), 3 -> both, 4 -> two of the four atomics
             const int ti = gr - H + ((PSX_NEAR_EXP & 1) ? 0 : ifx) + 1, tj = gc - H + ((PSX_NEAR_EXP & 1) ? 0 : ify) + 1;
             // ANY ray of the window whose base pixel falls in the accumulator is deposited, however long it is: the
             // share of a ray at target pixel t is gathered exactly when the source lies in the window of t's tile, and
@@ -557,8 +557,10 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
                 const v2f s1 = (ax * (v2f){wy, wy}) * (v2f){Is_, Is_};        // {(1-wx)wy, wx wy} * I
                 dep(0, s0.x);
                 dep(AW, s0.y);
-                dep(1, s1.x);
-                dep(AW + 1, s1.y);
+                if (!(PSX_NEAR_EXP & 4)) {           // timing experiment: two atomics per ray (what a packed pair of 32-bit fields would issue)
+                    dep(1, s1.x);
+                    dep(AW + 1, s1.y);
+                }
             } else {
             dep(0, Is_ * ((1.f - wx) * (1.f - wy)));
             dep(AW, Is_ * (wx * (1.f - wy)));
