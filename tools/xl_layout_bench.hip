@@ -42,6 +42,30 @@ __global__ __launch_bounds__(256) void k(float2 *img, float *sink, int nlines) {
     }
     if (acc == 12345.678f) sink[blockIdx.x] = acc;
 }
+// MODE 0 again through a buffer descriptor with cache-policy bits (AUX: 1 sc0, 2 nt, 16 sc1), 8-byte loads; W16: 16-byte loads (two
+// neighbouring lines' samples, one of them unused) of the same pieces
+template <int AUX, bool W16>
+__global__ __launch_bounds__(256) void kb(float2 *img, float *sink, int nlines) {
+    int cstart, clen, slot, nslot;
+    share(nlines, cstart, clen, slot, nslot);
+    float acc = 0.f;
+    for (int u = slot; u < clen; u += nslot) {
+        const int l = W16 ? ((cstart + u) & ~1) : cstart + u;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(img + ((size_t)(l / IB) * N) * IB + l % IB), 0, N * IB * 8, 0x00020000);
+        for (int s = threadIdx.x; s < N; s += 256) {
+            if (W16) {
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                const v4i r = __builtin_amdgcn_raw_buffer_load_b128(rs, s * IB * 8, 0, AUX);
+                acc += __int_as_float(r.x) + __int_as_float(r.y);
+            } else {
+                typedef int v2i __attribute__((ext_vector_type(2)));
+                const v2i r = __builtin_amdgcn_raw_buffer_load_b64(rs, s * IB * 8, 0, AUX);
+                acc += __int_as_float(r.x) + __int_as_float(r.y);
+            }
+        }
+    }
+    if (acc == 12345.678f) sink[blockIdx.x] = acc;
+}
 int main() {
     float2 *img; float *o;
     hipMalloc(&img, sizeof(float2) * (size_t)N * N); hipMalloc(&o, 1 << 16);
@@ -54,6 +78,13 @@ int main() {
         printf("%-62s %7.3f ms per image  %6.2f us per line and workgroup  %5.2f TB/s of useful bytes\n", nm, ms, ms * 1e3 / (nlines / 256.0), 2.147 / ms);
     };
     run("A pass 2: loads, 8 B of every 64-B piece", [&] { k<0><<<256, 256>>>(img, o, nlines); });
+    run("A pass 2 through a descriptor, aux 0", [&] { kb<0, false><<<256, 256>>>(img, o, nlines); });
+    run("A pass 2 through a descriptor, sc0", [&] { kb<1, false><<<256, 256>>>(img, o, nlines); });
+    run("A pass 2 through a descriptor, nt", [&] { kb<2, false><<<256, 256>>>(img, o, nlines); });
+    run("A pass 2 through a descriptor, sc1", [&] { kb<16, false><<<256, 256>>>(img, o, nlines); });
+    run("A pass 2 through a descriptor, sc0 sc1", [&] { kb<17, false><<<256, 256>>>(img, o, nlines); });
+    run("A pass 2 through a descriptor, sc0 sc1 nt", [&] { kb<19, false><<<256, 256>>>(img, o, nlines); });
+    run("A pass 2, 16-byte loads (half unused)", [&] { kb<0, true><<<256, 256>>>(img, o, nlines); });
     run("B pass 2: loads, whole 64-B pieces 1 MiB apart", [&] { k<1><<<256, 256>>>(img, o, nlines); });
     run("A pass 1: stores, whole 64-B pieces 1 MiB apart", [&] { k<2><<<256, 256>>>(img, o, nlines); });
     run("B pass 1: stores, 8 B into every 64-B piece", [&] { k<3><<<256, 256>>>(img, o, nlines); });
