@@ -468,6 +468,9 @@ def main():
                                "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "traffic_from": prof.get("_file") if prof else None,
+                               # a stale profile does not go unnoticed: were the counters collected on the kernel
+                               # sources this run was built from?  (null: a summary older than the stamp)
+                               "traffic_sources_match": (prof.get("_csrc_sha1") == csrc_sha1()) if prof and prof.get("_csrc_sha1") else None,
                                "traffic_note": "HBM bytes per launch from the committed rocprofv3 PMC passes of the same command on the "
                                                "same build (profiles/), not re-measured by this run",
                                "ms_per_launch": round(per[dom], 4), "algorithmic_bytes_per_launch": alg[dom],
@@ -1139,8 +1142,20 @@ def pmc_profile(N):
         except (OSError, ValueError, KeyError):
             continue
         prof["_file"] = os.path.relpath(f, ROOT)
+        prof["_csrc_sha1"] = json.load(open(f)).get("csrc_sha1")      # the kernel sources the profile was collected on
         return prof
     return None
+
+
+def csrc_sha1():
+    """The hash tools/summarise_profiles.py stamps into a PMC summary: paresis_amd/csrc/*.hip, *.hpp and the Makefile."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "paresis_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")) or f == "Makefile":
+            h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def pmc_value(prof, kernel, field):

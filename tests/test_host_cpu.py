@@ -411,6 +411,16 @@ def test_bench_finds_its_pmc_traffic():
     rows, cols = (bench.pmc_value(prof, k, "WRITE_SIZE_KB") for k in ("k_fresnel_rows", "k_fresnel_cols"))
     assert cols > 1.5 * rows                                         # pass 1 writes complex, pass 2 |.|^2: not mixed up
     assert bench.pmc_profile(2048) is None                           # a profile only serves the grid it was collected on
+    # the summary is stamped with a hash of the kernel sources it was collected on, and the line says whether that is the tree the
+    # run was built from (`roofline.traffic_sources_match`): a stale profile does not go unnoticed
+    assert isinstance(prof["_csrc_sha1"], str) and len(prof["_csrc_sha1"]) == 40 and len(bench.csrc_sha1()) == 40
+    sys_path = os.path.join(ROOT, "tools")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_sumprof_src", os.path.join(sys_path, "summarise_profiles.py"))
+    src = open(spec.origin).read()
+    ns = {"os": os}
+    exec(src[src.index("def csrc_sha1"):src.index("json.dump({\"csrc_sha1\"")], ns)        # the tool's copy of the function alone
+    assert ns["csrc_sha1"](ROOT) == bench.csrc_sha1()
 
 
 # ---- image formats: what main.py:98-110 writes through fabio in the reference

@@ -39,7 +39,19 @@ cmd = ("`python3 bench.py --only-configs --configs 16384 --no-config-parity` (co
        "membrane, halo picked by ops.tune_refract_halo -- its three candidates appear as three k_refract instances --, detector "
        "inside the step)") if sfx == "_cfg5" else (
        "`python3 bench.py --no-cpu-baseline --positions 0%s` (warm-up + timed steps + the per-kernel event pass)" % (" (" + sfx.strip("_") + "^2 grid)" if sfx else ""))
-json.dump({"note": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ counters each in its own run) of " + cmd + " on one MI355X; averages per " +
+def csrc_sha1(root="."):
+    """One hash over the kernel sources (paresis_amd/csrc/*.hip, *.hpp, Makefile, sorted by name): stamped into the summary so that
+    bench.py can say whether the profile it quotes was collected on the sources it runs (roofline.traffic_sources_match)."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(root, "paresis_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")) or f == "Makefile":
+            h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+json.dump({"csrc_sha1": csrc_sha1(), "note": "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ counters each in its own run) of " + cmd + " on one MI355X; averages per " +
                    "launch.  hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE reads half of a wide "
                    "coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section), WRITE_SIZE is exact.",
            "kernels": summary}, open("profiles/%s_pmc_summary%s.json" % (tag, sfx), "w"), indent=1)
