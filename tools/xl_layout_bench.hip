@@ -66,6 +66,23 @@ __global__ __launch_bounds__(256) void kb(float2 *img, float *sink, int nlines) 
     }
     if (acc == 12345.678f) sink[blockIdx.x] = acc;
 }
+// layout A with pieces of IBX samples (IBX * 8 bytes): pass 2 loads 8 B of every piece, pass 1 stores whole pieces N * IBX * 8 bytes apart
+template <int IBX, bool STORE>
+__global__ __launch_bounds__(256) void kib(float2 *img, float *sink, int nlines) {
+    int cstart, clen, slot, nslot;
+    share(nlines, cstart, clen, slot, nslot);
+    float acc = 0.f;
+    for (int u = slot; u < clen; u += nslot) {
+        const int l = cstart + u;
+        if (!STORE) {
+            const float2 *base = img + ((size_t)(l / IBX) * N) * IBX + l % IBX;
+            for (int s = threadIdx.x; s < N; s += 256) { const float2 v = base[(size_t)s * IBX]; acc += v.x + v.y; }
+        } else {                                // sample i of line l: ((i / IBX) * N + l) * IBX + i % IBX -- consecutive lanes, consecutive samples
+            for (int i = threadIdx.x; i < N; i += 256) img[((size_t)(i / IBX) * N + l) * IBX + i % IBX] = make_float2((float)i, (float)l);
+        }
+    }
+    if (acc == 12345.678f) sink[blockIdx.x] = acc;
+}
 int main() {
     float2 *img; float *o;
     hipMalloc(&img, sizeof(float2) * (size_t)N * N); hipMalloc(&o, 1 << 16);
@@ -85,6 +102,13 @@ int main() {
     run("A pass 2 through a descriptor, sc0 sc1", [&] { kb<17, false><<<256, 256>>>(img, o, nlines); });
     run("A pass 2 through a descriptor, sc0 sc1 nt", [&] { kb<19, false><<<256, 256>>>(img, o, nlines); });
     run("A pass 2, 16-byte loads (half unused)", [&] { kb<0, true><<<256, 256>>>(img, o, nlines); });
+    run("pieces of 4 samples (32 B): pass 2 loads 8 B of each", [&] { kib<4, false><<<256, 256>>>(img, o, nlines); });
+    run("pieces of 4 samples: pass 1 stores whole pieces (8-B lanes)", [&] { kib<4, true><<<256, 256>>>(img, o, nlines); });
+    run("pieces of 2 samples (16 B): pass 2 loads 8 B of each", [&] { kib<2, false><<<256, 256>>>(img, o, nlines); });
+    run("pieces of 2 samples: pass 1 stores whole pieces (8-B lanes)", [&] { kib<2, true><<<256, 256>>>(img, o, nlines); });
+    run("pieces of 8 samples: pass 1 stores whole pieces (8-B lanes)", [&] { kib<8, true><<<256, 256>>>(img, o, nlines); });
+    run("pieces of 16 samples (128 B): pass 2 loads 8 B of each", [&] { kib<16, false><<<256, 256>>>(img, o, nlines); });
+    run("pieces of 16 samples: pass 1 stores whole pieces (8-B lanes)", [&] { kib<16, true><<<256, 256>>>(img, o, nlines); });
     run("B pass 2: loads, whole 64-B pieces 1 MiB apart", [&] { k<1><<<256, 256>>>(img, o, nlines); });
     run("A pass 1: stores, whole 64-B pieces 1 MiB apart", [&] { k<2><<<256, 256>>>(img, o, nlines); });
     run("B pass 1: stores, 8 B into every 64-B piece", [&] { k<3><<<256, 256>>>(img, o, nlines); });
