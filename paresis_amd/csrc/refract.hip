@@ -394,17 +394,38 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
             }
         }
     }
-    for (int d = 0; d < a.ndist; ++d) {
+    // ... and with a wide halo such a tile takes its distances TWO at a time: once the differences sit in registers nobody reads the
+    // staged phase again, and its 34 KiB hold a second accumulator -- one barrier and one write-out phase per PAIR of distances
+    // (PSX_NEAR_PAIR; not the split call, whose sides ride in the staged phase).  A/B on one box (gpurun_out/r6s42), tiles +
+    // replay per 4-distance launch: 16384^2 halo 12 7.79 / 7.85 -> 7.54 / 7.57 ms, halo 16 8.49 -> 7.83, halo 8 8.0 -> 7.9; the
+    // narrow halos LOSE (4096^2 halo 6: tiles 0.2775 -> 0.2812 ms; 16384^2 halo 4: 10.05 -> 10.20): compiled in for halo >= 8.
+#ifndef PSX_NEAR_PAIR
+#define PSX_NEAR_PAIR 1
+#endif
+    static_assert(sizeof(double) * SR * SC >= sizeof(long long) * (ACC + G::TRASH), "the staged phase holds a second accumulator");
+    long long *const sacc2 = (long long *)sphi;
+    unsigned *const sfar2 = sfar + 3;                    // (sfar, smax[0], smax[1], sfar2: the 16 bytes behind the intensity window)
+    const bool pairs = PSX_NEAR_PAIR && H >= 8 && HOIST && !SPLITC && hoisted;      // uniform
+    if (pairs) {
+        __syncthreads();                                 // every thread holds its differences
+        for (int idx = tid; idx < ACC; idx += NTHREADS) sacc2[idx] = 0ll;
+        if (tid == 0) *sfar2 = 0u;
+        __syncthreads();
+    }
+    for (int d = 0; d < a.ndist; d += pairs ? 2 : 1) {
+    const int nd = pairs && d + 1 < a.ndist ? 2 : 1;     // distances of this step (uniform)
     // the per-thread index arithmetic is recomputed per distance rather than kept live across the loop (opaque copy of
     // the thread index): hoisted, it costs 40 VGPRs and the second workgroup of the CU
     int tl = tid;
     asm volatile("" : "+v"(tl));
     tl &= NTHREADS - 1;                 // tells the compiler the range again (unsigned shifts for the index split)
     const int lane = tl & 63;
+    const int d1 = nd == 2 ? d + 1 : d;
     const double dscale = a.dscale[d];
-    const double hscale = 0.5 * dscale;
+    const double hscale = 0.5 * dscale, hscale1 = 0.5 * a.dscale[d1];
     float *const I_out = a.I_out[d];
     FarRay *const far_list = a.far_list + ((size_t)d * nt + tile) * (TH * TW);
+    FarRay *const far_list1 = a.far_list + ((size_t)d1 * nt + tile) * (TH * TW);
     if (SPLITC && (d == 0 ? mside0 : mside1) == 0u) {    // split call: no source of this side in the window (uniform)
         if (!a.accumulate)
             for (int idx = tl; idx < TH * TW; idx += NTHREADS) {
@@ -416,13 +437,14 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
         continue;                                        // the accumulator and the list counter are untouched: no barrier owed
     }
     // D = gradient(phi) * dscale at staged pixel `sidx` (image pixel (i, j)), float64 differencing, float32 result
-    auto displacement = [&](auto inside_tag, int it, int i, int j, int sidx, bool inside, float &dx, float &dy) __attribute__((always_inline)) {
+    auto displacement = [&](auto inside_tag, int it, int dd, int i, int j, int sidx, bool inside, float &dx, float &dy) __attribute__((always_inline)) {
         constexpr bool IN = decltype(inside_tag)::value && (GR * GC) % NTHREADS == 0;
         double gx, gy;
         if constexpr (IN && HOIST) {
             if (hoisted) {                                                // uniform
-                dx = (float)(hgx[it] * hscale);
-                dy = (float)(hgy[it] * hscale);
+                const double hs = dd ? hscale1 : hscale;
+                dx = (float)(hgx[it] * hs);
+                dy = (float)(hgy[it] * hs);
                 return;
             }
         }
@@ -462,8 +484,13 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
         dx = (float)gx;
         dy = (float)gy;
     };
-    auto gather = [&](auto inside_tag) __attribute__((always_inline)) {
+    auto gather = [&](auto inside_tag, auto nd_tag) __attribute__((always_inline)) {
     constexpr bool IN = decltype(inside_tag)::value && (GR * GC) % NTHREADS == 0;   // every slot is a pixel inside the image
+    constexpr int ND = decltype(nd_tag)::value;          // distances deposited by this pass (2: into the two accumulators)
+    // (distance outside, sources inside: one source feeding both distances in turn keeps a dozen more values alive -- 2 spilled
+    // registers in the wide-halo instances; the pass is about the barrier and the write-out it saves, not about the sources)
+#pragma unroll
+    for (int dd = 0; dd < ND; ++dd) {
     for (int it = 0; it < ITERS; ++it) {
         const int idx = IN ? it * NTHREADS + tl : min(it * NTHREADS + tl, GR * GC - 1);
         const bool live = IN || it * NTHREADS + tl < GR * GC;
@@ -471,12 +498,13 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
         const int i = r0 - H + gr, j = c0 - H + gc;
         const bool inside = IN || (live && i >= 0 && i < a.Nx && j >= 0 && j < a.Ny);
         const bool core = gr >= H && gr < H + TH && gc >= H && gc < H + TW;
-        float I = live ? sI[idx] : 0.f;                              // 0 outside the image
+        float I0 = live ? sI[idx] : 0.f;                             // 0 outside the image
         const int sidx = (gr + 1) * SC + (gc + 1);                   // this pixel in the staged phase tile
         if constexpr (SPLITC)                                        // split call: only the sources of side d
-            I = (reinterpret_cast<const unsigned *>(sphi)[2 * sidx] & 1u) == (unsigned)d ? I : 0.f;
+            I0 = (reinterpret_cast<const unsigned *>(sphi)[2 * sidx] & 1u) == (unsigned)d ? I0 : 0.f;
+        float I = I0;
         float dx, dy;
-        displacement(inside_tag, it, i, j, sidx, inside, dx, dy);
+        displacement(inside_tag, it, dd, i, j, sidx, inside, dx, dy);
         // RF2:59-60 zeroes |D| < 1e-12.  For the deposit that is a no-op in float32 -- such a ray puts weight 1.0f on its
         // own pixel and less than 2^-30 of a unit elsewhere either way -- so only the displacement maps apply it.
         const bool clx = fabsf(dx) > a.clamp_xf, cly = fabsf(dy) > a.clamp_yf;   // RF2:61-64
@@ -526,7 +554,7 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
             // a miss goes to the column its target WOULD have had: the lanes of a wave then keep their distinct banks whether
             // they hit or miss (at column = lane, the eight halo-column lanes of every row collided with hits three or four
             // lanes away -- a two-way conflict in nearly every deposit instruction)
-            long long *acc = sacc + (hit ? aidx
+            long long *acc = (dd ? sacc2 : sacc) + (hit ? aidx
                                          : G::MISS == 0 ? ACC + 2 * lane
                                          : G::MISS == 1 ? (TH + 1) * AW + lane
                                                         : (TH + 1) * AW + (tj & (AW - 1)));
@@ -577,7 +605,7 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
         if (mask) {
             const int leader = __ffsll((long long)mask) - 1;
             unsigned base = 0;
-            if (lane == leader) base = atomicAdd(sfar, (unsigned)__popcll(mask));
+            if (lane == leader) base = atomicAdd(dd ? sfar2 : sfar, (unsigned)__popcll(mask));
             base = __shfl(base, leader);
             if (far) {
                 // set bits of `mask` below this lane: two v_mbcnt, formed here (the shift-and-popcount form was hoisted out of
@@ -585,12 +613,12 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                 FarRay fr;
                 fr.dx = Dxs; fr.dy = Dys; fr.I = Is; fr.src = i * a.Ny + j;
-                far_list[base + rank] = fr;
+                (dd ? far_list1 : far_list)[base + rank] = fr;
                 // order-independent replay: the scratch words this ray's shares may be added to start at zero.  (Round 4 did
                 // this in a pass of its own over the lists, FAR_PREP: 0.020 ms at 4096^2, 1.12 ms on config 5.)  A superset of
                 // what the replay deposits is fine -- only words that receive a share are ever read back.
                 if (a.det_acc) {                                     // wave-uniform
-                    long long *const accd = a.det_acc + (size_t)d * a.Nx * a.Ny;
+                    long long *const accd = a.det_acc + (size_t)(dd ? d1 : d) * a.Nx * a.Ny;
                     int bi, ni, bj, nj;
                     float w0, w1, w2, w3;
                     axis_split_ref(Dxs, i, bi, ni, w0, w1);
@@ -605,35 +633,46 @@ __device__ __forceinline__ void refract_near_body(const RefractArgs &a) {
             }
         }
     }
+    }   // distances of the pass
     };
-    if (window_inside)
-        gather(std::true_type{});
+    if (nd == 2)                                         // pairs imply an interior tile
+        gather(std::true_type{}, std::integral_constant<int, 2>{});
+    else if (window_inside)
+        gather(std::true_type{}, std::integral_constant<int, 1>{});
     else
-        gather(std::false_type{});
+        gather(std::false_type{}, std::integral_constant<int, 1>{});
     PSX_RSTAMP(3);
     __syncthreads();
     PSX_RSTAMP(4);
 
     // ---- write the tile once (coalesced rows of TW floats) and clear it for the next distance (the guard ring
     // is never read, so it may keep what it collected)
-    const bool more = d + 1 < a.ndist;
-    for (int idx = tl; idx < TH * TW; idx += NTHREADS) {
-        const int tr = idx / TW, tc = idx - tr * TW;
-        const int i = r0 + tr, j = c0 + tc;
-        const long long q = sacc[(tr + 1) * AW + tc + 1];
-        if (more) sacc[(tr + 1) * AW + tc + 1] = 0ll;
-        if (i < a.Nx && j < a.Ny) {
-            const int64_t p = (int64_t)i * a.Ny + j;
-            float v = finite_in ? a.out_scale * (float)((double)q * finv) : __uint_as_float(0x7fc00000u);
-            if (a.accumulate) v += I_out[p];
-            any_bad |= !(fabsf(v) <= 3.0e38f);
-            I_out[p] = v;
+    const bool more = d + nd < a.ndist;
+    for (int dd = 0; dd < nd; ++dd) {
+        long long *const accw = dd ? sacc2 : sacc;
+        float *const Io = dd ? a.I_out[d1] : I_out;
+        for (int idx = tl; idx < TH * TW; idx += NTHREADS) {
+            const int tr = idx / TW, tc = idx - tr * TW;
+            const int i = r0 + tr, j = c0 + tc;
+            const long long q = accw[(tr + 1) * AW + tc + 1];
+            if (more) accw[(tr + 1) * AW + tc + 1] = 0ll;
+            if (i < a.Nx && j < a.Ny) {
+                const int64_t p = (int64_t)i * a.Ny + j;
+                float v = finite_in ? a.out_scale * (float)((double)q * finv) : __uint_as_float(0x7fc00000u);
+                if (a.accumulate) v += Io[p];
+                any_bad |= !(fabsf(v) <= 3.0e38f);
+                Io[p] = v;
+            }
         }
     }
     PSX_RSTAMP(5);
     if (tl == 0) {
         a.far_count[(size_t)d * nt + tile] = *sfar;     // the barrier above ordered every append before this read
         *sfar = 0u;
+        if (nd == 2) {
+            a.far_count[(size_t)d1 * nt + tile] = *sfar2;
+            *sfar2 = 0u;
+        }
     }
     if (more) __syncthreads();
     }   // distances
