@@ -309,6 +309,14 @@ def main():
         run_step()
     barrier()
     dt_steady = time.perf_counter() - t1
+    # what this box sustains: the shader clock right behind the steady steps (psx_clock_probe: a 30 us spin on every CU).  The
+    # boxes of the pool differ by 12 % in step time with the same library; the probe says how much of a
+    # run's time is the box's clock.  Outside every timed region.
+    try:
+        shader_mhz = round(ops.clock_probe(), 1)
+    except Exception as exc:                               # diagnostics only: never fails the run
+        shader_mhz = None
+        sys.stderr.write("bench: clock probe failed: %s\n" % exc)
     # ... and K steps in the OTHER far-ray mode (order-independent fixed-point replay <-> float atomics), so that the cost of
     # reproducible sums is on the line whichever mode `value` was measured in
     other_mode = {"far_rays": "float atomics" if ops.get_deterministic() else "order-independent fixed-point replay"}
@@ -367,6 +375,9 @@ def main():
            "other_far_ray_mode": other_mode,
            "spinup": {"ms": spin["ms"], "steps": spin["steps"],
                       "note": "the same step run untimed BEFORE the W warm-up steps until the clocks have ramped (--spinup-ms)"},
+           "shader_clock_mhz": shader_mhz,
+           "shader_clock_note": "measured right behind the `steady` steps with the shader-clock and the 100 MHz counters (psx_clock_probe); "
+                                "the step time of one library scales with it from box to box",
            "steady": {"ms_per_step": round(dt_steady / a.steps * 1e3, 4),
                       "value": round(units * N * N * world / (dt_steady / a.steps) / 1e6, 1),
                       "note": "the same K un-instrumented steps timed a second time, after the per-kernel event pass: the device "

@@ -54,6 +54,10 @@ int psx_abi_version(void);
 const char *psx_last_error(void);
 /* 1 when the code object for the current device (gfx950) is loadable, else 0 with psx_last_error() set */
 int psx_device_ok(void);
+/* Diagnostics: the shader clock (MHz) the device runs at under load right now -- a 30 us spin on every CU, issued on `stream` behind
+ * whatever is queued there, bracketed by the shader-clock and the constant 100 MHz counters; synchronises the stream.  bench.py
+ * reports it next to its timings: the boxes of a pool differ by more than 10 % in what they sustain. */
+int psx_clock_probe(float *mhz, void *stream);
 
 /* ---- K1: AnalyticalSample.setWave (Sample.py:248-282) ------------------------------------------------------
  * wave_out[p] = amp * wave_in[p] * exp(sum_m catt[m]*T[m][p]) * exp(i * sum_m cphase[m]*T[m][p]),  p < n.

@@ -18,7 +18,7 @@ PSX_MAX_SRC = 16
 PSX_SUM_SLOTS, PSX_SUM_STRIDE = 32, 16
 ENGINE_AUTO, ENGINE_ROCFFT, ENGINE_LDS = 0, 1, 2
 STATUS_NONFINITE = 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class PsxError(RuntimeError):
@@ -35,6 +35,7 @@ PROTOTYPES = {
     "psx_abi_version": (c_int, []),
     "psx_last_error": (c_char_p, []),
     "psx_device_ok": (c_int, []),
+    "psx_clock_probe": (c_int, [POINTER(c_float), c_void_p]),
     "psx_transmit_wave_c64": (c_int, [_vp, c_float, _vpp, _dp, _dp, c_int, _vp, c_int64, _vp]),
     "psx_transmit_rt_f32": (c_int, [_vp, c_float, _vpp, _dp, _dp, c_int, _vp, _vp, _vp, c_int64, _vp]),
     "psx_accumulate_f32": (c_int, [_vp, _vp, c_float, _vpp, _dp, c_int, c_int, c_int64, _vp]),

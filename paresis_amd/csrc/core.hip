@@ -96,9 +96,26 @@ void prof_end(int handle, hipStream_t st) { (void)hipEventRecord(g_recs[handle].
 
 __global__ void psx_probe_kernel(int *out) { *out = 950; }
 
+// Shader clock under load: every workgroup spins on dependent FMAs for `ticks` of the constant 100 MHz clock; thread 0 of
+// workgroup 0 reads the shader-clock counter (s_memtime) and the constant one (s_memrealtime) either side of its spin.
+__global__ __launch_bounds__(256) void psx_clock_probe_kernel(unsigned long long *out, unsigned ticks, float seed) {
+    const unsigned long long r0 = wall_clock64(), c0 = clock64();
+    float acc = seed + threadIdx.x;
+    while (wall_clock64() - r0 < ticks) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) acc = fmaf(acc, 1.0000001f, 0.5f);
+    }
+    const unsigned long long c1 = clock64(), r1 = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+    }
+    if (acc == 12345.678f) out[2] = 1ull;
+}
+
 extern "C" {
 
-int psx_abi_version(void) { return 9; }   // 3: psx_debug_switch(es_active), psx_set_deterministic(1) allocation-free; 4: psx_darkfield_split_f32(num, den); 5: psx_get_deterministic; 6: psx_refract_split_f32, psx_darkfield_blur_prepared_f32(accumulate); 7: psx_set_deterministic_scale; 8: psx_detect_multi_f32; 9: psx_get_deterministic_scale
+int psx_abi_version(void) { return 10; }   // 3: psx_debug_switch(es_active), psx_set_deterministic(1) allocation-free; 4: psx_darkfield_split_f32(num, den); 5: psx_get_deterministic; 6: psx_refract_split_f32, psx_darkfield_blur_prepared_f32(accumulate); 7: psx_set_deterministic_scale; 8: psx_detect_multi_f32; 9: psx_get_deterministic_scale; 10: psx_clock_probe
 
 const char *psx_last_error(void) { return psx::err_buf(); }
 
@@ -119,6 +136,21 @@ int psx_device_ok(void) {
         return 0;
     }
     return 1;
+}
+
+int psx_clock_probe(float *mhz, void *stream) {
+    if (!mhz) return psx::fail(PSX_E_ARG, "psx_clock_probe: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *d = nullptr, h[2] = {0ull, 0ull};
+    PSX_HIP(hipMalloc((void **)&d, 3 * sizeof(unsigned long long)));
+    psx_clock_probe_kernel<<<psx::current_cu_count(), 256, 0, st>>>(d, 3000u, 1.0f);       // 30 us on every CU
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (e != hipSuccess || h[1] == 0ull) return psx::fail((int)e, "psx_clock_probe: %s", hipGetErrorString(e));
+    *mhz = (float)((double)h[0] / (double)h[1] * 100.0);
+    return 0;
 }
 
 int psx_debug_stamps(void *buf) {

@@ -526,6 +526,15 @@ def set_deterministic_scale(scale=0.0):
     check(lib().psx_set_deterministic_scale(c_float(float(scale))), "psx_set_deterministic_scale")
 
 
+def clock_probe():
+    """Shader clock in MHz the device sustains right now (psx_clock_probe: a 30 us spin on every CU behind what is queued on the
+    current stream, which it synchronises).  Diagnostics: the boxes of a pool differ by > 10 % in what they sustain."""
+    import ctypes
+    mhz = ctypes.c_float(0.0)
+    check(lib().psx_clock_probe(ctypes.byref(mhz), _stream()), "psx_clock_probe")
+    return float(mhz.value)
+
+
 def get_deterministic_scale():
     """The calling thread's replay scale (psx_get_deterministic_scale; 0 = the unit comes from each call's measured maximum)."""
     return float(lib().psx_get_deterministic_scale())

@@ -677,6 +677,14 @@ def test_order_independent_replay_has_no_float_fallback(ops, case, halo):
         ops.set_refract_halo(4)
 
 
+def test_clock_probe_reads_a_plausible_shader_clock(ops):
+    """psx_clock_probe: the shader-clock counter against the constant 100 MHz one over a 30 us spin on every CU -- MI355X runs
+    between 0.5 and 2.5 GHz; two probes in a row agree within 15 % (the second one is under the load of the first)."""
+    a, b = ops.clock_probe(), ops.clock_probe()
+    assert 400.0 < a < 3000.0 and 400.0 < b < 3000.0, (a, b)
+    assert abs(a - b) < 0.15 * max(a, b), (a, b)
+
+
 def test_pack_counts_roundtrip_and_overflow(ops):
     """psx_pack_counts_u16 / psx_unpack_counts_u16 (the gather of the per-position stacks moves photon counts as 16-bit
     integers): exact round trip for every count 0..65534 and, through the exception table, for larger counts up to 2^24;
