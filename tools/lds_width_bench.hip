@@ -28,6 +28,13 @@ __global__ __launch_bounds__(512) void k(unsigned long long *out, float seed) {
             *(volatile __attribute__((address_space(3))) v2f *)(__attribute__((address_space(3))) char *)p = (v2f){acc.x, acc.y};
             *(volatile __attribute__((address_space(3))) v2f *)(__attribute__((address_space(3))) char *)(p + 8) = (v2f){acc.z, acc.w};
         }
+        if (MODE == 7) asm volatile("ds_write2_b64 %0, %1, %2 offset0:0 offset1:64" ::"v"((unsigned)(size_t)(__attribute__((address_space(3))) char *)(smem + w * 9 * 1024 + ln * 8 + (i & 7) * 1024)), "v"((v2f){acc.x, acc.y}), "v"((v2f){acc.z, acc.w}) : "memory");      // two 8-byte stores 512 B apart: both conflict-free
+        if (MODE == 8) asm volatile("ds_write2st64_b64 %0, %1, %2 offset0:0 offset1:1" ::"v"((unsigned)(size_t)(__attribute__((address_space(3))) char *)(smem + w * 9 * 1024 + ln * 8 + (i & 7) * 1024)), "v"((v2f){acc.x, acc.y}), "v"((v2f){acc.z, acc.w}) : "memory");
+        if (MODE == 9) {
+            v4f r;
+            asm volatile("ds_read2_b64 %0, %1 offset0:0 offset1:64\n s_waitcnt lgkmcnt(0)" : "=v"(r) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) char *)(smem + w * 9 * 1024 + ln * 8 + (i & 7) * 1024)) : "memory");
+            acc.x += r.x;
+        }
         if (MODE == 3) { const v2f r = *(volatile __attribute__((address_space(3))) v2f *)(__attribute__((address_space(3))) char *)p; acc.x += r.x; }
         if (MODE == 4 || MODE == 5) {
             v4f r;
@@ -45,7 +52,7 @@ int main() {
     unsigned long long *d, h[256];
     (void)hipMalloc(&d, 2048 * sizeof(unsigned long long));
     const char *names[] = {"ds_write_b64  (8 B / lane)", "ds_write_b128 (16 B / lane, aligned)", "ds_write_b128 at 8-byte alignment", "ds_read_b64", "ds_read_b128 aligned (waited one by one)",
-                           "ds_read_b128 at 8-byte alignment (waited)", "2 x ds_write_b64 to adjacent slots"};
+                           "ds_read_b128 at 8-byte alignment (waited)", "2 x ds_write_b64 to adjacent slots", "ds_write2_b64 (two 8-byte stores 512 B apart)", "ds_write2st64_b64 (the same)", "ds_read2_b64 (waited)"};
     auto run = [&](int m, auto kern) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         kern<<<256, 512, 80 * 1024>>>(d, 1.f);
@@ -57,6 +64,6 @@ int main() {
         s /= 256;
         printf("%-44s %8.1f shader cycles per wave instruction with 8 waves issuing  (%.2f per instruction and CU)\n", names[m], s / REP, s / REP / 8);
     };
-    run(0, k<0>); run(1, k<1>); run(2, k<2>); run(6, k<6>); run(3, k<3>); run(4, k<4>); run(5, k<5>);
+    run(0, k<0>); run(1, k<1>); run(2, k<2>); run(6, k<6>); run(7, k<7>); run(8, k<8>); run(3, k<3>); run(4, k<4>); run(5, k<5>); run(9, k<9>);
     return 0;
 }
